@@ -1,0 +1,391 @@
+"""CPU oracle for dither_pie's hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module, and there only as the checker / the timed CPU baseline.  The product package
+(dither_pie_amd/) never imports it.
+
+Parity status: pinned by tests/golden/ (outputs of the reference itself, generated in the
+build container by tests/golden/make_golden.py).  The reference has no tests of its own.
+
+The heavy loops live in dp_oracle.c (plain C, gcc); this file is the numpy part:
+  * the uint8 / gamma wrapper of ImageDitherer.apply_dithering   dithering_lib.py:1952-1992
+  * threshold tables (as integer numerators)                     dithering_lib.py:1705-1768
+  * error-diffusion tap tables                                   dithering_lib.py:107-188
+  * strategy parameter defaults                                  dithering_lib.py:408-419, 460-480,
+                                                                 508-529, 592-610
+  * sklearn KMeans (k-means++ / Lloyd) restated in numpy         dithering_lib.py:1845-1857
+    (third-party: scikit-learn, unpinned by the reference, 1.7.2 in the build container)
+  * ColorReducer.generate_uniform_palette                        dithering_lib.py:1859-1872
+  * the seeded input generators of SURVEY.md Appendix B
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libdp_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_tree_sizeof.restype = C.c_size_t
+        L.orc_tree_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_tree_export.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        L.orc_tree_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_ign_thresholds.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.orc_ordered_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int]
+        L.orc_error_diffusion_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int]
+        L.orc_blue_noise.argtypes = [C.c_int, C.c_uint32, C.c_void_p]
+        L.orc_kmeans_step.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ----------------------------------------------------------------------------- KD-tree
+class Tree:
+    """scipy.spatial.KDTree(points) (leafsize 10) restated; see dp_oracle.c."""
+
+    def __init__(self, points):
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+        self.K = pts.shape[0]
+        self._buf = C.create_string_buffer(lib().orc_tree_sizeof())
+        rc = lib().orc_tree_build(self._buf, _p(pts), self.K)
+        if rc != 0:
+            raise ValueError("oracle tree: K out of range")
+
+    def export(self):
+        n = 2 * self.K + 2
+        idx = np.zeros(self.K, np.int32)
+        sd = np.zeros(n, np.int32)
+        sp = np.zeros(n, np.float64)
+        st, en, le, gr = (np.zeros(n, np.int32) for _ in range(4))
+        nn = lib().orc_tree_export(self._buf, _p(idx), _p(sd), _p(sp), _p(st), _p(en), _p(le), _p(gr))
+        return dict(indices=idx, split_dim=sd[:nn], split=sp[:nn], start=st[:nn], end=en[:nn],
+                    less=le[:nn], greater=gr[:nn])
+
+    def query(self, x, k):
+        """returns (squared distances [n,k] f64, indices [n,k] int32)"""
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, 3))
+        n = x.shape[0]
+        d2 = np.zeros((n, k), np.float64)
+        ii = np.zeros((n, k), np.int32)
+        lib().orc_tree_query_batch(self._buf, _p(x), n, k, _p(d2), _p(ii))
+        return d2, ii
+
+
+# ----------------------------------------------------------------------------- tables
+_BAYER_NUM = {
+    "2x2": (4, [[1, 3], [4, 2]]),
+    "4x4": (32, [[1, 17, 5, 21], [25, 9, 29, 13], [7, 23, 3, 19], [31, 15, 27, 11]]),
+    "8x8": (64, [[1, 33, 9, 41, 3, 35, 11, 43], [49, 17, 57, 25, 51, 19, 59, 27],
+                 [13, 45, 5, 37, 15, 47, 7, 39], [61, 29, 53, 21, 63, 31, 54, 22],
+                 [4, 36, 12, 44, 2, 34, 10, 42], [52, 20, 60, 28, 50, 18, 58, 26],
+                 [16, 48, 8, 40, 14, 46, 6, 38], [64, 32, 56, 24, 62, 30, 54, 22]]),
+    "psx4x4": (16, [[1, 9, 3, 11], [13, 5, 15, 7], [3, 11, 1, 9], [15, 7, 13, 5]]),
+}
+
+
+def _bayer16_num():
+    # dithering_lib.py:1728-1761; rows 0-7 are the canonical 16x16 Bayer matrix (v+1),
+    # rows 8-15 repeat the 8x8 table (x4) on the left half and a shifted copy on the right.
+    rows = [
+        [1, 129, 33, 161, 9, 137, 41, 169, 3, 131, 35, 163, 11, 139, 43, 171],
+        [193, 65, 225, 97, 201, 73, 233, 105, 195, 67, 227, 99, 203, 75, 235, 107],
+        [49, 177, 17, 145, 57, 185, 25, 153, 51, 179, 19, 147, 59, 187, 27, 155],
+        [241, 113, 209, 81, 249, 121, 217, 89, 243, 115, 211, 83, 251, 123, 219, 91],
+        [13, 141, 45, 173, 5, 133, 37, 165, 15, 143, 47, 175, 7, 135, 39, 167],
+        [205, 77, 237, 109, 197, 69, 229, 101, 207, 79, 239, 111, 199, 71, 231, 103],
+        [61, 189, 29, 157, 53, 181, 21, 149, 63, 191, 31, 159, 55, 183, 23, 151],
+        [253, 125, 221, 93, 245, 117, 213, 85, 255, 127, 223, 95, 247, 119, 215, 87],
+        [4, 132, 36, 164, 12, 140, 44, 172, 2, 130, 34, 162, 10, 138, 42, 170],
+        [196, 68, 228, 100, 204, 76, 236, 108, 194, 66, 226, 98, 202, 74, 234, 106],
+        [52, 180, 20, 148, 60, 188, 28, 156, 50, 178, 18, 146, 58, 186, 26, 154],
+        [244, 116, 212, 84, 252, 124, 220, 92, 242, 114, 210, 82, 250, 122, 218, 90],
+        [16, 144, 48, 176, 8, 136, 40, 168, 14, 142, 46, 174, 6, 134, 38, 166],
+        [208, 80, 240, 112, 200, 72, 232, 104, 206, 78, 238, 110, 198, 70, 230, 102],
+        [64, 192, 32, 160, 56, 184, 24, 152, 62, 190, 30, 158, 54, 182, 22, 150],
+        [256, 128, 224, 96, 248, 120, 216, 88, 254, 126, 222, 94, 246, 118, 214, 86],
+    ]
+    return 256, rows
+
+
+_BAYER_NUM["16x16"] = _bayer16_num()
+
+
+def bayer_matrix(size="4x4"):
+    """dithering_lib.py:431-442: unknown size -> 4x4; 'psx' aliases 'psx4x4'."""
+    if size == "psx":
+        size = "psx4x4"
+    den, num = _BAYER_NUM.get(size, _BAYER_NUM["4x4"])
+    return (np.array(num, dtype=np.float64) / den).astype(np.float32)
+
+
+ED_KERNELS = {  # (dx, dy, weight) in list order, divisor -- dithering_lib.py:107-188
+    "floyd_steinberg": ([(1, 0, 7), (-1, 1, 3), (0, 1, 5), (1, 1, 1)], 16),
+    "jjn": ([(1, 0, 7), (2, 0, 5), (-2, 1, 3), (-1, 1, 5), (0, 1, 7), (1, 1, 5), (2, 1, 3),
+             (-2, 2, 1), (-1, 2, 3), (0, 2, 5), (1, 2, 3), (2, 2, 1)], 48),
+    "stucki": ([(1, 0, 8), (2, 0, 4), (-2, 1, 2), (-1, 1, 4), (0, 1, 8), (1, 1, 4), (2, 1, 2),
+                (-2, 2, 1), (-1, 2, 2), (0, 2, 4), (1, 2, 2), (2, 2, 1)], 42),
+    "burkes": ([(1, 0, 8), (2, 0, 4), (-2, 1, 2), (-1, 1, 4), (0, 1, 8), (1, 1, 4), (2, 1, 2)], 32),
+    "atkinson": ([(1, 0, 1), (2, 0, 1), (-1, 1, 1), (0, 1, 1), (1, 1, 1), (0, 2, 1)], 8),
+    "sierra": ([(1, 0, 5), (2, 0, 3), (-2, 1, 2), (-1, 1, 4), (0, 1, 5), (1, 1, 4), (2, 1, 2),
+                (-1, 2, 2), (0, 2, 3), (1, 2, 2)], 32),
+    "sierra_two_row": ([(1, 0, 4), (2, 0, 3), (-2, 1, 1), (-1, 1, 2), (0, 1, 3), (1, 1, 2), (2, 1, 1)], 16),
+    "sierra_lite": ([(1, 0, 2), (-1, 1, 1), (0, 1, 1)], 4),
+}
+
+
+def ed_kernel(variant):
+    """dithering_lib.py:203: unknown variant -> floyd_steinberg."""
+    return ED_KERNELS.get(variant, ED_KERNELS["floyd_steinberg"])
+
+
+# ----------------------------------------------------------------------------- gamma
+def srgb_to_linear(c):
+    """dithering_lib.py:1788-1794 (float32 arithmetic, numpy power)."""
+    c = np.asarray(c, dtype=np.float32)
+    low = c <= 0.04045
+    out = np.empty_like(c, dtype=np.float32)
+    out[low] = c[low] / 12.92
+    out[~low] = ((c[~low] + 0.055) / 1.055) ** 2.4
+    return out
+
+
+def linear_to_srgb(c):
+    """dithering_lib.py:1796-1802."""
+    c = np.asarray(c, dtype=np.float32)
+    low = c <= 0.0031308
+    out = np.empty_like(c, dtype=np.float32)
+    out[low] = c[low] * 12.92
+    out[~low] = 1.055 * (c[~low] ** (1.0 / 2.4)) - 0.055
+    return out
+
+
+def gamma_luts():
+    """(lut_in, lut_out): the uint8->uint8 maps of dithering_lib.py:1957-1959 and :1986-1989."""
+    k = np.arange(256, dtype=np.uint8)
+    a01 = k.astype(np.float32) / 255.0
+    lut_in = np.clip(srgb_to_linear(a01) * 255.0, 0, 255).astype(np.uint8)
+    o01 = k.astype(np.float32) / 255.0
+    lut_out = np.clip(linear_to_srgb(np.clip(o01, 0, 1)) * 255.0, 0, 255).astype(np.uint8)
+    return lut_in, lut_out
+
+
+def prepare_palette(palette, use_gamma):
+    """-> (pal_f32 [K,3] as seen by the KD-tree, out_colors uint8 [K,3], lut_in or None)
+
+    dithering_lib.py:1970-1974 (palette), :1984-1990 (what a chosen entry becomes)."""
+    pal = np.array(palette, dtype=np.float32).reshape(-1, 3)
+    if not use_gamma:
+        return np.ascontiguousarray(pal), np.ascontiguousarray(pal.astype(np.uint8)), None
+    lut_in, lut_out = gamma_luts()
+    pal_lin = np.clip(srgb_to_linear(pal / 255.0) * 255.0, 0, 255).astype(np.float32)
+    out_lin8 = pal_lin.astype(np.uint8)
+    return np.ascontiguousarray(pal_lin), np.ascontiguousarray(lut_out[out_lin8]), lut_in
+
+
+# ----------------------------------------------------------------------------- thresholds
+def ign_thresholds(h, w, scale=1.0, seed=0, y0=0, x0=0):
+    out = np.zeros((h, w), np.float32)
+    lib().orc_ign_thresholds(h, w, y0, x0, float(scale), int(seed), _p(out))
+    return out
+
+
+_BN_CACHE = {}
+
+
+def blue_noise(size=64, seed=42):
+    key = (int(size), int(seed))
+    if key not in _BN_CACHE:
+        out = np.zeros((size, size), np.float32)
+        if lib().orc_blue_noise(int(size), int(seed), _p(out)) != 0:
+            raise MemoryError
+        _BN_CACHE[key] = out
+    return _BN_CACHE[key]
+
+
+# ----------------------------------------------------------------------------- dither
+MODE_DEFAULTS = {
+    "bayer": {"size": "4x4"},
+    "blue_noise": {"size": 64, "seed": 42},
+    "IGN": {"scale": 1.0, "seed": 0},
+    "error_diffusion": {"variant": "atkinson", "serpentine": "false"},
+    "none": {},
+}
+
+
+def ordered_u8(arr, pal_f32, out_colors, lut_in, mode, thr=None, scale=1.0, seed=0, y0=0, x0=0,
+               want_idx=False):
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    h, w, _ = arr.shape
+    out = np.empty_like(arr)
+    idx = np.empty((h, w), np.int32) if want_idx else None
+    K = pal_f32.shape[0]
+    m = {"none": 0, "matrix": 1, "ign": 2}[mode]
+    th_h = th_w = 1
+    if thr is not None:
+        thr = np.ascontiguousarray(thr, dtype=np.float32)
+        th_h, th_w = thr.shape
+    rc = lib().orc_ordered_u8(_p(arr), _p(out), _p(idx), h, w, y0, x0, _p(pal_f32), K, _p(out_colors),
+                              _p(lut_in), m, _p(thr), th_h, th_w, float(scale), int(seed))
+    if rc != 0:
+        raise ValueError("oracle ordered_u8 failed")
+    return (out, idx) if want_idx else out
+
+
+def error_diffusion_u8(arr, pal_f32, out_colors, lut_in, variant="atkinson", serpentine=False):
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    h, w, _ = arr.shape
+    out = np.empty_like(arr)
+    taps, div = ed_kernel(variant)
+    dx = np.array([t[0] for t in taps], np.int32)
+    dy = np.array([t[1] for t in taps], np.int32)
+    wq = np.array([t[2] / div for t in taps], np.float64)
+    rc = lib().orc_error_diffusion_u8(_p(arr), _p(out), h, w, _p(pal_f32), pal_f32.shape[0], _p(out_colors),
+                                      _p(lut_in), _p(dx), _p(dy), _p(wq), len(taps), 1 if serpentine else 0)
+    if rc != 0:
+        raise ValueError("oracle error_diffusion_u8 failed")
+    return out
+
+
+def apply_dithering(arr, palette, mode="bayer", params=None, use_gamma=False, y0=0, x0=0):
+    """uint8 HWC -> uint8 HWC; mirrors ImageDitherer.apply_dithering (dithering_lib.py:1952-1992)
+    for the in-scope modes.  (y0,x0) are the global coordinates of arr[0,0] for tile shards."""
+    p = dict(MODE_DEFAULTS[mode])
+    p.update(params or {})
+    pal_f32, out_colors, lut_in = prepare_palette(palette, use_gamma)
+    if mode == "none":
+        return ordered_u8(arr, pal_f32, out_colors, lut_in, "none", y0=y0, x0=x0)
+    if mode == "bayer":
+        return ordered_u8(arr, pal_f32, out_colors, lut_in, "matrix", thr=bayer_matrix(p["size"]), y0=y0, x0=x0)
+    if mode == "blue_noise":
+        return ordered_u8(arr, pal_f32, out_colors, lut_in, "matrix", thr=blue_noise(p["size"], p["seed"]),
+                          y0=y0, x0=x0)
+    if mode == "IGN":
+        return ordered_u8(arr, pal_f32, out_colors, lut_in, "ign", scale=float(p["scale"]), seed=int(p["seed"]),
+                          y0=y0, x0=x0)
+    if mode == "error_diffusion":
+        return error_diffusion_u8(arr, pal_f32, out_colors, lut_in, p["variant"], p["serpentine"] == "true")
+    raise ValueError(f"oracle: mode {mode!r} not in scope")
+
+
+# ----------------------------------------------------------------------------- palettes
+def generate_uniform_palette(n):
+    """dithering_lib.py:1859-1872."""
+    c = []
+    cube = int(math.ceil(n ** (1 / 3)))
+    for r in range(cube):
+        for g in range(cube):
+            for b in range(cube):
+                if len(c) >= n:
+                    break
+                rr = int(r * 255 / (cube - 1)) if cube > 1 else 128
+                gg = int(g * 255 / (cube - 1)) if cube > 1 else 128
+                bb = int(b * 255 / (cube - 1)) if cube > 1 else 128
+                c.append((rr, gg, bb))
+    return c[:n]
+
+
+# ----------------------------------------------------------------------------- k-means
+def kmeans_step(px, centers):
+    """one Lloyd pass: (int64 sums [K,3], int64 counts [K], inertia)."""
+    px = np.ascontiguousarray(px, dtype=np.uint8).reshape(-1, 3)
+    centers = np.ascontiguousarray(centers, dtype=np.float64)
+    K = centers.shape[0]
+    sums = np.zeros((K, 3), np.int64)
+    counts = np.zeros(K, np.int64)
+    inertia = C.c_double(0)
+    lib().orc_kmeans_step(_p(px), px.shape[0], _p(centers), K, _p(sums), _p(counts), C.byref(inertia))
+    return sums, counts, inertia.value
+
+
+def kmeans_plusplus(px, K, rs):
+    """sklearn.cluster._kmeans._kmeans_plusplus restated on the uint8 pixel sample (f64 arithmetic,
+    direct (x-c)^2 distances); rs is a numpy RandomState."""
+    X = np.asarray(px, dtype=np.float64).reshape(-1, 3)
+    n = X.shape[0]
+    trials = 2 + int(np.log(K))
+    centers = np.empty((K, 3), np.float64)
+    cid = rs.choice(n)
+    centers[0] = X[cid]
+    closest = ((X - centers[0]) ** 2).sum(1)
+    pot = closest.sum()
+    for c in range(1, K):
+        rv = rs.uniform(size=trials) * pot
+        cand = np.searchsorted(np.cumsum(closest), rv)
+        np.clip(cand, None, n - 1, out=cand)
+        dc = ((X[cand][:, None, :] - X[None, :, :]) ** 2).sum(2)
+        np.minimum(closest, dc, out=dc)
+        pots = dc.sum(1)
+        b = int(np.argmin(pots))
+        pot = pots[b]
+        closest = dc[b]
+        centers[c] = X[cand[b]]
+    return centers
+
+
+def kmeans_lloyd(px, init_centers, max_iter=300, tol=1e-4):
+    """sklearn _kmeans_single_lloyd semantics on exact integer sums:
+    stop on unchanged labels (detected through unchanged sums/counts) or squared centre shift
+    <= tol * mean(var(X)); empty clusters keep their previous centre."""
+    px = np.ascontiguousarray(px, dtype=np.uint8).reshape(-1, 3)
+    X = px.astype(np.float64)
+    tol_abs = float(np.mean(np.var(X, axis=0)) * tol)
+    centers = np.array(init_centers, dtype=np.float64)
+    prev = None
+    n_iter = 0
+    for n_iter in range(1, max_iter + 1):
+        sums, counts, _ = kmeans_step(px, centers)
+        new = centers.copy()
+        nz = counts > 0
+        new[nz] = sums[nz] / counts[nz, None]
+        shift = float(((new - centers) ** 2).sum())
+        same = prev is not None and np.array_equal(prev[0], sums) and np.array_equal(prev[1], counts)
+        centers = new
+        prev = (sums, counts)
+        if same or shift <= tol_abs:
+            break
+    _, _, inertia = kmeans_step(px, centers)
+    return centers, inertia, n_iter
+
+
+# ----------------------------------------------------------------------------- inputs
+def rnd(h, w, seed):
+    return np.random.RandomState(seed).randint(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def grad(h, w):
+    y, x = np.mgrid[0:h, 0:w]
+    return np.stack([x % 256, y % 256, ((x + y) // 2) % 256], -1).astype(np.uint8)
+
+
+def palr(K, seed=7):
+    return [tuple(int(v) for v in c) for c in np.random.RandomState(seed).randint(0, 256, (K, 3))]
+
+
+def H(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]

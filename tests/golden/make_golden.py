@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures from the REFERENCE itself (build container only).
+
+Run:  python tests/golden/make_golden.py            (needs /root/reference; ~3-4 min)
+
+Imports dobrosketchkun/dither_pie's dithering_lib from /root/reference (read-only; an
+in-memory stub stands in for the unused `pywt` import, nothing is written there) and
+records, for seeded synthetic inputs (formulas in oracle/oracle.py: rnd/grad/palr),
+the outputs of ImageDitherer.apply_dithering and friends.  Only DATA is stored:
+  kat.json     sha256[:16] of inputs/outputs for the known-answer tests (SURVEY.md App. B + more)
+  small.npz    full small arrays: threshold tables, blue-noise matrices, gamma LUTs,
+               IGN thresholds, small dither outputs, cKDTree structures and tie queries,
+               k-means fixtures
+Versions are recorded in kat.json["versions"].
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("DITHER_PIE_REFERENCE", "/root/reference")
+
+sys.modules.setdefault("pywt", types.ModuleType("pywt"))
+sys.path.insert(0, REF)
+import dithering_lib as dl  # noqa: E402  (the reference)
+from PIL import Image  # noqa: E402
+
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle.oracle import grad, palr, rnd  # noqa: E402  (input formulas only)
+
+
+def H(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def make_input(spec):
+    kind = spec[0]
+    if kind == "rnd":
+        return rnd(spec[1], spec[2], spec[3])
+    if kind == "grad":
+        return grad(spec[1], spec[2])
+    raise ValueError(spec)
+
+
+def make_palette(spec):
+    kind = spec[0]
+    if kind == "U":
+        return dl.ColorReducer.generate_uniform_palette(spec[1])
+    if kind == "palr":
+        return palr(spec[1], spec[2] if len(spec) > 2 else 7)
+    if kind == "list":
+        return [tuple(c) for c in spec[1]]
+    raise ValueError(spec)
+
+
+def run_ref(arr, pal, mode, params, gamma):
+    d = dl.ImageDitherer(len(pal), dl.DitherMode(mode), list(pal), gamma, dict(params))
+    return np.array(d.apply_dithering(Image.fromarray(arr)))
+
+
+ED_VARIANTS = ["floyd_steinberg", "jjn", "stucki", "burkes", "atkinson", "sierra", "sierra_two_row",
+               "sierra_lite"]
+
+# (name, mode, params, palette spec, input spec, gamma, keep_full_output)
+CASES = [
+    ("bayer4_U16_rnd512", "bayer", {"size": "4x4"}, ("U", 16), ("rnd", 512, 512, 1234), False, False),
+    ("bayer4_U16_grad", "bayer", {"size": "4x4"}, ("U", 16), ("grad", 333, 500), False, True),
+    ("bayer2_p32_grad", "bayer", {"size": "2x2"}, ("palr", 32), ("grad", 333, 500), False, False),
+    ("bayer8_p32_grad", "bayer", {"size": "8x8"}, ("palr", 32), ("grad", 333, 500), False, True),
+    ("bayer16_p32_grad", "bayer", {"size": "16x16"}, ("palr", 32), ("grad", 333, 500), False, False),
+    ("bayerpsx_p32_grad", "bayer", {"size": "psx4x4"}, ("palr", 32), ("grad", 333, 500), False, False),
+    ("bayerdefault_p32_grad", "bayer", {}, ("palr", 32), ("grad", 97, 131), False, True),
+    ("bayerbogus_p32_grad", "bayer", {"size": "nope"}, ("palr", 32), ("grad", 97, 131), False, True),
+    ("none_p256_grad1080", "none", {}, ("palr", 256), ("grad", 1080, 1920), False, False),
+    ("bayer8_p256_grad1080", "bayer", {"size": "8x8"}, ("palr", 256), ("grad", 1080, 1920), False, False),
+    ("bayer8_p256_rnd4k", "bayer", {"size": "8x8"}, ("palr", 256), ("rnd", 2160, 3840, 1234), False, False),
+    ("none_p256_rnd_small", "none", {}, ("palr", 256), ("rnd", 203, 317, 11), False, True),
+    ("bayer8_p256_rnd_small", "bayer", {"size": "8x8"}, ("palr", 256), ("rnd", 203, 317, 11), False, True),
+    ("bayer8_p256_grad_small", "bayer", {"size": "8x8"}, ("palr", 256), ("grad", 203, 317), False, True),
+    ("bayer4_p100_grad_small", "bayer", {"size": "4x4"}, ("palr", 100, 3), ("grad", 203, 317), False, True),
+    ("none_U16_grad_small", "none", {}, ("U", 16), ("grad", 203, 317), False, True),
+    ("none_p7_grad_small", "none", {}, ("palr", 7, 5), ("grad", 203, 317), False, True),
+    ("bayer4_p7_grad_small", "bayer", {"size": "4x4"}, ("palr", 7, 5), ("grad", 203, 317), False, True),
+    ("bayer4_p2_grad_small", "bayer", {"size": "4x4"}, ("palr", 2, 5), ("grad", 64, 96), False, True),
+    ("bayer4_dup_grad_small", "bayer", {"size": "4x4"},
+     ("list", [(10, 20, 30), (200, 100, 50), (10, 20, 30), (200, 100, 50), (0, 0, 0)]), ("grad", 64, 96), False, True),
+    ("bayer4_U64_grad_small", "bayer", {"size": "4x4"}, ("U", 64), ("grad", 203, 317), False, True),
+    ("bayer8_U256_rnd_small", "bayer", {"size": "8x8"}, ("U", 256), ("rnd", 128, 160, 21), False, True),
+    ("ign_p32_grad1080", "IGN", {}, ("palr", 32), ("grad", 1080, 1920), False, False),
+    ("ign_s25_p32_rnd", "IGN", {"scale": 2.5, "seed": 17}, ("palr", 32), ("rnd", 200, 300, 3), False, True),
+    ("ign_p256_grad_small", "IGN", {"scale": 0.7, "seed": 3}, ("palr", 256), ("grad", 203, 317), False, True),
+    ("blue64_p32_grad", "blue_noise", {}, ("palr", 32), ("grad", 333, 500), False, True),
+    ("blue32_p256_rnd_small", "blue_noise", {"size": 32, "seed": 42}, ("palr", 256), ("rnd", 203, 317, 12), False, True),
+    ("bayer4_U16_gamma_grad", "bayer", {"size": "4x4"}, ("U", 16), ("grad", 333, 500), True, True),
+    ("bayer8_p256_gamma_grad", "bayer", {"size": "8x8"}, ("palr", 256), ("grad", 333, 500), True, True),
+    ("none_p32_gamma_rnd", "none", {}, ("palr", 32), ("rnd", 120, 160, 9), True, True),
+    ("ign_p32_gamma_rnd", "IGN", {}, ("palr", 32), ("rnd", 120, 160, 9), True, True),
+    ("ed_fs_p16_rnd", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 16), ("rnd", 120, 160, 5), False, True),
+    ("ed_default_p256_grad", "error_diffusion", {}, ("palr", 256), ("grad", 64, 96), False, True),
+    ("ed_fs_U16_gamma_grad", "error_diffusion", {"variant": "floyd_steinberg"}, ("U", 16), ("grad", 64, 96), True, True),
+    ("ed_bogus_U16_grad", "error_diffusion", {"variant": "nope"}, ("U", 16), ("grad", 40, 56), False, True),
+    ("ed_jjn_p32_rnd_serp", "error_diffusion", {"variant": "jjn", "serpentine": "true"}, ("palr", 32), ("rnd", 50, 70, 8), False, True),
+    ("ed_fs_p16_tiny_w1", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 16), ("rnd", 17, 1, 2), False, True),
+    ("ed_stucki_p16_tiny_h1", "error_diffusion", {"variant": "stucki"}, ("palr", 16), ("rnd", 1, 23, 2), False, True),
+]
+for v in ED_VARIANTS:
+    for s in ("false", "true"):
+        CASES.append((f"ed_{v}_{s}_U16_grad", "error_diffusion", {"variant": v, "serpentine": s},
+                      ("U", 16), ("grad", 64, 96), False, True))
+
+
+def main():
+    import scipy
+    import sklearn
+    import PIL
+    from scipy.spatial import cKDTree
+    from sklearn.cluster import KMeans, kmeans_plusplus
+
+    kat = {"versions": {"numpy": np.__version__, "scipy": scipy.__version__, "sklearn": sklearn.__version__,
+                        "pillow": PIL.__version__, "python": sys.version.split()[0]},
+           "cases": [], "tables": {}, "misc": {}}
+    npz = {}
+
+    # ---- threshold tables
+    for name in ["BAYER2x2", "BAYER4x4", "BAYER8x8", "BAYER16x16", "PSX4x4"]:
+        m = getattr(dl.DitherUtils, name)
+        kat["tables"][name] = H(m)
+        npz["table_" + name] = m
+
+    # ---- gamma LUTs (dithering_lib.py:1957-1959, 1986-1989) and the palette linearisation table
+    k = np.arange(256, dtype=np.uint8)
+    lut_in = np.clip(dl.DitherUtils.srgb_to_linear(k.astype(np.float32) / 255.0) * 255.0, 0, 255).astype(np.uint8)
+    lut_out = np.clip(dl.DitherUtils.linear_to_srgb(np.clip(k.astype(np.float32) / 255.0, 0, 1)) * 255.0, 0, 255).astype(np.uint8)
+    pal_lin = np.clip(dl.DitherUtils.srgb_to_linear(k.astype(np.float32) / 255.0) * 255.0, 0, 255).astype(np.float32)
+    npz["lut_in"], npz["lut_out"], npz["pal_lin_table"] = lut_in, lut_out, pal_lin
+    kat["misc"]["lut_in"], kat["misc"]["lut_out"], kat["misc"]["pal_lin_table"] = H(lut_in), H(lut_out), H(pal_lin)
+
+    # ---- IGN thresholds
+    s = dl.InterleavedGradientNoiseDitherStrategy(1.0, 0)
+    npz["ign_8x8_s1_seed0"] = s._generate_thresholds((8, 8))
+    kat["misc"]["ign_8x8_s1_seed0"] = H(npz["ign_8x8_s1_seed0"])
+    s = dl.InterleavedGradientNoiseDitherStrategy(2.5, 17)
+    kat["misc"]["ign_1080_s25_seed17"] = H(s._generate_thresholds((1080, 1920)))
+    npz["ign_37x53_s25_seed17"] = s._generate_thresholds((37, 53))
+    s = dl.InterleavedGradientNoiseDitherStrategy(0.1, 9999)
+    npz["ign_64x64_s01_seed9999"] = s._generate_thresholds((64, 64))
+    s = dl.InterleavedGradientNoiseDitherStrategy(10.0, 4321)
+    kat["misc"]["ign_4k_s10_seed4321"] = H(s._generate_thresholds((2160, 3840)))
+
+    # ---- blue noise
+    for size, seed in [(32, 42), (64, 42), (32, 0), (33, 9999)]:
+        bn = dl.generate_blue_noise(size, seed)
+        npz[f"blue_{size}_{seed}"] = bn
+        kat["misc"][f"blue_{size}_{seed}"] = H(bn)
+        print("blue", size, seed, H(bn), flush=True)
+
+    # ---- dither cases
+    for name, mode, params, pspec, ispec, gamma, keep in CASES:
+        arr = make_input(ispec)
+        pal = make_palette(pspec)
+        out = run_ref(arr, pal, mode, params, gamma)
+        kat["cases"].append(dict(name=name, mode=mode, params=params, palette=list(pspec), input=list(ispec),
+                                 gamma=gamma, h_in=H(arr), h_out=H(out), full=keep))
+        if keep:
+            npz["out_" + name] = out
+        print(name, H(arr), H(out), flush=True)
+
+    # ---- cKDTree structures + tie-heavy queries (scipy.spatial.KDTree defaults: leafsize 10)
+    tree_pals = {
+        "p256": np.array(palr(256), np.float64), "p100": np.array(palr(100, 3), np.float64),
+        "p32": np.array(palr(32), np.float64), "p16": np.array(palr(16), np.float64),
+        "p11": np.array(palr(11, 2), np.float64),
+        "U16": np.array(dl.ColorReducer.generate_uniform_palette(16), np.float64),
+        "U64": np.array(dl.ColorReducer.generate_uniform_palette(64), np.float64),
+        "U256": np.array(dl.ColorReducer.generate_uniform_palette(256), np.float64),
+        "dup40": np.array(palr(20, 4) + palr(20, 4), np.float64),
+        "flat": np.array([(i % 7 * 30, 5, 200) for i in range(64)], np.float64),
+        "lin256": np.array(pal_lin[np.array(palr(256))], np.float64),
+    }
+    rs = np.random.RandomState(123)
+    for nm, P in tree_pals.items():
+        t = cKDTree(P, leafsize=10)
+        nodes = []
+
+        def walk(n):
+            i = len(nodes)
+            nodes.append(None)
+            if n.split_dim == -1:
+                nodes[i] = (-1, 0.0, n.start_idx, n.end_idx, -1, -1)
+            else:
+                l = walk(n.lesser)
+                g = walk(n.greater)
+                nodes[i] = (n.split_dim, n.split, n.start_idx, n.end_idx, l, g)
+            return i
+
+        walk(t.tree)
+        npz[f"tree_{nm}_pts"] = P
+        npz[f"tree_{nm}_indices"] = np.asarray(t.indices, np.int32)
+        npz[f"tree_{nm}_nodes"] = np.array([(a, c, d, e, f) for a, b, c, d, e, f in nodes], np.int32)
+        npz[f"tree_{nm}_splits"] = np.array([b for a, b, c, d, e, f in nodes], np.float64)
+        # queries: random integer points + points built to tie (midpoints / mirrored points)
+        q = [rs.randint(0, 256, (4000, 3)).astype(np.float64)]
+        a = P[rs.randint(0, len(P), 3000)]
+        b = P[rs.randint(0, len(P), 3000)]
+        q.append(np.floor((a + b) / 2))
+        q.append(P[rs.randint(0, len(P), 500)])
+        q.append(np.clip(P[rs.randint(0, len(P), 1500)] + rs.randint(-3, 4, (1500, 3)), 0, 255))
+        q = np.concatenate(q).astype(np.float32).astype(np.float64)  # what travels is f32
+        d1, i1 = t.query(q, k=1)
+        d2, i2 = t.query(q, k=2)
+        npz[f"tree_{nm}_q"] = q.astype(np.float32)
+        npz[f"tree_{nm}_i1"] = i1.astype(np.int32)
+        npz[f"tree_{nm}_i2"] = i2.astype(np.int32)
+        npz[f"tree_{nm}_d2"] = d2
+    kat["misc"]["tree_palettes"] = list(tree_pals.keys())
+
+    # ---- k-means (dithering_lib.py:1845-1857): <= 10000 px => deterministic in the reference
+    for nm, (hh, ww, seed, K) in {"km8": (100, 100, 31, 8), "km16": (80, 125, 32, 16), "km32": (100, 100, 33, 32)}.items():
+        arr = rnd(hh, ww, seed) if nm != "km16" else grad(hh, ww)
+        pal = dl.ColorReducer.generate_kmeans_palette(Image.fromarray(arr), K)
+        X = arr.reshape(-1, 3).astype(np.float64)
+        Xc = X - X.mean(axis=0)
+        _, init_idx = kmeans_plusplus(Xc, K, random_state=42)
+        km = KMeans(n_clusters=K, random_state=42).fit(arr.reshape(-1, 3))
+        km2 = KMeans(n_clusters=K, init=X[init_idx], n_init=1).fit(arr.reshape(-1, 3))
+        assert np.allclose(km.cluster_centers_, km2.cluster_centers_, atol=1e-9), "init replay mismatch"
+        npz[f"{nm}_palette"] = np.array(pal, np.int32)
+        npz[f"{nm}_init_idx"] = np.asarray(init_idx, np.int32)
+        npz[f"{nm}_centers"] = km.cluster_centers_
+        kat["misc"][nm] = dict(h=hh, w=ww, seed=seed, K=K, kind="grad" if nm == "km16" else "rnd",
+                               inertia=float(km.inertia_), n_iter=int(km.n_iter_))
+        print(nm, km.n_iter_, km.inertia_, flush=True)
+
+    # ---- palette producers used by the fixtures / benches
+    for n in (2, 8, 16, 27, 64, 256):
+        npz[f"uniform_{n}"] = np.array(dl.ColorReducer.generate_uniform_palette(n), np.int32)
+
+    # ---- strategy parameter metadata (drop-in boundary)
+    meta = {}
+    for m in dl.DitherMode:
+        info = dl.ImageDitherer.get_mode_parameters(m)
+        meta[m.value] = info
+    kat["misc"]["mode_parameters"] = meta
+    kat["misc"]["dither_modes"] = {m.name: m.value for m in dl.DitherMode}
+
+    np.savez_compressed(os.path.join(HERE, "small.npz"), **npz)
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, indent=1, sort_keys=True)
+    print("wrote", len(npz), "arrays,", len(kat["cases"]), "cases")
+
+
+if __name__ == "__main__":
+    main()
