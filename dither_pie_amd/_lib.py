@@ -1,0 +1,93 @@
+"""ctypes binding of libditherpie_hip.so (C ABI: include/ditherpie_hip.h).
+
+The library is the product: there is no CPU fallback.  If the shared object is missing or a
+call fails, a DitherPieError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libditherpie_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DP_OK, DP_EINVAL, DP_EUNSUPPORTED, DP_EHIP, DP_ENOMEM, DP_EWORKSPACE = range(6)
+DP_MAX_COLORS = 256
+MODE_NEAREST, MODE_MATRIX, MODE_IGN = 0, 1, 2
+
+
+class DitherPieError(RuntimeError):
+    """A libditherpie_hip call failed (the message is dp_last_error())."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libditherpie_hip error {code}: {msg}")
+        self.code = code
+
+
+_lock = threading.Lock()
+_lib = None
+
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+_SIGS = {
+    "dp_version": (C.c_int, []),
+    "dp_last_error": (C.c_char_p, []),
+    "dp_device_info": (_i, [C.POINTER(C.c_int), C.c_char_p, _sz]),
+    "dp_palette_create": (_i, [_vp, _vp, _i, _vp, C.POINTER(_vp)]),
+    "dp_palette_destroy": (None, [_vp]),
+    "dp_palette_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "dp_kdtree_build_host": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "dp_thresholds_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "dp_thresholds_blue_noise": (_i, [_i, C.c_uint32, _vp, C.POINTER(_vp)]),
+    "dp_thresholds_shape": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "dp_thresholds_download": (_i, [_vp, _vp]),
+    "dp_thresholds_destroy": (None, [_vp]),
+    "dp_ign_thresholds": (_i, [_vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "dp_ordered_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "dp_ordered_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _f, _i, _vp, _sz, _vp]),
+    "dp_error_diffusion_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "dp_error_diffusion_u8": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "dp_kmeans_step_u8": (_i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _vp]),
+    "dp_resize_nearest_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
+    return LIB_PATH
+
+
+def load():
+    """Return the loaded library; raises DitherPieError when it is not built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise DitherPieError(-1, f"{LIB_PATH} is missing: build it with "
+                                         f"`make -C {CSRC}` (or dither_pie_amd.build()); there is no CPU fallback")
+            L = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != DP_OK:
+        msg = load().dp_last_error()
+        raise DitherPieError(rc, msg.decode("utf-8", "replace") if msg else "unknown error")
+
+
+def device_info():
+    n = C.c_int(0)
+    buf = C.create_string_buffer(128)
+    check(load().dp_device_info(C.byref(n), buf, 128))
+    return n.value, buf.value.decode()

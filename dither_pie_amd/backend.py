@@ -1,0 +1,189 @@
+"""Thin tensor-level wrappers over the C ABI: frames live in torch uint8 tensors on the GPU
+(PyTorch-ROCm is used for device memory and streams only), kernels come from
+libditherpie_hip.so.  Nothing here computes pixels on the host."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MODE_IGN, MODE_MATRIX, MODE_NEAREST, DitherPieError, check
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise DitherPieError(-2, "no HIP device visible: the MI355X backend has no CPU fallback")
+
+
+class Palette:
+    """dp_palette: scipy-order KD-tree + colour tables resident in HBM.
+
+    pal_f32 [K,3] float32 as the KD-tree sees it; out_colors [K,3] uint8 written for each entry;
+    lut_in optional 256-entry uint8 map applied to the input bytes."""
+
+    def __init__(self, pal_f32, out_colors, lut_in=None):
+        require_gpu()
+        self.pal_f32 = np.ascontiguousarray(pal_f32, dtype=np.float32).reshape(-1, 3)
+        self.out_colors = np.ascontiguousarray(out_colors, dtype=np.uint8).reshape(-1, 3)
+        if self.pal_f32.shape != self.out_colors.shape:
+            raise ValueError("pal_f32 and out_colors must both be [K,3]")
+        self.lut_in = None if lut_in is None else np.ascontiguousarray(lut_in, dtype=np.uint8)
+        if self.lut_in is not None and self.lut_in.size != 256:
+            raise ValueError("lut_in must have 256 entries")
+        self.K = self.pal_f32.shape[0]
+        self._h = C.c_void_p()
+        self._destroy = _lib.load().dp_palette_destroy
+        check(_lib.load().dp_palette_create(_np_ptr(self.pal_f32), _np_ptr(self.out_colors), self.K,
+                                            _np_ptr(self.lut_in), C.byref(self._h)))
+        k, integer, nodes = C.c_int(), C.c_int(), C.c_int()
+        check(_lib.load().dp_palette_info(self._h, C.byref(k), C.byref(integer), C.byref(nodes)))
+        self.is_integer = bool(integer.value)
+        self.n_nodes = nodes.value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._destroy(h)
+            self._h = None
+
+
+class Thresholds:
+    """dp_thresholds: a threshold matrix resident in HBM."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._destroy = _lib.load().dp_thresholds_destroy
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(_lib.load().dp_thresholds_shape(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.shape = (a.value, b.value)
+        self.integer_form = bool(c.value)
+
+    @classmethod
+    def from_matrix(cls, m):
+        require_gpu()
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        if m.ndim != 2:
+            raise ValueError("threshold matrix must be 2-D")
+        h = C.c_void_p()
+        check(_lib.load().dp_thresholds_create(_np_ptr(m), m.shape[0], m.shape[1], C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def blue_noise(cls, size, seed):
+        require_gpu()
+        h = C.c_void_p()
+        check(_lib.load().dp_thresholds_blue_noise(int(size), int(seed) & 0xFFFFFFFF, _stream(), C.byref(h)))
+        return cls(h)
+
+    def numpy(self):
+        out = np.empty(self.shape, np.float32)
+        check(_lib.load().dp_thresholds_download(self._h, _np_ptr(out)))
+        return out
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._destroy(h)
+            self._h = None
+
+
+def _frames(t):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8):
+        raise TypeError("frames must be a CUDA uint8 tensor")
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.dim() != 4 or t.shape[-1] != 3:
+        raise ValueError("frames must be [N,H,W,3] or [H,W,3]")
+    return t.contiguous()
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """grow-only per-device scratch tensor (flags bitmap, error rows)"""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def ordered(frames, pal: Palette, mode, thr: Thresholds | None = None, ign_scale=1.0, ign_seed=0, y0=0, x0=0,
+            out=None):
+    """nearest / threshold-matrix / IGN dithering of uint8 frames already in HBM -> uint8 frames."""
+    f = _frames(frames)
+    n, h, w, _ = f.shape
+    if out is None:
+        out = torch.empty_like(f)
+    L = _lib.load()
+    ws_bytes = L.dp_ordered_workspace_bytes(n, h, w)
+    ws = _workspace(ws_bytes, f.device)
+    with torch.cuda.device(f.device):
+        check(L.dp_ordered_u8(f.data_ptr(), out.data_ptr(), n, h, w, int(y0), int(x0), pal._h, int(mode),
+                              thr._h if thr is not None else None, float(ign_scale), int(ign_seed),
+                              ws.data_ptr(), ws.numel(), _stream()))
+    return out if frames.dim() == 4 else out[0]
+
+
+def error_diffusion(frames, pal: Palette, taps, divisor, serpentine=False, out=None):
+    """taps: [(dx, dy, weight)] in the reference's list order."""
+    f = _frames(frames)
+    n, h, w, _ = f.shape
+    if out is None:
+        out = torch.empty_like(f)
+    dx = np.array([t[0] for t in taps], np.int32)
+    dy = np.array([t[1] for t in taps], np.int32)
+    wq = np.array([t[2] / divisor for t in taps], np.float64).astype(np.float32)
+    L = _lib.load()
+    ws_bytes = L.dp_error_diffusion_workspace_bytes(n, h, w)
+    ws = _workspace(ws_bytes, f.device)
+    with torch.cuda.device(f.device):
+        check(L.dp_error_diffusion_u8(f.data_ptr(), out.data_ptr(), n, h, w, pal._h, _np_ptr(dx), _np_ptr(dy),
+                                      _np_ptr(wq), len(taps), 1 if serpentine else 0, ws.data_ptr(), ws.numel(),
+                                      _stream()))
+    return out if frames.dim() == 4 else out[0]
+
+
+def ign_thresholds(h, w, scale=1.0, seed=0, y0=0, x0=0, device="cuda"):
+    require_gpu()
+    out = torch.empty((h, w), dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        check(_lib.load().dp_ign_thresholds(out.data_ptr(), h, w, y0, x0, float(scale), int(seed), _stream()))
+    return out
+
+
+def kmeans_step(px, centers):
+    """px: CUDA uint8 [...,3]; centers: CUDA float64 [K,3] -> (sums [K,3], counts [K], sumsq [K]) int64"""
+    if not (px.is_cuda and px.dtype == torch.uint8 and px.shape[-1] == 3):
+        raise TypeError("px must be a CUDA uint8 tensor [...,3]")
+    px = px.contiguous()
+    centers = centers.to(device=px.device, dtype=torch.float64).contiguous()
+    K = centers.shape[0]
+    sums = torch.empty((K, 3), dtype=torch.int64, device=px.device)
+    counts = torch.empty((K,), dtype=torch.int64, device=px.device)
+    sumsq = torch.empty((K,), dtype=torch.int64, device=px.device)
+    with torch.cuda.device(px.device):
+        check(_lib.load().dp_kmeans_step_u8(px.data_ptr(), px.numel() // 3, centers.data_ptr(), K, sums.data_ptr(),
+                                            counts.data_ptr(), sumsq.data_ptr(), _stream()))
+    return sums, counts, sumsq
+
+
+def resize_nearest(frames, oh, ow):
+    f = _frames(frames)
+    n, h, w, _ = f.shape
+    out = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=f.device)
+    with torch.cuda.device(f.device):
+        check(_lib.load().dp_resize_nearest_u8(f.data_ptr(), out.data_ptr(), n, h, w, int(oh), int(ow), _stream()))
+    return out if frames.dim() == 4 else out[0]

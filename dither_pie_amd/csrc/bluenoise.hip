@@ -1,0 +1,157 @@
+// generate_blue_noise(size, seed) (dithering_lib.py:381-399) on the device.
+//
+// One workgroup of 1024 lanes per matrix.  Lane 0 replays numpy's legacy
+// RandomState(seed).shuffle (MT19937 init_genrand + masked rejection sampling) over the
+// row-major coordinate list; then size^2 void-filling rounds run with every lane owning the list
+// positions p = lane + 1024*k: each round fuses "update min_dist against the point just placed"
+// with "first maximum of min_dist in list order" (max value, then smallest list position), reduced
+// across the wave with DPP shuffles and across waves through LDS.
+#include "dp_internal.h"
+
+namespace dp {
+namespace {
+
+constexpr int kThreads = 1024;
+
+struct Best {
+    float v;
+    uint32_t pos;
+};
+
+__device__ __forceinline__ Best better(const Best a, const Best b)
+{
+    // larger value wins; equal values: earlier list position wins (python max() keeps the first)
+    return (b.v > a.v || (b.v == a.v && b.pos < a.pos)) ? b : a;
+}
+
+__device__ uint32_t mt_next(uint32_t *mt, int &pos)
+{
+    if (pos == 624) {
+        for (int i = 0; i < 624; ++i) {
+            const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+            mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        pos = 0;
+    }
+    uint32_t y = mt[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// scratch layout (global): coords[n] uint32 (r*size+c in shuffled order), md[n] float, alive handled by md = -1
+__global__ __launch_bounds__(kThreads) void blue_noise_kernel(const int size, const uint32_t seed,
+                                                              float *__restrict__ out, uint32_t *__restrict__ coords,
+                                                              float *__restrict__ md)
+{
+    __shared__ uint32_t s_mt[624];
+    __shared__ Best s_part[kThreads / 64];
+    __shared__ Best s_best;
+    const int n = size * size;
+    const int tid = threadIdx.x;
+    const float inf = __int_as_float(0x7f800000);
+
+    for (int i = tid; i < n; i += kThreads) {
+        coords[i] = (uint32_t)i;
+        md[i] = inf;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        s_mt[0] = seed;
+        for (int i = 1; i < 624; ++i) s_mt[i] = 1812433253u * (s_mt[i - 1] ^ (s_mt[i - 1] >> 30)) + (uint32_t)i;
+        int pos = 624;
+        for (int i = n - 1; i >= 1; --i) {
+            uint32_t mask = (uint32_t)i;
+            mask |= mask >> 1;
+            mask |= mask >> 2;
+            mask |= mask >> 4;
+            mask |= mask >> 8;
+            mask |= mask >> 16;
+            uint32_t j;
+            do {
+                j = mt_next(s_mt, pos) & mask;
+            } while (j > (uint32_t)i);
+            const uint32_t t = coords[i];
+            coords[i] = coords[j];
+            coords[j] = t;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    const double denom = (double)(n - 1) + 1e-9;
+    int br = 0, bc = 0;
+    for (int it = 0; it < n; ++it) {
+        // update against the previous pick (none in round 0) and find this round's first maximum
+        Best mine;
+        mine.v = -1.0f;
+        mine.pos = 0xffffffffu;
+        for (int p = tid; p < n; p += kThreads) {
+            float v = md[p];
+            if (v < 0.0f) continue;  // already placed
+            if (it > 0) {
+                const int c = (int)coords[p];
+                const int rr = c / size, cc = c - rr * size;
+                const float d2 = (float)((rr - br) * (rr - br) + (cc - bc) * (cc - bc));
+                if (d2 < v) {
+                    v = d2;
+                    md[p] = v;
+                }
+            }
+            Best cand;
+            cand.v = v;
+            cand.pos = (uint32_t)p;
+            mine = better(mine, cand);
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            Best o;
+            o.v = __shfl_xor(mine.v, off);
+            o.pos = __shfl_xor(mine.pos, off);
+            mine = better(mine, o);
+        }
+        if ((tid & 63) == 0) s_part[tid >> 6] = mine;
+        __syncthreads();
+        if (tid < 64) {
+            Best b;
+            b.v = -1.0f;
+            b.pos = 0xffffffffu;
+            if (tid < kThreads / 64) b = s_part[tid];
+            for (int off = 8; off >= 1; off >>= 1) {
+                Best o;
+                o.v = __shfl_xor(b.v, off);
+                o.pos = __shfl_xor(b.pos, off);
+                b = better(b, o);
+            }
+            if (tid == 0) s_best = b;
+        }
+        __syncthreads();
+        const uint32_t bp = s_best.pos;
+        const int c = (int)coords[bp];
+        br = c / size;
+        bc = c - br * size;
+        if (tid == 0) {
+            out[c] = (float)((double)it / denom);
+            md[bp] = -1.0f;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+size_t blue_noise_scratch_bytes(int size) { return (size_t)size * size * (sizeof(uint32_t) + sizeof(float)); }
+
+int launch_blue_noise(int size, uint32_t seed, float *out_dev, void *scratch_dev, hipStream_t s)
+{
+    const size_t n = (size_t)size * size;
+    uint32_t *coords = reinterpret_cast<uint32_t *>(scratch_dev);
+    float *md = reinterpret_cast<float *>(coords + n);
+    hipLaunchKernelGGL(blue_noise_kernel, dim3(1), dim3(kThreads), 0, s, size, seed, out_dev, coords, md);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
+}  // namespace dp

@@ -1,0 +1,95 @@
+// Internal declarations shared by the translation units of libditherpie_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/ditherpie_hip.h"
+
+namespace dp {
+
+constexpr int kLeafSize = 10;     // scipy.spatial.KDTree default (dithering_lib.py:339)
+constexpr int kMaxNodes = 128;    // >= 2*ceil(256/5)-1 nodes for K <= 256
+constexpr int kQueueCap = 64;     // >= number of inner nodes for K <= 256 (<= 51)
+constexpr int kIdxBits = 8;       // palette index bits packed under the distance key
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define DP_HIP(call)                                   \
+    do {                                               \
+        hipError_t e__ = (call);                       \
+        if (e__ != hipSuccess) return dp::hip_fail(e__, #call); \
+    } while (0)
+
+// KD-tree as scipy builds it; node 0 is the root, children follow in pre-order.
+struct HostTree {
+    int K = 0;
+    std::vector<double> pts;  // K*3
+    std::vector<int32_t> indices;
+    std::vector<int32_t> split_dim, start, end, less, greater;
+    std::vector<double> split;
+    double mins[3], maxes[3];
+};
+void build_tree(const double *pts, int K, HostTree &t);
+
+// Device view of a prepared palette (plain pointers; passed to kernels by value).
+struct PalDev {
+    int K;
+    int n_nodes;
+    int is_integer;
+    const uint32_t *p4;        // K: r | g<<8 | b<<16          (integer palettes)
+    const int32_t *nkey;       // K: (|p|^2 << kIdxBits) | j   (integer palettes)
+    const double *pts;         // K*3 float64 coordinates as the tree sees them
+    const uint32_t *out_rgb;   // K: output bytes r | g<<8 | b<<16
+    const uint8_t *lut_in;     // 256 or nullptr
+    // tree
+    const int32_t *indices;    // K
+    const int32_t *split_dim;  // n_nodes (-1 = leaf)
+    const double *split;       // n_nodes
+    const int32_t *start, *end, *less, *greater;
+    double mins[3], maxes[3];
+};
+
+struct ThrDev {
+    int th_h, th_w;
+    const float *f32;     // th_h*th_w
+    const uint32_t *m;    // integer form: t = m / 2^sh (nullptr when not representable)
+    int sh;
+};
+
+}  // namespace dp
+
+struct dp_palette {
+    dp::PalDev dev;
+    void *blob;  // one device allocation backing every pointer in dev
+    size_t blob_bytes;
+    int device;
+};
+
+struct dp_thresholds {
+    dp::ThrDev dev;
+    void *blob;
+    int device;
+};
+
+// launchers (defined in the .hip files)
+namespace dp {
+int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int y0, int x0,
+                   const PalDev &pal, int mode, const ThrDev *thr, float ign_scale, int ign_seed, void *ws,
+                   size_t ws_bytes, hipStream_t s);
+int launch_ign_thresholds(float *out, int h, int w, int y0, int x0, float scale, int seed, hipStream_t s);
+int launch_blue_noise(int size, uint32_t seed, float *out_dev, void *scratch_dev, hipStream_t s);
+size_t blue_noise_scratch_bytes(int size);
+int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal,
+                           const int32_t *dx, const int32_t *dy, const float *wq, int ntaps, int serpentine,
+                           void *ws, size_t ws_bytes, hipStream_t s);
+size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w);
+int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int K, int64_t *sums, int64_t *counts,
+                       int64_t *sumsq, hipStream_t s);
+int launch_resize_nearest(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int oh, int ow,
+                          hipStream_t s);
+}  // namespace dp

@@ -1,0 +1,546 @@
+// Host side of libditherpie_hip.so: error text, KD-tree construction, palette / threshold objects
+// and the extern "C" entry points declared in include/ditherpie_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+#include "dp_internal.h"
+
+namespace dp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return e == hipErrorOutOfMemory ? DP_ENOMEM : DP_EHIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scipy.spatial.KDTree(points) with its defaults (leafsize=10, compact_nodes, balanced_tree), the
+// structure behind every palette search of the reference (dithering_lib.py:339, 358, 554, 655).
+// The permutation std::nth_element leaves behind decides scipy's tie order, so the same standard
+// algorithm (libstdc++ introselect) is used here, with scipy's coordinate-only comparator.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Builder {
+    HostTree &t;
+    const double *P;
+
+    double coord(int i, int d) const { return P[(size_t)i * 3 + d]; }
+
+    // two-pointer partition of indices[s,e) by coord < split; returns the first index of the >= part
+    int split_range(int s, int e, int d, double split)
+    {
+        int lo = s, hi = e - 1;
+        while (lo <= hi) {
+            if (coord(t.indices[lo], d) < split)
+                ++lo;
+            else if (coord(t.indices[hi], d) >= split)
+                --hi;
+            else
+                std::swap(t.indices[lo++], t.indices[hi--]);
+        }
+        return lo;
+    }
+
+    int add_node(int s, int e)
+    {
+        int id = (int)t.split_dim.size();
+        t.split_dim.push_back(-1);
+        t.split.push_back(0.0);
+        t.start.push_back(s);
+        t.end.push_back(e);
+        t.less.push_back(-1);
+        t.greater.push_back(-1);
+        return id;
+    }
+
+    int build(int s, int e)
+    {
+        const int id = add_node(s, e);
+        if (e - s <= kLeafSize) return id;
+
+        double lo[3], hi[3];
+        for (int d = 0; d < 3; ++d) lo[d] = hi[d] = coord(t.indices[s], d);
+        for (int j = s + 1; j < e; ++j)
+            for (int d = 0; d < 3; ++d) {
+                const double v = coord(t.indices[j], d);
+                hi[d] = hi[d] > v ? hi[d] : v;
+                lo[d] = lo[d] < v ? lo[d] : v;
+            }
+        int dim = 0;
+        double extent = 0;
+        for (int d = 0; d < 3; ++d)
+            if (hi[d] - lo[d] > extent) {
+                dim = d;
+                extent = hi[d] - lo[d];
+            }
+        if (hi[dim] == lo[dim]) return id;  // all points coincide
+
+        int32_t *first = t.indices.data() + s;
+        const int half = (e - s) / 2;
+        std::nth_element(first, first + half, first + (e - s),
+                         [&](int32_t a, int32_t b) { return coord(a, dim) < coord(b, dim); });
+        double split = coord(t.indices[s + half], dim);
+        int cut = split_range(s, e, dim, split);
+        if (cut == s) {
+            // nothing lies strictly below the median value: cut just above the minimum instead
+            double mn = coord(t.indices[s], dim);
+            for (int j = s + 1; j < e; ++j) mn = std::min(mn, coord(t.indices[j], dim));
+            split = std::nextafter(mn, std::numeric_limits<double>::infinity());
+            cut = split_range(s, e, dim, split);
+        }
+        t.split_dim[id] = dim;
+        t.split[id] = split;
+        const int l = build(s, cut);
+        const int g = build(cut, e);
+        t.less[id] = l;
+        t.greater[id] = g;
+        return id;
+    }
+};
+}  // namespace
+
+void build_tree(const double *pts, int K, HostTree &t)
+{
+    t = HostTree();
+    t.K = K;
+    t.pts.assign(pts, pts + (size_t)K * 3);
+    t.indices.resize(K);
+    std::iota(t.indices.begin(), t.indices.end(), 0);
+    for (int d = 0; d < 3; ++d) t.mins[d] = t.maxes[d] = pts[d];
+    for (int j = 1; j < K; ++j)
+        for (int d = 0; d < 3; ++d) {
+            t.mins[d] = std::min(t.mins[d], pts[(size_t)j * 3 + d]);
+            t.maxes[d] = std::max(t.maxes[d], pts[(size_t)j * 3 + d]);
+        }
+    Builder b{t, t.pts.data()};
+    b.build(0, K);
+}
+
+}  // namespace dp
+
+using namespace dp;
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int dp_version(void) { return 100; }
+
+const char *dp_last_error(void) { return g_err; }
+
+int dp_device_info(int *n_devices, char *arch_buf, size_t arch_buf_len)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        n = 0;
+        (void)hipGetLastError();
+    }
+    if (n_devices) *n_devices = n;
+    if (arch_buf && arch_buf_len) {
+        arch_buf[0] = 0;
+        if (n > 0) {
+            int dev = 0;
+            DP_HIP(hipGetDevice(&dev));
+            hipDeviceProp_t prop;
+            DP_HIP(hipGetDeviceProperties(&prop, dev));
+            snprintf(arch_buf, arch_buf_len, "%s", prop.gcnArchName);
+        }
+    }
+    return DP_OK;
+}
+
+int dp_kdtree_build_host(const double *pts, int K, int32_t *indices, int32_t *split_dim, double *split,
+                         int32_t *start, int32_t *end, int32_t *less, int32_t *greater, int *n_nodes)
+{
+    if (!pts || K < 1 || !indices || !split_dim || !split || !start || !end || !less || !greater || !n_nodes) {
+        set_error("dp_kdtree_build_host: bad argument");
+        return DP_EINVAL;
+    }
+    HostTree t;
+    build_tree(pts, K, t);
+    const size_t n = t.split_dim.size();
+    std::memcpy(indices, t.indices.data(), sizeof(int32_t) * (size_t)K);
+    std::memcpy(split_dim, t.split_dim.data(), sizeof(int32_t) * n);
+    std::memcpy(split, t.split.data(), sizeof(double) * n);
+    std::memcpy(start, t.start.data(), sizeof(int32_t) * n);
+    std::memcpy(end, t.end.data(), sizeof(int32_t) * n);
+    std::memcpy(less, t.less.data(), sizeof(int32_t) * n);
+    std::memcpy(greater, t.greater.data(), sizeof(int32_t) * n);
+    *n_nodes = (int)n;
+    return DP_OK;
+}
+
+// ---- palette ---------------------------------------------------------------------------------
+int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, const uint8_t *lut_in,
+                      dp_palette **out)
+{
+    if (!pal_f32 || !out_colors || !out || K < 1) {
+        set_error("dp_palette_create: bad argument");
+        return DP_EINVAL;
+    }
+    if (K > DP_MAX_COLORS) {
+        set_error("dp_palette_create: %d colours requested, this backend supports at most %d", K,
+                  DP_MAX_COLORS);
+        return DP_EUNSUPPORTED;
+    }
+    std::vector<double> pts((size_t)K * 3);
+    bool integer = (lut_in == nullptr);
+    for (int i = 0; i < K * 3; ++i) {
+        const float v = pal_f32[i];
+        if (!std::isfinite(v)) {
+            set_error("dp_palette_create: non-finite palette value");
+            return DP_EINVAL;
+        }
+        pts[i] = (double)v;
+        if (!(v >= 0.0f && v <= 255.0f && v == std::floor(v))) integer = false;
+    }
+    HostTree t;
+    build_tree(pts.data(), K, t);
+    const int nn = (int)t.split_dim.size();
+    if (nn > kMaxNodes) {
+        set_error("dp_palette_create: KD-tree with %d nodes exceeds the device limit %d", nn, kMaxNodes);
+        return DP_EUNSUPPORTED;
+    }
+    int inner = 0;
+    for (int i = 0; i < nn; ++i) inner += t.split_dim[i] >= 0;
+    if (inner > kQueueCap) {
+        set_error("dp_palette_create: KD-tree with %d inner nodes exceeds the device queue %d", inner, kQueueCap);
+        return DP_EUNSUPPORTED;
+    }
+
+    // pack everything into one blob
+    std::vector<uint8_t> blob;
+    auto put = [&](const void *src, size_t bytes) {
+        size_t off = (blob.size() + 15) & ~size_t(15);
+        blob.resize(off + bytes);
+        if (bytes) std::memcpy(blob.data() + off, src, bytes);
+        return off;
+    };
+    std::vector<uint32_t> p4(K), orgb(K);
+    std::vector<int32_t> nkey(K);
+    for (int j = 0; j < K; ++j) {
+        orgb[j] = (uint32_t)out_colors[3 * j] | ((uint32_t)out_colors[3 * j + 1] << 8) |
+                  ((uint32_t)out_colors[3 * j + 2] << 16);
+        if (integer) {
+            const uint32_t r = (uint32_t)pal_f32[3 * j], g = (uint32_t)pal_f32[3 * j + 1],
+                           b = (uint32_t)pal_f32[3 * j + 2];
+            p4[j] = r | (g << 8) | (b << 16);
+            nkey[j] = (int32_t)(((r * r + g * g + b * b) << kIdxBits) | (uint32_t)j);
+        } else {
+            p4[j] = 0;
+            nkey[j] = 0;
+        }
+    }
+    const size_t o_p4 = put(p4.data(), sizeof(uint32_t) * K);
+    const size_t o_nk = put(nkey.data(), sizeof(int32_t) * K);
+    const size_t o_pts = put(pts.data(), sizeof(double) * 3 * K);
+    const size_t o_org = put(orgb.data(), sizeof(uint32_t) * K);
+    const size_t o_lut = lut_in ? put(lut_in, 256) : 0;
+    const size_t o_idx = put(t.indices.data(), sizeof(int32_t) * K);
+    const size_t o_sd = put(t.split_dim.data(), sizeof(int32_t) * nn);
+    const size_t o_sp = put(t.split.data(), sizeof(double) * nn);
+    const size_t o_st = put(t.start.data(), sizeof(int32_t) * nn);
+    const size_t o_en = put(t.end.data(), sizeof(int32_t) * nn);
+    const size_t o_le = put(t.less.data(), sizeof(int32_t) * nn);
+    const size_t o_gr = put(t.greater.data(), sizeof(int32_t) * nn);
+
+    dp_palette *p = new (std::nothrow) dp_palette();
+    if (!p) return DP_ENOMEM;
+    p->blob = nullptr;
+    p->blob_bytes = blob.size();
+    hipError_t e = hipGetDevice(&p->device);
+    if (e == hipSuccess) e = hipMalloc(&p->blob, blob.size());
+    if (e == hipSuccess) e = hipMemcpy(p->blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->blob) (void)hipFree(p->blob);
+        delete p;
+        return hip_fail(e, "dp_palette_create upload");
+    }
+    const uint8_t *base = (const uint8_t *)p->blob;
+    PalDev &d = p->dev;
+    d.K = K;
+    d.n_nodes = nn;
+    d.is_integer = integer ? 1 : 0;
+    d.p4 = (const uint32_t *)(base + o_p4);
+    d.nkey = (const int32_t *)(base + o_nk);
+    d.pts = (const double *)(base + o_pts);
+    d.out_rgb = (const uint32_t *)(base + o_org);
+    d.lut_in = lut_in ? (base + o_lut) : nullptr;
+    d.indices = (const int32_t *)(base + o_idx);
+    d.split_dim = (const int32_t *)(base + o_sd);
+    d.split = (const double *)(base + o_sp);
+    d.start = (const int32_t *)(base + o_st);
+    d.end = (const int32_t *)(base + o_en);
+    d.less = (const int32_t *)(base + o_le);
+    d.greater = (const int32_t *)(base + o_gr);
+    for (int c = 0; c < 3; ++c) {
+        d.mins[c] = t.mins[c];
+        d.maxes[c] = t.maxes[c];
+    }
+    *out = p;
+    return DP_OK;
+}
+
+void dp_palette_destroy(dp_palette *p)
+{
+    if (!p) return;
+    if (p->blob) (void)hipFree(p->blob);
+    delete p;
+}
+
+int dp_palette_info(const dp_palette *p, int *K, int *is_integer, int *n_nodes)
+{
+    if (!p) {
+        set_error("dp_palette_info: NULL palette");
+        return DP_EINVAL;
+    }
+    if (K) *K = p->dev.K;
+    if (is_integer) *is_integer = p->dev.is_integer;
+    if (n_nodes) *n_nodes = p->dev.n_nodes;
+    return DP_OK;
+}
+
+// ---- thresholds --------------------------------------------------------------------------------
+static int thresholds_from_device_f32(float *dev_f32, int th_h, int th_w, const float *host_copy,
+                                      dp_thresholds **out)
+{
+    // integer form t = m / 2^sh with sh <= 13 and 0 <= t <= 1 lets the kernel decide in uint32
+    const int n = th_h * th_w;
+    int sh = -1;
+    std::vector<uint32_t> m;
+    for (int s = 0; s <= 13 && sh < 0; ++s) {
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i) {
+            const double v = (double)host_copy[i] * (double)(1u << s);
+            ok = host_copy[i] >= 0.0f && host_copy[i] <= 1.0f && v == std::floor(v);
+        }
+        if (ok) sh = s;
+    }
+    dp_thresholds *t = new (std::nothrow) dp_thresholds();
+    if (!t) return DP_ENOMEM;
+    t->blob = dev_f32;
+    (void)hipGetDevice(&t->device);
+    t->dev.th_h = th_h;
+    t->dev.th_w = th_w;
+    t->dev.f32 = dev_f32;
+    t->dev.m = nullptr;
+    t->dev.sh = 0;
+    if (sh >= 0) {
+        m.resize(n);
+        for (int i = 0; i < n; ++i) m[i] = (uint32_t)((double)host_copy[i] * (double)(1u << sh));
+        // the integer table lives behind the f32 table in the same allocation
+        uint32_t *dm = (uint32_t *)(dev_f32 + n);
+        hipError_t e = hipMemcpy(dm, m.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            delete t;
+            return hip_fail(e, "thresholds integer upload");
+        }
+        t->dev.m = dm;
+        t->dev.sh = sh;
+    }
+    *out = t;
+    return DP_OK;
+}
+
+int dp_thresholds_create(const float *thr_host, int th_h, int th_w, dp_thresholds **out)
+{
+    if (!thr_host || !out || th_h < 1 || th_w < 1 || (int64_t)th_h * th_w > (1 << 20)) {
+        set_error("dp_thresholds_create: bad argument");
+        return DP_EINVAL;
+    }
+    const int n = th_h * th_w;
+    for (int i = 0; i < n; ++i)
+        if (std::isnan(thr_host[i])) {
+            set_error("dp_thresholds_create: NaN threshold");
+            return DP_EINVAL;
+        }
+    float *d = nullptr;
+    DP_HIP(hipMalloc((void **)&d, sizeof(float) * 2 * (size_t)n));
+    hipError_t e = hipMemcpy(d, thr_host, sizeof(float) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(e, "dp_thresholds_create upload");
+    }
+    int rc = thresholds_from_device_f32(d, th_h, th_w, thr_host, out);
+    if (rc != DP_OK) (void)hipFree(d);
+    return rc;
+}
+
+int dp_thresholds_blue_noise(int size, uint32_t seed, void *stream, dp_thresholds **out)
+{
+    if (!out || size < 2 || size > 256) {
+        set_error("dp_thresholds_blue_noise: size must be in [2,256]");
+        return DP_EINVAL;
+    }
+    const int n = size * size;
+    float *d = nullptr;
+    void *scratch = nullptr;
+    DP_HIP(hipMalloc((void **)&d, sizeof(float) * 2 * (size_t)n));
+    hipError_t e = hipMalloc(&scratch, blue_noise_scratch_bytes(size));
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(e, "blue-noise scratch");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_blue_noise(size, seed, d, scratch, s);
+    std::vector<float> host(n);
+    if (rc == DP_OK) {
+        e = hipMemcpyAsync(host.data(), d, sizeof(float) * n, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = hip_fail(e, "blue-noise download");
+    }
+    (void)hipFree(scratch);
+    if (rc == DP_OK) rc = thresholds_from_device_f32(d, size, size, host.data(), out);
+    if (rc != DP_OK) (void)hipFree(d);
+    return rc;
+}
+
+int dp_thresholds_shape(const dp_thresholds *t, int *th_h, int *th_w, int *is_integer_form)
+{
+    if (!t) {
+        set_error("dp_thresholds_shape: NULL");
+        return DP_EINVAL;
+    }
+    if (th_h) *th_h = t->dev.th_h;
+    if (th_w) *th_w = t->dev.th_w;
+    if (is_integer_form) *is_integer_form = t->dev.m != nullptr;
+    return DP_OK;
+}
+
+int dp_thresholds_download(const dp_thresholds *t, float *thr_host)
+{
+    if (!t || !thr_host) {
+        set_error("dp_thresholds_download: NULL");
+        return DP_EINVAL;
+    }
+    DP_HIP(hipMemcpy(thr_host, t->dev.f32, sizeof(float) * (size_t)t->dev.th_h * t->dev.th_w,
+                     hipMemcpyDeviceToHost));
+    return DP_OK;
+}
+
+void dp_thresholds_destroy(dp_thresholds *t)
+{
+    if (!t) return;
+    if (t->blob) (void)hipFree(t->blob);
+    delete t;
+}
+
+// ---- compute entry points (argument checks here, kernels in the .hip files) ------------------------
+int dp_ign_thresholds(float *out_dev, int h, int w, int y0, int x0, float scale, int seed, void *stream)
+{
+    if (!out_dev || h < 1 || w < 1) {
+        set_error("dp_ign_thresholds: bad argument");
+        return DP_EINVAL;
+    }
+    return launch_ign_thresholds(out_dev, h, w, y0, x0, scale, seed, (hipStream_t)stream);
+}
+
+size_t dp_ordered_workspace_bytes(int64_t n_frames, int h, int w)
+{
+    if (n_frames < 0 || h < 0 || w < 0) return 0;
+    // one flag bit per pixel, written as 4 x u64 per 256-pixel wave tile (+ slack for the tail)
+    const int64_t npx = n_frames * (int64_t)h * w;
+    const int64_t tiles = (npx + 255) / 256;
+    return (size_t)(tiles * 32 + 256);
+}
+
+int dp_ordered_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int y0, int x0,
+                  const dp_palette *pal, int mode, const dp_thresholds *thr, float ign_scale, int ign_seed,
+                  void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    if (!in_dev || !out_dev || !pal || n_frames < 0 || h < 1 || w < 1 || y0 < 0 || x0 < 0) {
+        set_error("dp_ordered_u8: bad argument");
+        return DP_EINVAL;
+    }
+    if (mode != DP_MODE_NEAREST && mode != DP_MODE_MATRIX && mode != DP_MODE_IGN) {
+        set_error("dp_ordered_u8: unknown mode %d", mode);
+        return DP_EINVAL;
+    }
+    if (mode == DP_MODE_MATRIX && !thr) {
+        set_error("dp_ordered_u8: DP_MODE_MATRIX needs a threshold matrix");
+        return DP_EINVAL;
+    }
+    if ((int64_t)h * w > (int64_t)1 << 30 || (int64_t)y0 + h > (int64_t)1 << 30 || (int64_t)x0 + w > (int64_t)1 << 30) {
+        set_error("dp_ordered_u8: frame too large");
+        return DP_EINVAL;
+    }
+    if (n_frames == 0) return DP_OK;
+    if (!workspace_dev || workspace_bytes < dp_ordered_workspace_bytes(n_frames, h, w) ||
+        ((uintptr_t)workspace_dev & 15)) {
+        set_error("dp_ordered_u8: workspace too small or misaligned (need %zu bytes, 16-byte aligned)",
+                  dp_ordered_workspace_bytes(n_frames, h, w));
+        return DP_EWORKSPACE;
+    }
+    return launch_ordered(in_dev, out_dev, n_frames, h, w, y0, x0, pal->dev, mode, thr ? &thr->dev : nullptr,
+                          ign_scale, ign_seed, workspace_dev, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t dp_error_diffusion_workspace_bytes(int64_t n_frames, int h, int w)
+{
+    if (n_frames < 0 || h < 0 || w < 0) return 0;
+    return error_diffusion_ws_bytes(n_frames, h, w);
+}
+
+int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
+                          const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *wq,
+                          int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
+                          void *stream)
+{
+    if (!in_dev || !out_dev || !pal || n_frames < 0 || h < 1 || w < 1 || ntaps < 0 || ntaps > 16 ||
+        (ntaps && (!dx || !dy || !wq))) {
+        set_error("dp_error_diffusion_u8: bad argument");
+        return DP_EINVAL;
+    }
+    for (int k = 0; k < ntaps; ++k) {
+        const bool forward = dy[k] > 0 || (dy[k] == 0 && dx[k] > 0);
+        if (!forward || dy[k] > 2 || dx[k] < -2 || dx[k] > 2) {
+            set_error("dp_error_diffusion_u8: tap %d (dx=%d, dy=%d) is outside the supported causal window", k,
+                      dx[k], dy[k]);
+            return DP_EUNSUPPORTED;
+        }
+    }
+    if (n_frames == 0) return DP_OK;
+    if (!workspace_dev || workspace_bytes < dp_error_diffusion_workspace_bytes(n_frames, h, w)) {
+        set_error("dp_error_diffusion_u8: workspace too small (need %zu bytes)",
+                  dp_error_diffusion_workspace_bytes(n_frames, h, w));
+        return DP_EWORKSPACE;
+    }
+    return launch_error_diffusion(in_dev, out_dev, n_frames, h, w, pal->dev, dx, dy, wq, ntaps, serpentine,
+                                  workspace_dev, workspace_bytes, (hipStream_t)stream);
+}
+
+int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
+                      int64_t *counts_dev, int64_t *sumsq_dev, void *stream)
+{
+    if ((!px_dev && n > 0) || n < 0 || !centers_dev || K < 1 || K > 1024 || !sums_dev || !counts_dev || !sumsq_dev) {
+        set_error("dp_kmeans_step_u8: bad argument");
+        return DP_EINVAL;
+    }
+    return launch_kmeans_step(px_dev, n, centers_dev, K, sums_dev, counts_dev, sumsq_dev, (hipStream_t)stream);
+}
+
+int dp_resize_nearest_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int oh,
+                         int ow, void *stream)
+{
+    if (!in_dev || !out_dev || n_frames < 0 || h < 1 || w < 1 || oh < 1 || ow < 1) {
+        set_error("dp_resize_nearest_u8: bad argument");
+        return DP_EINVAL;
+    }
+    if (n_frames == 0) return DP_OK;
+    return launch_resize_nearest(in_dev, out_dev, n_frames, h, w, oh, ow, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,505 @@
+// Ordered / nearest-palette kernels for gfx950.
+//
+// Replaces NoDitherStrategy.dither (dithering_lib.py:337-341), MatrixDitherStrategy.dither
+// (:355-378) and the IGN strategy (:551-568) for packed uint8 RGB frames.
+//
+// Pass 1 (ordered_int_kernel / ordered_f64_kernel): each lane owns 4 consecutive pixels = 12 bytes
+//   = three dword loads and three dword stores, fully coalesced across the wave (768 B per wave each
+//   way).  Integer palettes: exact squared distances through v_dot4_u32_u8, the three smallest
+//   (distance, index) keys kept with v_min/v_med3, and the reference's float64 decision
+//   `s0/(s0+s1) <= t` evaluated exactly in integers (d0 * 2^sh <= m * (d0+d1) for t = m/2^sh), which
+//   is provably the same decision except when both sides are equal.  Pixels whose result depends on
+//   scipy's visiting order (distance ties) or on float64 rounding (exact equality) only set a flag bit.
+// Pass 2 (fixup_kernel): the flagged pixels (~0.1-0.5 %) are compacted per workgroup into LDS and
+//   resolved densely through the scipy-order KD-tree emulation and the literal float64 chain.
+#include "dp_internal.h"
+#include "tree_query.cuh"
+
+namespace dp {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kListCap = 24576;           // LDS pixel list of the fix-up pass (96 KiB)
+constexpr int kDrainAt = kListCap - kBlock * 64;
+
+struct Geo {
+    uint32_t n_px;   // pixels in this launch (< 2^31)
+    uint32_t hw, w, h;
+    double inv_hw, inv_w;
+    int y0, x0;      // global coordinates of pixel (0,0)
+    int ty0, tx0;    // y0 % th_h, x0 % th_w
+    int aligned;     // in/out are 4-byte aligned
+};
+
+__device__ __forceinline__ int med3i(const int a, const int b, const int c)
+{
+    return max(min(a, b), min(max(a, b), c));
+}
+
+// p -> (frame-local y, x) without integer division
+__device__ __forceinline__ void locate(const Geo &g, const uint32_t p, uint32_t &y, uint32_t &x)
+{
+    uint32_t f = (uint32_t)((double)p * g.inv_hw);
+    int32_t q = (int32_t)(p - f * g.hw);
+    if (q < 0) q += (int32_t)g.hw;
+    else if ((uint32_t)q >= g.hw) q -= (int32_t)g.hw;
+    uint32_t yy = (uint32_t)((double)q * g.inv_w);
+    int32_t xx = q - (int32_t)(yy * g.w);
+    if (xx < 0) { xx += (int32_t)g.w; --yy; }
+    else if ((uint32_t)xx >= g.w) { xx -= (int32_t)g.w; ++yy; }
+    y = yy;
+    x = (uint32_t)xx;
+}
+
+struct Cursor {  // walks 4 consecutive pixels in raster order, tracking the threshold-tile position
+    uint32_t y, x;
+    int ty, tx;
+};
+
+__device__ __forceinline__ void cursor_init(const Geo &g, const ThrDev &thr, const uint32_t p, Cursor &c,
+                                            const bool need_tile)
+{
+    locate(g, p, c.y, c.x);
+    c.ty = c.tx = 0;
+    if (need_tile) {
+        c.ty = (int)(((uint32_t)g.y0 + c.y) % (uint32_t)thr.th_h);
+        c.tx = (int)(((uint32_t)g.x0 + c.x) % (uint32_t)thr.th_w);
+    }
+}
+
+__device__ __forceinline__ void cursor_next(const Geo &g, const ThrDev &thr, Cursor &c)
+{
+    ++c.x;
+    if (++c.tx == thr.th_w) c.tx = 0;
+    if (c.x == g.w) {
+        c.x = 0;
+        c.tx = g.tx0;
+        ++c.y;
+        if (++c.ty == thr.th_h) c.ty = 0;
+        if (c.y == g.h) {
+            c.y = 0;
+            c.ty = g.ty0;
+        }
+    }
+}
+
+__device__ __forceinline__ void load4(const uint8_t *__restrict__ in, const Geo &g, const uint32_t gidx,
+                                      uint32_t px[4])
+{
+    const uint32_t p0 = gidx * 4u;
+    if (g.aligned && p0 + 4u <= g.n_px) {
+        const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in) + (size_t)gidx * 3;
+        const uint32_t w0 = in32[0], w1 = in32[1], w2 = in32[2];
+        px[0] = w0 & 0xffffffu;
+        px[1] = (w0 >> 24) | ((w1 & 0xffffu) << 8);
+        px[2] = (w1 >> 16) | ((w2 & 0xffu) << 16);
+        px[3] = w2 >> 8;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            px[q] = 0;
+            if (p0 + q < g.n_px) {
+                const uint8_t *b = in + (size_t)(p0 + q) * 3;
+                px[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void store4(uint8_t *__restrict__ out, const Geo &g, const uint32_t gidx,
+                                       const uint32_t c[4])
+{
+    const uint32_t p0 = gidx * 4u;
+    if (g.aligned && p0 + 4u <= g.n_px) {
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (size_t)gidx * 3;
+        o32[0] = c[0] | (c[1] << 24);
+        o32[1] = (c[1] >> 8) | (c[2] << 16);
+        o32[2] = (c[2] >> 16) | (c[3] << 8);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (p0 + q < g.n_px) {
+                uint8_t *b = out + (size_t)(p0 + q) * 3;
+                b[0] = (uint8_t)c[q];
+                b[1] = (uint8_t)(c[q] >> 8);
+                b[2] = (uint8_t)(c[q] >> 16);
+            }
+    }
+}
+
+__device__ __forceinline__ void store_flags(unsigned long long *__restrict__ flags, const uint32_t gidx,
+                                            const bool slow[4])
+{
+    const uint32_t tile = gidx >> 6;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned long long b = __ballot(slow[q]);
+        if (lane == q) flags[(size_t)tile * 4 + q] = b;
+    }
+}
+
+// MODE: 0 nearest only; 1 matrix in integer form (uint32 compare); 2 matrix f32; 3 IGN
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void ordered_int_kernel(const uint8_t *__restrict__ in,
+                                                             uint8_t *__restrict__ out,
+                                                             unsigned long long *__restrict__ flags, const Geo g,
+                                                             const PalDev pal, const ThrDev thr, const float sx,
+                                                             const float sy, const float sc)
+{
+    __shared__ uint32_t s_out[DP_MAX_COLORS];
+    __shared__ uint32_t s_thr[MODE == 1 ? 256 : 1];
+    for (int i = threadIdx.x; i < pal.K; i += kBlock) s_out[i] = pal.out_rgb[i];
+    if (MODE == 1)
+        for (int i = threadIdx.x; i < thr.th_h * thr.th_w; i += kBlock) s_thr[i] = thr.m[i];
+    __syncthreads();
+
+    const uint32_t gidx = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t p0 = gidx * 4u;
+    uint32_t px[4];
+    load4(in, g, gidx, px);
+
+    constexpr int kBig = 0x7fffffff;
+    int m0[4], m1[4], m2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m0[q] = m1[q] = m2[q] = kBig;
+
+    const int K = pal.K;
+#pragma unroll 4
+    for (int j = 0; j < K; ++j) {
+        const uint32_t pj = pal.p4[j];  // wave-uniform: scalar loads
+        const int nk = pal.nkey[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int dot = (int)__builtin_amdgcn_udot4(px[q], pj, 0u, false);
+            const int key = nk - (dot << (kIdxBits + 1));  // ((|p|^2 - 2 x.p) << 8) | j
+            const int n2 = med3i(m1[q], m2[q], key);
+            const int n1 = med3i(m0[q], m1[q], key);
+            m0[q] = min(m0[q], key);
+            m1[q] = n1;
+            m2[q] = n2;
+        }
+    }
+
+    Cursor cur;
+    cursor_init(g, thr, p0 < g.n_px ? p0 : 0u, cur, MODE == 1 || MODE == 2);
+    uint32_t col[4];
+    bool slow[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int xx = (int)__builtin_amdgcn_udot4(px[q], px[q], 0u, false);
+        const uint32_t d0 = (uint32_t)((m0[q] >> kIdxBits) + xx);
+        const uint32_t d1 = (uint32_t)((m1[q] >> kIdxBits) + xx);
+        const uint32_t d2 = (uint32_t)((m2[q] >> kIdxBits) + xx);
+        const int i0 = m0[q] & ((1 << kIdxBits) - 1);
+        const int i1 = m1[q] & ((1 << kIdxBits) - 1);
+        bool nearest = true, s;
+        if (MODE == 0) {
+            s = (d0 == d1);
+        } else {
+            const uint32_t S = d0 + d1;
+            bool eq;
+            if (MODE == 1) {
+                const uint32_t mt = s_thr[cur.ty * thr.th_w + cur.tx];
+                const uint32_t lhs = d0 << thr.sh;
+                const uint32_t rhs = __umul24(mt, S);
+                nearest = lhs <= rhs;
+                eq = lhs == rhs;
+            } else {
+                float t;
+                if (MODE == 2)
+                    t = thr.f32[cur.ty * thr.th_w + cur.tx];
+                else
+                    t = ign_threshold(g.x0 + (int)cur.x, g.y0 + (int)cur.y, sx, sy, sc);
+                // exact: a 24-bit significand times a 19-bit integer fits a double
+                const double lhs = (double)d0, rhs = __dmul_rn((double)t, (double)S);
+                nearest = lhs <= rhs;
+                eq = lhs == rhs;
+            }
+            s = (d0 == d1) | eq | ((d1 == d2) & !nearest);
+        }
+        slow[q] = s & (p0 + q < g.n_px);
+        col[q] = s_out[nearest ? i0 : i1];
+        cursor_next(g, thr, cur);
+    }
+    store4(out, g, gidx, col);
+    store_flags(flags, gidx, slow);
+}
+
+// General palettes (non-integer: gamma on) -- float64 brute force with the reference's arithmetic.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void ordered_f64_kernel(const uint8_t *__restrict__ in,
+                                                             uint8_t *__restrict__ out,
+                                                             unsigned long long *__restrict__ flags, const Geo g,
+                                                             const PalDev pal, const ThrDev thr, const float sx,
+                                                             const float sy, const float sc)
+{
+    __shared__ uint32_t s_out[DP_MAX_COLORS];
+    __shared__ uint8_t s_lut[256];
+    for (int i = threadIdx.x; i < pal.K; i += kBlock) s_out[i] = pal.out_rgb[i];
+    for (int i = threadIdx.x; i < 256; i += kBlock) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
+    __syncthreads();
+
+    const uint32_t gidx = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t p0 = gidx * 4u;
+    uint32_t px[4];
+    load4(in, g, gidx, px);
+
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    Cursor cur;
+    cursor_init(g, thr, p0 < g.n_px ? p0 : 0u, cur, MODE == 1 || MODE == 2);
+    uint32_t col[4];
+    bool slow[4];
+    const int K = pal.K;
+    for (int q = 0; q < 4; ++q) {
+        const double x0 = (double)s_lut[px[q] & 255u], x1 = (double)s_lut[(px[q] >> 8) & 255u],
+                     x2 = (double)s_lut[(px[q] >> 16) & 255u];
+        double b0 = inf, b1 = inf, b2 = inf;
+        int i0 = 0, i1 = 0;
+        for (int j = 0; j < K; ++j) {
+            const double d = sq_dist3(pal.pts + 3 * j, x0, x1, x2);
+            if (d < b2) {
+                if (d < b1) {
+                    b2 = b1;
+                    if (d < b0) {
+                        b1 = b0;
+                        i1 = i0;
+                        b0 = d;
+                        i0 = j;
+                    } else {
+                        b1 = d;
+                        i1 = j;
+                    }
+                } else {
+                    b2 = d;
+                }
+            }
+        }
+        bool nearest = true, s;
+        if (MODE == 0) {
+            s = (b0 == b1);
+        } else {
+            float t;
+            if (MODE == 3)
+                t = ign_threshold(g.x0 + (int)cur.x, g.y0 + (int)cur.y, sx, sy, sc);
+            else
+                t = thr.f32[cur.ty * thr.th_w + cur.tx];
+            nearest = ordered_use_nearest(b0, b1, t);
+            s = (b0 == b1) | ((b1 == b2) & !nearest & (b1 != inf));
+        }
+        slow[q] = s & (p0 + q < g.n_px);
+        col[q] = s_out[nearest ? i0 : i1];
+        cursor_next(g, thr, cur);
+    }
+    store4(out, g, gidx, col);
+    store_flags(flags, gidx, slow);
+}
+
+// Pass 2: resolve flagged pixels in scipy's order.
+template <int MODE>  // 0 nearest, 2 matrix (f32 thresholds), 3 IGN
+__global__ __launch_bounds__(kBlock) void fixup_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                       const unsigned long long *__restrict__ flags,
+                                                       const uint32_t n_words, const Geo g, const PalDev pal,
+                                                       const ThrDev thr, const float sx, const float sy,
+                                                       const float sc)
+{
+    __shared__ uint32_t s_list[kListCap];
+    __shared__ uint32_t s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+
+    auto drain = [&]() {
+        const uint32_t n = s_count;
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+            const uint32_t p = s_list[i];
+            const uint8_t *b = in + (size_t)p * 3;
+            uint32_t c0 = b[0], c1 = b[1], c2 = b[2];
+            if (pal.lut_in) {
+                c0 = pal.lut_in[c0];
+                c1 = pal.lut_in[c1];
+                c2 = pal.lut_in[c2];
+            }
+            double d2[2];
+            int ii[2];
+            int pick;
+            if (MODE == 0) {
+                tree_query<1>(pal, (double)c0, (double)c1, (double)c2, d2, ii);
+                pick = ii[0];
+            } else {
+                tree_query<2>(pal, (double)c0, (double)c1, (double)c2, d2, ii);
+                uint32_t y, x;
+                locate(g, p, y, x);
+                float t;
+                if (MODE == 3)
+                    t = ign_threshold(g.x0 + (int)x, g.y0 + (int)y, sx, sy, sc);
+                else
+                    t = thr.f32[(((uint32_t)g.y0 + y) % (uint32_t)thr.th_h) * thr.th_w +
+                                (((uint32_t)g.x0 + x) % (uint32_t)thr.th_w)];
+                pick = ordered_use_nearest(d2[0], d2[1], t) ? ii[0] : ii[1];
+                if (pick >= pal.K) pick = ii[0];
+            }
+            const uint32_t c = pal.out_rgb[pick];
+            uint8_t *o = out + (size_t)p * 3;
+            o[0] = (uint8_t)c;
+            o[1] = (uint8_t)(c >> 8);
+            o[2] = (uint8_t)(c >> 16);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_count = 0;
+        __syncthreads();
+    };
+
+    for (uint32_t base = blockIdx.x * kBlock; base < n_words; base += gridDim.x * kBlock) {
+        const uint32_t wi = base + threadIdx.x;
+        unsigned long long word = (wi < n_words) ? flags[wi] : 0ull;
+        if (word) {
+            const int n = __popcll(word);
+            uint32_t pos = atomicAdd(&s_count, (uint32_t)n);
+            const uint32_t tile = wi >> 2, q = wi & 3u;
+            while (word) {
+                const int lane = __ffsll((long long)word) - 1;
+                word &= word - 1;
+                s_list[pos++] = ((tile * 64u + (uint32_t)lane) << 2) + q;
+            }
+        }
+        __syncthreads();
+        if (s_count > (uint32_t)kDrainAt) drain();  // uniform: every thread reads the same s_count
+    }
+    drain();
+}
+
+__global__ void ign_field_kernel(float *__restrict__ out, const int h, const int w, const int y0, const int x0,
+                                 const float sx, const float sy, const float sc)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x < w && y < h) out[(size_t)y * w + x] = ign_threshold(x0 + x, y0 + y, sx, sy, sc);
+}
+
+__global__ void resize_nearest_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int h,
+                                      const int w, const int oh, const int ow, const double sy, const double sx)
+{
+    // Pillow NEAREST (Resample.c / Geometry.c nearest filter): source = floor((dst + 0.5) * scale)
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const size_t f = blockIdx.z;
+    if (x >= ow || y >= oh) return;
+    int yi = (int)(((double)y + 0.5) * sy);
+    int xi = (int)(((double)x + 0.5) * sx);
+    yi = yi < h ? yi : h - 1;
+    xi = xi < w ? xi : w - 1;
+    const uint8_t *s = in + (f * h * w + (size_t)yi * w + xi) * 3;
+    uint8_t *d = out + (f * oh * ow + (size_t)y * ow + x) * 3;
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+}
+
+template <int MODE>
+void launch_pass1(bool integer, dim3 grid, hipStream_t s, const uint8_t *in, uint8_t *out, unsigned long long *flags,
+                  const Geo &g, const PalDev &pal, const ThrDev &thr, float sx, float sy, float sc)
+{
+    if (integer)
+        hipLaunchKernelGGL(ordered_int_kernel<MODE>, grid, dim3(kBlock), 0, s, in, out, flags, g, pal, thr, sx, sy, sc);
+    else
+        hipLaunchKernelGGL(ordered_f64_kernel<MODE>, grid, dim3(kBlock), 0, s, in, out, flags, g, pal, thr, sx, sy, sc);
+}
+
+}  // namespace
+
+int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int y0, int x0,
+                   const PalDev &pal, int mode, const ThrDev *thr_in, float ign_scale, int ign_seed, void *ws,
+                   size_t ws_bytes, hipStream_t s)
+{
+    (void)ws_bytes;
+    ThrDev thr;
+    thr.th_h = thr.th_w = 1;
+    thr.f32 = nullptr;
+    thr.m = nullptr;
+    thr.sh = 0;
+    if (mode == DP_MODE_MATRIX) thr = *thr_in;
+    // a single colour: every pixel maps to it, and the k=2 query of the reference has no second entry
+    if (pal.K == 1) mode = DP_MODE_NEAREST;
+
+    const float sx = (float)((double)ign_seed * 0.37), sy = (float)((double)ign_seed * 0.73);
+    const int64_t hw = (int64_t)h * w;
+    // frames per launch so that pixel indices stay below 2^31
+    const int64_t max_frames = std::max<int64_t>(1, ((int64_t)1 << 31) / hw - 1);
+    unsigned long long *flags = reinterpret_cast<unsigned long long *>(ws);
+
+    for (int64_t f0 = 0; f0 < n_frames; f0 += max_frames) {
+        const int64_t nf = std::min(max_frames, n_frames - f0);
+        const uint8_t *in_c = in + (size_t)f0 * hw * 3;
+        uint8_t *out_c = out + (size_t)f0 * hw * 3;
+        Geo g;
+        g.n_px = (uint32_t)(nf * hw);
+        g.hw = (uint32_t)hw;
+        g.w = (uint32_t)w;
+        g.h = (uint32_t)h;
+        g.inv_hw = 1.0 / (double)hw;
+        g.inv_w = 1.0 / (double)w;
+        g.y0 = y0;
+        g.x0 = x0;
+        g.ty0 = y0 % thr.th_h;
+        g.tx0 = x0 % thr.th_w;
+        g.aligned = (((uintptr_t)in_c | (uintptr_t)out_c) & 3) == 0;
+        const uint32_t groups = (g.n_px + 3) / 4;
+        const uint32_t blocks = (groups + kBlock - 1) / kBlock;
+        const uint32_t n_words = blocks * (kBlock / 64) * 4;
+        unsigned long long *fl = flags + (size_t)(f0 * hw / 256) * 4;
+        const bool integer = pal.is_integer != 0;
+        int fix_mode;
+        if (mode == DP_MODE_NEAREST) {
+            launch_pass1<0>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);
+            fix_mode = 0;
+        } else if (mode == DP_MODE_IGN) {
+            launch_pass1<3>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);
+            fix_mode = 3;
+        } else {
+            const bool int_thr = integer && thr.m != nullptr && thr.th_h * thr.th_w <= 256;
+            if (int_thr)
+                launch_pass1<1>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);
+            else
+                launch_pass1<2>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);
+            fix_mode = 2;
+        }
+        DP_HIP(hipGetLastError());
+        const uint32_t fgrid = std::min<uint32_t>((n_words + kBlock - 1) / kBlock, 2048u);
+        if (fix_mode == 0)
+            hipLaunchKernelGGL(fixup_kernel<0>, dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale);
+        else if (fix_mode == 3)
+            hipLaunchKernelGGL(fixup_kernel<3>, dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale);
+        else
+            hipLaunchKernelGGL(fixup_kernel<2>, dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale);
+        DP_HIP(hipGetLastError());
+    }
+    return DP_OK;
+}
+
+int launch_ign_thresholds(float *out, int h, int w, int y0, int x0, float scale, int seed, hipStream_t s)
+{
+    const float sx = (float)((double)seed * 0.37), sy = (float)((double)seed * 0.73);
+    if (h > 65535) {
+        set_error("dp_ign_thresholds: h > 65535 not supported");
+        return DP_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(ign_field_kernel, dim3((w + 255) / 256, h), dim3(256), 0, s, out, h, w, y0, x0, sx, sy, scale);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
+int launch_resize_nearest(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int oh, int ow,
+                          hipStream_t s)
+{
+    if (oh > 65535 || n_frames > 65535) {
+        set_error("dp_resize_nearest_u8: oh or n_frames > 65535 not supported");
+        return DP_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3((ow + 255) / 256, oh, (unsigned)n_frames), dim3(256), 0, s, in, out,
+                       h, w, oh, ow, (double)h / oh, (double)w / ow);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
+}  // namespace dp

@@ -1,0 +1,134 @@
+/*
+ * ditherpie_hip.h -- C ABI of libditherpie_hip.so, the MI355X (gfx950) backend for the
+ * per-pixel hot path of dobrosketchkun/dither_pie.
+ *
+ * The reference is pure Python; it has no FFI of its own.  Each entry point below names the
+ * reference interface (file:line under the reference repo) whose arithmetic it replaces.  The
+ * binding a maintainer adds on the reference side is a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a DP_E* code otherwise; dp_last_error() gives the
+ *     text for the calling thread.  Nothing aborts.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller (e.g. torch tensors);
+ *     "host" pointers are ordinary host memory.  The library never frees caller memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     enqueued asynchronously on it; the caller synchronises.
+ *   - images are packed uint8 RGB, HWC, row pitch = 3*w bytes, frames back to back
+ *     (frame stride = 3*h*w bytes).  Output has the same layout.
+ *   - the library uses the calling thread's current HIP device.
+ *   - re-entrant and thread-safe: no mutable global state besides the thread-local error text.
+ */
+#ifndef DITHERPIE_HIP_H
+#define DITHERPIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DP_OK 0
+#define DP_EINVAL 1      /* bad argument (NULL pointer, size out of range, ...) */
+#define DP_EUNSUPPORTED 2 /* e.g. palette larger than DP_MAX_COLORS */
+#define DP_EHIP 3        /* a HIP runtime call failed; see dp_last_error() */
+#define DP_ENOMEM 4
+#define DP_EWORKSPACE 5  /* workspace too small; see the *_workspace_bytes query */
+
+#define DP_MAX_COLORS 256
+
+#define DP_MODE_NEAREST 0 /* NoDitherStrategy                     dithering_lib.py:333-341 */
+#define DP_MODE_MATRIX 1  /* MatrixDitherStrategy (Bayer, blue)   dithering_lib.py:346-378 */
+#define DP_MODE_IGN 2     /* InterleavedGradientNoiseDitherStrategy dithering_lib.py:502-571 */
+
+typedef struct dp_palette dp_palette;       /* prepared palette, device resident */
+typedef struct dp_thresholds dp_thresholds; /* threshold matrix, device resident */
+
+/* library / device ---------------------------------------------------------------------- */
+int dp_version(void);
+const char *dp_last_error(void);
+/* number of HIP devices visible and the gcnArchName of the current one (buf may be NULL) */
+int dp_device_info(int *n_devices, char *arch_buf, size_t arch_buf_len);
+
+/* palette ----------------------------------------------------------------------------------
+ * Replaces `KDTree(palette_arr)` at dithering_lib.py:339, 358, 554, 655 plus the palette /
+ * output conversions of ImageDitherer.apply_dithering (dithering_lib.py:1970-1974, 1984-1990).
+ *   pal_f32     host, K x 3 float32: the colours the KD-tree sees (sRGB ints, or the linearised
+ *               non-integer values when use_gamma is on)
+ *   out_colors  host, K x 3 uint8: the bytes written when entry i is chosen
+ *   lut_in      host, NULL or 256 uint8: per-channel map applied to every input byte before the
+ *               search (the uint8-quantised sRGB->linear map of dithering_lib.py:1957-1959)
+ * Builds scipy.spatial.KDTree's structure (leafsize 10, sliding-midpoint rules, libstdc++
+ * nth_element order) on the host, uploads it, and picks the exact-integer fast path when every
+ * palette value is an integer in [0,255] and lut_in is NULL. */
+int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, const uint8_t *lut_in,
+                      dp_palette **out);
+void dp_palette_destroy(dp_palette *p);
+int dp_palette_info(const dp_palette *p, int *K, int *is_integer, int *n_nodes);
+
+/* Host-only (no GPU needed): the KD-tree build used by dp_palette_create, exported so that it can
+ * be checked against scipy on any machine.  Arrays: indices[K]; nodes up to 2*K entries each.
+ * Returns the number of nodes through *n_nodes. */
+int dp_kdtree_build_host(const double *pts, int K, int32_t *indices, int32_t *split_dim, double *split,
+                         int32_t *start, int32_t *end, int32_t *less, int32_t *greater, int *n_nodes);
+
+/* thresholds -------------------------------------------------------------------------------
+ * dp_thresholds_create: upload a th_h x th_w float32 matrix (Bayer tables
+ * dithering_lib.py:1705-1768, polka-dot, any MatrixDitherStrategy matrix).
+ * dp_thresholds_blue_noise: generate_blue_noise(size, seed) (dithering_lib.py:381-399) computed on
+ * the device, including numpy's legacy RandomState(seed).shuffle.
+ * dp_thresholds_download copies the float32 matrix to host memory (th_h*th_w floats). */
+int dp_thresholds_create(const float *thr_host, int th_h, int th_w, dp_thresholds **out);
+int dp_thresholds_blue_noise(int size, uint32_t seed, void *stream, dp_thresholds **out);
+int dp_thresholds_shape(const dp_thresholds *t, int *th_h, int *th_w, int *is_integer_form);
+int dp_thresholds_download(const dp_thresholds *t, float *thr_host);
+void dp_thresholds_destroy(dp_thresholds *t);
+
+/* IGN threshold field (dithering_lib.py:539-549) written to out_dev[h*w] float32; (y0,x0) are the
+ * global coordinates of out_dev[0]. */
+int dp_ign_thresholds(float *out_dev, int h, int w, int y0, int x0, float scale, int seed, void *stream);
+
+/* ordered / nearest family -------------------------------------------------------------------
+ * Replaces NoDitherStrategy.dither (dithering_lib.py:337-341), MatrixDitherStrategy.dither
+ * (:355-378) and InterleavedGradientNoiseDitherStrategy.dither (:551-568) together with the
+ * uint8 conversions around them (:1953, 1977, 1984).
+ *   in_dev/out_dev  n_frames x h x w x 3 uint8
+ *   (y0,x0)         global coordinates of pixel (0,0) of every frame (row-band / tile sharding)
+ *   thr             required for DP_MODE_MATRIX, ignored otherwise
+ *   workspace_dev   at least dp_ordered_workspace_bytes(n_frames,h,w) bytes, 16-byte aligned
+ * Results are bit-identical to the reference including scipy's tie order. */
+size_t dp_ordered_workspace_bytes(int64_t n_frames, int h, int w);
+int dp_ordered_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int y0, int x0,
+                  const dp_palette *pal, int mode, const dp_thresholds *thr, float ign_scale, int ign_seed,
+                  void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* error diffusion ------------------------------------------------------------------------------
+ * Replaces ErrorDiffusionDitherStrategy.dither, pure-Python branch (dithering_lib.py:655-690).
+ *   dx,dy,wq  host arrays of ntaps entries in the reference's list order (ErrorDiffusionKernel,
+ *             dithering_lib.py:107-188); wq[k] = (float)(weight/divisor)
+ *   serpentine  0/1 (dithering_lib.py:659-664) */
+size_t dp_error_diffusion_workspace_bytes(int64_t n_frames, int h, int w);
+int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
+                          const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *wq,
+                          int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
+                          void *stream);
+
+/* k-means palette extraction ---------------------------------------------------------------------
+ * One Lloyd pass of the KMeans fit at dithering_lib.py:1854-1856 over n uint8 RGB pixels: nearest
+ * centre in float64 (lowest index on ties) and exact int64 per-cluster totals: channel sums
+ * sums_dev[K*3], member counts counts_dev[K] and squared norms sumsq_dev[K] (sum of r^2+g^2+b^2),
+ * all overwritten.  Being integers, the totals all-reduce exactly across ranks (RCCL, any order);
+ * the caller updates the centres and derives the inertia
+ *   sum_k ( sumsq_k - 2 c_k . sums_k + counts_k |c_k|^2 ). */
+int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
+                      int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
+
+/* NEAREST resize of packed RGB frames (pixelize_regular / final upscale,
+ * video_processor.py:563-577, 393-420): out[y][x] = in[(y*h)/oh][(x*w)/ow] (Pillow NEAREST). */
+int dp_resize_nearest_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int oh,
+                         int ow, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DITHERPIE_HIP_H */

@@ -1,0 +1,195 @@
+"""GPU tier: the HIP kernels, called through the C ABI, against the oracle and the golden fixtures.
+
+Bit-exact for every mode (ordered modes, palette assignment AND error diffusion: the decisions are
+discrete, so anything but identical float32 sums would show up as different palette colours)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, case_input, case_palette
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, "kat.json")) as _f:
+    _KAT = json.load(_f)
+_CASES = _KAT["cases"]
+
+
+@pytest.fixture(scope="module")
+def be():
+    import torch
+    from dither_pie_amd import backend
+    assert torch.cuda.is_available(), "GPU tier needs a HIP device"
+    return backend
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _run_case(be, orc, arr, pal, mode, params, gamma, y0=0, x0=0):
+    p = dict(orc.MODE_DEFAULTS[mode])
+    p.update(params or {})
+    pal_f32, out_colors, lut_in = orc.prepare_palette(pal, gamma)
+    P = be.Palette(pal_f32, out_colors, lut_in)
+    x = _dev(arr)
+    if mode == "none":
+        out = be.ordered(x, P, be.MODE_NEAREST, y0=y0, x0=x0)
+    elif mode == "bayer":
+        out = be.ordered(x, P, be.MODE_MATRIX, thr=be.Thresholds.from_matrix(orc.bayer_matrix(p["size"])), y0=y0, x0=x0)
+    elif mode == "blue_noise":
+        out = be.ordered(x, P, be.MODE_MATRIX, thr=be.Thresholds.blue_noise(p["size"], p["seed"]), y0=y0, x0=x0)
+    elif mode == "IGN":
+        out = be.ordered(x, P, be.MODE_IGN, ign_scale=p["scale"], ign_seed=p["seed"], y0=y0, x0=x0)
+    elif mode == "error_diffusion":
+        taps, div = orc.ed_kernel(p["variant"])
+        out = be.error_diffusion(x, P, taps, div, p["serpentine"] == "true")
+    else:
+        raise ValueError(mode)
+    return out.cpu().numpy()
+
+
+def _assert_same(out, ref, what=""):
+    if not np.array_equal(out, ref):
+        bad = np.argwhere((out != ref).any(-1))
+        raise AssertionError(f"{what}: {len(bad)} of {ref.shape[0] * ref.shape[1]} pixels differ, first {bad[:5].tolist()}")
+
+
+@pytest.mark.parametrize("case", _CASES, ids=lambda c: c["name"])
+def test_golden_cases(be, orc, gold, case):
+    arr = case_input(orc, case["input"])
+    pal = case_palette(orc, case["palette"])
+    out = _run_case(be, orc, arr, pal, case["mode"], case["params"], case["gamma"])
+    if case["full"]:
+        _assert_same(out, gold["out_" + case["name"]], case["name"])
+    assert orc.H(out) == case["h_out"]
+
+
+@pytest.mark.parametrize("K,seed", [(2, 1), (3, 2), (10, 3), (11, 4), (16, 5), (57, 6), (128, 7), (256, 8)])
+@pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "8x8"}), ("bayer", {"size": "2x2"}),
+                                         ("IGN", {"scale": 1.7, "seed": 23}), ("blue_noise", {"size": 32, "seed": 5})])
+def test_ordered_vs_oracle(be, orc, K, seed, mode, params):
+    pal = orc.palr(K, seed)
+    for arr in (orc.rnd(67, 93, seed), orc.grad(70, 131)):
+        out = _run_case(be, orc, arr, pal, mode, params, False)
+        ref = orc.apply_dithering(arr, pal, mode, params, False)
+        _assert_same(out, ref, f"{mode} K={K}")
+
+
+def test_single_colour_palette(be, orc):
+    arr = orc.rnd(20, 30, 1)
+    for mode, params in [("none", {}), ("bayer", {}), ("IGN", {})]:
+        out = _run_case(be, orc, arr, [(12, 200, 99)], mode, params, False)
+        assert (out == np.array([12, 200, 99], np.uint8)).all()
+
+
+def test_duplicate_palette_entries_all_ties(be, orc):
+    pal = [(50, 60, 70)] * 3 + [(200, 10, 10)] * 2 + [(50, 60, 70)]
+    arr = orc.grad(64, 80)
+    for mode, params in [("none", {}), ("bayer", {"size": "4x4"})]:
+        out = _run_case(be, orc, arr, pal, mode, params, False)
+        _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False), mode)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (5, 1), (3, 5), (17, 33), (64, 64), (2, 1025)])
+def test_ragged_shapes(be, orc, shape):
+    arr = orc.rnd(shape[0], shape[1], 77)
+    pal = orc.palr(32)
+    for mode, params in [("none", {}), ("bayer", {"size": "16x16"}), ("IGN", {})]:
+        out = _run_case(be, orc, arr, pal, mode, params, False)
+        _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False), f"{mode} {shape}")
+
+
+def test_batched_frames_and_tile_offsets(be, orc):
+    import torch
+    pal = orc.palr(64, 9)
+    pal_f32, out_colors, lut_in = orc.prepare_palette(pal, False)
+    P = be.Palette(pal_f32, out_colors, lut_in)
+    frames = np.stack([orc.rnd(45, 71, s) for s in range(5)])
+    thr = be.Thresholds.from_matrix(orc.bayer_matrix("8x8"))
+    out = be.ordered(_dev(frames), P, be.MODE_MATRIX, thr=thr).cpu().numpy()
+    for i in range(5):
+        _assert_same(out[i], orc.apply_dithering(frames[i], pal, "bayer", {"size": "8x8"}), f"frame {i}")
+    # row bands with global offsets reproduce the full image (config 4's tiling)
+    big = orc.grad(96, 128)
+    full = orc.apply_dithering(big, pal, "IGN", {"scale": 1.3, "seed": 5})
+    for (ya, yb) in [(0, 33), (33, 64), (64, 96)]:
+        o = be.ordered(_dev(big[ya:yb]), P, be.MODE_IGN, ign_scale=1.3, ign_seed=5, y0=ya).cpu().numpy()
+        _assert_same(o, full[ya:yb], f"band {ya}")
+    del torch
+
+
+def test_unaligned_input_pointer(be, orc):
+    import torch
+    pal = orc.palr(16)
+    pal_f32, out_colors, lut_in = orc.prepare_palette(pal, False)
+    P = be.Palette(pal_f32, out_colors, lut_in)
+    arr = orc.rnd(31, 47, 3)
+    buf = torch.empty(arr.size + 8, dtype=torch.uint8, device="cuda")
+    view = buf[1:1 + arr.size].view(31, 47, 3)
+    view.copy_(_dev(arr))
+    thr = be.Thresholds.from_matrix(orc.bayer_matrix("4x4"))
+    out = be.ordered(view, P, be.MODE_MATRIX, thr=thr).cpu().numpy()
+    _assert_same(out, orc.apply_dithering(arr, pal, "bayer", {"size": "4x4"}), "unaligned")
+
+
+@pytest.mark.parametrize("size,seed", [(32, 42), (64, 42), (32, 0), (33, 9999)])
+def test_blue_noise_on_device(be, gold, size, seed):
+    bn = be.Thresholds.blue_noise(size, seed).numpy()
+    assert np.array_equal(bn, gold[f"blue_{size}_{seed}"])
+
+
+def test_ign_field(be, orc, gold):
+    assert np.array_equal(be.ign_thresholds(8, 8, 1.0, 0).cpu().numpy(), gold["ign_8x8_s1_seed0"])
+    assert np.array_equal(be.ign_thresholds(37, 53, 2.5, 17).cpu().numpy(), gold["ign_37x53_s25_seed17"])
+    assert np.array_equal(be.ign_thresholds(64, 64, 0.1, 9999).cpu().numpy(), gold["ign_64x64_s01_seed9999"])
+    assert orc.H(be.ign_thresholds(1080, 1920, 2.5, 17).cpu().numpy()) == _KAT["misc"]["ign_1080_s25_seed17"]
+
+
+@pytest.mark.parametrize("variant", ["floyd_steinberg", "jjn", "stucki", "burkes", "atkinson", "sierra",
+                                     "sierra_two_row", "sierra_lite"])
+@pytest.mark.parametrize("serp", ["false", "true"])
+def test_error_diffusion_vs_oracle(be, orc, variant, serp):
+    for arr, pal in [(orc.rnd(150, 97, 4), orc.palr(16, 3)), (orc.grad(131, 200), orc.generate_uniform_palette(16)),
+                     (orc.rnd(70, 40, 5), orc.palr(40, 9))]:
+        params = {"variant": variant, "serpentine": serp}
+        out = _run_case(be, orc, arr, pal, "error_diffusion", params, False)
+        _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, False), f"{variant} {serp}")
+
+
+def test_error_diffusion_batch_and_gamma(be, orc):
+    pal = orc.palr(16, 3)
+    frames = np.stack([orc.rnd(80, 60, s) for s in range(3)])
+    pal_f32, out_colors, lut_in = orc.prepare_palette(pal, True)
+    P = be.Palette(pal_f32, out_colors, lut_in)
+    taps, div = orc.ed_kernel("floyd_steinberg")
+    for serp in (False, True):
+        out = be.error_diffusion(_dev(frames), P, taps, div, serp).cpu().numpy()
+        for i in range(3):
+            ref = orc.apply_dithering(frames[i], pal, "error_diffusion",
+                                      {"variant": "floyd_steinberg", "serpentine": "true" if serp else "false"}, True)
+            _assert_same(out[i], ref, f"frame {i} serp={serp}")
+
+
+def test_kmeans_step(be, orc):
+    import torch
+    px = orc.rnd(211, 173, 6).reshape(-1, 3)
+    centers = px[:32].astype(np.float64) + 0.25
+    sums, counts, sumsq = be.kmeans_step(_dev(px), torch.from_numpy(centers).cuda())
+    rs, rc, rin = orc.kmeans_step(px, centers)
+    assert np.array_equal(sums.cpu().numpy(), rs) and np.array_equal(counts.cpu().numpy(), rc)
+    c = torch.from_numpy(centers)
+    inertia = float((sumsq.cpu().double() - 2 * (c * sums.cpu().double()).sum(1) + counts.cpu().double() * (c * c).sum(1)).sum())
+    assert abs(inertia - rin) <= 1e-9 * rin
+
+
+def test_resize_nearest_matches_pillow(be, orc):
+    from PIL import Image
+    arr = orc.rnd(97, 131, 8)
+    for (oh, ow) in [(48, 65), (194, 262), (33, 131), (97, 50), (291, 393)]:
+        ref = np.array(Image.fromarray(arr).resize((ow, oh), Image.NEAREST))
+        out = be.resize_nearest(_dev(arr), oh, ow).cpu().numpy()
+        assert np.array_equal(out, ref), (oh, ow)
