@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- dither+quantize throughput of the MI355X backend (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload = "C2"): Bayer 8x8 + 256-colour nearest-palette on 3840x2160 RGB frames
+(BASELINE.json configs[1]); one step = one pass of ImageDitherer.apply_dithering_frames over a batch of
+24 distinct synthetic 4K frames (597 MB in, 597 MB out: larger than the 256 MiB Infinity Cache) that are
+already resident in HBM.  With N > 1 every rank runs the same batch on its own GPU (frames shard with no
+collective; weak scaling) and `value` is the whole-job pixel rate = N * pixels / max-over-ranks time.
+
+One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (ordered pass 1), timed with
+HIP events on its own stream inside the library (dp_profile_*); `cpu_baseline` is the CPU oracle
+(oracle/, the checker -- never the product path) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H4K, W4K = 2160, 3840
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
+BYTES_PER_PX = 6       # algorithmic: 3 B read + 3 B written per pixel
+
+
+def palr(K, seed=7):
+    return [tuple(int(v) for v in c) for c in np.random.RandomState(seed).randint(0, 256, (K, 3))]
+
+
+def make_frames(torch, n, h, w, dev, first_seed=None):
+    """n synthetic uint8 frames in HBM: i.i.d. uniform bytes (frame 0 optionally the numpy-seeded KAT frame)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    frames = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device=dev, generator=g)
+    if first_seed is not None:
+        kat = np.random.RandomState(first_seed).randint(0, 256, (h, w, 3), dtype=np.uint8)
+        frames[0].copy_(torch.from_numpy(kat))
+    return frames
+
+
+def cpu_baseline(n_frames=2):
+    """The CPU oracle (C restatement, OpenMP over rows) on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    orc.build()
+    pal = orc.palr(256)
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    orc.apply_dithering(orc.rnd(16, W4K, 1), pal, "bayer", {"size": "8x8"})  # warm-up (OpenMP pool, page-in)
+    px, dt = 0, 0.0
+    for i in range(n_frames):
+        arr = orc.rnd(H4K, W4K, 1234 + i)
+        t0 = time.perf_counter()
+        orc.apply_dithering(arr, pal, "bayer", {"size": "8x8"})
+        dt += time.perf_counter() - t0
+        px += arr.shape[0] * arr.shape[1]
+    return {"value": round(px / dt / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
+            "sample": f"{n_frames} full 3840x2160 frames rnd(2160,3840,1234+i), Bayer 8x8, 256 colours; C oracle "
+                      f"(scipy-order KD-tree query per pixel), OpenMP over rows on {threads} threads, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=24, help="4K frames per batch (per GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary 1080p / error-diffusion lines")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dither_pie_amd import backend
+    from dither_pie_amd.dithering_lib import DitherMode, ImageDitherer
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # ---------------- headline: C2 --------------------------------------------------------------
+    pal256 = palr(256)
+    dith = ImageDitherer(256, DitherMode.BAYER, pal256, False, {"size": "8x8"})
+    frames = make_frames(torch, args.frames, H4K, W4K, dev, first_seed=1234)
+    out = torch.empty_like(frames)
+    px_per_step = args.frames * H4K * W4K
+
+    def step():
+        dith.apply_dithering_frames(frames, out=out)
+
+    step()
+    torch.cuda.synchronize()
+    import hashlib
+    kat_ok = hashlib.sha256(out[0].cpu().numpy().tobytes()).hexdigest()[:16] == "7041bd52fdea90b5"
+
+    backend.profile_enable(True)
+    dt = timed(step, args.steps, args.warmup)
+    main_ms, fix_ms, launches = backend.profile_read()
+    backend.profile_enable(False)
+    # warm-up launches are in the record too: average per launch is what matters
+    k_ms = main_ms / max(launches, 1)
+    value = world * px_per_step * args.steps / dt / 1e6
+    achieved = BYTES_PER_PX * px_per_step / (k_ms * 1e-3) / 1e9
+    result = {
+        "metric": "Mpixel/s dither+quantize @4K 256-color (Bayer 8x8 + nearest-palette, uint8 RGB in/out)",
+        "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "C2: Bayer 8x8 + 256-colour nearest palette, 3840x2160 RGB, "
+                               f"{args.frames} distinct frames per GPU resident in HBM, frames sharded per rank",
+                   "frames_per_gpu": args.frames, "h": H4K, "w": W4K, "colors": 256, "matrix": "8x8",
+                   "parallelism": f"frames x{world}"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "ordered_int_kernel<1>", "kernel_ms": round(k_ms, 4),
+                     "fixup_ms": round(fix_ms / max(launches, 1), 4), "launches": launches,
+                     "algorithmic_bytes_per_launch": BYTES_PER_PX * px_per_step},
+        "parity_kat_4k": bool(kat_ok),
+    }
+
+    # ---------------- secondary lines (same process, after the headline) -------------------------
+    if not args.no_extra:
+        extra = {}
+        del out
+        # C5: 1000 synthetic 1080p frames, Bayer 4x4, 16 uniform colours, frames sharded over the ranks
+        from dither_pie_amd.dithering_lib import ColorReducer
+        total = 1000
+        lo, hi = rank * total // world, (rank + 1) * total // world
+        d5 = ImageDitherer(16, DitherMode.BAYER, ColorReducer.generate_uniform_palette(16), False, {"size": "4x4"})
+        chunk = 100
+        f5 = make_frames(torch, min(chunk, hi - lo), 1080, 1920, dev)
+        o5 = torch.empty_like(f5)
+
+        def video_pass():
+            done = 0
+            while done < hi - lo:
+                n = min(chunk, hi - lo - done)
+                d5.apply_dithering_frames(f5[:n], out=o5[:n])
+                done += n
+
+        t5 = timed(video_pass, 3, 1)
+        extra["c5_1080p_bayer4_k16_frames_per_s"] = round(total * 3 / t5, 1)
+        extra["c5_note"] = "1000 frames total split into contiguous blocks per rank (strong scaling), compute only"
+        del f5, o5
+        # C3: Floyd-Steinberg, 16 colours, 4K, a batch of frames (one wave per frame)
+        nf3 = 64
+        d3 = ImageDitherer(16, DitherMode.ERROR_DIFFUSION, ColorReducer.generate_uniform_palette(16), False,
+                           {"variant": "floyd_steinberg", "serpentine": "false"})
+        f3 = frames[:min(nf3, args.frames)].repeat((nf3 + args.frames - 1) // args.frames, 1, 1, 1)[:nf3]
+        o3 = torch.empty_like(f3)
+        t3 = timed(lambda: d3.apply_dithering_frames(f3, out=o3), 1, 1)
+        extra["c3_fs_k16_4k_mpixel_per_s"] = round(world * nf3 * H4K * W4K / t3 / 1e6, 2)
+        extra["c3_note"] = f"{nf3} frames in flight per GPU, bit-exact float32 error accumulation"
+        result["extra"] = extra
+
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

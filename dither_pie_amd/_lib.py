@@ -51,6 +51,8 @@ _SIGS = {
     "dp_error_diffusion_u8": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "dp_kmeans_step_u8": (_i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _vp]),
     "dp_resize_nearest_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "dp_profile_enable": (_i, [_i]),
+    "dp_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -187,3 +187,15 @@ def resize_nearest(frames, oh, ow):
     with torch.cuda.device(f.device):
         check(_lib.load().dp_resize_nearest_u8(f.data_ptr(), out.data_ptr(), n, h, w, int(oh), int(ow), _stream()))
     return out if frames.dim() == 4 else out[0]
+
+
+def profile_enable(on=True):
+    check(_lib.load().dp_profile_enable(1 if on else 0))
+
+
+def profile_read():
+    """-> (main kernel ms, fix-up ms, launches) accumulated since the last read (HIP events on the
+    launch stream)."""
+    a, b, n = C.c_double(), C.c_double(), C.c_int64()
+    check(_lib.load().dp_profile_read(C.byref(a), C.byref(b), C.byref(n)))
+    return a.value, b.value, n.value

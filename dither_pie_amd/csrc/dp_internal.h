@@ -76,6 +76,19 @@ struct dp_thresholds {
     int device;
 };
 
+// per-thread HIP-event profiling (dp_profile_enable / dp_profile_read)
+namespace dp {
+struct ProfMark {
+    hipEvent_t ev[3];  // start, after main kernel, after fix-up
+    int n;
+};
+bool prof_on();
+// returns nullptr when profiling is off; otherwise a mark whose events the launcher records
+ProfMark *prof_begin(hipStream_t s);
+void prof_mid(ProfMark *m, hipStream_t s);
+void prof_end(ProfMark *m, hipStream_t s);
+}  // namespace dp
+
 // launchers (defined in the .hip files)
 namespace dp {
 int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int y0, int x0,

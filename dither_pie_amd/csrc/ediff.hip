@@ -239,6 +239,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         t.dx[i] = t.dy[i] = 0;
         t.wq[i] = 0.f;
     }
+    ProfMark *pm = prof_begin(s);
     if (!serpentine && skew * 2 + 2 < kRing) {
         if (n_frames > 0x7fffffff) {
             set_error("dp_error_diffusion_u8: too many frames for one launch");
@@ -251,6 +252,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         hipLaunchKernelGGL(ed_serial_kernel, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h, w, pal, t,
                            serpentine, reinterpret_cast<float *>(ws));
     }
+    prof_end(pm, s);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }

@@ -129,6 +129,45 @@ void build_tree(const double *pts, int K, HostTree &t)
     b.build(0, K);
 }
 
+// ---- profiling ------------------------------------------------------------------------------
+static thread_local bool g_prof = false;
+static thread_local std::vector<ProfMark> *g_marks = nullptr;
+
+bool prof_on() { return g_prof; }
+
+ProfMark *prof_begin(hipStream_t s)
+{
+    if (!g_prof) return nullptr;
+    if (!g_marks) g_marks = new std::vector<ProfMark>();
+    if (g_marks->capacity() < 65536) g_marks->reserve(65536);  // keep pointers stable
+    if (g_marks->size() >= 65536) return nullptr;
+    ProfMark m;
+    m.n = 0;
+    for (auto &e : m.ev) {
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    }
+    g_marks->push_back(m);
+    ProfMark *p = &g_marks->back();
+    (void)hipEventRecord(p->ev[0], s);
+    p->n = 1;
+    return p;
+}
+
+void prof_mid(ProfMark *m, hipStream_t s)
+{
+    if (!m) return;
+    (void)hipEventRecord(m->ev[1], s);
+    m->n = 2;
+}
+
+void prof_end(ProfMark *m, hipStream_t s)
+{
+    if (!m) return;
+    if (m->n == 1) prof_mid(m, s);
+    (void)hipEventRecord(m->ev[2], s);
+    m->n = 3;
+}
+
 }  // namespace dp
 
 using namespace dp;
@@ -541,6 +580,37 @@ int dp_resize_nearest_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_fram
     }
     if (n_frames == 0) return DP_OK;
     return launch_resize_nearest(in_dev, out_dev, n_frames, h, w, oh, ow, (hipStream_t)stream);
+}
+
+int dp_profile_enable(int on)
+{
+    g_prof = on != 0;
+    return DP_OK;
+}
+
+int dp_profile_read(double *main_ms, double *fixup_ms, int64_t *n_launches)
+{
+    double a = 0, b = 0;
+    int64_t n = 0;
+    if (g_marks) {
+        for (auto &m : *g_marks) {
+            if (m.n == 3) {
+                float t1 = 0, t2 = 0;
+                DP_HIP(hipEventSynchronize(m.ev[2]));
+                DP_HIP(hipEventElapsedTime(&t1, m.ev[0], m.ev[1]));
+                DP_HIP(hipEventElapsedTime(&t2, m.ev[1], m.ev[2]));
+                a += t1;
+                b += t2;
+                ++n;
+            }
+            for (auto &e : m.ev) (void)hipEventDestroy(e);
+        }
+        g_marks->clear();
+    }
+    if (main_ms) *main_ms = a;
+    if (fixup_ms) *fixup_ms = b;
+    if (n_launches) *n_launches = n;
+    return DP_OK;
 }
 
 }  // extern "C"

@@ -104,10 +104,12 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
         set_error("dp_kmeans_step_u8: too many pixels for one launch");
         return DP_EINVAL;
     }
+    ProfMark *pm = prof_begin(s);
     const size_t smem = sizeof(double) * 3 * K + sizeof(unsigned long long) * K + sizeof(uint32_t) * 4 * K;
     hipLaunchKernelGGL(kmeans_step_kernel, dim3((unsigned)blocks), dim3(kBlock), smem, s, px, n, centers, K,
                        reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
                        reinterpret_cast<unsigned long long *>(sumsq));
+    prof_end(pm, s);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }

@@ -447,9 +447,10 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         const uint32_t groups = (g.n_px + 3) / 4;
         const uint32_t blocks = (groups + kBlock - 1) / kBlock;
         const uint32_t n_words = blocks * (kBlock / 64) * 4;
-        unsigned long long *fl = flags + (size_t)(f0 * hw / 256) * 4;
+        unsigned long long *fl = flags;  // chunks run back to back on one stream: the bitmap is reused
         const bool integer = pal.is_integer != 0;
         int fix_mode;
+        ProfMark *pm = prof_begin(s);
         if (mode == DP_MODE_NEAREST) {
             launch_pass1<0>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);
             fix_mode = 0;
@@ -465,6 +466,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             fix_mode = 2;
         }
         DP_HIP(hipGetLastError());
+        prof_mid(pm, s);
         const uint32_t fgrid = std::min<uint32_t>((n_words + kBlock - 1) / kBlock, 2048u);
         if (fix_mode == 0)
             hipLaunchKernelGGL(fixup_kernel<0>, dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale);
@@ -472,6 +474,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             hipLaunchKernelGGL(fixup_kernel<3>, dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale);
         else
             hipLaunchKernelGGL(fixup_kernel<2>, dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale);
+        prof_end(pm, s);
         DP_HIP(hipGetLastError());
     }
     return DP_OK;

@@ -1,0 +1,607 @@
+"""Drop-in counterpart of dither_pie's `dithering_lib` for the hot path, on MI355X.
+
+Same public names, constructor arguments, parameter metadata and error behaviour as the reference
+module (reference lines cited per item), so `from dither_pie_amd.dithering_lib import ImageDitherer,
+DitherMode, ColorReducer` can replace `from dithering_lib import ...` in dither_cli.py /
+dither_pie_gui.py / video_processor.py.  Pixel work happens in libditherpie_hip.so on the GPU; this
+file is host plumbing only (palette preparation, parameter handling, tensor hand-off).  There is no
+CPU fallback: without the shared library or a HIP device the calls raise DitherPieError.
+
+In scope: none, bayer, blue_noise, IGN, error_diffusion; k-means / uniform /
+median-cut palettes.  The other DitherMode members exist for configuration compatibility and raise
+NotImplementedError when used.
+
+Extras that the reference does not have (all optional): ImageDitherer.apply_dithering_frames() for
+batches of frames already resident in HBM, and tile offsets (y0, x0) for row-band sharding.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from enum import Enum
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _tables
+
+__all__ = [
+    "DitherMode", "PixelizeMethod", "PaletteSource", "ImageDitherer", "ColorReducer", "DitherUtils",
+    "BaseDitherStrategy", "ErrorDiffusionKernel", "NoDitherStrategy", "MatrixDitherStrategy",
+    "BayerDitherStrategy", "BlueNoiseDitherStrategy", "InterleavedGradientNoiseDitherStrategy",
+    "ErrorDiffusionDitherStrategy", "generate_blue_noise",
+]
+
+
+# ------------------------------------------------------------------------------------- enums
+class DitherMode(Enum):
+    """dithering_lib.py:61-75 (same member names and string values, incl. the upper-case "IGN")."""
+    NONE = "none"
+    BAYER = "bayer"
+    ERROR_DIFFUSION = "error_diffusion"
+    RIEMERSMA = "riemersma"
+    BLUE_NOISE = "blue_noise"
+    INTERLEAVED_GRADIENT_NOISE = "IGN"
+    POLKA_DOT = "polka_dot"
+    WAVELET = "wavelet"
+    ADAPTIVE_VARIANCE = "adaptive_variance"
+    PERCEPTUAL = "perceptual"
+    HYBRID = "hybrid"
+    HALFTONE = "halftone"
+    OSTROMOUKHOV = "ostromoukhov"
+
+
+class PixelizeMethod(Enum):
+    """dithering_lib.py:78-82"""
+    NONE = "none"
+    REGULAR = "regular"
+    NEURAL = "neural"
+
+
+class PaletteSource(Enum):
+    """dithering_lib.py:85-91"""
+    MEDIAN_CUT = "median_cut"
+    KMEANS = "kmeans"
+    UNIFORM = "uniform"
+    CUSTOM = "custom"
+    FROM_FILE = "file"
+
+
+_OUT_OF_SCOPE = {
+    DitherMode.RIEMERSMA, DitherMode.POLKA_DOT, DitherMode.WAVELET, DitherMode.ADAPTIVE_VARIANCE,
+    DitherMode.PERCEPTUAL, DitherMode.HYBRID, DitherMode.HALFTONE, DitherMode.OSTROMOUKHOV,
+}
+
+
+# ------------------------------------------------------------------------------------- tap tables
+def _kernel(taps, divisor, description, rows):
+    return {"weights": taps, "divisor": divisor, "description": description, "rows": rows}
+
+
+class ErrorDiffusionKernel:
+    """Error-diffusion tap tables: (dx, dy, weight) lists and divisors (dithering_lib.py:96-209)."""
+
+    FLOYD_STEINBERG = _kernel([(1, 0, 7), (-1, 1, 3), (0, 1, 5), (1, 1, 1)], 16,
+                              "Classic Floyd-Steinberg (4 neighbors)", 2)
+    JJN = _kernel([(1, 0, 7), (2, 0, 5)]
+                  + [(dx, 1, wt) for dx, wt in zip(range(-2, 3), (3, 5, 7, 5, 3))]
+                  + [(dx, 2, wt) for dx, wt in zip(range(-2, 3), (1, 3, 5, 3, 1))], 48,
+                  "Jarvis-Judice-Ninke (12 neighbors, smooth gradients)", 3)
+    STUCKI = _kernel([(1, 0, 8), (2, 0, 4)]
+                     + [(dx, 1, wt) for dx, wt in zip(range(-2, 3), (2, 4, 8, 4, 2))]
+                     + [(dx, 2, wt) for dx, wt in zip(range(-2, 3), (1, 2, 4, 2, 1))], 42,
+                     "Stucki (12 neighbors, photographic quality)", 3)
+    BURKES = _kernel([(1, 0, 8), (2, 0, 4)]
+                     + [(dx, 1, wt) for dx, wt in zip(range(-2, 3), (2, 4, 8, 4, 2))], 32,
+                     "Burkes (7 neighbors, fast)", 2)
+    ATKINSON = _kernel([(1, 0, 1), (2, 0, 1), (-1, 1, 1), (0, 1, 1), (1, 1, 1), (0, 2, 1)], 8,
+                       "Atkinson (6 neighbors, classic Mac look)", 3)
+    SIERRA = _kernel([(1, 0, 5), (2, 0, 3)]
+                     + [(dx, 1, wt) for dx, wt in zip(range(-2, 3), (2, 4, 5, 4, 2))]
+                     + [(dx, 2, wt) for dx, wt in zip(range(-1, 2), (2, 3, 2))], 32,
+                     "Sierra Full (10 neighbors, high quality)", 3)
+    SIERRA_TWO_ROW = _kernel([(1, 0, 4), (2, 0, 3)]
+                             + [(dx, 1, wt) for dx, wt in zip(range(-2, 3), (1, 2, 3, 2, 1))], 16,
+                             "Sierra Two-Row (8 neighbors, balanced)", 2)
+    SIERRA_LITE = _kernel([(1, 0, 2), (-1, 1, 1), (0, 1, 1)], 4, "Sierra Lite (4 neighbors, fastest)", 2)
+
+    _NAMES = ("floyd_steinberg", "jjn", "stucki", "burkes", "atkinson", "sierra", "sierra_two_row",
+              "sierra_lite")
+
+    @classmethod
+    def get_kernel(cls, name: str) -> Dict[str, Any]:
+        """Unknown names fall back to Floyd-Steinberg (dithering_lib.py:203)."""
+        if name in cls._NAMES:
+            return getattr(cls, name.upper())
+        return cls.FLOYD_STEINBERG
+
+    @classmethod
+    def list_kernels(cls) -> List[str]:
+        return list(cls._NAMES)
+
+
+# ------------------------------------------------------------------------------------- threshold tables
+def _table(den, rows):
+    return (np.array(rows, dtype=np.float64) / den).astype(np.float32)
+
+
+class DitherUtils:
+    """Threshold tables (stored as integer numerators over a power of two; the float32 values equal
+    dithering_lib.py:1705-1768 bit for bit, including the two non-canonical entries at the end of
+    BAYER8x8 row 3) and the gamma helpers (dithering_lib.py:1788-1802)."""
+
+    BAYER2x2 = _table(4, [[1, 3], [4, 2]])
+    BAYER4x4 = _table(32, [[1, 17, 5, 21], [25, 9, 29, 13], [7, 23, 3, 19], [31, 15, 27, 11]])
+    BAYER8x8 = _table(64, [
+        [1, 33, 9, 41, 3, 35, 11, 43], [49, 17, 57, 25, 51, 19, 59, 27],
+        [13, 45, 5, 37, 15, 47, 7, 39], [61, 29, 53, 21, 63, 31, 54, 22],
+        [4, 36, 12, 44, 2, 34, 10, 42], [52, 20, 60, 28, 50, 18, 58, 26],
+        [16, 48, 8, 40, 14, 46, 6, 38], [64, 32, 56, 24, 62, 30, 54, 22]])
+    BAYER16x16 = _table(256, [
+        [1, 129, 33, 161, 9, 137, 41, 169, 3, 131, 35, 163, 11, 139, 43, 171],
+        [193, 65, 225, 97, 201, 73, 233, 105, 195, 67, 227, 99, 203, 75, 235, 107],
+        [49, 177, 17, 145, 57, 185, 25, 153, 51, 179, 19, 147, 59, 187, 27, 155],
+        [241, 113, 209, 81, 249, 121, 217, 89, 243, 115, 211, 83, 251, 123, 219, 91],
+        [13, 141, 45, 173, 5, 133, 37, 165, 15, 143, 47, 175, 7, 135, 39, 167],
+        [205, 77, 237, 109, 197, 69, 229, 101, 207, 79, 239, 111, 199, 71, 231, 103],
+        [61, 189, 29, 157, 53, 181, 21, 149, 63, 191, 31, 159, 55, 183, 23, 151],
+        [253, 125, 221, 93, 245, 117, 213, 85, 255, 127, 223, 95, 247, 119, 215, 87],
+        [4, 132, 36, 164, 12, 140, 44, 172, 2, 130, 34, 162, 10, 138, 42, 170],
+        [196, 68, 228, 100, 204, 76, 236, 108, 194, 66, 226, 98, 202, 74, 234, 106],
+        [52, 180, 20, 148, 60, 188, 28, 156, 50, 178, 18, 146, 58, 186, 26, 154],
+        [244, 116, 212, 84, 252, 124, 220, 92, 242, 114, 210, 82, 250, 122, 218, 90],
+        [16, 144, 48, 176, 8, 136, 40, 168, 14, 142, 46, 174, 6, 134, 38, 166],
+        [208, 80, 240, 112, 200, 72, 232, 104, 206, 78, 238, 110, 198, 70, 230, 102],
+        [64, 192, 32, 160, 56, 184, 24, 152, 62, 190, 30, 158, 54, 182, 22, 150],
+        [256, 128, 224, 96, 248, 120, 216, 88, 254, 126, 222, 94, 246, 118, 214, 86]])
+    PSX4x4 = _table(16, [[1, 9, 3, 11], [13, 5, 15, 7], [3, 11, 1, 9], [15, 7, 13, 5]])
+
+    _BY_SIZE = {"2x2": "BAYER2x2", "4x4": "BAYER4x4", "8x8": "BAYER8x8", "16x16": "BAYER16x16",
+                "psx4x4": "PSX4x4", "psx": "PSX4x4"}
+
+    @staticmethod
+    def get_threshold_matrix(mode: DitherMode, size: str = "4x4") -> np.ndarray:
+        """dithering_lib.py:1770-1786"""
+        if mode == DitherMode.NONE:
+            return np.ones((1, 1), dtype=np.float32)
+        if mode == DitherMode.BAYER:
+            return getattr(DitherUtils, DitherUtils._BY_SIZE.get(size, "BAYER4x4"))
+        raise ValueError(f"Unsupported matrix mode: {mode}")
+
+    @staticmethod
+    def srgb_to_linear(c: np.ndarray) -> np.ndarray:
+        """dithering_lib.py:1788-1794"""
+        c = np.asarray(c)
+        out = np.empty_like(c, dtype=np.float32)
+        lo = c <= 0.04045
+        out[lo] = c[lo] / 12.92
+        out[~lo] = ((c[~lo] + 0.055) / 1.055) ** 2.4
+        return out
+
+    @staticmethod
+    def linear_to_srgb(c: np.ndarray) -> np.ndarray:
+        """dithering_lib.py:1796-1802"""
+        c = np.asarray(c)
+        out = np.empty_like(c, dtype=np.float32)
+        lo = c <= 0.0031308
+        out[lo] = c[lo] * 12.92
+        out[~lo] = 1.055 * (c[~lo] ** (1.0 / 2.4)) - 0.055
+        return out
+
+
+# ------------------------------------------------------------------------------------- device-object caches
+class _LRU(OrderedDict):
+    def __init__(self, cap):
+        super().__init__()
+        self.cap = cap
+
+    def get_or_make(self, key, make):
+        if key in self:
+            self.move_to_end(key)
+            return self[key]
+        val = make()
+        self[key] = val
+        while len(self) > self.cap:
+            self.popitem(last=False)
+        return val
+
+
+# device handles are process-local and never stored on the (picklable) ditherer objects
+_PALETTES = _LRU(32)
+_THRESHOLDS = _LRU(32)
+
+
+def _device_index():
+    import torch
+    return torch.cuda.current_device() if torch.cuda.is_available() else -1
+
+
+def _device_palette(pal_f32, out_colors, lut_in):
+    from . import backend
+    key = (_device_index(), pal_f32.tobytes(), out_colors.tobytes(), None if lut_in is None else lut_in.tobytes())
+    return _PALETTES.get_or_make(key, lambda: backend.Palette(pal_f32, out_colors, lut_in))
+
+
+def _device_thresholds_matrix(matrix):
+    from . import backend
+    m = np.ascontiguousarray(matrix, dtype=np.float32)
+    key = (_device_index(), "m", m.shape, m.tobytes())
+    return _THRESHOLDS.get_or_make(key, lambda: backend.Thresholds.from_matrix(m))
+
+
+def _device_thresholds_blue(size, seed):
+    from . import backend
+    key = (_device_index(), "bn", int(size), int(seed))
+    return _THRESHOLDS.get_or_make(key, lambda: backend.Thresholds.blue_noise(size, seed))
+
+
+def prepare_palette(palette, use_gamma):
+    """Host-side palette conversion of ImageDitherer.apply_dithering.
+
+    -> (pal_f32 [K,3]: what the nearest-colour search sees (dithering_lib.py:1970-1974),
+        out_colors [K,3] uint8: the bytes a chosen entry becomes (:1984-1990),
+        lut_in: uint8[256] applied to the image first (:1957-1959), or None)"""
+    pal = np.array(palette, dtype=np.float32).reshape(-1, 3)
+    if not use_gamma:
+        return np.ascontiguousarray(pal), np.ascontiguousarray(pal.astype(np.uint8)), None
+    ints = pal.astype(np.int64)
+    if np.array_equal(ints.astype(np.float32), pal) and ints.min() >= 0 and ints.max() <= 255:
+        pal_lin = _tables.PAL_LIN[ints]
+    else:  # values outside the uint8 grid: evaluate the reference's formula directly
+        pal_lin = np.clip(DitherUtils.srgb_to_linear(pal / 255.0) * 255.0, 0, 255).astype(np.float32)
+    out_colors = _tables.LUT_OUT[pal_lin.astype(np.uint8)]
+    return np.ascontiguousarray(pal_lin, dtype=np.float32), np.ascontiguousarray(out_colors), _tables.LUT_IN
+
+
+def _index_palette(palette_arr):
+    """A device palette whose output bytes encode the chosen index (for the strategy-level API)."""
+    pal = np.ascontiguousarray(palette_arr, dtype=np.float32).reshape(-1, 3)
+    K = pal.shape[0]
+    idx = np.arange(K)
+    enc = np.stack([idx & 255, idx >> 8, np.zeros_like(idx)], axis=1).astype(np.uint8)
+    return _device_palette(pal, enc, None)
+
+
+def _pixels_to_frame(pixels, image_size):
+    import torch
+    h, w = image_size
+    px = np.asarray(pixels)
+    if px.shape != (h * w, 3):
+        raise ValueError(f"pixels must have shape ({h * w}, 3)")
+    u8 = px.astype(np.uint8)
+    if not np.array_equal(u8.astype(px.dtype), px):
+        raise ValueError("the MI355X backend dithers uint8 images: pixel values must be integers in [0, 255]")
+    return torch.from_numpy(np.ascontiguousarray(u8.reshape(h, w, 3))).cuda()
+
+
+def _decode(out_frame, palette_arr):
+    o = out_frame.cpu().numpy().reshape(-1, 3)
+    idx = o[:, 0].astype(np.int64) | (o[:, 1].astype(np.int64) << 8)
+    return np.asarray(palette_arr)[idx, :]
+
+
+# ------------------------------------------------------------------------------------- strategies
+class BaseDitherStrategy:
+    """dithering_lib.py:313-330: dither(pixels [N,3] f32, palette_arr [K,3] f32, (h, w)) -> [N,3]."""
+
+    def dither(self, pixels: np.ndarray, palette_arr: np.ndarray, image_size: Tuple[int, int]) -> np.ndarray:
+        raise NotImplementedError
+
+    @staticmethod
+    def get_parameter_info() -> Optional[Dict[str, Any]]:
+        return None
+
+    def get_current_parameters(self) -> Dict[str, Any]:
+        return {}
+
+    # device-level entry used by ImageDitherer: uint8 frames in HBM -> uint8 frames in HBM
+    def _run(self, frames, pal, y0=0, x0=0, out=None):
+        raise NotImplementedError
+
+
+class NoDitherStrategy(BaseDitherStrategy):
+    """Nearest palette colour (dithering_lib.py:333-341)."""
+
+    def _run(self, frames, pal, y0=0, x0=0, out=None):
+        from . import backend
+        return backend.ordered(frames, pal, backend.MODE_NEAREST, y0=y0, x0=x0, out=out)
+
+    def dither(self, pixels, palette_arr, image_size):
+        out = self._run(_pixels_to_frame(pixels, image_size), _index_palette(palette_arr))
+        return _decode(out, palette_arr)
+
+
+class MatrixDitherStrategy(BaseDitherStrategy):
+    """Threshold-matrix dithering between the two nearest colours (dithering_lib.py:346-378)."""
+
+    def __init__(self, threshold_matrix: np.ndarray):
+        self.threshold_matrix = threshold_matrix
+
+    def _thresholds(self):
+        return _device_thresholds_matrix(self.threshold_matrix)
+
+    def _run(self, frames, pal, y0=0, x0=0, out=None):
+        from . import backend
+        return backend.ordered(frames, pal, backend.MODE_MATRIX, thr=self._thresholds(), y0=y0, x0=x0, out=out)
+
+    def dither(self, pixels, palette_arr, image_size):
+        out = self._run(_pixels_to_frame(pixels, image_size), _index_palette(palette_arr))
+        return _decode(out, palette_arr)
+
+
+def generate_blue_noise(size: int = 64, seed: int = 42) -> np.ndarray:
+    """Void-filling blue-noise matrix (dithering_lib.py:381-399), generated on the GPU."""
+    return _device_thresholds_blue(size, seed).numpy()
+
+
+class BayerDitherStrategy(MatrixDitherStrategy):
+    """dithering_lib.py:402-448"""
+
+    @staticmethod
+    def get_parameter_info() -> Dict[str, Any]:
+        return {
+            "size": {
+                "type": "choice",
+                "default": "4x4",
+                "choices": ["2x2", "4x4", "8x8", "16x16", "psx4x4"],
+                "label": "Matrix",
+                "description": "Bayer matrix size or PSX 4x4 variant (larger = finer patterns)",
+            }
+        }
+
+    def __init__(self, size: str = "4x4"):
+        self.size = size
+        super().__init__(DitherUtils.get_threshold_matrix(DitherMode.BAYER, size))
+
+    def get_current_parameters(self) -> Dict[str, Any]:
+        return {"size": self.size}
+
+
+class BlueNoiseDitherStrategy(MatrixDitherStrategy):
+    """dithering_lib.py:451-499 (the matrix is generated and cached on the device per (size, seed))."""
+
+    @staticmethod
+    def get_parameter_info() -> Dict[str, Any]:
+        return {
+            "size": {
+                "type": "int", "default": 64, "min": 32, "max": 128, "label": "Matrix Size",
+                "description": "Size of the blue noise matrix (larger = more detail but slower)",
+            },
+            "seed": {
+                "type": "int", "default": 42, "min": 0, "max": 9999, "label": "Random Seed",
+                "description": "Seed for noise generation (different seeds = different patterns)",
+            },
+        }
+
+    def __init__(self, size: int = 64, seed: int = 42):
+        self.size = size
+        self.seed = seed
+        self._matrix = None
+
+    @property
+    def threshold_matrix(self):
+        if self._matrix is None:
+            self._matrix = generate_blue_noise(self.size, self.seed)
+        return self._matrix
+
+    def _thresholds(self):
+        return _device_thresholds_blue(self.size, self.seed)
+
+    def get_current_parameters(self) -> Dict[str, Any]:
+        return {"size": self.size, "seed": self.seed}
+
+    def __getstate__(self):
+        return {"size": self.size, "seed": self.seed, "_matrix": None}
+
+
+class InterleavedGradientNoiseDitherStrategy(BaseDitherStrategy):
+    """dithering_lib.py:502-571"""
+
+    @staticmethod
+    def get_parameter_info() -> Dict[str, Any]:
+        return {
+            "scale": {
+                "type": "float", "default": 1.0, "min": 0.1, "max": 10.0, "step": 0.1, "label": "Scale",
+                "description": "Noise frequency (lower = larger pattern, higher = finer grain)",
+            },
+            "seed": {
+                "type": "int", "default": 0, "min": 0, "max": 9999, "label": "Seed",
+                "description": "Deterministic offset to shift the pattern",
+            },
+        }
+
+    def __init__(self, scale: float = 1.0, seed: int = 0):
+        self.scale = float(scale)
+        self.seed = int(seed)
+
+    def _generate_thresholds(self, image_size: Tuple[int, int]) -> np.ndarray:
+        from . import backend
+        h, w = image_size
+        return backend.ign_thresholds(h, w, self.scale, self.seed).cpu().numpy()
+
+    def _run(self, frames, pal, y0=0, x0=0, out=None):
+        from . import backend
+        return backend.ordered(frames, pal, backend.MODE_IGN, ign_scale=self.scale, ign_seed=self.seed,
+                               y0=y0, x0=x0, out=out)
+
+    def dither(self, pixels, palette_arr, image_size):
+        out = self._run(_pixels_to_frame(pixels, image_size), _index_palette(palette_arr))
+        return _decode(out, palette_arr)
+
+    def get_current_parameters(self) -> Dict[str, Any]:
+        return {"scale": self.scale, "seed": self.seed}
+
+
+class ErrorDiffusionDitherStrategy(BaseDitherStrategy):
+    """dithering_lib.py:576-690 (semantics of the pure-Python branch, which is what runs when numba is
+    not installed; parameters are the reference's strings)."""
+
+    @staticmethod
+    def get_parameter_info() -> Dict[str, Any]:
+        return {
+            "variant": {
+                "type": "choice", "default": "atkinson", "choices": ErrorDiffusionKernel.list_kernels(),
+                "label": "Algorithm", "description": "Error diffusion algorithm variant",
+            },
+            "serpentine": {
+                "type": "choice", "default": "false", "choices": ["true", "false"], "label": "Serpentine Scan",
+                "description": "Alternates direction each row to reduce artifacts",
+            },
+        }
+
+    def __init__(self, variant: str = "atkinson", serpentine: str = "false"):
+        self.variant = variant
+        self.serpentine = (serpentine == "true")
+        self._kernel = ErrorDiffusionKernel.get_kernel(variant)
+
+    def get_current_parameters(self) -> Dict[str, Any]:
+        return {"variant": self.variant, "serpentine": "true" if self.serpentine else "false"}
+
+    def _run(self, frames, pal, y0=0, x0=0, out=None):
+        from . import backend
+        if y0 or x0:
+            raise ValueError("error diffusion carries state across the whole raster and cannot be tiled")
+        return backend.error_diffusion(frames, pal, self._kernel["weights"], self._kernel["divisor"],
+                                       self.serpentine, out=out)
+
+    def dither(self, pixels, palette_arr, image_size):
+        out = self._run(_pixels_to_frame(pixels, image_size), _index_palette(palette_arr))
+        return _decode(out, palette_arr)
+
+
+# ------------------------------------------------------------------------------------- palettes
+class ColorReducer:
+    """Palette producers (dithering_lib.py:1807-1872)."""
+
+    @staticmethod
+    def find_dominant_channel(colors: List[Tuple[int, int, int]]) -> int:
+        spans = [max(c[ch] for c in colors) - min(c[ch] for c in colors) for ch in range(3)]
+        return spans.index(max(spans))
+
+    @staticmethod
+    def median_cut(colors: List[Tuple[int, int, int]], depth: int) -> List[Tuple[int, int, int]]:
+        """dithering_lib.py:1822-1833: stable sort on the widest channel, split at len//2, bucket mean
+        truncated per channel; an empty bucket yields (0, 0, 0)."""
+        if not colors:
+            return [(0, 0, 0)]
+        if depth == 0:
+            n = len(colors)
+            return [tuple(int(sum(col) / n) for col in zip(*colors))]
+        ch = ColorReducer.find_dominant_channel(colors)
+        colors.sort(key=lambda c: c[ch])
+        half = len(colors) // 2
+        return ColorReducer.median_cut(colors[:half], depth - 1) + ColorReducer.median_cut(colors[half:], depth - 1)
+
+    @staticmethod
+    def reduce_colors(image, num_colors: int) -> List[Tuple[int, int, int]]:
+        """Median cut over the image's unique colours; returns 2**int(log2(n)) entries
+        (dithering_lib.py:1835-1843).  Host-side: the unique-colour set is iterated in Python's set
+        order exactly as the reference does, because the stable sort makes that order observable."""
+        image = image.convert("RGB")
+        unique = list(set(image.getdata()))
+        n = max(int(num_colors), 1)
+        depth = int(math.log2(n)) if n > 1 else 0
+        return ColorReducer.median_cut(unique, depth)
+
+    @staticmethod
+    def generate_kmeans_palette(img, num_colors: int, random_state=42) -> List[Tuple[int, int, int]]:
+        """k-means palette (dithering_lib.py:1845-1857).  The reference fits sklearn KMeans on an
+        UNSEEDED random sample of 10 000 pixels, so its result is not reproducible; here Lloyd runs on
+        the GPU over every pixel with exact integer sums, k-means++ seeded from `random_state`
+        (see dither_pie_amd/kmeans.py for the parity definition)."""
+        from .kmeans import kmeans_palette_from_image
+        return kmeans_palette_from_image(img, num_colors, random_state)
+
+    @staticmethod
+    def generate_uniform_palette(num_colors: int) -> List[Tuple[int, int, int]]:
+        """dithering_lib.py:1859-1872: the first n points of a ceil(n^(1/3))^3 grid, r slowest."""
+        side = int(math.ceil(num_colors ** (1 / 3)))
+        if side <= 1:
+            return [(128, 128, 128)][:num_colors]
+        levels = [int(v * 255 / (side - 1)) for v in range(side)]
+        grid = [(r, g, b) for r in levels for g in levels for b in levels]
+        return grid[:num_colors]
+
+
+# ------------------------------------------------------------------------------------- ImageDitherer
+class ImageDitherer:
+    """dithering_lib.py:1877-1992.  Plain attributes only, so instances pickle like the reference's
+    (video_processor.py:312-322 ships them to worker processes)."""
+
+    _STRATEGIES = {
+        DitherMode.NONE: NoDitherStrategy,
+        DitherMode.BAYER: BayerDitherStrategy,
+        DitherMode.BLUE_NOISE: BlueNoiseDitherStrategy,
+        DitherMode.INTERLEAVED_GRADIENT_NOISE: InterleavedGradientNoiseDitherStrategy,
+        DitherMode.ERROR_DIFFUSION: ErrorDiffusionDitherStrategy,
+    }
+
+    def __init__(self, num_colors: int = 16, dither_mode: Optional[DitherMode] = DitherMode.BAYER,
+                 palette: Optional[List[Tuple[int, int, int]]] = None, use_gamma: bool = False,
+                 dither_params: Optional[Dict[str, Any]] = None):
+        self.num_colors = num_colors
+        self.dither_mode = dither_mode
+        self.palette = palette
+        self.use_gamma = use_gamma
+        self.dither_params = dither_params or {}
+
+    @staticmethod
+    def get_mode_parameters(mode: DitherMode) -> Optional[Dict[str, Any]]:
+        """Parameter metadata for the GUI/CLI (dithering_lib.py:1893-1911); None for modes without
+        parameters and for the modes this backend does not implement."""
+        cls = ImageDitherer._STRATEGIES.get(mode)
+        if cls is None or cls is NoDitherStrategy:
+            return None
+        return cls.get_parameter_info()
+
+    @staticmethod
+    def mode_has_parameters(mode: DitherMode) -> bool:
+        return ImageDitherer.get_mode_parameters(mode) is not None
+
+    def _get_dither_strategy(self, mode: DitherMode) -> BaseDitherStrategy:
+        """Defaults from get_parameter_info() overlaid by dither_params (dithering_lib.py:1918-1950);
+        unknown mode -> ValueError, unknown parameter -> TypeError from the constructor."""
+        if mode in _OUT_OF_SCOPE:
+            raise NotImplementedError(
+                f"dither mode {mode.value!r} is outside the MI355X backend's scope "
+                "(none, bayer, blue_noise, IGN, error_diffusion)")
+        cls = self._STRATEGIES.get(mode)
+        if cls is None:
+            raise ValueError(f"Unrecognized DitherMode: {mode}")
+        info = cls.get_parameter_info()
+        if not info:
+            return cls()
+        settings = {name: meta["default"] for name, meta in info.items()}
+        settings.update(self.dither_params)
+        return cls(**settings)
+
+    # -- host plumbing ------------------------------------------------------------------------
+    def _ensure_palette(self, first_frame_u8: np.ndarray):
+        """palette=None: median cut of the (linearised, when gamma is on) image, kept on the object
+        (dithering_lib.py:1960-1966)."""
+        if self.palette is None:
+            from PIL import Image
+            src = _tables.LUT_IN[first_frame_u8] if self.use_gamma else first_frame_u8
+            self.palette = ColorReducer.reduce_colors(Image.fromarray(src, "RGB"), self.num_colors)
+
+    def apply_dithering_frames(self, frames, y0: int = 0, x0: int = 0, out=None):
+        """uint8 CUDA tensor [N,H,W,3] (or [H,W,3]) -> dithered uint8 CUDA tensor of the same shape.
+        Frames stay in HBM; (y0, x0) are the global coordinates of each frame's first pixel when the
+        frames are row bands / tiles of a larger image (ordered modes only)."""
+        if not self.dither_mode:
+            self.dither_mode = DitherMode.NONE
+        if self.palette is None:
+            first = frames if frames.dim() == 3 else frames[0]
+            self._ensure_palette(first.cpu().numpy())
+        strategy = self._get_dither_strategy(self.dither_mode)
+        pal = _device_palette(*prepare_palette(self.palette, self.use_gamma))
+        return strategy._run(frames, pal, y0=y0, x0=x0, out=out)
+
+    def apply_dithering(self, image):
+        """PIL image -> PIL 'RGB' image (dithering_lib.py:1952-1992)."""
+        import torch
+        from PIL import Image
+        arr = np.array(image.convert("RGB"), dtype=np.uint8)
+        self._ensure_palette(arr)
+        out = self.apply_dithering_frames(torch.from_numpy(arr).cuda())
+        return Image.fromarray(out.cpu().numpy(), "RGB")

@@ -128,6 +128,15 @@ int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_de
 int dp_resize_nearest_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int oh,
                          int ow, void *stream);
 
+/* measurement -----------------------------------------------------------------------------------
+ * Per-thread kernel timing with HIP events recorded on the stream the kernels run on.  While
+ * enabled, every dp_ordered_u8 / dp_error_diffusion_u8 / dp_kmeans_step_u8 launch made by the calling
+ * thread is bracketed by events; dp_profile_read synchronises them, returns the summed milliseconds
+ * of the main kernel (pass 1 for dp_ordered_u8) and of the fix-up pass, and the number of main-kernel
+ * launches, then clears the record. */
+int dp_profile_enable(int on);
+int dp_profile_read(double *main_ms, double *fixup_ms, int64_t *n_launches);
+
 #ifdef __cplusplus
 }
 #endif
