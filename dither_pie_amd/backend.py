@@ -49,6 +49,9 @@ class Palette:
         check(_lib.load().dp_palette_info(self._h, C.byref(k), C.byref(integer), C.byref(nodes)))
         self.is_integer = bool(integer.value)
         self.n_nodes = nodes.value
+        pe, mc = C.c_int(), C.c_int()
+        check(_lib.load().dp_palette_accel_info(self._h, C.byref(pe), C.byref(mc)))
+        self.accel_entries, self.accel_max_list = pe.value, mc.value
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -52,6 +52,13 @@ struct PalDev {
     const double *split;       // n_nodes
     const int32_t *start, *end, *less, *greater;
     double mins[3], maxes[3];
+    // search accelerator (accel.hip); cell_desc == nullptr when absent
+    const uint32_t *cell_desc;  // 4096: list offset (bits 0..19) | padded count (bits 20..27)
+    const uint32_t *cell_pool;  // pool_entries packed colours r | g<<8 | b<<16, lists sorted by palette index
+    int pool_entries;
+    int max_cell;
+    const uint32_t *code1;      // 2 bits per colour: tie outcome of the k=1 query
+    const uint32_t *code2;      //                     ... of the k=2 query
 };
 
 struct ThrDev {
@@ -67,6 +74,8 @@ struct dp_palette {
     dp::PalDev dev;
     void *blob;  // one device allocation backing every pointer in dev
     size_t blob_bytes;
+    void *accel_blob;  // cell lists + tie codes (may be null)
+    size_t accel_bytes;
     int device;
 };
 
@@ -91,6 +100,7 @@ void prof_end(ProfMark *m, hipStream_t s);
 
 // launchers (defined in the .hip files)
 namespace dp {
+int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_out, size_t *blob_bytes);
 int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int y0, int x0,
                    const PalDev &pal, int mode, const ThrDev *thr, float ign_scale, int ign_seed, void *ws,
                    size_t ws_bytes, hipStream_t s);

@@ -329,6 +329,24 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
         d.mins[c] = t.mins[c];
         d.maxes[c] = t.maxes[c];
     }
+    d.cell_desc = nullptr;
+    d.cell_pool = nullptr;
+    d.pool_entries = 0;
+    d.max_cell = 0;
+    d.code1 = d.code2 = nullptr;
+    p->accel_blob = nullptr;
+    p->accel_bytes = 0;
+    // cell lists + tie codes: integer palettes whose output bytes are the palette colours themselves
+    bool same_out = integer && K >= 8;
+    for (int j = 0; j < K && same_out; ++j) same_out = (orgb[j] == p4[j]);
+    if (same_out) {
+        int rc = build_accel(d, p4, &p->accel_blob, &p->accel_bytes);
+        if (rc != DP_OK) {
+            (void)hipFree(p->blob);
+            delete p;
+            return rc;
+        }
+    }
     *out = p;
     return DP_OK;
 }
@@ -337,6 +355,7 @@ void dp_palette_destroy(dp_palette *p)
 {
     if (!p) return;
     if (p->blob) (void)hipFree(p->blob);
+    if (p->accel_blob) (void)hipFree(p->accel_blob);
     delete p;
 }
 
@@ -349,6 +368,17 @@ int dp_palette_info(const dp_palette *p, int *K, int *is_integer, int *n_nodes)
     if (K) *K = p->dev.K;
     if (is_integer) *is_integer = p->dev.is_integer;
     if (n_nodes) *n_nodes = p->dev.n_nodes;
+    return DP_OK;
+}
+
+int dp_palette_accel_info(const dp_palette *p, int *pool_entries, int *max_cell)
+{
+    if (!p) {
+        set_error("dp_palette_accel_info: NULL palette");
+        return DP_EINVAL;
+    }
+    if (pool_entries) *pool_entries = p->dev.cell_desc ? p->dev.pool_entries : 0;
+    if (max_cell) *max_cell = p->dev.cell_desc ? p->dev.max_cell : 0;
     return DP_OK;
 }
 
@@ -493,7 +523,7 @@ size_t dp_ordered_workspace_bytes(int64_t n_frames, int h, int w)
     // one flag bit per pixel, written as 4 x u64 per 256-pixel wave tile (+ slack for the tail)
     const int64_t npx = n_frames * (int64_t)h * w;
     const int64_t tiles = (npx + 255) / 256;
-    return (size_t)(tiles * 32 + 256);
+    return (size_t)(tiles * 32 + 1024);
 }
 
 int dp_ordered_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int y0, int x0,

@@ -227,6 +227,140 @@ __global__ __launch_bounds__(kBlock) void ordered_int_kernel(const uint8_t *__re
     store_flags(flags, gidx, slow);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2: integer palettes with a search accelerator (accel.hip).  One persistent 1024-lane workgroup
+// per CU keeps the cell table in LDS (16 KB of descriptors + the candidate pool) and walks
+// 4096-pixel tiles.  Per pixel: one descriptor read, ceil(cnt/4) ds_read_b128 of packed candidate
+// colours, 8 VALU ops per candidate (two v_dot4, key build, min/med3/med3), exact integer decision.
+// Distance ties take their outcome from the 2-bit tie code of the colour (a rare L2 read); exact
+// equality in the decision replays the reference's float64 chain inline; only code 3 (a tie pattern
+// outside the table) is flagged for the fix-up pass.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCellBlock = 1024;
+
+__device__ __forceinline__ void cand_eval(const uint32_t x, const uint32_t c, const int idx, int &m0, int &m1, int &m2)
+{
+    const int nn = (int)__builtin_amdgcn_udot4(c, c, 0u, false);
+    const int xp = (int)__builtin_amdgcn_udot4(x, c, 0u, false);
+    const int key = ((nn << kIdxBits) + idx) - (xp << (kIdxBits + 1));
+    const int n2 = med3i(m1, m2, key);
+    const int n1 = med3i(m0, m1, key);
+    m0 = min(m0, key);
+    m1 = n1;
+    m2 = n2;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t *__restrict__ in,
+                                                                  uint8_t *__restrict__ out,
+                                                                  unsigned long long *__restrict__ flags,
+                                                                  const Geo g, const PalDev pal, const ThrDev thr,
+                                                                  const float sx, const float sy, const float sc,
+                                                                  const uint32_t n_tiles)
+{
+    extern __shared__ __align__(16) uint32_t smem[];
+    uint32_t *s_desc = smem;
+    uint32_t *s_pool = smem + 4096;
+    uint32_t *s_thr = s_pool + pal.pool_entries;
+    for (int i = threadIdx.x; i < 4096; i += kCellBlock) s_desc[i] = pal.cell_desc[i];
+    for (int i = threadIdx.x * 4; i < pal.pool_entries; i += kCellBlock * 4)
+        *reinterpret_cast<uint4 *>(&s_pool[i]) = *reinterpret_cast<const uint4 *>(&pal.cell_pool[i]);
+    if (MODE == 1)
+        for (int i = threadIdx.x; i < thr.th_h * thr.th_w; i += kCellBlock) s_thr[i] = thr.m[i];
+    __syncthreads();
+
+    constexpr int kBig = 0x7fffffff;
+    constexpr int IM = (1 << kIdxBits) - 1;
+    const float thr_scale = 1.0f / (float)(1u << thr.sh);
+
+    uint32_t px[4];
+    uint32_t tile = blockIdx.x;
+    if (tile < n_tiles) load4(in, g, tile * kCellBlock + threadIdx.x, px);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t gidx = tile * kCellBlock + threadIdx.x;
+        const uint32_t p0 = gidx * 4u;
+        uint32_t cur_px[4] = {px[0], px[1], px[2], px[3]};
+        const uint32_t next = tile + gridDim.x;
+        if (next < n_tiles) load4(in, g, next * kCellBlock + threadIdx.x, px);  // prefetch the next tile
+
+        Cursor cur;
+        cursor_init(g, thr, p0 < g.n_px ? p0 : 0u, cur, MODE == 1 || MODE == 2);
+        uint32_t col[4];
+        bool slow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t x = cur_px[q];
+            const uint32_t cell = ((x & 0xf0u) << 4) | ((x >> 8) & 0xf0u) | ((x >> 20) & 0xfu);
+            const uint32_t desc = s_desc[cell];
+            const uint32_t off = desc & 0xfffffu;
+            const int cnt = (int)(desc >> 20);
+            int m0 = kBig, m1 = kBig, m2 = kBig;
+            for (int i = 0; i < cnt; i += 4) {
+                const uint4 c = *reinterpret_cast<const uint4 *>(&s_pool[off + i]);
+                cand_eval(x, c.x, i, m0, m1, m2);
+                cand_eval(x, c.y, i + 1, m0, m1, m2);
+                cand_eval(x, c.z, i + 2, m0, m1, m2);
+                cand_eval(x, c.w, i + 3, m0, m1, m2);
+            }
+            const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
+            const uint32_t d0 = (uint32_t)((m0 >> kIdxBits) + xx);
+            const uint32_t d1 = (uint32_t)((m1 >> kIdxBits) + xx);
+            const uint32_t d2 = (uint32_t)((m2 >> kIdxBits) + xx);
+            uint32_t a = s_pool[off + (m0 & IM)];  // colour reported as nearest
+            uint32_t b = s_pool[off + (m1 & IM)];  // colour reported as second
+            bool s = false;
+            bool nearest = true;
+            if (MODE == 0) {
+                if (d0 == d1) {
+                    const uint32_t code = (pal.code1[x >> 4] >> ((x & 15u) * 2)) & 3u;
+                    if (code == 1) a = b;
+                    else if (code == 2) a = s_pool[off + (m2 & IM)];
+                    else if (code == 3) s = true;
+                }
+            } else {
+                if (d0 == d1 || d1 == d2) {
+                    const uint32_t code = (pal.code2[x >> 4] >> ((x & 15u) * 2)) & 3u;
+                    if (code == 1) {
+                        const uint32_t t = a;
+                        a = b;
+                        b = t;
+                    } else if (code == 2) {
+                        b = s_pool[off + (m2 & IM)];
+                    } else if (code == 3) {
+                        s = true;
+                    }
+                }
+                const uint32_t S = d0 + d1;
+                float t;
+                bool eq;
+                if (MODE == 1) {
+                    const uint32_t mt = s_thr[cur.ty * thr.th_w + cur.tx];
+                    const uint32_t lhs = d0 << thr.sh;
+                    const uint32_t rhs = __umul24(mt, S);
+                    nearest = lhs <= rhs;
+                    eq = lhs == rhs;
+                    t = __fmul_rn((float)mt, thr_scale);
+                } else {
+                    if (MODE == 2)
+                        t = thr.f32[cur.ty * thr.th_w + cur.tx];
+                    else
+                        t = ign_threshold(g.x0 + (int)cur.x, g.y0 + (int)cur.y, sx, sy, sc);
+                    const double lhs = (double)d0, rhs = __dmul_rn((double)t, (double)S);
+                    nearest = lhs <= rhs;
+                    eq = lhs == rhs;
+                }
+                if (eq) nearest = ordered_use_nearest((double)d0, (double)d1, t);  // rare: the literal float64 chain
+            }
+            slow[q] = s & (p0 + q < g.n_px);
+            col[q] = nearest ? a : b;
+            cursor_next(g, thr, cur);
+        }
+        store4(out, g, gidx, col);
+        store_flags(flags, gidx, slow);
+    }
+}
+
 // General palettes (non-integer: gamma on) -- float64 brute force with the reference's arithmetic.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void ordered_f64_kernel(const uint8_t *__restrict__ in,
@@ -396,6 +530,34 @@ __global__ void resize_nearest_kernel(const uint8_t *__restrict__ in, uint8_t *_
     d[2] = s[2];
 }
 
+
+int num_cus()
+{
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached = n;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
+template <int MODE>
+int launch_cell(uint32_t grid, size_t lds, hipStream_t s, const uint8_t *in, uint8_t *out, unsigned long long *flags,
+                const Geo &g, const PalDev &pal, const ThrDev &thr, float sx, float sy, float sc, uint32_t n_tiles)
+{
+    auto kern = ordered_cell_kernel<MODE>;
+    // more than 64 KB of dynamic LDS has to be granted per function (once per device is enough,
+    // repeating it is cheap)
+    DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kCellBlock), lds, s, in, out, flags, g, pal, thr, sx, sy, sc, n_tiles);
+    return DP_OK;
+}
+
 template <int MODE>
 void launch_pass1(bool integer, dim3 grid, hipStream_t s, const uint8_t *in, uint8_t *out, unsigned long long *flags,
                   const Geo &g, const PalDev &pal, const ThrDev &thr, float sx, float sy, float sc)
@@ -446,20 +608,41 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         g.aligned = (((uintptr_t)in_c | (uintptr_t)out_c) & 3) == 0;
         const uint32_t groups = (g.n_px + 3) / 4;
         const uint32_t blocks = (groups + kBlock - 1) / kBlock;
-        const uint32_t n_words = blocks * (kBlock / 64) * 4;
+        uint32_t n_words = blocks * (kBlock / 64) * 4;
         unsigned long long *fl = flags;  // chunks run back to back on one stream: the bitmap is reused
         const bool integer = pal.is_integer != 0;
         int fix_mode;
         ProfMark *pm = prof_begin(s);
-        if (mode == DP_MODE_NEAREST) {
+        const bool int_thr_ok = thr.m != nullptr && thr.th_h * thr.th_w <= 256;
+        if (integer && pal.cell_desc != nullptr) {
+            // v2: LDS cell lists + tie codes, persistent 1024-lane workgroups over 4096-pixel tiles
+            const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
+            n_words = n_tiles * (kCellBlock / 64) * 4;
+            const size_t lds = sizeof(uint32_t) * (4096 + (size_t)pal.pool_entries + 256);
+            const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus());
+            int rc;
+            if (mode == DP_MODE_NEAREST) {
+                rc = launch_cell<0>(cgrid, lds, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles);
+                fix_mode = 0;
+            } else if (mode == DP_MODE_IGN) {
+                rc = launch_cell<3>(cgrid, lds, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles);
+                fix_mode = 3;
+            } else if (int_thr_ok) {
+                rc = launch_cell<1>(cgrid, lds, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles);
+                fix_mode = 2;
+            } else {
+                rc = launch_cell<2>(cgrid, lds, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles);
+                fix_mode = 2;
+            }
+            if (rc != DP_OK) return rc;
+        } else if (mode == DP_MODE_NEAREST) {
             launch_pass1<0>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);
             fix_mode = 0;
         } else if (mode == DP_MODE_IGN) {
             launch_pass1<3>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);
             fix_mode = 3;
         } else {
-            const bool int_thr = integer && thr.m != nullptr && thr.th_h * thr.th_w <= 256;
-            if (int_thr)
+            if (integer && int_thr_ok)
                 launch_pass1<1>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);
             else
                 launch_pass1<2>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);

@@ -193,3 +193,33 @@ def test_resize_nearest_matches_pillow(be, orc):
         ref = np.array(Image.fromarray(arr).resize((ow, oh), Image.NEAREST))
         out = be.resize_nearest(_dev(arr), oh, ow).cpu().numpy()
         assert np.array_equal(out, ref), (oh, ow)
+
+
+def test_accelerator_is_built_for_integer_palettes(be, orc):
+    P = be.Palette(*orc.prepare_palette(orc.palr(256), False))
+    assert P.is_integer and P.accel_entries > 0 and 4 <= P.accel_max_list <= 64
+    Pg = be.Palette(*orc.prepare_palette(orc.palr(256), True))
+    assert not Pg.is_integer and Pg.accel_entries == 0
+
+
+@pytest.mark.parametrize("K,seed", [(8, 1), (16, 2), (64, 3), (200, 4), (256, 5)])
+def test_tie_heavy_inputs(be, orc, K, seed):
+    """every pixel sits on a bisector of two palette colours (midpoints), or on a palette colour"""
+    pal = orc.palr(K, seed)
+    P = np.array(pal)
+    rs = np.random.RandomState(seed)
+    a, b = P[rs.randint(0, K, 6000)], P[rs.randint(0, K, 6000)]
+    pts = np.concatenate([(a + b) // 2, (a + b + 1) // 2, P[rs.randint(0, K, 1000)]]).astype(np.uint8)
+    arr = pts[: (len(pts) // 100) * 100].reshape(-1, 100, 3)
+    for mode, params in [("none", {}), ("bayer", {"size": "8x8"}), ("IGN", {}), ("blue_noise", {"size": 32, "seed": 0})]:
+        out = _run_case(be, orc, arr, pal, mode, params, False)
+        _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False), f"{mode} K={K}")
+
+
+def test_clustered_palette_long_lists(be, orc):
+    rs = np.random.RandomState(3)
+    pal = [tuple(int(v) for v in np.clip(rs.normal(128, 6, 3), 0, 255)) for _ in range(200)] + orc.palr(56, 2)
+    arr = np.clip(rs.normal(128, 10, (90, 120, 3)), 0, 255).astype(np.uint8)
+    for mode, params in [("none", {}), ("bayer", {"size": "4x4"})]:
+        out = _run_case(be, orc, arr, pal, mode, params, False)
+        _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False), mode)
