@@ -7,9 +7,14 @@
 // of an image, so they are tabulated per palette:
 //
 //   cell lists   for each of the 16x16x16 cells of the RGB cube, the exact union of T(x) over the
-//                cell's 4096 colours, sorted by palette index and padded to a multiple of 4 with
-//                further (harmless) palette entries.  ~5 entries per cell for a 256-colour palette;
-//                the whole table (~100 KB) lives in LDS in the dither kernel.
+//                cell's 4096 colours (~5 entries for a 256-colour palette), sorted by palette index
+//                and padded to exactly 8 with further (harmless) palette entries: one 32-byte block
+//                per cell at a fixed stride, so the dither kernel needs no descriptor and no loop.
+//                The few cells with more than 8 members (~1.5 %) hold a marker instead and are split
+//                octree-fashion into eight half-size sub-cells (8^3, then 4^3, 2^3, single colours),
+//                each with its own 8-entry block; only a single colour with more than 8 equidistant
+//                candidates is marked "slow" (its pixels go to the generic fix-up pass).
+//                The whole table (128 KB + ~64 words per split) lives in LDS in the dither kernel.
 //   tie codes    2 bits per colour and per query kind (k=1, k=2): for colours whose three smallest
 //                distances contain a tie, the outcome of scipy's traversal (tree_query) expressed
 //                relative to the candidates sorted by (distance, index):
@@ -35,8 +40,8 @@ __device__ __forceinline__ int med3i(const int a, const int b, const int c)
 __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint32_t *__restrict__ masks,
                                                          uint32_t *__restrict__ code1, uint32_t *__restrict__ code2)
 {
-    __shared__ uint32_t s_mask[8];
-    if (threadIdx.x < 8) s_mask[threadIdx.x] = 0;
+    __shared__ uint32_t s_mask[9][8];  // [0] the whole cell, [1+s] its 8x8x8 sub-cell s
+    if (threadIdx.x < 72) (&s_mask[0][0])[threadIdx.x] = 0;
     __syncthreads();
     const int cell = blockIdx.x;
     const int rc = cell >> 8, gc = (cell >> 4) & 15, bc = cell & 15;
@@ -62,14 +67,19 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
         }
         const int d0 = m0 >> kIdxBits, d1 = m1 >> kIdxBits, d2 = m2 >> kIdxBits, d3 = m3 >> kIdxBits;
         const int c0 = m0 & IM, c1 = m1 & IM, c2 = m2 & IM;
-        atomicOr(&s_mask[c0 >> 5], 1u << (c0 & 31));
-        if (K > 1) atomicOr(&s_mask[c1 >> 5], 1u << (c1 & 31));
-        if (K > 2 && d2 == d1) atomicOr(&s_mask[c2 >> 5], 1u << (c2 & 31));
+        const int sub = 1 + (((((id >> 8) >> 3) & 1) << 2) | (((((id >> 4) & 15) >> 3) & 1) << 1) | (((id & 15) >> 3) & 1));
+        auto mark = [&](int j) {
+            atomicOr(&s_mask[0][j >> 5], 1u << (j & 31));
+            atomicOr(&s_mask[sub][j >> 5], 1u << (j & 31));
+        };
+        mark(c0);
+        if (K > 1) mark(c1);
+        if (K > 2 && d2 == d1) mark(c2);
         if (K > 3 && d3 == d1) {  // four or more at the second distance: take every one of them
             for (int j = 0; j < K; ++j) {
                 const int dot = (int)__builtin_amdgcn_udot4(x4, pal.p4[j], 0u, false);
                 const int dj = (pal.nkey[j] - (dot << (kIdxBits + 1))) >> kIdxBits;
-                if (dj <= d1) atomicOr(&s_mask[j >> 5], 1u << (j & 31));
+                if (dj <= d1) mark(j);
             }
         }
         if (K < 2) continue;
@@ -98,7 +108,54 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
         }
     }
     __syncthreads();
-    if (threadIdx.x < 8) masks[cell * 8 + threadIdx.x] = s_mask[threadIdx.x];
+    if (threadIdx.x < 72) masks[cell * 72 + threadIdx.x] = (&s_mask[0][0])[threadIdx.x];
+}
+
+
+// T(x)-union masks for arbitrary axis-aligned boxes of colours (used below the 8x8x8 level)
+struct Box {
+    int r0, g0, b0, size;
+};
+
+__global__ __launch_bounds__(64) void accel_box_kernel(const PalDev pal, const Box *__restrict__ boxes,
+                                                       uint32_t *__restrict__ masks)
+{
+    __shared__ uint32_t s_mask[8];
+    if (threadIdx.x < 8) s_mask[threadIdx.x] = 0;
+    __syncthreads();
+    const Box bx = boxes[blockIdx.x];
+    const int K = pal.K;
+    constexpr int kBig = 0x7fffffff;
+    constexpr int IM = (1 << kIdxBits) - 1;
+    const int n = bx.size * bx.size * bx.size;
+    for (int id = threadIdx.x; id < n; id += 64) {
+        const uint32_t r = bx.r0 + id / (bx.size * bx.size), g = bx.g0 + (id / bx.size) % bx.size, b = bx.b0 + id % bx.size;
+        const uint32_t x4 = r | (g << 8) | (b << 16);
+        int m0 = kBig, m1 = kBig, m2 = kBig, m3 = kBig;
+        for (int j = 0; j < K; ++j) {
+            const int dot = (int)__builtin_amdgcn_udot4(x4, pal.p4[j], 0u, false);
+            const int key = pal.nkey[j] - (dot << (kIdxBits + 1));
+            const int n3 = med3i(m2, m3, key);
+            const int n2 = med3i(m1, m2, key);
+            const int n1 = med3i(m0, m1, key);
+            m0 = min(m0, key);
+            m1 = n1;
+            m2 = n2;
+            m3 = n3;
+        }
+        const int d1 = m1 >> kIdxBits, d2 = m2 >> kIdxBits, d3 = m3 >> kIdxBits;
+        atomicOr(&s_mask[(m0 & IM) >> 5], 1u << (m0 & 31));
+        if (K > 1) atomicOr(&s_mask[(m1 & IM) >> 5], 1u << (m1 & 31));
+        if (K > 2 && d2 == d1) atomicOr(&s_mask[(m2 & IM) >> 5], 1u << (m2 & 31));
+        if (K > 3 && d3 == d1)
+            for (int j = 0; j < K; ++j) {
+                const int dot = (int)__builtin_amdgcn_udot4(x4, pal.p4[j], 0u, false);
+                const int dj = (pal.nkey[j] - (dot << (kIdxBits + 1))) >> kIdxBits;
+                if (dj <= d1) atomicOr(&s_mask[j >> 5], 1u << (j & 31));
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) masks[blockIdx.x * 8 + threadIdx.x] = s_mask[threadIdx.x];
 }
 
 }  // namespace
@@ -112,13 +169,13 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     const int K = dev.K;
     constexpr size_t kCodeWords = (size_t)1 << 20;  // 2^24 colours x 2 bits
     constexpr int kCells = 4096;
+    constexpr int kTabCapWords = (160 * 1024 - 2048) / 4;  // LDS budget of the dither kernel
     uint32_t *d_masks = nullptr;
     uint8_t *blob = nullptr;
-    // layout: code1 | code2 | desc[4096] | pool[cap]
-    constexpr int kPoolCap = 36 * 1024;  // entries; desc(16 KB) + pool(144 KB) stays inside 160 KB of LDS
-    const size_t bytes = sizeof(uint32_t) * (2 * kCodeWords + kCells + kPoolCap);
+    // layout: code1 | code2 | table[cap]
+    const size_t bytes = sizeof(uint32_t) * (2 * kCodeWords + kTabCapWords);
     DP_HIP(hipMalloc((void **)&blob, bytes));
-    hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 8);
+    hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 72);
     if (e == hipSuccess) e = hipMemset(blob, 0, sizeof(uint32_t) * 2 * kCodeWords);
     if (e != hipSuccess) {
         (void)hipFree(blob);
@@ -127,10 +184,9 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     }
     uint32_t *code1 = reinterpret_cast<uint32_t *>(blob);
     uint32_t *code2 = code1 + kCodeWords;
-    uint32_t *d_desc = code2 + kCodeWords;
-    uint32_t *d_pool = d_desc + kCells;
+    uint32_t *d_tab = code2 + kCodeWords;
     hipLaunchKernelGGL(accel_scan_kernel, dim3(kCells), dim3(256), 0, 0, dev, d_masks, code1, code2);
-    std::vector<uint32_t> masks((size_t)kCells * 8);
+    std::vector<uint32_t> masks((size_t)kCells * 72);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(masks.data(), d_masks, sizeof(uint32_t) * masks.size(), hipMemcpyDeviceToHost);
     (void)hipFree(d_masks);
@@ -139,51 +195,130 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         return hip_fail(e, "accelerator scan");
     }
 
-    std::vector<uint32_t> desc(kCells), pool;
-    pool.reserve(kPoolCap);
+    std::vector<uint32_t> tab((size_t)kCells * 8, 0u);
     std::vector<int> list, extra;
-    int max_cnt = 0;
-    for (int cell = 0; cell < kCells; ++cell) {
+    int n_split = 0, n_slow = 0, max_cnt = 0;
+    // members of a mask, padded to 8 with the unused entries nearest to (cr,cg,cb); false if > 8
+    auto make_block = [&](const uint32_t *mask, int cr, int cg, int cb, uint32_t *out8) {
         list.clear();
-        for (int j = 0; j < K; ++j)
-            if (masks[(size_t)cell * 8 + (j >> 5)] >> (j & 31) & 1u) list.push_back(j);
-        const int want = ((int)list.size() + 3) & ~3;
-        if (want > K || want > 252) {  // cannot pad with distinct entries
-            (void)hipFree(blob);
-            return DP_OK;              // no accelerator: the brute-force kernel stays in charge
-        }
-        if ((int)list.size() < want) {
-            // pad with the unused entries closest to the cell centre (any real entry is harmless)
-            const int cr = (cell >> 8) * 16 + 8, cg = ((cell >> 4) & 15) * 16 + 8, cb = (cell & 15) * 16 + 8;
-            extra.clear();
-            for (int j = 0; j < K; ++j)
-                if (!(masks[(size_t)cell * 8 + (j >> 5)] >> (j & 31) & 1u)) extra.push_back(j);
+        extra.clear();
+        for (int j = 0; j < K; ++j) ((mask[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
+        max_cnt = std::max(max_cnt, (int)list.size());
+        if (list.size() > 8) return false;
+        if (list.size() < 8) {
             auto dist = [&](int j) {
                 const int r = p4_host[j] & 255, g = (p4_host[j] >> 8) & 255, b = (p4_host[j] >> 16) & 255;
                 return (r - cr) * (r - cr) + (g - cg) * (g - cg) + (b - cb) * (b - cb);
             };
             std::stable_sort(extra.begin(), extra.end(), [&](int a, int b) { return dist(a) < dist(b); });
-            for (int i = 0; (int)list.size() < want; ++i) list.push_back(extra[i]);
-            std::sort(list.begin(), list.end());
+            for (int i = 0; list.size() < 8; ++i) list.push_back(extra[i]);
+            std::sort(list.begin(), list.end());  // key ties must break towards the lower palette index
         }
-        if (pool.size() + list.size() > (size_t)kPoolCap) {
-            (void)hipFree(blob);
-            return DP_OK;
+        for (int i = 0; i < 8; ++i) out8[i] = p4_host[list[i]];
+        return true;
+    };
+    // pending splits below the 8^3 level: (block position in tab, box) resolved level by level
+    struct Pending {
+        size_t pos;
+        Box box;
+    };
+    std::vector<Pending> pending;
+    bool too_big = false;
+    // turn the block at `pos` into a split node with 8 children of half size; children masks come
+    // either from `child_masks` (8 x 8 words) or, if null, are requested for the next round
+    auto split = [&](size_t pos, const Box &bx, const uint32_t *child_masks) {
+        const size_t base = tab.size();
+        if (base + 64 > (size_t)kTabCapWords) {
+            too_big = true;
+            return;
         }
-        desc[cell] = (uint32_t)pool.size() | ((uint32_t)list.size() << 20);
-        for (int j : list) pool.push_back(p4_host[j]);
-        max_cnt = std::max(max_cnt, (int)list.size());
+        tab.resize(base + 64, 0u);
+        tab[pos] = 0x80000000u | (uint32_t)((base - (size_t)kCells * 8) / 64);
+        ++n_split;
+        const int hs = bx.size / 2;
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            Box c{bx.r0 + ((sidx >> 2) & 1) * hs, bx.g0 + ((sidx >> 1) & 1) * hs, bx.b0 + (sidx & 1) * hs, hs};
+            const size_t cpos = base + (size_t)sidx * 8;
+            if (child_masks) {
+                uint32_t blk[8];
+                if (make_block(child_masks + 8 * sidx, c.r0 + hs / 2, c.g0 + hs / 2, c.b0 + hs / 2, blk))
+                    std::copy(blk, blk + 8, tab.begin() + cpos);
+                else
+                    pending.push_back({cpos, c});
+            } else {
+                pending.push_back({cpos, c});
+            }
+        }
+    };
+    for (int cell = 0; cell < kCells && !too_big; ++cell) {
+        const uint32_t *m = &masks[(size_t)cell * 72];
+        const int r0 = (cell >> 8) * 16, g0 = ((cell >> 4) & 15) * 16, b0 = (cell & 15) * 16;
+        uint32_t blk[8];
+        if (make_block(m, r0 + 8, g0 + 8, b0 + 8, blk))
+            std::copy(blk, blk + 8, tab.begin() + (size_t)cell * 8);
+        else
+            split((size_t)cell * 8, Box{r0, g0, b0, 16}, m + 8);
     }
-    e = hipMemcpy(d_desc, desc.data(), sizeof(uint32_t) * kCells, hipMemcpyHostToDevice);
-    if (e == hipSuccess && !pool.empty())
-        e = hipMemcpy(d_pool, pool.data(), sizeof(uint32_t) * pool.size(), hipMemcpyHostToDevice);
+    // deeper levels: boxes that still hold more than 8 members are split again (their children's
+    // masks come from accel_box_kernel); a single colour that still overflows is left to the fix-up pass
+    while (!pending.empty() && !too_big) {
+        std::vector<Pending> todo;
+        todo.swap(pending);
+        std::vector<Pending> kids;  // children whose masks we need this round
+        for (const Pending &pd : todo) {
+            if (pd.box.size == 1) {
+                tab[pd.pos] = 0xC0000000u;
+                ++n_slow;
+                continue;
+            }
+            const size_t before = pending.size();
+            split(pd.pos, pd.box, nullptr);
+            if (too_big) break;
+            for (size_t q = before; q < pending.size(); ++q) kids.push_back(pending[q]);
+            pending.resize(before);
+        }
+        if (too_big || kids.empty()) break;
+        std::vector<Box> boxes(kids.size());
+        for (size_t q = 0; q < kids.size(); ++q) boxes[q] = kids[q].box;
+        Box *d_boxes = nullptr;
+        uint32_t *d_bm = nullptr;
+        std::vector<uint32_t> bm(kids.size() * 8);
+        e = hipMalloc((void **)&d_boxes, sizeof(Box) * boxes.size());
+        if (e == hipSuccess) e = hipMalloc((void **)&d_bm, sizeof(uint32_t) * bm.size());
+        if (e == hipSuccess) e = hipMemcpy(d_boxes, boxes.data(), sizeof(Box) * boxes.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(accel_box_kernel, dim3((unsigned)boxes.size()), dim3(64), 0, 0, dev, d_boxes, d_bm);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(bm.data(), d_bm, sizeof(uint32_t) * bm.size(), hipMemcpyDeviceToHost);
+        if (d_boxes) (void)hipFree(d_boxes);
+        if (d_bm) (void)hipFree(d_bm);
+        if (e != hipSuccess) {
+            (void)hipFree(blob);
+            return hip_fail(e, "accelerator refinement");
+        }
+        for (size_t q = 0; q < kids.size(); ++q) {
+            const Box &c = kids[q].box;
+            uint32_t blk[8];
+            if (make_block(&bm[q * 8], c.r0 + c.size / 2, c.g0 + c.size / 2, c.b0 + c.size / 2, blk))
+                std::copy(blk, blk + 8, tab.begin() + kids[q].pos);
+            else
+                pending.push_back(kids[q]);
+        }
+    }
+    if (too_big) {
+        (void)hipFree(blob);
+        return DP_OK;  // table would not fit in LDS: the brute-force kernel stays in charge
+    }
+    e = hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(blob);
         return hip_fail(e, "accelerator upload");
     }
-    dev.cell_desc = d_desc;
-    dev.cell_pool = d_pool;
-    dev.pool_entries = (int)pool.size();
+    dev.cell_tab = d_tab;
+    dev.tab_words = (int)tab.size();
+    dev.n_split = n_split;
+    dev.n_slow_blocks = n_slow;
     dev.max_cell = max_cnt;
     dev.code1 = code1;
     dev.code2 = code2;

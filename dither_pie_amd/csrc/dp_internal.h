@@ -52,10 +52,13 @@ struct PalDev {
     const double *split;       // n_nodes
     const int32_t *start, *end, *less, *greater;
     double mins[3], maxes[3];
-    // search accelerator (accel.hip); cell_desc == nullptr when absent
-    const uint32_t *cell_desc;  // 4096: list offset (bits 0..19) | padded count (bits 20..27)
-    const uint32_t *cell_pool;  // pool_entries packed colours r | g<<8 | b<<16, lists sorted by palette index
-    int pool_entries;
+    // search accelerator (accel.hip); cell_tab == nullptr when absent
+    const uint32_t *cell_tab;   // [4096 cells][8] packed colours r | g<<8 | b<<16 (sorted by palette index),
+                                // then [n_split][8 sub-cells][8]; word 0 of a block with bit 31 set is a marker:
+                                // 0x80000000|split index (cell is split) or 0xC0000000 (resolve in the fix-up pass)
+    int tab_words;
+    int n_split;
+    int n_slow_blocks;
     int max_cell;
     const uint32_t *code1;      // 2 bits per colour: tie outcome of the k=1 query
     const uint32_t *code2;      //                     ... of the k=2 query

@@ -329,9 +329,9 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
         d.mins[c] = t.mins[c];
         d.maxes[c] = t.maxes[c];
     }
-    d.cell_desc = nullptr;
-    d.cell_pool = nullptr;
-    d.pool_entries = 0;
+    d.cell_tab = nullptr;
+    d.tab_words = 0;
+    d.n_split = d.n_slow_blocks = 0;
     d.max_cell = 0;
     d.code1 = d.code2 = nullptr;
     p->accel_blob = nullptr;
@@ -377,8 +377,8 @@ int dp_palette_accel_info(const dp_palette *p, int *pool_entries, int *max_cell)
         set_error("dp_palette_accel_info: NULL palette");
         return DP_EINVAL;
     }
-    if (pool_entries) *pool_entries = p->dev.cell_desc ? p->dev.pool_entries : 0;
-    if (max_cell) *max_cell = p->dev.cell_desc ? p->dev.max_cell : 0;
+    if (pool_entries) *pool_entries = p->dev.cell_tab ? p->dev.tab_words : 0;
+    if (max_cell) *max_cell = p->dev.cell_tab ? p->dev.max_cell : 0;
     return DP_OK;
 }
 

@@ -30,6 +30,7 @@ struct Geo {
     int y0, x0;      // global coordinates of pixel (0,0)
     int ty0, tx0;    // y0 % th_h, x0 % th_w
     int aligned;     // in/out are 4-byte aligned
+    int neg2;        // -(2 << kIdxBits), kept in a register on purpose (see cand_eval)
 };
 
 __device__ __forceinline__ int med3i(const int a, const int b, const int c)
@@ -229,21 +230,25 @@ __global__ __launch_bounds__(kBlock) void ordered_int_kernel(const uint8_t *__re
 
 
 // ---------------------------------------------------------------------------------------------
-// v2: integer palettes with a search accelerator (accel.hip).  One persistent 1024-lane workgroup
-// per CU keeps the cell table in LDS (16 KB of descriptors + the candidate pool) and walks
-// 4096-pixel tiles.  Per pixel: one descriptor read, ceil(cnt/4) ds_read_b128 of packed candidate
-// colours, 8 VALU ops per candidate (two v_dot4, key build, min/med3/med3), exact integer decision.
-// Distance ties take their outcome from the 2-bit tie code of the colour (a rare L2 read); exact
-// equality in the decision replays the reference's float64 chain inline; only code 3 (a tie pattern
-// outside the table) is flagged for the fix-up pass.
+// Fast path: integer palettes with a search accelerator (accel.hip).  One persistent 1024-lane
+// workgroup per CU keeps the cell table in LDS (4096 blocks of 8 packed colours at a 32-byte stride,
+// plus the blocks of split cells) and walks 4096-pixel tiles.  Per lane: 4 consecutive pixels; the
+// eight ds_read_b128 of their candidate blocks are issued back to back, then everything is
+// straight-line code: 7 VALU ops per candidate (two v_dot4, v_lshl_add, v_mad_i32_i24, min/med3/med3)
+// and the exact integer decision.  Distance ties take their outcome from the 2-bit tie code of the
+// colour (a rare L2 read); exact equality in the decision replays the reference's float64 chain
+// inline; only tie code 3 and overflowing sub-cells are flagged for the fix-up pass.
 // ---------------------------------------------------------------------------------------------
 constexpr int kCellBlock = 1024;
 
-__device__ __forceinline__ void cand_eval(const uint32_t x, const uint32_t c, const int idx, int &m0, int &m1, int &m2)
+template <int IDX>
+__device__ __forceinline__ void cand_eval(const uint32_t x, const uint32_t c, const int neg2, int &m0, int &m1, int &m2)
 {
     const int nn = (int)__builtin_amdgcn_udot4(c, c, 0u, false);
     const int xp = (int)__builtin_amdgcn_udot4(x, c, 0u, false);
-    const int key = ((nn << kIdxBits) + idx) - (xp << (kIdxBits + 1));
+    // ((|p|^2 - 2 x.p) << 8) | IDX as v_lshl_add + v_mad_i32_i24; neg2 = -(2 << 8) arrives in an SGPR so
+    // that the multiply is not strength-reduced into a shift and a subtract; x.p < 2^18 keeps it exact
+    const int key = __mul24(xp, neg2) + ((nn << kIdxBits) + IDX);
     const int n2 = med3i(m1, m2, key);
     const int n1 = med3i(m0, m1, key);
     m0 = min(m0, key);
@@ -260,12 +265,10 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
                                                                   const uint32_t n_tiles)
 {
     extern __shared__ __align__(16) uint32_t smem[];
-    uint32_t *s_desc = smem;
-    uint32_t *s_pool = smem + 4096;
-    uint32_t *s_thr = s_pool + pal.pool_entries;
-    for (int i = threadIdx.x; i < 4096; i += kCellBlock) s_desc[i] = pal.cell_desc[i];
-    for (int i = threadIdx.x * 4; i < pal.pool_entries; i += kCellBlock * 4)
-        *reinterpret_cast<uint4 *>(&s_pool[i]) = *reinterpret_cast<const uint4 *>(&pal.cell_pool[i]);
+    uint32_t *s_tab = smem;
+    uint32_t *s_thr = smem + pal.tab_words;
+    for (int i = threadIdx.x * 4; i < pal.tab_words; i += kCellBlock * 4)
+        *reinterpret_cast<uint4 *>(&s_tab[i]) = *reinterpret_cast<const uint4 *>(&pal.cell_tab[i]);
     if (MODE == 1)
         for (int i = threadIdx.x; i < thr.th_h * thr.th_w; i += kCellBlock) s_thr[i] = thr.m[i];
     __syncthreads();
@@ -280,42 +283,65 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
     for (; tile < n_tiles; tile += gridDim.x) {
         const uint32_t gidx = tile * kCellBlock + threadIdx.x;
         const uint32_t p0 = gidx * 4u;
-        uint32_t cur_px[4] = {px[0], px[1], px[2], px[3]};
+        const uint32_t xq[4] = {px[0], px[1], px[2], px[3]};
         const uint32_t next = tile + gridDim.x;
         if (next < n_tiles) load4(in, g, next * kCellBlock + threadIdx.x, px);  // prefetch the next tile
+
+        // candidate blocks of the four pixels: all LDS reads in flight together
+        uint32_t blk[4];
+        uint4 ca[4], cb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t x = xq[q];
+            blk[q] = (((x & 0xf0u) << 4) | ((x >> 8) & 0xf0u) | ((x >> 20) & 0xfu)) * 8u;
+            ca[q] = *reinterpret_cast<const uint4 *>(&s_tab[blk[q]]);
+            cb[q] = *reinterpret_cast<const uint4 *>(&s_tab[blk[q] + 4]);
+        }
+        bool slow[4] = {false, false, false, false};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // rare: the cell is split octree-fashion; descend by one colour bit per level
+            for (int bit = 3; (ca[q].x >> 31) != 0; --bit) {
+                if ((ca[q].x & 0x40000000u) || bit < 0) {
+                    slow[q] = true;  // a single colour with more than 8 candidates: fix-up pass
+                    break;
+                }
+                const uint32_t x = xq[q];
+                const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
+                blk[q] = 4096u * 8u + ((ca[q].x & 0xffffffu) * 8u + sub) * 8u;
+                ca[q] = *reinterpret_cast<const uint4 *>(&s_tab[blk[q]]);
+                cb[q] = *reinterpret_cast<const uint4 *>(&s_tab[blk[q] + 4]);
+            }
+        }
 
         Cursor cur;
         cursor_init(g, thr, p0 < g.n_px ? p0 : 0u, cur, MODE == 1 || MODE == 2);
         uint32_t col[4];
-        bool slow[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t x = cur_px[q];
-            const uint32_t cell = ((x & 0xf0u) << 4) | ((x >> 8) & 0xf0u) | ((x >> 20) & 0xfu);
-            const uint32_t desc = s_desc[cell];
-            const uint32_t off = desc & 0xfffffu;
-            const int cnt = (int)(desc >> 20);
+            const uint32_t x = xq[q];
             int m0 = kBig, m1 = kBig, m2 = kBig;
-            for (int i = 0; i < cnt; i += 4) {
-                const uint4 c = *reinterpret_cast<const uint4 *>(&s_pool[off + i]);
-                cand_eval(x, c.x, i, m0, m1, m2);
-                cand_eval(x, c.y, i + 1, m0, m1, m2);
-                cand_eval(x, c.z, i + 2, m0, m1, m2);
-                cand_eval(x, c.w, i + 3, m0, m1, m2);
-            }
+            cand_eval<0>(x, ca[q].x, g.neg2, m0, m1, m2);
+            cand_eval<1>(x, ca[q].y, g.neg2, m0, m1, m2);
+            cand_eval<2>(x, ca[q].z, g.neg2, m0, m1, m2);
+            cand_eval<3>(x, ca[q].w, g.neg2, m0, m1, m2);
+            cand_eval<4>(x, cb[q].x, g.neg2, m0, m1, m2);
+            cand_eval<5>(x, cb[q].y, g.neg2, m0, m1, m2);
+            cand_eval<6>(x, cb[q].z, g.neg2, m0, m1, m2);
+            cand_eval<7>(x, cb[q].w, g.neg2, m0, m1, m2);
             const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
             const uint32_t d0 = (uint32_t)((m0 >> kIdxBits) + xx);
             const uint32_t d1 = (uint32_t)((m1 >> kIdxBits) + xx);
             const uint32_t d2 = (uint32_t)((m2 >> kIdxBits) + xx);
-            uint32_t a = s_pool[off + (m0 & IM)];  // colour reported as nearest
-            uint32_t b = s_pool[off + (m1 & IM)];  // colour reported as second
-            bool s = false;
+            uint32_t a = s_tab[blk[q] + (m0 & IM)];  // colour reported as nearest
+            uint32_t b = s_tab[blk[q] + (m1 & IM)];  // colour reported as second
+            bool s = slow[q];
             bool nearest = true;
             if (MODE == 0) {
                 if (d0 == d1) {
                     const uint32_t code = (pal.code1[x >> 4] >> ((x & 15u) * 2)) & 3u;
                     if (code == 1) a = b;
-                    else if (code == 2) a = s_pool[off + (m2 & IM)];
+                    else if (code == 2) a = s_tab[blk[q] + (m2 & IM)];
                     else if (code == 3) s = true;
                 }
             } else {
@@ -326,7 +352,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
                         a = b;
                         b = t;
                     } else if (code == 2) {
-                        b = s_pool[off + (m2 & IM)];
+                        b = s_tab[blk[q] + (m2 & IM)];
                     } else if (code == 3) {
                         s = true;
                     }
@@ -606,6 +632,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         g.ty0 = y0 % thr.th_h;
         g.tx0 = x0 % thr.th_w;
         g.aligned = (((uintptr_t)in_c | (uintptr_t)out_c) & 3) == 0;
+        g.neg2 = -(2 << kIdxBits);
         const uint32_t groups = (g.n_px + 3) / 4;
         const uint32_t blocks = (groups + kBlock - 1) / kBlock;
         uint32_t n_words = blocks * (kBlock / 64) * 4;
@@ -614,11 +641,11 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         int fix_mode;
         ProfMark *pm = prof_begin(s);
         const bool int_thr_ok = thr.m != nullptr && thr.th_h * thr.th_w <= 256;
-        if (integer && pal.cell_desc != nullptr) {
-            // v2: LDS cell lists + tie codes, persistent 1024-lane workgroups over 4096-pixel tiles
+        if (integer && pal.cell_tab != nullptr) {
+            // fast path: LDS cell table + tie codes, persistent 1024-lane workgroups over 4096-pixel tiles
             const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
             n_words = n_tiles * (kCellBlock / 64) * 4;
-            const size_t lds = sizeof(uint32_t) * (4096 + (size_t)pal.pool_entries + 256);
+            const size_t lds = sizeof(uint32_t) * ((size_t)pal.tab_words + 256);
             const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus());
             int rc;
             if (mode == DP_MODE_NEAREST) {

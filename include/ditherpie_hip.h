@@ -65,8 +65,9 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
                       dp_palette **out);
 void dp_palette_destroy(dp_palette *p);
 int dp_palette_info(const dp_palette *p, int *K, int *is_integer, int *n_nodes);
-/* search accelerator of the palette (per-cell candidate lists + tie codes): total list entries and the
- * longest list; both 0 when the palette runs on the brute-force kernels. */
+/* search accelerator of the palette (per-cell candidate lists + tie codes): size of the LDS table in
+ * 32-bit words and the longest exact candidate list; both 0 when the palette runs on the brute-force
+ * kernels. */
 int dp_palette_accel_info(const dp_palette *p, int *pool_entries, int *max_cell);
 
 /* Host-only (no GPU needed): the KD-tree build used by dp_palette_create, exported so that it can
