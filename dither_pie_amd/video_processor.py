@@ -1,0 +1,250 @@
+"""Drop-in counterpart of dither_pie's `video_processor` for the frame path, on MI355X.
+
+Same public names and call signatures as the reference module (video_processor.py:27-46, 98, 172-178,
+393-475, 547-577).  What changes is where frames are processed: the reference forks a
+multiprocessing.Pool of <= 4 workers per 15-frame batch and pickles the ditherer into each
+(video_processor.py:304-346); a HIP context must not cross fork(), and frames are independent, so here
+frames are processed IN PROCESS in batches that stay resident in HBM between the stages
+(NEAREST down-scale -> dither -> NEAREST up-scale, all through libditherpie_hip.so).
+ffmpeg/ffprobe remain external subprocesses exactly as in the reference (frame extraction to PNG,
+libx264 re-encode with audio/subtitle copy); that I/O is outside the hot path.
+Failure policy kept: a frame that fails is retried twice, then copied from the nearest good frame;
+the whole call returns False on any other error; progress_callback(fraction, message) gets the same
+milestones (0.0, 0.05, 0.1 ... 0.9, 1.0).
+"""
+from __future__ import annotations
+
+import shutil
+import subprocess
+import sys
+import tempfile
+from multiprocessing import cpu_count
+from pathlib import Path
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+from PIL import Image
+
+from .dithering_lib import ImageDitherer, PixelizeMethod
+
+__all__ = ["VideoProcessor", "pixelize_regular", "NeuralPixelizer", "process_frames"]
+
+
+def _even_dimensions(orig_w: int, orig_h: int, max_size: int) -> Tuple[int, int]:
+    """video_processor.py:547-560: the smaller side becomes max_size (made even), the other keeps the
+    aspect ratio, rounded and made even."""
+    small = max_size if max_size % 2 == 0 else max_size - 1
+    if orig_w >= orig_h:
+        other = int(round((orig_w / orig_h) * small))
+        return other + (other % 2), small
+    other = int(round((orig_h / orig_w) * small))
+    return small, other + (other % 2)
+
+
+class NeuralPixelizer:
+    """The GAN pixelizer (video_processor.py:478-545) is a separate model-inference workload whose
+    weights are not part of the repository; only the dimension helper is provided."""
+
+    _compute_even_dimensions = staticmethod(_even_dimensions)
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("neural pixelization is outside the MI355X backend's scope")
+
+
+def pixelize_regular(image: Image.Image, max_size: int) -> Image.Image:
+    """NEAREST down-scale to even dimensions (video_processor.py:563-577), on the GPU."""
+    import torch
+    from . import backend
+    tw, th = _even_dimensions(image.size[0], image.size[1], max_size)
+    arr = np.array(image.convert("RGB"), dtype=np.uint8)
+    out = backend.resize_nearest(torch.from_numpy(arr).cuda(), th, tw)
+    return Image.fromarray(out.cpu().numpy(), "RGB")
+
+
+def _final_size(w: int, h: int, multiplier: int) -> Tuple[int, int]:
+    """video_processor.py:408-415: integer multiple, bumped to even for yuv420p."""
+    nw, nh = w * multiplier, h * multiplier
+    return nw + (nw % 2), nh + (nh % 2)
+
+
+def _apply_final_resize_to_frame(image: Image.Image, multiplier: int) -> Image.Image:
+    """video_processor.py:393-420"""
+    import torch
+    from . import backend
+    nw, nh = _final_size(image.size[0], image.size[1], multiplier)
+    arr = np.array(image.convert("RGB"), dtype=np.uint8)
+    out = backend.resize_nearest(torch.from_numpy(arr).cuda(), nh, nw)
+    return Image.fromarray(out.cpu().numpy(), "RGB")
+
+
+def process_frames(frames, ditherer: ImageDitherer, pixelize_method: Optional[str] = None, max_size: int = 64,
+                   final_resize_multiplier: Optional[int] = None):
+    """The per-frame pipeline of _process_single_frame (video_processor.py:423-475) for a batch of
+    equally sized frames resident in HBM: uint8 CUDA tensor [N,H,W,3] -> uint8 CUDA tensor [N,H',W',3]."""
+    from . import backend
+    if pixelize_method in (PixelizeMethod.NEURAL.value, "neural"):
+        raise NotImplementedError("neural pixelization is outside the MI355X backend's scope")
+    x = frames
+    if pixelize_method in (PixelizeMethod.REGULAR.value, "regular"):
+        tw, th = _even_dimensions(x.shape[2], x.shape[1], max_size)
+        x = backend.resize_nearest(x, th, tw)
+    x = ditherer.apply_dithering_frames(x)
+    if final_resize_multiplier:
+        nw, nh = _final_size(x.shape[2], x.shape[1], final_resize_multiplier)
+        x = backend.resize_nearest(x, nh, nw)
+    return x
+
+
+def _process_single_frame(frame_path: Path, ditherer: ImageDitherer, pixelize_method: Optional[str] = None,
+                          max_size: int = 64, final_resize_multiplier: Optional[int] = None) -> bool:
+    """One PNG in place; True on success, False (with a message on stderr) on any error
+    (video_processor.py:423-475)."""
+    try:
+        import torch
+        frame_path = Path(frame_path)
+        arr = np.array(Image.open(frame_path).convert("RGB"), dtype=np.uint8)
+        out = process_frames(torch.from_numpy(arr).cuda().unsqueeze(0), ditherer, pixelize_method, max_size,
+                             final_resize_multiplier)
+        Image.fromarray(out[0].cpu().numpy(), "RGB").save(frame_path)
+        if not frame_path.exists() or frame_path.stat().st_size == 0:
+            raise ValueError(f"Frame {frame_path} not saved properly")
+        return True
+    except Exception as e:  # noqa: BLE001 - the reference swallows everything here too
+        print(f"Error processing frame {frame_path}: {e}", file=sys.stderr)
+        return False
+
+
+class VideoProcessor:
+    """video_processor.py:27-390"""
+
+    def __init__(self, num_workers: Optional[int] = None,
+                 progress_callback: Optional[Callable[[float, str], None]] = None):
+        if num_workers is None:
+            num_workers = min(4, max(1, cpu_count() - 1))
+        self.num_workers = num_workers  # kept for interface compatibility; frames batch on the GPU instead
+        self.progress_callback = progress_callback
+
+    def _report_progress(self, fraction: float, message: str):
+        if self.progress_callback:
+            self.progress_callback(fraction, message)
+
+    def _fix_failed_frames(self, failed_frames: list, all_frames: list):
+        """Copy the nearest good frame (previous first, then next) over each failed one
+        (video_processor.py:53-96)."""
+        bad = set(failed_frames)
+        for f in failed_frames:
+            if f not in all_frames:
+                print(f"Could not find index for {f.name}", file=sys.stderr)
+                continue
+            i = all_frames.index(f)
+            order = list(range(i - 1, -1, -1)) + list(range(i + 1, len(all_frames)))
+            src = next((all_frames[j] for j in order if all_frames[j] not in bad and all_frames[j].exists()), None)
+            if src is None:
+                print(f"ERROR: Could not find any successful frame to copy for {f.name}", file=sys.stderr)
+                continue
+            try:
+                shutil.copy2(src, f)
+                print(f"Fixed {f.name} by copying from {src.name}", file=sys.stderr)
+            except Exception as e:  # noqa: BLE001
+                print(f"Failed to copy frame {src.name} to {f.name}: {e}", file=sys.stderr)
+
+    def get_video_info(self, video_path: str) -> dict:
+        """fps / width / height / duration / frame_count via ffprobe, with the reference's defaults when
+        probing fails (video_processor.py:98-170)."""
+        def probe(entries):
+            r = subprocess.run(["ffprobe", "-v", "error", "-select_streams", "v:0", "-show_entries",
+                                f"stream={entries}", "-of", "default=nokey=1:noprint_wrappers=1", video_path],
+                               capture_output=True, text=True, check=True)
+            return r.stdout.strip()
+        try:
+            rate = probe("r_frame_rate")
+            if "/" in rate:
+                a, b = rate.split("/")
+                fps = float(a) / float(b)
+            else:
+                fps = float(rate) if rate else 30.0
+            dims = probe("width,height").split("\n")
+            width = int(dims[0]) if len(dims) > 0 else 1920
+            height = int(dims[1]) if len(dims) > 1 else 1080
+            duration = frame_count = None
+            for line in probe("duration,nb_frames").split("\n"):
+                if line and line != "N/A":
+                    try:
+                        v = float(line)
+                    except ValueError:
+                        continue
+                    if v > 100:
+                        frame_count = int(v)
+                    else:
+                        duration = v
+            if frame_count is None and duration is not None:
+                frame_count = int(duration * fps)
+            return {"fps": fps, "width": width, "height": height, "duration": duration, "frame_count": frame_count}
+        except Exception as e:  # noqa: BLE001
+            print(f"Warning: Could not get video info: {e}", file=sys.stderr)
+            return {"fps": 30.0, "width": 1920, "height": 1080, "duration": None, "frame_count": None}
+
+    def _process_batch(self, files, ditherer, pixelize_method, max_size, final_resize_multiplier):
+        """One batch of PNG files through the GPU; returns the list of files that failed."""
+        import torch
+        try:
+            arrs = [np.array(Image.open(f).convert("RGB"), dtype=np.uint8) for f in files]
+            if len({a.shape for a in arrs}) != 1:
+                raise ValueError("frames of one batch differ in size")
+            out = process_frames(torch.from_numpy(np.stack(arrs)).cuda(), ditherer, pixelize_method, max_size,
+                                 final_resize_multiplier).cpu().numpy()
+            for f, o in zip(files, out):
+                Image.fromarray(o, "RGB").save(f)
+                if not f.exists() or f.stat().st_size == 0:
+                    raise ValueError(f"Frame {f} not saved properly")
+            return []
+        except Exception as e:  # noqa: BLE001
+            print(f"Batch failed ({e}); retrying frame by frame", file=sys.stderr)
+        failed = []
+        for f in files:
+            if not any(_process_single_frame(f, ditherer, pixelize_method, max_size, final_resize_multiplier)
+                       for _ in range(3)):
+                failed.append(f)
+        return failed
+
+    def process_video_streaming(self, input_path: str, output_path: str, ditherer: ImageDitherer,
+                                pixelize_func=None, batch_size: int = 15,
+                                final_resize_multiplier: Optional[int] = None) -> bool:
+        """video_processor.py:172-390; pixelize_func is the reference's tuple (method_str, max_size) or None."""
+        try:
+            info = self.get_video_info(input_path)
+            fps = info["fps"]
+            self._report_progress(0.0, "Initializing video processing...")
+            with tempfile.TemporaryDirectory() as tmp:
+                tmp_dir = Path(tmp)
+                self._report_progress(0.05, "Extracting frames...")
+                pattern = str(tmp_dir / "frame_%05d.png")
+                subprocess.run(["ffmpeg", "-i", input_path, "-qscale:v", "2", pattern], stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, check=True)
+                frames = sorted(tmp_dir.glob("frame_*.png"))
+                total = len(frames)
+                if total == 0:
+                    raise ValueError("No frames extracted from video")
+                self._report_progress(0.1, f"Processing {total} frames...")
+                method, max_size = (None, 64) if pixelize_func is None else pixelize_func
+                failed, done = [], 0
+                for lo in range(0, total, batch_size):
+                    batch = frames[lo:lo + batch_size]
+                    failed += self._process_batch(batch, ditherer, method, max_size, final_resize_multiplier)
+                    done += len(batch)
+                    self._report_progress(0.1 + 0.8 * (done / total), f"Processed {done}/{total} frames")
+                if failed:
+                    print(f"Fixing {len(failed)} failed frames by copying from nearest frames...", file=sys.stderr)
+                    self._fix_failed_frames(failed, frames)
+                self._report_progress(0.9, "Encoding final video...")
+                subprocess.run(["ffmpeg", "-y", "-framerate", f"{fps:.5f}", "-i", pattern, "-i", input_path,
+                                "-map", "0:v:0", "-map", "1:a?", "-map", "1:s?", "-c:v", "libx264", "-preset",
+                                "medium", "-crf", "18", "-pix_fmt", "yuv420p", "-vframes", str(total), "-c:a", "copy",
+                                "-c:s", "copy", output_path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               check=True)
+                self._report_progress(1.0, "Video processing complete!")
+                return True
+        except Exception as e:  # noqa: BLE001
+            self._report_progress(1.0, f"Error: {str(e)}")
+            print(f"Video processing error: {e}", file=sys.stderr)
+            return False

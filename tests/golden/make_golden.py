@@ -239,6 +239,27 @@ def main():
     for n in (2, 8, 16, 27, 64, 256):
         npz[f"uniform_{n}"] = np.array(dl.ColorReducer.generate_uniform_palette(n), np.int32)
 
+    # ---- median cut (ColorReducer.reduce_colors, dithering_lib.py:1813-1843) incl. the palette=None paths
+    mc = {}
+    for nm, arr in {"rnd40x50": rnd(40, 50, 41), "grad64x96": grad(64, 96)}.items():
+        for n in (1, 2, 8, 16, 20):
+            mc[f"{nm}_{n}"] = [list(map(int, c)) for c in dl.ColorReducer.reduce_colors(Image.fromarray(arr), n)]
+    kat["misc"]["median_cut"] = mc
+    for gamma in (False, True):
+        d = dl.ImageDitherer(8, dl.DitherMode.BAYER, None, gamma, {"size": "4x4"})
+        arr = rnd(48, 64, 17)
+        out = np.array(d.apply_dithering(Image.fromarray(arr)))
+        kat["misc"][f"auto_palette_gamma{int(gamma)}"] = dict(palette=[list(map(int, c)) for c in d.palette], h_out=H(out))
+
+    # ---- video helpers (video_processor.py:547-560, 408-415)
+    import video_processor as vp
+    kat["misc"]["even_dims"] = [[a, b, c, list(vp.NeuralPixelizer._compute_even_dimensions(a, b, c))]
+                                for a, b, c in [(1920, 1080, 64), (1080, 1920, 65), (300, 300, 33), (641, 359, 64),
+                                                (100, 37, 17), (37, 100, 128)]]
+    img = Image.fromarray(rnd(37, 53, 5))
+    npz["pixelize_regular_37x53_to16"] = np.array(vp.pixelize_regular(img, 16))
+    npz["final_resize_37x53_x3"] = np.array(vp._apply_final_resize_to_frame(img, 3))
+
     # ---- strategy parameter metadata (drop-in boundary)
     meta = {}
     for m in dl.DitherMode:

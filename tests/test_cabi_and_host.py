@@ -1,0 +1,205 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/ditherpie_hip.h declares (no compute
+calls), and the host-side logic of the drop-in mirror matches the golden fixtures / the oracle."""
+import ctypes as C
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import dither_pie_amd
+    if not os.path.exists(dither_pie_amd._lib.LIB_PATH):
+        dither_pie_amd.build()
+    return dither_pie_amd.load()
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "ditherpie_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from dither_pie_amd import _lib
+    declared = _header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in the header but not exported"
+    assert sorted(_lib.EXPORTS) == declared, "ctypes signature table and header disagree"
+    assert lib.dp_version() >= 100
+
+
+def test_error_reporting_without_gpu(lib):
+    # argument errors are detected before any HIP call
+    from dither_pie_amd._lib import DP_EINVAL
+    assert lib.dp_palette_info(None, None, None, None) == DP_EINVAL
+    assert b"NULL" in lib.dp_last_error()
+    assert lib.dp_ordered_workspace_bytes(24, 2160, 3840) >= 24 * 2160 * 3840 // 8
+
+
+def test_product_kdtree_build_matches_golden_and_scipy(lib, gold, kat):
+    def build(P):
+        P = np.ascontiguousarray(P, np.float64)
+        K = len(P)
+        n = 2 * K + 2
+        idx = np.zeros(K, np.int32)
+        sd, st, en, le, gr = (np.zeros(n, np.int32) for _ in range(5))
+        sp = np.zeros(n, np.float64)
+        nn = C.c_int()
+        rc = lib.dp_kdtree_build_host(P.ctypes.data, K, idx.ctypes.data, sd.ctypes.data, sp.ctypes.data, st.ctypes.data,
+                                      en.ctypes.data, le.ctypes.data, gr.ctypes.data, C.byref(nn))
+        assert rc == 0
+        m = nn.value
+        return idx, sd[:m], sp[:m], st[:m], en[:m], le[:m], gr[:m]
+
+    for nm in kat["misc"]["tree_palettes"]:
+        idx, sd, sp, st, en, le, gr = build(gold[f"tree_{nm}_pts"])
+        nodes = gold[f"tree_{nm}_nodes"]
+        assert np.array_equal(idx, gold[f"tree_{nm}_indices"]), nm
+        assert np.array_equal(sd, nodes[:, 0]) and np.array_equal(st, nodes[:, 1]) and np.array_equal(en, nodes[:, 2])
+        assert np.array_equal(le, nodes[:, 3]) and np.array_equal(gr, nodes[:, 4])
+        inner = nodes[:, 0] >= 0
+        assert np.array_equal(sp[inner], gold[f"tree_{nm}_splits"][inner])
+    sp_spatial = pytest.importorskip("scipy.spatial")
+    rs = np.random.RandomState(11)
+    for trial in range(40):
+        K = int(rs.randint(1, 257))
+        P = (rs.randint(0, 256, (K, 3)) if trial % 2 else rs.randint(0, 6, (K, 3)) * 51).astype(np.float64)
+        assert np.array_equal(build(P)[0], np.asarray(sp_spatial.cKDTree(P, leafsize=10).indices))
+
+
+def test_enums_tables_and_tap_tables(orc, gold, kat):
+    from dither_pie_amd import dithering_lib as d
+    assert {m.name: m.value for m in d.DitherMode} == kat["misc"]["dither_modes"]
+    assert d.DitherMode("IGN") is d.DitherMode.INTERLEAVED_GRADIENT_NOISE
+    for name in ["BAYER2x2", "BAYER4x4", "BAYER8x8", "BAYER16x16", "PSX4x4"]:
+        m = getattr(d.DitherUtils, name)
+        assert m.dtype == np.float32 and np.array_equal(m, gold["table_" + name])
+    assert np.array_equal(d.DitherUtils.get_threshold_matrix(d.DitherMode.NONE), np.ones((1, 1), np.float32))
+    with pytest.raises(ValueError):
+        d.DitherUtils.get_threshold_matrix(d.DitherMode.HALFTONE)
+    for k, (taps, div) in orc.ED_KERNELS.items():
+        kk = d.ErrorDiffusionKernel.get_kernel(k)
+        assert kk["weights"] == taps and kk["divisor"] == div
+    assert d.ErrorDiffusionKernel.get_kernel("nope") is d.ErrorDiffusionKernel.FLOYD_STEINBERG
+    assert d.ErrorDiffusionKernel.list_kernels() == list(orc.ED_KERNELS)
+
+
+def test_parameter_metadata_matches_reference(kat):
+    from dither_pie_amd import dithering_lib as d
+    ref = kat["misc"]["mode_parameters"]
+    for mode in (d.DitherMode.BAYER, d.DitherMode.BLUE_NOISE, d.DitherMode.INTERLEAVED_GRADIENT_NOISE,
+                 d.DitherMode.ERROR_DIFFUSION):
+        assert d.ImageDitherer.get_mode_parameters(mode) == ref[mode.value]
+        assert d.ImageDitherer.mode_has_parameters(mode)
+    assert d.ImageDitherer.get_mode_parameters(d.DitherMode.NONE) is None and ref["none"] is None
+
+
+def test_strategy_construction_and_errors():
+    from dither_pie_amd import dithering_lib as d
+    it = d.ImageDitherer(16, d.DitherMode.BAYER, [(0, 0, 0), (255, 255, 255)], False, {"size": "8x8"})
+    s = it._get_dither_strategy(it.dither_mode)
+    assert isinstance(s, d.BayerDitherStrategy) and s.get_current_parameters() == {"size": "8x8"}
+    s = d.ImageDitherer(dither_mode=d.DitherMode.ERROR_DIFFUSION)._get_dither_strategy(d.DitherMode.ERROR_DIFFUSION)
+    assert s.get_current_parameters() == {"variant": "atkinson", "serpentine": "false"}
+    with pytest.raises(TypeError):  # unknown parameter -> TypeError from the constructor, as in the reference
+        d.ImageDitherer(dither_params={"bogus": 1})._get_dither_strategy(d.DitherMode.BAYER)
+    with pytest.raises(ValueError):
+        d.ImageDitherer()._get_dither_strategy("not a mode")
+    with pytest.raises(NotImplementedError):
+        d.ImageDitherer()._get_dither_strategy(d.DitherMode.HALFTONE)
+    blob = pickle.dumps(it)
+    assert len(blob) < 600 and pickle.loads(blob).dither_params == {"size": "8x8"}
+
+
+def test_palette_preparation_and_gamma_tables(orc, gold):
+    from dither_pie_amd import _tables, dithering_lib as d
+    assert np.array_equal(_tables.LUT_IN, gold["lut_in"]) and np.array_equal(_tables.LUT_OUT, gold["lut_out"])
+    assert np.array_equal(_tables.PAL_LIN, gold["pal_lin_table"])
+    for pal in (orc.palr(256), orc.generate_uniform_palette(16), [(0, 0, 0)]):
+        for gamma in (False, True):
+            a, b = d.prepare_palette(pal, gamma), orc.prepare_palette(pal, gamma)
+            for x, y in zip(a, b):
+                assert (x is None and y is None) or np.array_equal(x, y)
+
+
+def test_palette_producers(orc, gold, kat):
+    from PIL import Image
+    from dither_pie_amd.dithering_lib import ColorReducer
+    for n in (0, 1, 2, 8, 16, 27, 64, 100, 256):
+        assert ColorReducer.generate_uniform_palette(n) == orc.generate_uniform_palette(n)
+    for n in (2, 8, 16, 27, 64, 256):
+        assert np.array_equal(np.array(ColorReducer.generate_uniform_palette(n), np.int32), gold[f"uniform_{n}"])
+    imgs = {"rnd40x50": orc.rnd(40, 50, 41), "grad64x96": orc.grad(64, 96)}
+    for key, ref in kat["misc"]["median_cut"].items():
+        nm, n = key.rsplit("_", 1)
+        got = ColorReducer.reduce_colors(Image.fromarray(imgs[nm]), int(n))
+        assert [list(map(int, c)) for c in got] == ref, key
+    assert ColorReducer.median_cut([], 3) == [(0, 0, 0)]
+
+
+def test_video_helpers(kat):
+    from dither_pie_amd import video_processor as v
+    for a, b, c, ref in kat["misc"]["even_dims"]:
+        assert list(v.NeuralPixelizer._compute_even_dimensions(a, b, c)) == ref
+        assert list(v._even_dimensions(a, b, c)) == ref
+    assert v._final_size(53, 37, 3) == (160, 112)
+    seen = []
+    vp = v.VideoProcessor(progress_callback=lambda f, m: seen.append((f, m)))
+    assert vp.process_video_streaming("/nonexistent/in.mp4", "/tmp/out.mp4", None) is False  # no ffmpeg / no file
+    assert seen[0][0] == 0.0 and seen[-1][0] == 1.0 and seen[-1][1].startswith("Error")
+    info = vp.get_video_info("/nonexistent/in.mp4")
+    assert info == {"fps": 30.0, "width": 1920, "height": 1080, "duration": None, "frame_count": None}
+
+
+def test_fix_failed_frames_copies_nearest(tmp_path):
+    from dither_pie_amd.video_processor import VideoProcessor
+    files = []
+    for i in range(5):
+        f = tmp_path / f"frame_{i:05d}.png"
+        f.write_bytes(bytes([i]) * 10)
+        files.append(f)
+    VideoProcessor()._fix_failed_frames([files[0], files[3]], files)
+    assert files[0].read_bytes() == files[1].read_bytes() == bytes([1]) * 10  # no previous: take the next good one
+    assert files[3].read_bytes() == bytes([2]) * 10                            # previous good frame
+
+
+def test_sharding_helpers():
+    from dither_pie_amd import sharding as s
+    for n, world in [(1000, 8), (7, 3), (3, 8), (0, 2)]:
+        blocks = [s.shard_range(n, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        assert max(hi - lo for lo, hi in blocks) - min(hi - lo for lo, hi in blocks) <= 1
+    assert s.row_bands(4320, 8) == [(i * 540, (i + 1) * 540) for i in range(8)]
+    with pytest.raises(ValueError):
+        s.shard_range(10, 3, 2)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    from dither_pie_amd import DitherPieError, backend
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(DitherPieError):
+        backend.Palette(np.zeros((2, 3), np.float32), np.zeros((2, 3), np.uint8))
+
+
+def test_product_never_imports_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import dither_pie_amd, dither_pie_amd.dithering_lib, "
+            "dither_pie_amd.video_processor, dither_pie_amd.kmeans, dither_pie_amd.sharding, dither_pie_amd.backend; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'") % ROOT
+    subprocess.check_call([sys.executable, "-c", code])
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dither_pie_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".cuh")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "from oracle" not in src and "import oracle" not in src and "dp_oracle" not in src, f

@@ -1,0 +1,96 @@
+"""CPU tier: the N>1 path (k-means exchange, frame/row-band partition) with world_size-2 gloo.
+
+The device kernel is replaced by the oracle's Lloyd pass as `step_fn` (the checker standing in for the
+kernel, in tests only); what is under test is the host logic: packing of the integer totals, the single
+all-reduce per iteration, the seeding sample gathered from sharded bands, and rank-count independence."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_step(px, centers):
+    import torch
+    from oracle import oracle as orc
+    p = px.reshape(-1, 3).cpu().numpy()
+    c = centers.cpu().numpy()
+    sums, counts, _ = orc.kmeans_step(p, c)
+    sq = np.zeros(len(c), np.int64)
+    x = p.astype(np.int64)
+    d = ((x[:, None, :] - c[None, :, :]) ** 2).sum(2)
+    lab = d.argmin(1)
+    np.add.at(sq, lab, (x * x).sum(1))
+    return torch.from_numpy(sums), torch.from_numpy(counts), torch.from_numpy(sq)
+
+
+def _worker(rank, world, port, h, w, K, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dither_pie_amd import kmeans, sharding
+        from oracle import oracle as orc
+        img = orc.rnd(h, w, 77)
+        lo, hi = sharding.shard_range(h, rank, world)
+        band = torch.from_numpy(np.ascontiguousarray(img[lo:hi]))
+        sample = kmeans.seed_sample(band, h * w, lo * w, 42)
+        init = kmeans.kmeans_plusplus(sample, K, np.random.RandomState(42))
+        centers, inertia, n_iter = kmeans.lloyd(band, init, step_fn=_oracle_step)
+        q.put((rank, centers, inertia, n_iter, sample))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_kmeans_two_ranks_equal_one_rank():
+    import torch
+    import torch.multiprocessing as mp
+    from dither_pie_amd import kmeans
+    from oracle import oracle as orc
+    h, w, K = 120, 101, 8   # 12120 px > 10000: the seeding sample is a strict subset
+    img = orc.rnd(h, w, 77)
+    full = torch.from_numpy(img)
+    sample1 = kmeans.seed_sample(full, h * w, 0, 42)
+    init = kmeans.kmeans_plusplus(sample1, K, np.random.RandomState(42))
+    c1, i1, n1 = kmeans.lloyd(full, init, step_fn=_oracle_step)
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, h, w, K, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, c, i, n, sample in res:
+        assert np.array_equal(sample, sample1)
+        assert np.array_equal(c, c1), "centres must be byte-identical for any rank count"
+        assert i == i1 and n == n1
+    # and the host loop agrees with the oracle's own Lloyd from the same start
+    c_or, i_or, _ = orc.kmeans_lloyd(img.reshape(-1, 3), init)
+    assert np.abs(c_or - c1).max() < 1e-9 and abs(i_or - i1) <= 1e-9 * i_or
+
+
+def test_lloyd_matches_sklearn_fixture_from_same_init(gold, kat):
+    import torch
+    from dither_pie_amd import kmeans
+    from oracle import oracle as orc
+    m = kat["misc"]["km16"]
+    arr = orc.grad(m["h"], m["w"])
+    px = arr.reshape(-1, 3)
+    init = px[gold["km16_init_idx"]].astype(np.float64)
+    centers, inertia, n_iter = kmeans.lloyd(torch.from_numpy(px), init, step_fn=_oracle_step)
+    assert np.abs(centers - gold["km16_centers"]).max() < 1e-6
+    assert abs(inertia - m["inertia"]) <= 1e-6 * m["inertia"]

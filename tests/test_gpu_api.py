@@ -1,0 +1,175 @@
+"""GPU tier: the drop-in classes (ImageDitherer, strategies, ColorReducer, VideoProcessor helpers) end to end
+against the reference-generated fixtures and the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import GOLDEN, case_input, case_palette
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, "kat.json")) as _f:
+    _KAT = json.load(_f)
+
+
+@pytest.fixture(scope="module")
+def d():
+    import torch
+    assert torch.cuda.is_available()
+    from dither_pie_amd import dithering_lib
+    return dithering_lib
+
+
+@pytest.mark.parametrize("case", _KAT["cases"], ids=lambda c: c["name"])
+def test_image_ditherer_matches_reference(d, orc, gold, case):
+    arr = case_input(orc, case["input"])
+    pal = case_palette(orc, case["palette"])
+    it = d.ImageDitherer(len(pal), d.DitherMode(case["mode"]), pal, case["gamma"], dict(case["params"]))
+    out = np.array(it.apply_dithering(Image.fromarray(arr)))
+    assert out.dtype == np.uint8 and out.shape == arr.shape
+    if case["full"]:
+        assert np.array_equal(out, gold["out_" + case["name"]])
+    assert orc.H(out) == case["h_out"]
+
+
+def test_palette_none_uses_median_cut_and_keeps_it(d, orc, kat):
+    for gamma in (False, True):
+        ref = kat["misc"][f"auto_palette_gamma{int(gamma)}"]
+        it = d.ImageDitherer(8, d.DitherMode.BAYER, None, gamma, {"size": "4x4"})
+        out = np.array(it.apply_dithering(Image.fromarray(orc.rnd(48, 64, 17))))
+        assert [list(map(int, c)) for c in it.palette] == ref["palette"]
+        assert orc.H(out) == ref["h_out"]
+
+
+def test_strategy_contract(d, orc):
+    arr = orc.grad(37, 53)
+    pal = np.array(orc.palr(40, 3), np.float32)
+    px = arr.reshape(-1, 3).astype(np.float32)
+    for strat, mode, params in [(d.NoDitherStrategy(), "none", {}), (d.BayerDitherStrategy("8x8"), "bayer", {"size": "8x8"}),
+                                (d.InterleavedGradientNoiseDitherStrategy(2.0, 7), "IGN", {"scale": 2.0, "seed": 7}),
+                                (d.BlueNoiseDitherStrategy(32, 1), "blue_noise", {"size": 32, "seed": 1}),
+                                (d.ErrorDiffusionDitherStrategy("sierra", "true"), "error_diffusion",
+                                 {"variant": "sierra", "serpentine": "true"}),
+                                (d.MatrixDitherStrategy(np.linspace(0, 1, 35, dtype=np.float32).reshape(5, 7)), None, None)]:
+        out = strat.dither(px, pal, (37, 53))
+        assert out.shape == px.shape and out.dtype == np.float32
+        if mode is not None:
+            ref = orc.apply_dithering(arr, [tuple(int(v) for v in c) for c in pal], mode, params)
+            assert np.array_equal(out.astype(np.uint8).reshape(arr.shape), ref), mode
+        else:
+            pf, oc, _ = orc.prepare_palette(pal.tolist(), False)
+            ref = orc.ordered_u8(arr, pf, oc, None, "matrix", thr=strat.threshold_matrix)
+            assert np.array_equal(out.astype(np.uint8).reshape(arr.shape), ref)
+    with pytest.raises(ValueError):
+        d.NoDitherStrategy().dither(px + 0.5, pal, (37, 53))
+    # non-integer (linearised) palettes keep their float rows in the strategy-level API
+    lin = np.array(orc.prepare_palette(orc.palr(16), True)[0])
+    out = d.NoDitherStrategy().dither(px, lin, (37, 53))
+    assert set(map(tuple, np.unique(out, axis=0))) <= set(map(tuple, lin))
+
+
+def test_generate_blue_noise_and_ign_helpers(d, gold):
+    assert np.array_equal(d.generate_blue_noise(32, 42), gold["blue_32_42"])
+    s = d.InterleavedGradientNoiseDitherStrategy(2.5, 17)
+    assert np.array_equal(s._generate_thresholds((37, 53)), gold["ign_37x53_s25_seed17"])
+
+
+def test_frames_api_tiles_and_pickle(d, orc):
+    import pickle
+    import torch
+    pal = orc.palr(64, 9)
+    it = pickle.loads(pickle.dumps(d.ImageDitherer(64, d.DitherMode.BLUE_NOISE, pal, False, {"size": 32, "seed": 3})))
+    frames = np.stack([orc.rnd(50, 70, s) for s in range(4)])
+    out = it.apply_dithering_frames(torch.from_numpy(frames).cuda()).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(out[i], orc.apply_dithering(frames[i], pal, "blue_noise", {"size": 32, "seed": 3}))
+    big = orc.grad(90, 64)
+    full = orc.apply_dithering(big, pal, "blue_noise", {"size": 32, "seed": 3})
+    from dither_pie_amd import sharding
+    for lo, hi in sharding.row_bands(90, 4):
+        band = sharding.dither_band(it, torch.from_numpy(np.ascontiguousarray(big[lo:hi])).cuda(), lo)
+        assert np.array_equal(band.cpu().numpy(), full[lo:hi])
+    with pytest.raises(ValueError):
+        d.ImageDitherer(16, d.DitherMode.ERROR_DIFFUSION, pal).apply_dithering_frames(torch.from_numpy(big).cuda(), y0=4)
+    with pytest.raises(NotImplementedError):
+        d.ImageDitherer(16, d.DitherMode.HALFTONE, pal).apply_dithering(Image.fromarray(big))
+
+
+def test_too_many_colours_is_reported(d, orc):
+    from dither_pie_amd import DitherPieError
+    pal = orc.palr(300, 1)
+    with pytest.raises(DitherPieError):
+        d.ImageDitherer(300, d.DitherMode.NONE, pal).apply_dithering(Image.fromarray(orc.rnd(8, 8, 1)))
+
+
+def test_kmeans_gpu_matches_sklearn_fixture_and_oracle(d, orc, gold, kat):
+    import torch
+    from dither_pie_amd import kmeans
+    for nm in ("km8", "km16", "km32"):
+        m = kat["misc"][nm]
+        arr = orc.rnd(m["h"], m["w"], m["seed"]) if m["kind"] == "rnd" else orc.grad(m["h"], m["w"])
+        px = arr.reshape(-1, 3)
+        init = px[gold[f"{nm}_init_idx"]].astype(np.float64)
+        centers, inertia, n_iter = kmeans.lloyd(torch.from_numpy(px).cuda(), init)
+        assert np.abs(centers - gold[f"{nm}_centers"]).max() < 1e-6
+        assert abs(inertia - m["inertia"]) <= 1e-6 * m["inertia"]
+        c_or, i_or, n_or = orc.kmeans_lloyd(px, init)
+        assert np.abs(centers - c_or).max() < 1e-9
+        diff = np.abs(centers.astype(int) - gold[f"{nm}_palette"])
+        assert diff.max() <= 1 and (diff > 0).mean() <= 0.05
+
+
+def test_generate_kmeans_palette_quality_and_determinism(d, orc):
+    """A.6 (ii): inertia over the full image <= 1.01 x the inertia of an sklearn-style fit on a 10k sample."""
+    arr = np.concatenate([orc.grad(150, 200), orc.rnd(150, 200, 3) // 2 + 60], axis=0)
+    img = Image.fromarray(arr)
+    p1 = d.ColorReducer.generate_kmeans_palette(img, 16)
+    p2 = d.ColorReducer.generate_kmeans_palette(img, 16, random_state=42)
+    assert p1 == p2 and len(p1) == 16 and all(len(c) == 3 and all(isinstance(v, int) for v in c) for c in p1)
+    px = arr.reshape(-1, 3)
+
+    def inertia(pal):
+        P = np.array(pal, np.float64)
+        return float((((px[:, None, :].astype(np.float64) - P[None]) ** 2).sum(2)).min(1).sum())
+
+    rs = np.random.RandomState(0)
+    sample = px[rs.choice(len(px), 10000, replace=False)]
+    c_ref, _, _ = orc.kmeans_lloyd(sample, orc.kmeans_plusplus(sample, 16, np.random.RandomState(42)))
+    assert inertia(p1) <= 1.01 * inertia(c_ref.astype(int))
+
+
+def test_video_frame_pipeline(d, orc, gold, tmp_path):
+    import torch
+    from dither_pie_amd import video_processor as v
+    img = Image.fromarray(orc.rnd(37, 53, 5))
+    assert np.array_equal(np.array(v.pixelize_regular(img, 16)), gold["pixelize_regular_37x53_to16"])
+    assert np.array_equal(np.array(v._apply_final_resize_to_frame(img, 3)), gold["final_resize_37x53_x3"])
+    pal = orc.generate_uniform_palette(16)
+    it = d.ImageDitherer(16, d.DitherMode.BAYER, pal, False, {"size": "4x4"})
+    frames = np.stack([orc.rnd(60, 80, s) for s in range(3)])
+    out = v.process_frames(torch.from_numpy(frames).cuda(), it, "regular", 16, 2).cpu().numpy()
+    for i in range(3):
+        small = np.array(Image.fromarray(frames[i]).resize(v._even_dimensions(80, 60, 16), Image.NEAREST))
+        dith = orc.apply_dithering(small, pal, "bayer", {"size": "4x4"})
+        ref = np.array(Image.fromarray(dith).resize(v._final_size(dith.shape[1], dith.shape[0], 2), Image.NEAREST))
+        assert np.array_equal(out[i], ref)
+    # the PNG worker, in place
+    f = tmp_path / "frame_00001.png"
+    Image.fromarray(frames[0]).save(f)
+    assert v._process_single_frame(f, it, "regular", 16, 2) is True
+    assert np.array_equal(np.array(Image.open(f)), out[0])
+    assert v._process_single_frame(tmp_path / "missing.png", it) is False
+    # a batch through VideoProcessor's batch helper, with one unreadable file -> retried, then reported failed
+    files = []
+    for i in range(3):
+        p = tmp_path / f"b_{i:05d}.png"
+        Image.fromarray(frames[i]).save(p)
+        files.append(p)
+    bad = tmp_path / "b_00003.png"
+    bad.write_bytes(b"not a png")
+    failed = v.VideoProcessor()._process_batch(files + [bad], it, None, 64, None)
+    assert failed == [bad]
+    assert np.array_equal(np.array(Image.open(files[1])), orc.apply_dithering(frames[1], pal, "bayer", {"size": "4x4"}))
