@@ -537,25 +537,39 @@ __global__ void ign_field_kernel(float *__restrict__ out, const int h, const int
     if (x < w && y < h) out[(size_t)y * w + x] = ign_threshold(x0 + x, y0 + y, sx, sy, sc);
 }
 
-__global__ void resize_nearest_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int h,
-                                      const int w, const int oh, const int ow, const double sy, const double sx)
+// Pillow's NEAREST resize (ImagingScaleAffine): the source index of output column x is int(xo_x) with
+// xo_0 = 0.5*scale and xo_{x+1} = xo_x + scale ACCUMULATED in double -- not (x+0.5)*scale, which differs
+// whenever the product is an exact integer.  Thread 0 builds the column table, thread 1 the row table.
+__global__ void resize_tables_kernel(int *__restrict__ xtab, int *__restrict__ ytab, const int w, const int ow,
+                                     const int h, const int oh)
 {
-    // Pillow NEAREST (Resample.c / Geometry.c nearest filter): source = floor((dst + 0.5) * scale)
+    const int which = threadIdx.x;
+    if (which > 1) return;
+    const int n_in = which ? h : w, n_out = which ? oh : ow;
+    int *tab = which ? ytab : xtab;
+    const double a = (double)n_in / (double)n_out;
+    double xo = __dmul_rn(a, 0.5);
+    for (int x = 0; x < n_out; ++x) {
+        int v = (int)xo;
+        tab[x] = v < n_in ? v : n_in - 1;
+        xo = __dadd_rn(xo, a);
+    }
+}
+
+__global__ void resize_nearest_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int h,
+                                      const int w, const int oh, const int ow, const int *__restrict__ xtab,
+                                      const int *__restrict__ ytab)
+{
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     const size_t f = blockIdx.z;
     if (x >= ow || y >= oh) return;
-    int yi = (int)(((double)y + 0.5) * sy);
-    int xi = (int)(((double)x + 0.5) * sx);
-    yi = yi < h ? yi : h - 1;
-    xi = xi < w ? xi : w - 1;
-    const uint8_t *s = in + (f * h * w + (size_t)yi * w + xi) * 3;
+    const uint8_t *s = in + (f * h * w + (size_t)ytab[y] * w + xtab[x]) * 3;
     uint8_t *d = out + (f * oh * ow + (size_t)y * ow + x) * 3;
     d[0] = s[0];
     d[1] = s[1];
     d[2] = s[2];
 }
-
 
 int num_cus()
 {
@@ -709,9 +723,14 @@ int launch_resize_nearest(const uint8_t *in, uint8_t *out, int64_t n_frames, int
         set_error("dp_resize_nearest_u8: oh or n_frames > 65535 not supported");
         return DP_EUNSUPPORTED;
     }
+    int *tabs = nullptr;
+    DP_HIP(hipMallocAsync((void **)&tabs, sizeof(int) * ((size_t)ow + oh), s));  // stream-ordered scratch
+    hipLaunchKernelGGL(resize_tables_kernel, dim3(1), dim3(64), 0, s, tabs, tabs + ow, w, ow, h, oh);
     hipLaunchKernelGGL(resize_nearest_kernel, dim3((ow + 255) / 256, oh, (unsigned)n_frames), dim3(256), 0, s, in, out,
-                       h, w, oh, ow, (double)h / oh, (double)w / ow);
-    DP_HIP(hipGetLastError());
+                       h, w, oh, ow, tabs, tabs + ow);
+    hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(tabs, s);
+    if (e != hipSuccess) return hip_fail(e, "resize launch");
     return DP_OK;
 }
 

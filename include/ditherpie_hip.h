@@ -128,7 +128,8 @@ int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_de
                       int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
 
 /* NEAREST resize of packed RGB frames (pixelize_regular / final upscale,
- * video_processor.py:563-577, 393-420): out[y][x] = in[(y*h)/oh][(x*w)/ow] (Pillow NEAREST). */
+ * video_processor.py:563-577, 393-420), bit-identical to Pillow's Image.resize(..., NEAREST): source indices
+ * come from Pillow's double-accumulated coordinate tables. */
 int dp_resize_nearest_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int oh,
                          int ow, void *stream);
 

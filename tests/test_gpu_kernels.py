@@ -189,10 +189,14 @@ def test_kmeans_step(be, orc):
 def test_resize_nearest_matches_pillow(be, orc):
     from PIL import Image
     arr = orc.rnd(97, 131, 8)
-    for (oh, ow) in [(48, 65), (194, 262), (33, 131), (97, 50), (291, 393)]:
+    for (oh, ow) in [(48, 65), (194, 262), (33, 131), (97, 50), (291, 393), (16, 22), (27, 36), (1, 1), (5, 400)]:
         ref = np.array(Image.fromarray(arr).resize((ow, oh), Image.NEAREST))
         out = be.resize_nearest(_dev(arr), oh, ow).cpu().numpy()
         assert np.array_equal(out, ref), (oh, ow)
+    frames = np.stack([orc.rnd(60, 80, s) for s in range(3)])
+    out = be.resize_nearest(_dev(frames), 16, 22).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(out[i], np.array(Image.fromarray(frames[i]).resize((22, 16), Image.NEAREST)))
 
 
 def test_accelerator_is_built_for_integer_palettes(be, orc):
