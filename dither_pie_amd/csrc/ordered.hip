@@ -30,7 +30,8 @@ struct Geo {
     int y0, x0;      // global coordinates of pixel (0,0)
     int ty0, tx0;    // y0 % th_h, x0 % th_w
     int aligned;     // in/out are 4-byte aligned
-    int neg2;        // -(2 << kIdxBits), kept in a register on purpose (see cand_eval)
+    int neg2;        // -(2 << kIdxBits), kept in a register on purpose (see cand8)
+    uint32_t adv_y, adv_x;  // (tile stride in pixels) mod hw, split into rows and columns (persistent kernel)
 };
 
 __device__ __forceinline__ int med3i(const int a, const int b, const int c)
@@ -241,19 +242,76 @@ __global__ __launch_bounds__(kBlock) void ordered_int_kernel(const uint8_t *__re
 // ---------------------------------------------------------------------------------------------
 constexpr int kCellBlock = 1024;
 
-template <int IDX>
-__device__ __forceinline__ void cand_eval(const uint32_t x, const uint32_t c, const int neg2, int &m0, int &m1, int &m2)
+// Keys of the 8 candidates of one block and the three smallest of them.
+//   key = ((|p|^2 - 2 x.p) << 8) | (4*idx)      (4*idx = byte offset of the candidate inside its block)
+// Hand scheduled: hipcc neither fuses the shift/add/multiply into v_lshl_add + v_mad_i32_i24 nor keeps
+// med3 for the running top-3, and it has to pad DOT results with s_nop; here all eight v_dot4 pairs are
+// issued first (a DOT result must not be read for 3 issue slots), then 2 ops per key, then the insertion
+// network (0 + 2 + 3 + 5x3 ops).  `neg2` = -512 must sit in an SGPR (v_mad_i32_i24 takes no literal).
+__device__ __forceinline__ void cand8(const uint32_t x, const uint4 ca, const uint4 cb, const int neg2, int &m0,
+                                      int &m1, int &m2)
 {
-    const int nn = (int)__builtin_amdgcn_udot4(c, c, 0u, false);
-    const int xp = (int)__builtin_amdgcn_udot4(x, c, 0u, false);
-    // ((|p|^2 - 2 x.p) << 8) | IDX as v_lshl_add + v_mad_i32_i24; neg2 = -(2 << 8) arrives in an SGPR so
-    // that the multiply is not strength-reduced into a shift and a subtract; x.p < 2^18 keeps it exact
-    const int key = __mul24(xp, neg2) + ((nn << kIdxBits) + IDX);
-    const int n2 = med3i(m1, m2, key);
-    const int n1 = med3i(m0, m1, key);
-    m0 = min(m0, key);
-    m1 = n1;
-    m2 = n2;
+    int n0, n1, n2, n3, n4, n5, n6, n7, p0, p1, p2, p3, p4, p5, p6, p7;
+    asm volatile(
+        "v_dot4_u32_u8 %[n0], %[c0], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[p0], %[x], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[n1], %[c1], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[p1], %[x], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[n2], %[c2], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[p2], %[x], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[n3], %[c3], %[c3], 0\n\t"
+        "v_dot4_u32_u8 %[p3], %[x], %[c3], 0\n\t"
+        "v_dot4_u32_u8 %[n4], %[c4], %[c4], 0\n\t"
+        "v_dot4_u32_u8 %[p4], %[x], %[c4], 0\n\t"
+        "v_dot4_u32_u8 %[n5], %[c5], %[c5], 0\n\t"
+        "v_dot4_u32_u8 %[p5], %[x], %[c5], 0\n\t"
+        "v_dot4_u32_u8 %[n6], %[c6], %[c6], 0\n\t"
+        "v_dot4_u32_u8 %[p6], %[x], %[c6], 0\n\t"
+        "v_dot4_u32_u8 %[n7], %[c7], %[c7], 0\n\t"
+        "v_dot4_u32_u8 %[p7], %[x], %[c7], 0\n\t"
+        "v_lshl_add_u32 %[n0], %[n0], 8, 0\n\t"
+        "v_lshl_add_u32 %[n1], %[n1], 8, 4\n\t"
+        "v_lshl_add_u32 %[n2], %[n2], 8, 8\n\t"
+        "v_lshl_add_u32 %[n3], %[n3], 8, 12\n\t"
+        "v_lshl_add_u32 %[n4], %[n4], 8, 16\n\t"
+        "v_lshl_add_u32 %[n5], %[n5], 8, 20\n\t"
+        "v_lshl_add_u32 %[n6], %[n6], 8, 24\n\t"
+        "v_lshl_add_u32 %[n7], %[n7], 8, 28\n\t"
+        "v_mad_i32_i24 %[n0], %[p0], %[ng], %[n0]\n\t"
+        "v_mad_i32_i24 %[n1], %[p1], %[ng], %[n1]\n\t"
+        "v_mad_i32_i24 %[n2], %[p2], %[ng], %[n2]\n\t"
+        "v_mad_i32_i24 %[n3], %[p3], %[ng], %[n3]\n\t"
+        "v_mad_i32_i24 %[n4], %[p4], %[ng], %[n4]\n\t"
+        "v_mad_i32_i24 %[n5], %[p5], %[ng], %[n5]\n\t"
+        "v_mad_i32_i24 %[n6], %[p6], %[ng], %[n6]\n\t"
+        "v_mad_i32_i24 %[n7], %[p7], %[ng], %[n7]\n\t"
+        // top-3 insertion network (m0 <= m1 <= m2)
+        "v_min_i32 %[m0], %[n0], %[n1]\n\t"
+        "v_max_i32 %[m1], %[n0], %[n1]\n\t"
+        "v_max_i32 %[m2], %[m1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n2]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n2]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n3]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n3]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n3]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n4]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n4]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n4]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n5]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n5]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n5]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n6]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n6]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n6]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n7]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n7]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n7]\n\t"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [n4] "=&v"(n4), [n5] "=&v"(n5),
+          [n6] "=&v"(n6), [n7] "=&v"(n7), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3),
+          [p4] "=&v"(p4), [p5] "=&v"(p5), [p6] "=&v"(p6), [p7] "=&v"(p7), [m0] "=&v"(m0), [m1] "=&v"(m1),
+          [m2] "=&v"(m2)
+        : [x] "v"(x), [c0] "v"(ca.x), [c1] "v"(ca.y), [c2] "v"(ca.z), [c3] "v"(ca.w), [c4] "v"(cb.x),
+          [c5] "v"(cb.y), [c6] "v"(cb.z), [c7] "v"(cb.w), [ng] "s"(neg2));
 }
 
 template <int MODE>
@@ -272,14 +330,20 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
     if (MODE == 1)
         for (int i = threadIdx.x; i < thr.th_h * thr.th_w; i += kCellBlock) s_thr[i] = thr.m[i];
     __syncthreads();
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_tab);
 
-    constexpr int kBig = 0x7fffffff;
-    constexpr int IM = (1 << kIdxBits) - 1;
     const float thr_scale = 1.0f / (float)(1u << thr.sh);
+    // threshold-tile addressing without divisions when both dimensions are powers of two (every Bayer table)
+    const bool pow2 = (MODE == 1) && ((thr.th_w & (thr.th_w - 1)) == 0) && ((thr.th_h & (thr.th_h - 1)) == 0);
 
     uint32_t px[4];
     uint32_t tile = blockIdx.x;
-    if (tile < n_tiles) load4(in, g, tile * kCellBlock + threadIdx.x, px);
+    uint32_t fy = 0, fx = 0;  // frame-local coordinates of this lane's first pixel, advanced incrementally
+    if (tile < n_tiles) {
+        const uint32_t gidx0 = tile * kCellBlock + threadIdx.x;
+        load4(in, g, gidx0, px);
+        locate(g, gidx0 * 4u < g.n_px ? gidx0 * 4u : 0u, fy, fx);
+    }
     for (; tile < n_tiles; tile += gridDim.x) {
         const uint32_t gidx = tile * kCellBlock + threadIdx.x;
         const uint32_t p0 = gidx * 4u;
@@ -288,14 +352,15 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
         if (next < n_tiles) load4(in, g, next * kCellBlock + threadIdx.x, px);  // prefetch the next tile
 
         // candidate blocks of the four pixels: all LDS reads in flight together
-        uint32_t blk[4];
+        uint32_t blk[4];  // byte offset of the block in LDS
         uint4 ca[4], cb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t x = xq[q];
-            blk[q] = (((x & 0xf0u) << 4) | ((x >> 8) & 0xf0u) | ((x >> 20) & 0xfu)) * 8u;
-            ca[q] = *reinterpret_cast<const uint4 *>(&s_tab[blk[q]]);
-            cb[q] = *reinterpret_cast<const uint4 *>(&s_tab[blk[q] + 4]);
+            // (r>>4)<<8 | (g>>4)<<4 | (b>>4), times 32 bytes
+            blk[q] = ((x & 0xf0u) << 9) | ((x & 0xf000u) >> 3) | ((x >> 15) & 0x1e0u);
+            ca[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q]);
+            cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
         }
         bool slow[4] = {false, false, false, false};
 #pragma unroll
@@ -308,51 +373,61 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
                 }
                 const uint32_t x = xq[q];
                 const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
-                blk[q] = 4096u * 8u + ((ca[q].x & 0xffffffu) * 8u + sub) * 8u;
-                ca[q] = *reinterpret_cast<const uint4 *>(&s_tab[blk[q]]);
-                cb[q] = *reinterpret_cast<const uint4 *>(&s_tab[blk[q] + 4]);
+                blk[q] = (4096u * 8u + ((ca[q].x & 0xffffffu) * 8u + sub) * 8u) * 4u;
+                ca[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q]);
+                cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
             }
         }
 
+        // threshold positions of the four pixels
         Cursor cur;
-        cursor_init(g, thr, p0 < g.n_px ? p0 : 0u, cur, MODE == 1 || MODE == 2);
+        cur.y = fy;
+        cur.x = fx;
+        cur.ty = cur.tx = 0;
+        const bool same_row = pow2 && (fx + 3u < g.w);
+        uint32_t trow = 0, tcol = 0;
+        if (MODE == 1) {
+            if (same_row) {
+                trow = (((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1)) * (uint32_t)thr.th_w;
+                tcol = (uint32_t)g.x0 + fx;
+            } else {
+                cur.ty = (int)(((uint32_t)g.y0 + fy) % (uint32_t)thr.th_h);
+                cur.tx = (int)(((uint32_t)g.x0 + fx) % (uint32_t)thr.th_w);
+            }
+        } else if (MODE == 2) {
+            cur.ty = (int)(((uint32_t)g.y0 + fy) % (uint32_t)thr.th_h);
+            cur.tx = (int)(((uint32_t)g.x0 + fx) % (uint32_t)thr.th_w);
+        }
+
         uint32_t col[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t x = xq[q];
-            int m0 = kBig, m1 = kBig, m2 = kBig;
-            cand_eval<0>(x, ca[q].x, g.neg2, m0, m1, m2);
-            cand_eval<1>(x, ca[q].y, g.neg2, m0, m1, m2);
-            cand_eval<2>(x, ca[q].z, g.neg2, m0, m1, m2);
-            cand_eval<3>(x, ca[q].w, g.neg2, m0, m1, m2);
-            cand_eval<4>(x, cb[q].x, g.neg2, m0, m1, m2);
-            cand_eval<5>(x, cb[q].y, g.neg2, m0, m1, m2);
-            cand_eval<6>(x, cb[q].z, g.neg2, m0, m1, m2);
-            cand_eval<7>(x, cb[q].w, g.neg2, m0, m1, m2);
+            int m0, m1, m2;
+            cand8(x, ca[q], cb[q], g.neg2, m0, m1, m2);
             const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
-            const uint32_t d0 = (uint32_t)((m0 >> kIdxBits) + xx);
-            const uint32_t d1 = (uint32_t)((m1 >> kIdxBits) + xx);
-            const uint32_t d2 = (uint32_t)((m2 >> kIdxBits) + xx);
-            uint32_t a = s_tab[blk[q] + (m0 & IM)];  // colour reported as nearest
-            uint32_t b = s_tab[blk[q] + (m1 & IM)];  // colour reported as second
+            const int a0 = m0 >> kIdxBits, a1 = m1 >> kIdxBits, a2 = m2 >> kIdxBits;
+            const uint32_t d0 = (uint32_t)(a0 + xx), d1 = (uint32_t)(a1 + xx);
+            uint32_t a = *reinterpret_cast<const uint32_t *>(s_bytes + blk[q] + (m0 & 0xfc));  // reported nearest
+            uint32_t b = *reinterpret_cast<const uint32_t *>(s_bytes + blk[q] + (m1 & 0xfc));  // reported second
             bool s = slow[q];
             bool nearest = true;
             if (MODE == 0) {
-                if (d0 == d1) {
+                if (a0 == a1) {
                     const uint32_t code = (pal.code1[x >> 4] >> ((x & 15u) * 2)) & 3u;
                     if (code == 1) a = b;
-                    else if (code == 2) a = s_tab[blk[q] + (m2 & IM)];
+                    else if (code == 2) a = *reinterpret_cast<const uint32_t *>(s_bytes + blk[q] + (m2 & 0xfc));
                     else if (code == 3) s = true;
                 }
             } else {
-                if (d0 == d1 || d1 == d2) {
+                if (a0 == a1 || a1 == a2) {
                     const uint32_t code = (pal.code2[x >> 4] >> ((x & 15u) * 2)) & 3u;
                     if (code == 1) {
                         const uint32_t t = a;
                         a = b;
                         b = t;
                     } else if (code == 2) {
-                        b = s_tab[blk[q] + (m2 & IM)];
+                        b = *reinterpret_cast<const uint32_t *>(s_bytes + blk[q] + (m2 & 0xfc));
                     } else if (code == 3) {
                         s = true;
                     }
@@ -361,7 +436,8 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
                 float t;
                 bool eq;
                 if (MODE == 1) {
-                    const uint32_t mt = s_thr[cur.ty * thr.th_w + cur.tx];
+                    const uint32_t mt = same_row ? s_thr[trow + ((tcol + q) & (uint32_t)(thr.th_w - 1))]
+                                                 : s_thr[cur.ty * thr.th_w + cur.tx];
                     const uint32_t lhs = d0 << thr.sh;
                     const uint32_t rhs = __umul24(mt, S);
                     nearest = lhs <= rhs;
@@ -380,10 +456,19 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
             }
             slow[q] = s & (p0 + q < g.n_px);
             col[q] = nearest ? a : b;
-            cursor_next(g, thr, cur);
+            if (!(MODE == 1 && same_row) && MODE != 0) cursor_next(g, thr, cur);
         }
         store4(out, g, gidx, col);
         store_flags(flags, gidx, slow);
+
+        // advance this lane's coordinates to its group in the next tile (no division)
+        fx += g.adv_x;
+        fy += g.adv_y;
+        if (fx >= g.w) {
+            fx -= g.w;
+            ++fy;
+        }
+        if (fy >= g.h) fy -= g.h;
     }
 }
 
@@ -647,6 +732,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         g.tx0 = x0 % thr.th_w;
         g.aligned = (((uintptr_t)in_c | (uintptr_t)out_c) & 3) == 0;
         g.neg2 = -(2 << kIdxBits);
+        g.adv_y = g.adv_x = 0;
         const uint32_t groups = (g.n_px + 3) / 4;
         const uint32_t blocks = (groups + kBlock - 1) / kBlock;
         uint32_t n_words = blocks * (kBlock / 64) * 4;
@@ -661,6 +747,11 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             n_words = n_tiles * (kCellBlock / 64) * 4;
             const size_t lds = sizeof(uint32_t) * ((size_t)pal.tab_words + 256);
             const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus());
+            {
+                const uint64_t adv = ((uint64_t)cgrid * kCellBlock * 4u) % (uint64_t)hw;
+                g.adv_y = (uint32_t)(adv / (uint64_t)w);
+                g.adv_x = (uint32_t)(adv % (uint64_t)w);
+            }
             int rc;
             if (mode == DP_MODE_NEAREST) {
                 rc = launch_cell<0>(cgrid, lds, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles);
