@@ -44,6 +44,7 @@ struct PalDev {
     const uint32_t *p4;        // K: r | g<<8 | b<<16          (integer palettes)
     const int32_t *nkey;       // K: (|p|^2 << kIdxBits) | j   (integer palettes)
     const double *pts;         // K*3 float64 coordinates as the tree sees them
+    const float *pts_f32;      // the same values as float32 (they are float32 values to begin with)
     const uint32_t *out_rgb;   // K: output bytes r | g<<8 | b<<16
     const uint8_t *lut_in;     // 256 or nullptr
     // tree

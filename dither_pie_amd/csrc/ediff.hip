@@ -8,17 +8,24 @@
 // order inside a row), which reproduces the same float32 sums bit for bit.  The taps arrive
 // pre-sorted in that order (dy descending, dx descending) from the launcher.
 //
-// ed_wavefront_kernel (serpentine off): one 64-lane wave per frame, lane = image row inside a
-//   64-row band, anti-diagonal schedule: lane L works on x = t - skew*L at step t, so every source
-//   pixel of a row above was finished `skew` steps earlier.  Errors live in a 16-deep per-row ring
-//   in LDS; the two rows that cross a band boundary go through a small global buffer.
+// ed_wavefront_kernel (serpentine off): one workgroup per frame, up to 16 waves.  A wave owns a band of
+//   64 image rows (lane = row) and walks it on the anti-diagonal schedule: lane L works on
+//   x = t - skew*L at step t, so every source pixel of a row above was finished `skew` steps
+//   earlier.  Bands of one frame are pipelined across the waves of the workgroup: band b+1 behaves
+//   like "lanes 64.." of band b, trailing it by 63*skew+3 steps; it spins on a progress word in LDS
+//   that the producing wave publishes after its stores are acknowledged.  Nothing on the dependency
+//   chain touches HBM latency: errors live in an 8-deep per-row LDS ring, the two rows that cross a
+//   band boundary travel through a global row buffer (L2) and are prefetched one step ahead into a
+//   small LDS ring, and input pixels are prefetched two steps ahead into an LDS ring.
 // ed_serial_kernel (any scan, used for serpentine): rows are strictly sequential under a
 //   serpentine scan (the first pixel of row y+1 needs the last pixel of row y), so parallelism
 //   comes from frames only: lane = frame, error rows interleaved across lanes in global memory.
 //
-// Nearest colour: brute force in float64 with the KD-tree's arithmetic; an exact tie between the
-// two smallest distances (they do occur: diffused errors are dyadic) is resolved by replaying
-// scipy's traversal (tree_query<1>) unless the palette fits one leaf (then the lowest index wins).
+// Nearest colour: a float32 scan keeps the two smallest distances; if they are separated by more than
+// the float32 error margin the float32 winner is provably the float64 winner.  Otherwise (near ties)
+// brute force in float64 with the KD-tree's arithmetic, and an exact tie between the two smallest
+// distances (they do occur: diffused errors are dyadic) is resolved by replaying scipy's traversal
+// (tree_query<1>) unless the palette fits one leaf (then the lowest index wins).
 #include "dp_internal.h"
 #include "tree_query.cuh"
 
@@ -26,7 +33,10 @@ namespace dp {
 namespace {
 
 constexpr int kMaxTaps = 16;
-constexpr int kRing = 16;  // per-row error ring depth (positions), power of two
+constexpr int kRing = 8;    // per-row error ring depth (positions): skew*dy+dx <= 8 for every supported tap set
+constexpr int kVRing = 16;  // ring of the two boundary rows prefetched from the previous band
+constexpr int kPixRing = 8;
+constexpr int kMaxWaves = 16;
 
 struct Taps {
     int n;
@@ -61,75 +71,144 @@ __device__ __forceinline__ int nearest_f64(const PalDev &pal, const float o0, co
     return i0;
 }
 
+// float32 prefilter: |d_f32 - d| <= ~3.6e-7 d (one rounding per subtract, square and add), so a gap of
+// 2e-6 (relative) between the two smallest float32 distances proves the float64 order
+__device__ __forceinline__ int nearest_color(const PalDev &pal, const float o0, const float o1, const float o2)
+{
+    float b0 = __int_as_float(0x7f800000), b1 = b0;
+    int i0 = 0;
+    const int K = pal.K;
+    for (int j = 0; j < K; ++j) {
+        const float a = pal.pts_f32[3 * j] - o0, b = pal.pts_f32[3 * j + 1] - o1, c = pal.pts_f32[3 * j + 2] - o2;
+        const float d = a * a + b * b + c * c;
+        if (d < b0) {
+            b1 = b0;
+            b0 = d;
+            i0 = j;
+        } else if (d < b1) {
+            b1 = d;
+        }
+    }
+    if (b1 > b0 * 1.000002f) return i0;
+    return nearest_f64(pal, o0, o1, o2);
+}
+
 __device__ __forceinline__ float clamp255(const float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
 
-__global__ __launch_bounds__(64) void ed_wavefront_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                          const int h, const int w, const PalDev pal, const Taps taps,
-                                                          float *__restrict__ bnd_all)
+__global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
+                                                                      uint8_t *__restrict__ out, const int h,
+                                                                      const int w, const PalDev pal, const Taps taps,
+                                                                      float *__restrict__ bnd_all)
 {
-    __shared__ float s_ring[64][kRing][3];
+    __shared__ float s_ring[kMaxWaves][64][kRing][3];   // errors of the band's own rows
+    __shared__ float s_vring[kMaxWaves][2][kVRing][3];  // errors of the two rows above the band
+    __shared__ uint32_t s_pix[kMaxWaves][64][kPixRing]; // prefetched input pixels (r | g<<8 | b<<16)
     __shared__ uint8_t s_lut[256];
-    const int L = threadIdx.x;
+    __shared__ volatile uint32_t s_prog[kMaxWaves];     // (band << 16) | steps whose stores are acknowledged
+    const int L = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
     const size_t f = blockIdx.x;
-    for (int i = L; i < 256; i += 64) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
+    if (threadIdx.x < kMaxWaves) s_prog[threadIdx.x] = 0;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
-    // boundary rows: [2 buffers][2 rows][w][3] floats per frame
-    float *bnd = bnd_all + f * (size_t)4 * w * 3;
+    float *bnd = bnd_all + f * (size_t)4 * w * 3;  // [2 buffers][2 rows][w][3]
     const int skew = taps.skew;
     const int n_bands = (h + 63) / 64;
-    __syncthreads();
+    __syncthreads();  // the only workgroup barrier: from here on waves only meet through s_prog
 
-    for (int band = 0; band < n_bands; ++band) {
+    for (int band = wv; band < n_bands; band += NW) {
         const int r = band * 64 + L;
-        const float *bprev = bnd + (size_t)((band + 1) & 1) * 2 * w * 3;  // written by the previous band
+        const float *bprev = bnd + (size_t)((band + 1) & 1) * 2 * w * 3;  // written by band-1
         float *bnext = bnd + (size_t)(band & 1) * 2 * w * 3;
         const int rows_here = min(64, h - band * 64);
         const int steps = w + skew * (rows_here - 1);
-        for (int t = 0; t < steps; ++t) {
+        const int pw = (wv + NW - 1) % NW;  // wave that owns band-1
+        const bool row_ok = r < h;
+        uint32_t pf_pix = 0;    // pixel loaded in the previous step, to be parked in s_pix
+        int pf_pix_x = -1;
+        float pv0 = 0.f, pv1 = 0.f, pv2 = 0.f;  // boundary errors loaded in the previous step (lanes 0,1)
+        int pf_b_x = -1;
+        for (int t = -3; t < steps; ++t) {
             const int x = t - skew * L;
-            const bool act = (r < h) && x >= 0 && x < w;
+            // ---- park what the previous step fetched (its latency was hidden behind that step's compute)
+            if (pf_pix_x >= 0) s_pix[wv][L][pf_pix_x & (kPixRing - 1)] = pf_pix;
+            if (pf_b_x >= 0 && L < 2) {
+                s_vring[wv][L][pf_b_x & (kVRing - 1)][0] = pv0;
+                s_vring[wv][L][pf_b_x & (kVRing - 1)][1] = pv1;
+                s_vring[wv][L][pf_b_x & (kVRing - 1)][2] = pv2;
+            }
+            // every store of the previous steps is acknowledged (the loads above were waited for, and
+            // vmcnt retires in order): publish progress for the wave that owns the next band
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (L == 0 && t >= 0) s_prog[wv] = ((uint32_t)band << 16) | (uint32_t)t;
+            // ---- fetch ahead: the pixel two steps ahead, the boundary errors three columns ahead
+            pf_pix_x = -1;
+            if (row_ok && x + 2 >= 0 && x + 2 < w) {
+                const uint8_t *p = fin + ((size_t)r * w + (x + 2)) * 3;
+                pf_pix = (uint32_t)s_lut[p[0]] | ((uint32_t)s_lut[p[1]] << 8) | ((uint32_t)s_lut[p[2]] << 16);
+                pf_pix_x = x + 2;
+            }
+            pf_b_x = -1;
+            if (band > 0) {
+                const int pb = t + 3;  // wave-uniform column
+                if (pb < w) {
+                    // row band*64-1 (lane 63 of band-1) finishes column pb in its step pb+63*skew
+                    const uint32_t need = (uint32_t)(pb + 63 * skew + 1);
+                    for (;;) {
+                        const uint32_t v = s_prog[pw];
+                        if ((int)(v >> 16) > band - 1 || ((int)(v >> 16) == band - 1 && (v & 0xffffu) >= need)) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (L < 2) {
+                        // lane 0 -> row -2 (lane 62 of band-1), lane 1 -> row -1 (lane 63); bypass L1: the
+                        // buffer was written by another wave of this workgroup and is reused every 2 bands
+                        const float *b = bprev + ((size_t)L * w + pb) * 3;
+                        pv0 = __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pv1 = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pv2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pf_b_x = pb;
+                    }
+                }
+            }
+            // ---- this step's pixel
+            const bool act = row_ok && x >= 0 && x < w;
             float e0 = 0.f, e1 = 0.f, e2 = 0.f;
             if (act) {
-                const uint8_t *p = fin + ((size_t)r * w + x) * 3;
-                float a0 = (float)s_lut[p[0]], a1 = (float)s_lut[p[1]], a2 = (float)s_lut[p[2]];
+                const uint32_t pxv = s_pix[wv][L][x & (kPixRing - 1)];
+                float a0 = (float)(pxv & 255u), a1 = (float)((pxv >> 8) & 255u), a2 = (float)(pxv >> 16);
                 for (int k = 0; k < taps.n; ++k) {
                     const int sxp = x - taps.dx[k];
                     const int sr = r - taps.dy[k];
                     if (sxp < 0 || sxp >= w || sr < 0) continue;
                     const int rel = L - taps.dy[k];
-                    float s0, s1, s2;
-                    if (rel >= 0) {
-                        s0 = s_ring[rel][sxp & (kRing - 1)][0];
-                        s1 = s_ring[rel][sxp & (kRing - 1)][1];
-                        s2 = s_ring[rel][sxp & (kRing - 1)][2];
-                    } else {
-                        const float *b = bprev + ((size_t)(rel + 2) * w + sxp) * 3;
-                        s0 = b[0];
-                        s1 = b[1];
-                        s2 = b[2];
-                    }
+                    const float *src = rel >= 0 ? &s_ring[wv][rel][sxp & (kRing - 1)][0]
+                                                : &s_vring[wv][rel + 2][sxp & (kVRing - 1)][0];
                     const float wq = taps.wq[k];
-                    a0 = __fadd_rn(a0, __fmul_rn(s0, wq));
-                    a1 = __fadd_rn(a1, __fmul_rn(s1, wq));
-                    a2 = __fadd_rn(a2, __fmul_rn(s2, wq));
+                    a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
+                    a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
+                    a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
                 }
                 const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-                const int j = nearest_f64(pal, o0, o1, o2);
-                e0 = __fsub_rn(o0, (float)pal.pts[3 * j]);
-                e1 = __fsub_rn(o1, (float)pal.pts[3 * j + 1]);
-                e2 = __fsub_rn(o2, (float)pal.pts[3 * j + 2]);
+                const int j = nearest_color(pal, o0, o1, o2);
+                e0 = __fsub_rn(o0, pal.pts_f32[3 * j]);
+                e1 = __fsub_rn(o1, pal.pts_f32[3 * j + 1]);
+                e2 = __fsub_rn(o2, pal.pts_f32[3 * j + 2]);
                 const uint32_t c = pal.out_rgb[j];
                 uint8_t *o = fout + ((size_t)r * w + x) * 3;
                 o[0] = (uint8_t)c;
                 o[1] = (uint8_t)(c >> 8);
                 o[2] = (uint8_t)(c >> 16);
             }
-            __syncthreads();  // every pull of this step is done before any ring slot is overwritten
+            // every pull of this step precedes the ring writes below (slot x&7 still holds column x-8, which the
+            // row two below reads in this very step for a dx=+2 tap)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             if (act) {
-                s_ring[L][x & (kRing - 1)][0] = e0;
-                s_ring[L][x & (kRing - 1)][1] = e1;
-                s_ring[L][x & (kRing - 1)][2] = e2;
+                s_ring[wv][L][x & (kRing - 1)][0] = e0;
+                s_ring[wv][L][x & (kRing - 1)][1] = e1;
+                s_ring[wv][L][x & (kRing - 1)][2] = e2;
                 if (L >= 62) {
                     float *b = bnext + ((size_t)(L - 62) * w + x) * 3;
                     b[0] = e0;
@@ -137,10 +216,12 @@ __global__ __launch_bounds__(64) void ed_wavefront_kernel(const uint8_t *__restr
                     b[2] = e2;
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __threadfence();
-        __syncthreads();
+        // band finished: once its boundary stores are acknowledged the next band may read any column
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (L == 0) s_prog[wv] = ((uint32_t)(band + 1) << 16);
     }
 }
 
@@ -180,7 +261,7 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
                 a2 = __fadd_rn(a2, __fmul_rn(e[2 * nf], wq));
             }
             const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-            const int j = nearest_f64(pal, o0, o1, o2);
+            const int j = nearest_color(pal, o0, o1, o2);
             float *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
             e[0] = __fsub_rn(o0, (float)pal.pts[3 * j]);
             e[nf] = __fsub_rn(o1, (float)pal.pts[3 * j + 1]);
@@ -240,12 +321,14 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         t.wq[i] = 0.f;
     }
     ProfMark *pm = prof_begin(s);
-    if (!serpentine && skew * 2 + 2 < kRing) {
+    if (!serpentine && skew * 2 + 2 <= kRing && w + 64 * skew < 65000) {
         if (n_frames > 0x7fffffff) {
             set_error("dp_error_diffusion_u8: too many frames for one launch");
             return DP_EINVAL;
         }
-        hipLaunchKernelGGL(ed_wavefront_kernel, dim3((unsigned)n_frames), dim3(64), 0, s, in, out, h, w, pal, t,
+        const int n_bands = (h + 63) / 64;
+        const int nw = n_bands < kMaxWaves ? n_bands : kMaxWaves;
+        hipLaunchKernelGGL(ed_wavefront_kernel, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h, w, pal, t,
                            reinterpret_cast<float *>(ws));
     } else {
         const int64_t blocks = (n_frames + 63) / 64;

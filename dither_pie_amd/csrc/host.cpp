@@ -286,6 +286,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     const size_t o_p4 = put(p4.data(), sizeof(uint32_t) * K);
     const size_t o_nk = put(nkey.data(), sizeof(int32_t) * K);
     const size_t o_pts = put(pts.data(), sizeof(double) * 3 * K);
+    const size_t o_pf = put(pal_f32, sizeof(float) * 3 * K);
     const size_t o_org = put(orgb.data(), sizeof(uint32_t) * K);
     const size_t o_lut = lut_in ? put(lut_in, 256) : 0;
     const size_t o_idx = put(t.indices.data(), sizeof(int32_t) * K);
@@ -316,6 +317,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.p4 = (const uint32_t *)(base + o_p4);
     d.nkey = (const int32_t *)(base + o_nk);
     d.pts = (const double *)(base + o_pts);
+    d.pts_f32 = (const float *)(base + o_pf);
     d.out_rgb = (const uint32_t *)(base + o_org);
     d.lut_in = lut_in ? (base + o_lut) : nullptr;
     d.indices = (const int32_t *)(base + o_idx);
