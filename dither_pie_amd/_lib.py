@@ -38,6 +38,7 @@ _SIGS = {
     "dp_palette_create": (_i, [_vp, _vp, _i, _vp, C.POINTER(_vp)]),
     "dp_palette_destroy": (None, [_vp]),
     "dp_palette_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "dp_palette_build_accel": (_i, [_vp]),
     "dp_palette_accel_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "dp_kdtree_build_host": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "dp_thresholds_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),

@@ -31,7 +31,10 @@ class Palette:
     pal_f32 [K,3] float32 as the KD-tree sees it; out_colors [K,3] uint8 written for each entry;
     lut_in optional 256-entry uint8 map applied to the input bytes."""
 
-    def __init__(self, pal_f32, out_colors, lut_in=None):
+    # pixels in one call from which building the search accelerator (tens of ms, once) pays off
+    ACCEL_MIN_PIXELS = 1 << 20
+
+    def __init__(self, pal_f32, out_colors, lut_in=None, accel=False):
         require_gpu()
         self.pal_f32 = np.ascontiguousarray(pal_f32, dtype=np.float32).reshape(-1, 3)
         self.out_colors = np.ascontiguousarray(out_colors, dtype=np.uint8).reshape(-1, 3)
@@ -49,6 +52,18 @@ class Palette:
         check(_lib.load().dp_palette_info(self._h, C.byref(k), C.byref(integer), C.byref(nodes)))
         self.is_integer = bool(integer.value)
         self.n_nodes = nodes.value
+        self.accel_entries = self.accel_max_list = 0
+        self._accel_tried = False
+        if accel:
+            self.build_accel()
+
+    def build_accel(self):
+        """Build the LDS cell table + tie codes (synchronous, idempotent; a no-op for palettes that do
+        not qualify)."""
+        if self._accel_tried:
+            return
+        self._accel_tried = True
+        check(_lib.load().dp_palette_build_accel(self._h))
         pe, mc = C.c_int(), C.c_int()
         check(_lib.load().dp_palette_accel_info(self._h, C.byref(pe), C.byref(mc)))
         self.accel_entries, self.accel_max_list = pe.value, mc.value
@@ -134,6 +149,8 @@ def ordered(frames, pal: Palette, mode, thr: Thresholds | None = None, ign_scale
     ws_bytes = L.dp_ordered_workspace_bytes(n, h, w)
     ws = _workspace(ws_bytes, f.device)
     with torch.cuda.device(f.device):
+        if n * h * w >= Palette.ACCEL_MIN_PIXELS:
+            pal.build_accel()
         check(L.dp_ordered_u8(f.data_ptr(), out.data_ptr(), n, h, w, int(y0), int(x0), pal._h, int(mode),
                               thr._h if thr is not None else None, float(ign_scale), int(ign_seed),
                               ws.data_ptr(), ws.numel(), _stream()))

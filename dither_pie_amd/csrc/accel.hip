@@ -197,6 +197,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
 
     std::vector<uint32_t> tab((size_t)kCells * 8, 0u);
     std::vector<int> list, extra;
+    std::vector<uint64_t> dkey;
     int n_split = 0, n_slow = 0, max_cnt = 0;
     // members of a mask, padded to 8 with the unused entries nearest to (cr,cg,cb); false if > 8
     auto make_block = [&](const uint32_t *mask, int cr, int cg, int cb, uint32_t *out8) {
@@ -206,12 +207,16 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         max_cnt = std::max(max_cnt, (int)list.size());
         if (list.size() > 8) return false;
         if (list.size() < 8) {
-            auto dist = [&](int j) {
-                const int r = p4_host[j] & 255, g = (p4_host[j] >> 8) & 255, b = (p4_host[j] >> 16) & 255;
-                return (r - cr) * (r - cr) + (g - cg) * (g - cg) + (b - cb) * (b - cb);
-            };
-            std::stable_sort(extra.begin(), extra.end(), [&](int a, int b) { return dist(a) < dist(b); });
-            for (int i = 0; list.size() < 8; ++i) list.push_back(extra[i]);
+            // pad with the unused entries nearest to the centre (any real entry is harmless); at most 7 picks
+            const size_t need = 8 - list.size();
+            dkey.resize(extra.size());
+            for (size_t q = 0; q < extra.size(); ++q) {
+                const uint32_t c = p4_host[extra[q]];
+                const int r = c & 255, g = (c >> 8) & 255, b = (c >> 16) & 255;
+                dkey[q] = ((uint64_t)((r - cr) * (r - cr) + (g - cg) * (g - cg) + (b - cb) * (b - cb)) << 16) | (uint64_t)extra[q];
+            }
+            std::partial_sort(dkey.begin(), dkey.begin() + need, dkey.end());
+            for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
             std::sort(list.begin(), list.end());  // key ties must break towards the lower palette index
         }
         for (int i = 0; i < 8; ++i) out8[i] = p4_host[list[i]];

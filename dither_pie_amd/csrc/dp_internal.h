@@ -80,6 +80,8 @@ struct dp_palette {
     size_t blob_bytes;
     void *accel_blob;  // cell lists + tie codes (may be null)
     size_t accel_bytes;
+    bool accel_tried, same_out;
+    std::vector<uint32_t> p4_host;
     int device;
 };
 

@@ -338,17 +338,10 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.code1 = d.code2 = nullptr;
     p->accel_blob = nullptr;
     p->accel_bytes = 0;
-    // cell lists + tie codes: integer palettes whose output bytes are the palette colours themselves
-    bool same_out = integer && K >= 8;
-    for (int j = 0; j < K && same_out; ++j) same_out = (orgb[j] == p4[j]);
-    if (same_out) {
-        int rc = build_accel(d, p4, &p->accel_blob, &p->accel_bytes);
-        if (rc != DP_OK) {
-            (void)hipFree(p->blob);
-            delete p;
-            return rc;
-        }
-    }
+    p->accel_tried = false;
+    p->p4_host = p4;
+    p->same_out = integer && K >= 8;
+    for (int j = 0; j < K && p->same_out; ++j) p->same_out = (orgb[j] == p4[j]);
     *out = p;
     return DP_OK;
 }
@@ -371,6 +364,18 @@ int dp_palette_info(const dp_palette *p, int *K, int *is_integer, int *n_nodes)
     if (is_integer) *is_integer = p->dev.is_integer;
     if (n_nodes) *n_nodes = p->dev.n_nodes;
     return DP_OK;
+}
+
+int dp_palette_build_accel(dp_palette *p)
+{
+    if (!p) {
+        set_error("dp_palette_build_accel: NULL palette");
+        return DP_EINVAL;
+    }
+    if (p->accel_tried || !p->same_out) return DP_OK;
+    p->accel_tried = true;
+    // cell lists + tie codes: integer palettes whose output bytes are the palette colours themselves
+    return build_accel(p->dev, p->p4_host, &p->accel_blob, &p->accel_bytes);
 }
 
 int dp_palette_accel_info(const dp_palette *p, int *pool_entries, int *max_cell)

@@ -30,11 +30,11 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _run_case(be, orc, arr, pal, mode, params, gamma, y0=0, x0=0):
+def _run_case(be, orc, arr, pal, mode, params, gamma, y0=0, x0=0, accel=True):
     p = dict(orc.MODE_DEFAULTS[mode])
     p.update(params or {})
     pal_f32, out_colors, lut_in = orc.prepare_palette(pal, gamma)
-    P = be.Palette(pal_f32, out_colors, lut_in)
+    P = be.Palette(pal_f32, out_colors, lut_in, accel=accel)
     x = _dev(arr)
     if mode == "none":
         out = be.ordered(x, P, be.MODE_NEAREST, y0=y0, x0=x0)
@@ -74,9 +74,10 @@ def test_golden_cases(be, orc, gold, case):
 def test_ordered_vs_oracle(be, orc, K, seed, mode, params):
     pal = orc.palr(K, seed)
     for arr in (orc.rnd(67, 93, seed), orc.grad(70, 131)):
-        out = _run_case(be, orc, arr, pal, mode, params, False)
         ref = orc.apply_dithering(arr, pal, mode, params, False)
-        _assert_same(out, ref, f"{mode} K={K}")
+        for accel in (True, False):  # LDS cell-table kernel and brute-force kernel
+            out = _run_case(be, orc, arr, pal, mode, params, False, accel=accel)
+            _assert_same(out, ref, f"{mode} K={K} accel={accel}")
 
 
 def test_single_colour_palette(be, orc):
@@ -107,7 +108,7 @@ def test_batched_frames_and_tile_offsets(be, orc):
     import torch
     pal = orc.palr(64, 9)
     pal_f32, out_colors, lut_in = orc.prepare_palette(pal, False)
-    P = be.Palette(pal_f32, out_colors, lut_in)
+    P = be.Palette(pal_f32, out_colors, lut_in, accel=True)
     frames = np.stack([orc.rnd(45, 71, s) for s in range(5)])
     thr = be.Thresholds.from_matrix(orc.bayer_matrix("8x8"))
     out = be.ordered(_dev(frames), P, be.MODE_MATRIX, thr=thr).cpu().numpy()
@@ -126,7 +127,7 @@ def test_unaligned_input_pointer(be, orc):
     import torch
     pal = orc.palr(16)
     pal_f32, out_colors, lut_in = orc.prepare_palette(pal, False)
-    P = be.Palette(pal_f32, out_colors, lut_in)
+    P = be.Palette(pal_f32, out_colors, lut_in, accel=True)
     arr = orc.rnd(31, 47, 3)
     buf = torch.empty(arr.size + 8, dtype=torch.uint8, device="cuda")
     view = buf[1:1 + arr.size].view(31, 47, 3)
@@ -164,7 +165,7 @@ def test_error_diffusion_batch_and_gamma(be, orc):
     pal = orc.palr(16, 3)
     frames = np.stack([orc.rnd(80, 60, s) for s in range(3)])
     pal_f32, out_colors, lut_in = orc.prepare_palette(pal, True)
-    P = be.Palette(pal_f32, out_colors, lut_in)
+    P = be.Palette(pal_f32, out_colors, lut_in, accel=True)
     taps, div = orc.ed_kernel("floyd_steinberg")
     for serp in (False, True):
         out = be.error_diffusion(_dev(frames), P, taps, div, serp).cpu().numpy()
@@ -200,9 +201,9 @@ def test_resize_nearest_matches_pillow(be, orc):
 
 
 def test_accelerator_is_built_for_integer_palettes(be, orc):
-    P = be.Palette(*orc.prepare_palette(orc.palr(256), False))
+    P = be.Palette(*orc.prepare_palette(orc.palr(256), False), accel=True)
     assert P.is_integer and P.accel_entries > 0 and 4 <= P.accel_max_list <= 64
-    Pg = be.Palette(*orc.prepare_palette(orc.palr(256), True))
+    Pg = be.Palette(*orc.prepare_palette(orc.palr(256), True), accel=True)
     assert not Pg.is_integer and Pg.accel_entries == 0
 
 
