@@ -7,8 +7,8 @@ dither_pie_gui.py / video_processor.py.  Pixel work happens in libditherpie_hip.
 file is host plumbing only (palette preparation, parameter handling, tensor hand-off).  There is no
 CPU fallback: without the shared library or a HIP device the calls raise DitherPieError.
 
-In scope: none, bayer, blue_noise, IGN, error_diffusion; k-means / uniform /
-median-cut palettes.  The other DitherMode members exist for configuration compatibility and raise
+In scope: none, bayer, blue_noise, IGN, error_diffusion, polka_dot; k-means /
+uniform / median-cut palettes.  The other DitherMode members exist for configuration compatibility and raise
 NotImplementedError when used.
 
 Extras that the reference does not have (all optional): ImageDitherer.apply_dithering_frames() for
@@ -29,7 +29,7 @@ __all__ = [
     "DitherMode", "PixelizeMethod", "PaletteSource", "ImageDitherer", "ColorReducer", "DitherUtils",
     "BaseDitherStrategy", "ErrorDiffusionKernel", "NoDitherStrategy", "MatrixDitherStrategy",
     "BayerDitherStrategy", "BlueNoiseDitherStrategy", "InterleavedGradientNoiseDitherStrategy",
-    "ErrorDiffusionDitherStrategy", "generate_blue_noise",
+    "ErrorDiffusionDitherStrategy", "PolkaDotDitherStrategy", "generate_blue_noise",
 ]
 
 
@@ -68,7 +68,7 @@ class PaletteSource(Enum):
 
 
 _OUT_OF_SCOPE = {
-    DitherMode.RIEMERSMA, DitherMode.POLKA_DOT, DitherMode.WAVELET, DitherMode.ADAPTIVE_VARIANCE,
+    DitherMode.RIEMERSMA, DitherMode.WAVELET, DitherMode.ADAPTIVE_VARIANCE,
     DitherMode.PERCEPTUAL, DitherMode.HYBRID, DitherMode.HALFTONE, DitherMode.OSTROMOUKHOV,
 }
 
@@ -394,6 +394,41 @@ class BlueNoiseDitherStrategy(MatrixDitherStrategy):
         return {"size": self.size, "seed": self.seed, "_matrix": None}
 
 
+class PolkaDotDitherStrategy(MatrixDitherStrategy):
+    """Circular-dot threshold tile (dithering_lib.py:695-766): the decision rule is MatrixDitherStrategy's,
+    only the tile differs; the tile_size x tile_size matrix is host setup exactly as in the reference."""
+
+    @staticmethod
+    def get_parameter_info() -> Dict[str, Any]:
+        return {
+            "tile_size": {
+                "type": "int", "default": 8, "min": 4, "max": 32, "label": "Tile Size",
+                "description": "Size of the repeating dot pattern",
+            },
+            "gamma": {
+                "type": "float", "default": 1.5, "min": 0.5, "max": 3.0, "step": 0.1, "label": "Gamma",
+                "description": "Controls dot shape curve (higher = sharper edges)",
+            },
+        }
+
+    def __init__(self, tile_size: int = 8, gamma: float = 1.5):
+        self.tile_size = tile_size
+        self.gamma = gamma
+        super().__init__(self._generate_polka_dot_matrix(tile_size, gamma))
+
+    def get_current_parameters(self) -> Dict[str, Any]:
+        return {"tile_size": self.tile_size, "gamma": self.gamma}
+
+    @staticmethod
+    def _generate_polka_dot_matrix(tile_size: int, gamma: float) -> np.ndarray:
+        """1 - (distance to the tile centre / corner distance)^gamma, float64 then float32
+        (dithering_lib.py:733-743)."""
+        c = (tile_size - 1) / 2
+        xv, yv = np.meshgrid(np.arange(tile_size), np.arange(tile_size))
+        norm = np.sqrt((xv - c) ** 2 + (yv - c) ** 2) / (np.sqrt(c ** 2 + c ** 2) + 1e-9)
+        return np.clip(1.0 - norm ** gamma, 0, 1).astype(np.float32)
+
+
 class InterleavedGradientNoiseDitherStrategy(BaseDitherStrategy):
     """dithering_lib.py:502-571"""
 
@@ -534,6 +569,7 @@ class ImageDitherer:
         DitherMode.BLUE_NOISE: BlueNoiseDitherStrategy,
         DitherMode.INTERLEAVED_GRADIENT_NOISE: InterleavedGradientNoiseDitherStrategy,
         DitherMode.ERROR_DIFFUSION: ErrorDiffusionDitherStrategy,
+        DitherMode.POLKA_DOT: PolkaDotDitherStrategy,
     }
 
     def __init__(self, num_colors: int = 16, dither_mode: Optional[DitherMode] = DitherMode.BAYER,
@@ -564,7 +600,7 @@ class ImageDitherer:
         if mode in _OUT_OF_SCOPE:
             raise NotImplementedError(
                 f"dither mode {mode.value!r} is outside the MI355X backend's scope "
-                "(none, bayer, blue_noise, IGN, error_diffusion)")
+                "(none, bayer, blue_noise, IGN, error_diffusion, polka_dot)")
         cls = self._STRATEGIES.get(mode)
         if cls is None:
             raise ValueError(f"Unrecognized DitherMode: {mode}")

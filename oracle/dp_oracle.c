@@ -34,6 +34,7 @@
  * -ffp-contract=off matters: every f32/f64 product is rounded before it is added.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -313,6 +314,13 @@ int orc_tree_build(orc_tree *t, const double *pts, int K)
 }
 
 size_t orc_tree_sizeof(void) { return sizeof(orc_tree); }
+
+/* worker threads of the row-parallel loops (bench.py's cpu_baseline states how many it used) */
+int orc_set_threads(int n)
+{
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+}
 
 /* flat export for tests: arrays must hold nnodes (<= 2K) entries */
 int orc_tree_export(const orc_tree *t, int *idx, int *split_dim, double *split, int *start, int *end,

@@ -43,6 +43,8 @@ def lib():
             build()
         L = C.CDLL(so)
         L.orc_tree_sizeof.restype = C.c_size_t
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads.restype = C.c_int
         L.orc_tree_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_tree_export.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         L.orc_tree_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
@@ -58,6 +60,11 @@ def lib():
                                       C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def set_threads(n):
+    """OpenMP threads used by the row-parallel C loops; returns the number in effect."""
+    return lib().orc_set_threads(int(n))
 
 
 def _p(a):
@@ -229,12 +236,23 @@ def blue_noise(size=64, seed=42):
 
 # ----------------------------------------------------------------------------- dither
 MODE_DEFAULTS = {
+    "polka_dot": {"tile_size": 8, "gamma": 1.5},
     "bayer": {"size": "4x4"},
     "blue_noise": {"size": 64, "seed": 42},
     "IGN": {"scale": 1.0, "seed": 0},
     "error_diffusion": {"variant": "atkinson", "serpentine": "false"},
     "none": {},
 }
+
+
+def polka_dot_matrix(tile_size=8, gamma=1.5):
+    """dithering_lib.py:733-743"""
+    x = np.arange(tile_size)
+    xv, yv = np.meshgrid(x, x)
+    c = (tile_size - 1) / 2
+    dist = np.sqrt((xv - c) ** 2 + (yv - c) ** 2)
+    norm = dist / (np.sqrt(c ** 2 + c ** 2) + 1e-9)
+    return np.clip(1.0 - (norm ** gamma), 0, 1).astype(np.float32)
 
 
 def ordered_u8(arr, pal_f32, out_colors, lut_in, mode, thr=None, scale=1.0, seed=0, y0=0, x0=0,
@@ -281,6 +299,9 @@ def apply_dithering(arr, palette, mode="bayer", params=None, use_gamma=False, y0
         return ordered_u8(arr, pal_f32, out_colors, lut_in, "none", y0=y0, x0=x0)
     if mode == "bayer":
         return ordered_u8(arr, pal_f32, out_colors, lut_in, "matrix", thr=bayer_matrix(p["size"]), y0=y0, x0=x0)
+    if mode == "polka_dot":
+        return ordered_u8(arr, pal_f32, out_colors, lut_in, "matrix", thr=polka_dot_matrix(p["tile_size"], p["gamma"]),
+                          y0=y0, x0=x0)
     if mode == "blue_noise":
         return ordered_u8(arr, pal_f32, out_colors, lut_in, "matrix", thr=blue_noise(p["size"], p["seed"]),
                           y0=y0, x0=x0)

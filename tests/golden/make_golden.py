@@ -99,6 +99,9 @@ CASES = [
     ("bayer8_p256_gamma_grad", "bayer", {"size": "8x8"}, ("palr", 256), ("grad", 333, 500), True, True),
     ("none_p32_gamma_rnd", "none", {}, ("palr", 32), ("rnd", 120, 160, 9), True, True),
     ("ign_p32_gamma_rnd", "IGN", {}, ("palr", 32), ("rnd", 120, 160, 9), True, True),
+    ("polka_default_p32_grad", "polka_dot", {}, ("palr", 32), ("grad", 203, 317), False, True),
+    ("polka_t5_g07_p256_rnd", "polka_dot", {"tile_size": 5, "gamma": 0.7}, ("palr", 256), ("rnd", 203, 317, 13), False, True),
+    ("polka_t32_g3_U16_gamma_grad", "polka_dot", {"tile_size": 32, "gamma": 3.0}, ("U", 16), ("grad", 97, 131), True, True),
     ("ed_fs_p16_rnd", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 16), ("rnd", 120, 160, 5), False, True),
     ("ed_default_p256_grad", "error_diffusion", {}, ("palr", 256), ("grad", 64, 96), False, True),
     ("ed_fs_U16_gamma_grad", "error_diffusion", {"variant": "floyd_steinberg"}, ("U", 16), ("grad", 64, 96), True, True),
@@ -259,6 +262,9 @@ def main():
     img = Image.fromarray(rnd(37, 53, 5))
     npz["pixelize_regular_37x53_to16"] = np.array(vp.pixelize_regular(img, 16))
     npz["final_resize_37x53_x3"] = np.array(vp._apply_final_resize_to_frame(img, 3))
+
+    npz["polka_8_15"] = dl.PolkaDotDitherStrategy(8, 1.5).threshold_matrix
+    npz["polka_5_07"] = dl.PolkaDotDitherStrategy(5, 0.7).threshold_matrix
 
     # ---- strategy parameter metadata (drop-in boundary)
     meta = {}

@@ -40,6 +40,9 @@ def _run_case(be, orc, arr, pal, mode, params, gamma, y0=0, x0=0, accel=True):
         out = be.ordered(x, P, be.MODE_NEAREST, y0=y0, x0=x0)
     elif mode == "bayer":
         out = be.ordered(x, P, be.MODE_MATRIX, thr=be.Thresholds.from_matrix(orc.bayer_matrix(p["size"])), y0=y0, x0=x0)
+    elif mode == "polka_dot":
+        out = be.ordered(x, P, be.MODE_MATRIX, thr=be.Thresholds.from_matrix(orc.polka_dot_matrix(p["tile_size"], p["gamma"])),
+                         y0=y0, x0=x0)
     elif mode == "blue_noise":
         out = be.ordered(x, P, be.MODE_MATRIX, thr=be.Thresholds.blue_noise(p["size"], p["seed"]), y0=y0, x0=x0)
     elif mode == "IGN":
