@@ -80,14 +80,11 @@ __device__ __forceinline__ int nearest_color(const PalDev &pal, const float o0, 
     const int K = pal.K;
     for (int j = 0; j < K; ++j) {
         const float a = pal.pts_f32[3 * j] - o0, b = pal.pts_f32[3 * j + 1] - o1, c = pal.pts_f32[3 * j + 2] - o2;
-        const float d = a * a + b * b + c * c;
-        if (d < b0) {
-            b1 = b0;
-            b0 = d;
-            i0 = j;
-        } else if (d < b1) {
-            b1 = d;
-        }
+        const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, c * c));  // a filter only: any rounding within the margin
+        const bool lt0 = d < b0;
+        b1 = lt0 ? b0 : (d < b1 ? d : b1);
+        i0 = lt0 ? j : i0;
+        b0 = lt0 ? d : b0;
     }
     if (b1 > b0 * 1.000002f) return i0;
     return nearest_f64(pal, o0, o1, o2);
