@@ -46,7 +46,7 @@ def make_frames(torch, n, h, w, dev, first_seed=None):
     return frames
 
 
-def cpu_baseline(n_frames=4):
+def cpu_baseline(n_frames=16):
     """The CPU oracle (C restatement, OpenMP over rows) on a bounded sample of the same workload."""
     from oracle import oracle as orc
     orc.build()
