@@ -137,6 +137,17 @@ def main():
     k_ms = main_ms / max(launches, 1)
     value = world * px_per_step * args.steps / dt / 1e6
     achieved = BYTES_PER_PX * px_per_step / (k_ms * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
+    # comes from the committed rocprofv3 --pmc pass of this same command (profiles/pmc_pass.sh)
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_final_pmc_ordered_cell.json")
+    if args.frames == 24 and os.path.exists(pmc_file):
+        try:
+            with open(pmc_file) as f:
+                traffic = int(json.load(f)["derived"]["hbm_traffic_bytes_per_launch"])
+            traffic_src = "profiles/r01_final_pmc_ordered_cell.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+        except Exception:  # noqa: BLE001
+            traffic = None
     result = {
         "metric": "Mpixel/s dither+quantize @4K 256-color (Bayer 8x8 + nearest-palette, uint8 RGB in/out)",
         "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -147,7 +158,7 @@ def main():
                    "frames_per_gpu": args.frames, "h": H4K, "w": W4K, "colors": 256, "matrix": "8x8",
                    "parallelism": f"frames x{world}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "ordered_cell_kernel<1>", "kernel_ms": round(k_ms, 4),
                      "fixup_ms": round(fix_ms / max(launches, 1), 4), "launches": launches,
                      "algorithmic_bytes_per_launch": BYTES_PER_PX * px_per_step},

@@ -537,6 +537,7 @@ int dp_ordered_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int
                   const dp_palette *pal, int mode, const dp_thresholds *thr, float ign_scale, int ign_seed,
                   void *workspace_dev, size_t workspace_bytes, void *stream)
 {
+    if (n_frames == 0 && pal && h >= 1 && w >= 1) return DP_OK;  // nothing to do (pointers may be null)
     if (!in_dev || !out_dev || !pal || n_frames < 0 || h < 1 || w < 1 || y0 < 0 || x0 < 0) {
         set_error("dp_ordered_u8: bad argument");
         return DP_EINVAL;
@@ -575,6 +576,7 @@ int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_fra
                           int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
                           void *stream)
 {
+    if (n_frames == 0 && pal && h >= 1 && w >= 1) return DP_OK;  // nothing to do (pointers may be null)
     if (!in_dev || !out_dev || !pal || n_frames < 0 || h < 1 || w < 1 || ntaps < 0 || ntaps > 16 ||
         (ntaps && (!dx || !dy || !wq))) {
         set_error("dp_error_diffusion_u8: bad argument");
@@ -611,6 +613,7 @@ int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_de
 int dp_resize_nearest_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int oh,
                          int ow, void *stream)
 {
+    if (n_frames == 0 && h >= 1 && w >= 1 && oh >= 1 && ow >= 1) return DP_OK;
     if (!in_dev || !out_dev || n_frames < 0 || h < 1 || w < 1 || oh < 1 || ow < 1) {
         set_error("dp_resize_nearest_u8: bad argument");
         return DP_EINVAL;

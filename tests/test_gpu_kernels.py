@@ -231,3 +231,49 @@ def test_clustered_palette_long_lists(be, orc):
     for mode, params in [("none", {}), ("bayer", {"size": "4x4"})]:
         out = _run_case(be, orc, arr, pal, mode, params, False)
         _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False), mode)
+
+
+def test_empty_batch_and_degenerate_shapes(be, orc):
+    import torch
+    P = be.Palette(*orc.prepare_palette(orc.palr(16), False), accel=True)
+    thr = be.Thresholds.from_matrix(orc.bayer_matrix("4x4"))
+    empty = torch.empty((0, 8, 8, 3), dtype=torch.uint8, device="cuda")
+    assert be.ordered(empty, P, be.MODE_MATRIX, thr=thr).shape == (0, 8, 8, 3)
+    taps, div = orc.ed_kernel("floyd_steinberg")
+    assert be.error_diffusion(empty, P, taps, div).shape == (0, 8, 8, 3)
+    for shape in [(1, 9001), (3, 4097), (4099, 2)]:  # wider than a 4096-pixel tile, very tall and thin
+        arr = orc.rnd(shape[0], shape[1], 5)
+        for mode, params in [("bayer", {"size": "16x16"}), ("IGN", {"scale": 0.3, "seed": 9})]:
+            out = _run_case(be, orc, arr, orc.palr(16), mode, params, False)
+            _assert_same(out, orc.apply_dithering(arr, orc.palr(16), mode, params, False), f"{mode} {shape}")
+
+
+def test_full_size_properties_and_2g_pixel_chunking(be, orc):
+    """BASELINE sizes through size-independent properties: every copy of a frame in a > 2^31-pixel batch
+    (the launcher splits such batches) dithers to the bytes of the single-frame call, whose hash is the KAT;
+    the output only uses palette colours; dithering is idempotent for mode 'none'."""
+    import hashlib
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    n = 260  # 260 * 3840 * 2160 = 2.157e9 pixels > 2^31
+    if free < 2.2 * n * 2160 * 3840 * 3:
+        pytest.skip("not enough free HBM")
+    pal = orc.palr(256)
+    P = be.Palette(*orc.prepare_palette(pal, False), accel=True)
+    thr = be.Thresholds.from_matrix(orc.bayer_matrix("8x8"))
+    frame = _dev(orc.rnd(2160, 3840, 1234))
+    single = be.ordered(frame, P, be.MODE_MATRIX, thr=thr)
+    assert hashlib.sha256(single.cpu().numpy().tobytes()).hexdigest()[:16] == "7041bd52fdea90b5"
+    batch = frame.unsqueeze(0).expand(n, -1, -1, -1).contiguous()
+    out = be.ordered(batch, P, be.MODE_MATRIX, thr=thr)
+    del batch
+    for i in (0, 1, 127, 128, 129, 255, 256, 259):  # around the chunk boundary too
+        assert torch.equal(out[i], single), i
+    assert bool((out == single.unsqueeze(0)).all())
+    del out
+    # palette closure + idempotence of nearest-colour assignment at 4K
+    near = be.ordered(frame, P, be.MODE_NEAREST)
+    packed = (near[..., 0].to(torch.int64) << 16) | (near[..., 1].to(torch.int64) << 8) | near[..., 2].to(torch.int64)
+    palset = torch.tensor([(r << 16) | (g << 8) | b for r, g, b in pal], device="cuda")
+    assert bool(torch.isin(packed, palset).all())
+    assert torch.equal(be.ordered(near, P, be.MODE_NEAREST), near)
