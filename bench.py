@@ -199,6 +199,28 @@ def main():
         extra["c3_fs_k16_4k_mpixel_per_s"] = round(world * nf3 * H4K * W4K / t3 / 1e6, 2)
         extra["c3_note"] = (f"{nf3} frames in flight per GPU (one workgroup of 16 waves per frame), "
                             "bit-exact float32 error accumulation")
+        # C4: k-means 32-colour palette from a 7680x4320 image + blue-noise dither, the image split into row
+        # bands over the ranks; the per-iteration exchange is one RCCL all-reduce of [32,5] int64
+        from dither_pie_amd import kmeans, sharding
+        del f3, o3
+        g4 = torch.Generator(device=dev)
+        g4.manual_seed(99)
+        lo4, hi4 = sharding.shard_range(4320, rank, world)
+        img = torch.randint(0, 256, (4320, 7680, 3), dtype=torch.uint8, device=dev, generator=g4)
+        band = img[lo4:hi4].contiguous()
+        del img
+
+        def c4():
+            pal, _, _, iters = kmeans.fit_palette(band.reshape(-1, 3), 32, 42, n_total=4320 * 7680, offset=lo4 * 7680)
+            d4 = ImageDitherer(32, DitherMode.BLUE_NOISE, pal, False, {"size": 64, "seed": 42})
+            sharding.dither_band(d4, band, lo4)
+            return iters
+
+        iters4 = c4()
+        t4 = timed(c4, 1, 0)
+        extra["c4_8k_kmeans32_plus_blue_noise_seconds"] = round(t4, 4)
+        extra["c4_note"] = (f"7680x4320 in {world} row band(s), Lloyd over all pixels ({iters4} iterations, one int64 "
+                            "all-reduce each), blue-noise(64,42) dither of the band with global coordinates")
         result["extra"] = extra
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:

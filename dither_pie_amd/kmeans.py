@@ -55,49 +55,55 @@ def _all_reduce_totals(totals, group):
 def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None):
     """Lloyd iterations over the uint8 pixels `px` ([...,3] tensor; on the GPU unless step_fn is given).
 
-    Each iteration: local assignment + integer totals (step_fn, default backend.kmeans_step), one
-    all-reduce of the packed [K,5] int64 totals when a process group is active, centre update in
-    float64 on the host.  Returns (centers float64 [K,3], inertia, n_iter)."""
+    Each iteration: local assignment + integer totals (step_fn, default backend.kmeans_step), ONE
+    all-reduce of the packed [K,5] int64 totals when a process group is active, then the centre update,
+    shift and inertia in float64 on the device that holds the totals; a single 3-number read-back per
+    iteration drives the convergence test.  Returns (centers float64 [K,3] numpy, inertia, n_iter)."""
     import torch
     if step_fn is None:
         from . import backend
         step_fn = backend.kmeans_step
-    centers = np.array(init_centers, dtype=np.float64).reshape(-1, 3)
+    centers = torch.as_tensor(np.array(init_centers, dtype=np.float64).reshape(-1, 3))
     K = centers.shape[0]
+    dev = None
     tol_abs = None
     prev = None
-    n_iter = 0
     inertia = float("nan")
-    for n_iter in range(1, max_iter + 2):
-        sums, counts, sumsq = step_fn(px, torch.from_numpy(centers))
-        totals = torch.cat([sums.reshape(K, 3), counts.reshape(K, 1), sumsq.reshape(K, 1)], dim=1).contiguous()
-        totals = _all_reduce_totals(totals, group).cpu().numpy()
-        s, n, q = totals[:, :3].astype(np.float64), totals[:, 3].astype(np.float64), totals[:, 4].astype(np.float64)
-        inertia = float((q - 2.0 * (centers * s).sum(1) + n * (centers * centers).sum(1)).sum())
-        if tol_abs is None:
+    n_iter = 0
+
+    def totals_for(c):
+        sums, counts, sumsq = step_fn(px, c)
+        t = torch.cat([sums.reshape(K, 3), counts.reshape(K, 1), sumsq.reshape(K, 1)], dim=1).contiguous()
+        return _all_reduce_totals(t, group)
+
+    def inertia_of(c, t):
+        s, n, q = t[:, :3].double(), t[:, 3].double(), t[:, 4].double()
+        return (q - 2.0 * (c * s).sum(1) + n * (c * c).sum(1)).sum()
+
+    for n_iter in range(1, max_iter + 1):
+        totals = totals_for(centers)
+        if dev is None:
+            dev = totals.device
+            centers = centers.to(dev)
+        s, n = totals[:, :3].double(), totals[:, 3].double()
+        if tol_abs is None:  # sklearn: tol * mean of the per-channel variances (from the exact totals)
             N = n.sum()
             mean = s.sum(0) / N
-            tol_abs = tol * float((q.sum() / N - (mean * mean).sum()) / 3.0)
-        if n_iter > max_iter:  # the extra pass only refreshes the inertia for the final centres
-            n_iter = max_iter
-            break
-        new = centers.copy()
-        nz = n > 0
-        new[nz] = s[nz] / n[nz, None]
-        shift = float(((new - centers) ** 2).sum())
-        same = prev is not None and np.array_equal(prev, totals[:, :4])
-        prev = totals[:, :4].copy()
-        if same:
+            tol_abs = tol * float(((totals[:, 4].double().sum() / N - (mean * mean).sum()) / 3.0).item())
+        new = torch.where((n > 0).unsqueeze(1), s / n.clamp(min=1.0).unsqueeze(1), centers)
+        shift = ((new - centers) ** 2).sum()
+        same = torch.zeros((), dtype=torch.float64, device=dev) if prev is None else \
+            (prev == totals[:, :4]).all().double()
+        stats = torch.stack([shift, inertia_of(centers, totals), same]).cpu()
+        prev = totals[:, :4].clone()
+        inertia = float(stats[1])
+        if bool(stats[2] > 0):   # assignments did not change: strict convergence, centres stay
             break
         centers = new
-        if shift <= tol_abs:
-            sums, counts, sumsq = step_fn(px, torch.from_numpy(centers))
-            totals = torch.cat([sums.reshape(K, 3), counts.reshape(K, 1), sumsq.reshape(K, 1)], dim=1).contiguous()
-            totals = _all_reduce_totals(totals, group).cpu().numpy()
-            s, n, q = totals[:, :3].astype(np.float64), totals[:, 3].astype(np.float64), totals[:, 4].astype(np.float64)
-            inertia = float((q - 2.0 * (centers * s).sum(1) + n * (centers * centers).sum(1)).sum())
+        if float(stats[0]) <= tol_abs or n_iter == max_iter:
+            inertia = float(inertia_of(centers, totals_for(centers)).item())  # inertia of the final centres
             break
-    return centers, inertia, n_iter
+    return centers.cpu().numpy(), inertia, n_iter
 
 
 def seed_sample(px, n_total, offset, random_state, group=None):
