@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libditherpie_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_OK, DP_EINVAL, DP_EUNSUPPORTED, DP_EHIP, DP_ENOMEM, DP_EWORKSPACE = range(6)
-DP_MAX_COLORS = 256
+DP_MAX_COLORS = 1024
 MODE_NEAREST, MODE_MATRIX, MODE_IGN = 0, 1, 2
 
 

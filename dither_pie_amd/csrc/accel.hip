@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
         double dd[2];
         int ii[2];
         {
-            tree_query<2>(pal, (double)r, (double)g, (double)b, dd, ii);
+            tree_query<2, kQueueSmall>(pal, (double)r, (double)g, (double)b, dd, ii);
             const uint32_t on = pal.out_rgb[ii[0]], os = pal.out_rgb[ii[1]];
             uint32_t code = 3;
             if (on == o0 && os == o1) code = 0;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
             if (code) atomicOr(&code2[x4 >> 4], code << ((x4 & 15u) * 2));
         }
         if (tie01) {
-            tree_query<1>(pal, (double)r, (double)g, (double)b, dd, ii);
+            tree_query<1, kQueueSmall>(pal, (double)r, (double)g, (double)b, dd, ii);
             const uint32_t on = pal.out_rgb[ii[0]];
             uint32_t code = 3;
             if (on == o0) code = 0;

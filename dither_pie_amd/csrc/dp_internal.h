@@ -12,9 +12,10 @@
 namespace dp {
 
 constexpr int kLeafSize = 10;     // scipy.spatial.KDTree default (dithering_lib.py:339)
-constexpr int kMaxNodes = 128;    // >= 2*ceil(256/5)-1 nodes for K <= 256
-constexpr int kQueueCap = 64;     // >= number of inner nodes for K <= 256 (<= 51)
-constexpr int kIdxBits = 8;       // palette index bits packed under the distance key
+constexpr int kQueueSmall = 64;   // traversal queue entries: every balanced tree of K <= 256 has <= 51 inner nodes
+constexpr int kQueueLarge = 256;  // ... larger palettes (K <= 1024) and degenerate trees use the large instantiation
+constexpr int kIdxBits = 10;      // palette index bits packed under the distance key (brute-force kernels)
+constexpr int kLocalBits = 8;     // byte offset of a candidate inside its block (cell-table kernel)
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
@@ -40,6 +41,7 @@ void build_tree(const double *pts, int K, HostTree &t);
 struct PalDev {
     int K;
     int n_nodes;
+    int n_inner;               // inner nodes of the tree = upper bound of the traversal queue
     int is_integer;
     const uint32_t *p4;        // K: r | g<<8 | b<<16          (integer palettes)
     const int32_t *nkey;       // K: (|p|^2 << kIdxBits) | j   (integer palettes)

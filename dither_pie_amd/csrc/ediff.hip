@@ -45,6 +45,7 @@ struct Taps {
     float wq[kMaxTaps];
 };
 
+template <int CAP>
 __device__ __forceinline__ int nearest_f64(const PalDev &pal, const float o0, const float o1, const float o2)
 {
     const double x0 = (double)o0, x1 = (double)o1, x2 = (double)o2;
@@ -65,7 +66,7 @@ __device__ __forceinline__ int nearest_f64(const PalDev &pal, const float o0, co
     if (b0 == b1 && K > kLeafSize) {
         double d2[1];
         int ii[1];
-        tree_query<1>(pal, x0, x1, x2, d2, ii);
+        tree_query<1, CAP>(pal, x0, x1, x2, d2, ii);
         i0 = ii[0];
     }
     return i0;
@@ -73,6 +74,7 @@ __device__ __forceinline__ int nearest_f64(const PalDev &pal, const float o0, co
 
 // float32 prefilter: |d_f32 - d| <= ~3.6e-7 d (one rounding per subtract, square and add), so a gap of
 // 2e-6 (relative) between the two smallest float32 distances proves the float64 order
+template <int CAP>
 __device__ __forceinline__ int nearest_color(const PalDev &pal, const float o0, const float o1, const float o2)
 {
     float b0 = __int_as_float(0x7f800000), b1 = b0;
@@ -87,11 +89,12 @@ __device__ __forceinline__ int nearest_color(const PalDev &pal, const float o0, 
         b0 = lt0 ? d : b0;
     }
     if (b1 > b0 * 1.000002f) return i0;
-    return nearest_f64(pal, o0, o1, o2);
+    return nearest_f64<CAP>(pal, o0, o1, o2);
 }
 
 __device__ __forceinline__ float clamp255(const float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
 
+template <int CAP>
 __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                     a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
                 }
                 const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-                const int j = nearest_color(pal, o0, o1, o2);
+                const int j = nearest_color<CAP>(pal, o0, o1, o2);
                 e0 = __fsub_rn(o0, pal.pts_f32[3 * j]);
                 e1 = __fsub_rn(o1, pal.pts_f32[3 * j + 1]);
                 e2 = __fsub_rn(o2, pal.pts_f32[3 * j + 2]);
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
 }
 
 // lane = frame; err rows: ring[3][w][3][n_frames] floats (frame index fastest => coalesced)
+template <int CAP>
 __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                        const int64_t n_frames, const int h, const int w,
                                                        const PalDev pal, const Taps taps, const int serpentine,
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
                 a2 = __fadd_rn(a2, __fmul_rn(e[2 * nf], wq));
             }
             const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-            const int j = nearest_color(pal, o0, o1, o2);
+            const int j = nearest_color<CAP>(pal, o0, o1, o2);
             float *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
             e[0] = __fsub_rn(o0, (float)pal.pts[3 * j]);
             e[nf] = __fsub_rn(o1, (float)pal.pts[3 * j + 1]);
@@ -325,12 +329,20 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         }
         const int n_bands = (h + 63) / 64;
         const int nw = n_bands < kMaxWaves ? n_bands : kMaxWaves;
-        hipLaunchKernelGGL(ed_wavefront_kernel, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h, w, pal, t,
-                           reinterpret_cast<float *>(ws));
+        if (pal.n_inner > kQueueSmall)
+            hipLaunchKernelGGL(ed_wavefront_kernel<kQueueLarge>, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h,
+                               w, pal, t, reinterpret_cast<float *>(ws));
+        else
+            hipLaunchKernelGGL(ed_wavefront_kernel<kQueueSmall>, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h,
+                               w, pal, t, reinterpret_cast<float *>(ws));
     } else {
         const int64_t blocks = (n_frames + 63) / 64;
-        hipLaunchKernelGGL(ed_serial_kernel, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h, w, pal, t,
-                           serpentine, reinterpret_cast<float *>(ws));
+        if (pal.n_inner > kQueueSmall)
+            hipLaunchKernelGGL(ed_serial_kernel<kQueueLarge>, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h,
+                               w, pal, t, serpentine, reinterpret_cast<float *>(ws));
+        else
+            hipLaunchKernelGGL(ed_serial_kernel<kQueueSmall>, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h,
+                               w, pal, t, serpentine, reinterpret_cast<float *>(ws));
     }
     prof_end(pm, s);
     DP_HIP(hipGetLastError());

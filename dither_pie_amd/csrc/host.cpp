@@ -249,14 +249,11 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     HostTree t;
     build_tree(pts.data(), K, t);
     const int nn = (int)t.split_dim.size();
-    if (nn > kMaxNodes) {
-        set_error("dp_palette_create: KD-tree with %d nodes exceeds the device limit %d", nn, kMaxNodes);
-        return DP_EUNSUPPORTED;
-    }
     int inner = 0;
     for (int i = 0; i < nn; ++i) inner += t.split_dim[i] >= 0;
-    if (inner > kQueueCap) {
-        set_error("dp_palette_create: KD-tree with %d inner nodes exceeds the device queue %d", inner, kQueueCap);
+    if (inner > kQueueLarge) {
+        set_error("dp_palette_create: KD-tree with %d inner nodes exceeds the device traversal queue (%d)", inner,
+                  kQueueLarge);
         return DP_EUNSUPPORTED;
     }
 
@@ -313,6 +310,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     PalDev &d = p->dev;
     d.K = K;
     d.n_nodes = nn;
+    d.n_inner = inner;
     d.is_integer = integer ? 1 : 0;
     d.p4 = (const uint32_t *)(base + o_p4);
     d.nkey = (const int32_t *)(base + o_nk);
@@ -340,7 +338,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     p->accel_bytes = 0;
     p->accel_tried = false;
     p->p4_host = p4;
-    p->same_out = integer && K >= 8;
+    p->same_out = integer && K >= 8 && K <= 256 && inner <= kQueueSmall;  // what the accelerator handles
     for (int j = 0; j < K && p->same_out; ++j) p->same_out = (orgb[j] == p4[j]);
     *out = p;
     return DP_OK;

@@ -30,7 +30,7 @@ struct Geo {
     int y0, x0;      // global coordinates of pixel (0,0)
     int ty0, tx0;    // y0 % th_h, x0 % th_w
     int aligned;     // in/out are 4-byte aligned
-    int neg2;        // -(2 << kIdxBits), kept in a register on purpose (see cand8)
+    int neg2;        // -(2 << kLocalBits), kept in a register on purpose (see cand8)
     uint32_t adv_y, adv_x;  // (tile stride in pixels) mod hw, split into rows and columns (persistent kernel)
 };
 
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void ordered_int_kernel(const uint8_t *__re
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int dot = (int)__builtin_amdgcn_udot4(px[q], pj, 0u, false);
-            const int key = nk - (dot << (kIdxBits + 1));  // ((|p|^2 - 2 x.p) << 8) | j
+            const int key = nk - (dot << (kIdxBits + 1));  // ((|p|^2 - 2 x.p) << kIdxBits) | j
             const int n2 = med3i(m1[q], m2[q], key);
             const int n1 = med3i(m0[q], m1[q], key);
             m0[q] = min(m0[q], key);
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
             int m0, m1, m2;
             cand8(x, ca[q], cb[q], g.neg2, m0, m1, m2);
             const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
-            const int a0 = m0 >> kIdxBits, a1 = m1 >> kIdxBits, a2 = m2 >> kIdxBits;
+            const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits, a2 = m2 >> kLocalBits;
             const uint32_t d0 = (uint32_t)(a0 + xx), d1 = (uint32_t)(a1 + xx);
             uint32_t a = *reinterpret_cast<const uint32_t *>(s_bytes + blk[q] + (m0 & 0xfc));  // reported nearest
             uint32_t b = *reinterpret_cast<const uint32_t *>(s_bytes + blk[q] + (m1 & 0xfc));  // reported second
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kBlock) void ordered_f64_kernel(const uint8_t *__re
 }
 
 // Pass 2: resolve flagged pixels in scipy's order.
-template <int MODE>  // 0 nearest, 2 matrix (f32 thresholds), 3 IGN
+template <int MODE, int CAP>  // MODE: 0 nearest, 2 matrix (f32 thresholds), 3 IGN; CAP: traversal queue entries
 __global__ __launch_bounds__(kBlock) void fixup_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                        const unsigned long long *__restrict__ flags,
                                                        const uint32_t n_words, const Geo g, const PalDev pal,
@@ -569,10 +569,10 @@ __global__ __launch_bounds__(kBlock) void fixup_kernel(const uint8_t *__restrict
             int ii[2];
             int pick;
             if (MODE == 0) {
-                tree_query<1>(pal, (double)c0, (double)c1, (double)c2, d2, ii);
+                tree_query<1, CAP>(pal, (double)c0, (double)c1, (double)c2, d2, ii);
                 pick = ii[0];
             } else {
-                tree_query<2>(pal, (double)c0, (double)c1, (double)c2, d2, ii);
+                tree_query<2, CAP>(pal, (double)c0, (double)c1, (double)c2, d2, ii);
                 uint32_t y, x;
                 locate(g, p, y, x);
                 float t;
@@ -731,7 +731,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         g.ty0 = y0 % thr.th_h;
         g.tx0 = x0 % thr.th_w;
         g.aligned = (((uintptr_t)in_c | (uintptr_t)out_c) & 3) == 0;
-        g.neg2 = -(2 << kIdxBits);
+        g.neg2 = -(2 << kLocalBits);
         g.adv_y = g.adv_x = 0;
         const uint32_t groups = (g.n_px + 3) / 4;
         const uint32_t blocks = (groups + kBlock - 1) / kBlock;
@@ -783,12 +783,16 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         DP_HIP(hipGetLastError());
         prof_mid(pm, s);
         const uint32_t fgrid = std::min<uint32_t>((n_words + kBlock - 1) / kBlock, 2048u);
-        if (fix_mode == 0)
-            hipLaunchKernelGGL(fixup_kernel<0>, dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale);
-        else if (fix_mode == 3)
-            hipLaunchKernelGGL(fixup_kernel<3>, dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale);
-        else
-            hipLaunchKernelGGL(fixup_kernel<2>, dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale);
+#define DP_FIX(M, C) hipLaunchKernelGGL((fixup_kernel<M, C>), dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale)
+        const bool big_q = pal.n_inner > kQueueSmall;
+        if (fix_mode == 0) {
+            if (big_q) DP_FIX(0, kQueueLarge); else DP_FIX(0, kQueueSmall);
+        } else if (fix_mode == 3) {
+            if (big_q) DP_FIX(3, kQueueLarge); else DP_FIX(3, kQueueSmall);
+        } else {
+            if (big_q) DP_FIX(2, kQueueLarge); else DP_FIX(2, kQueueSmall);
+        }
+#undef DP_FIX
         prof_end(pm, s);
         DP_HIP(hipGetLastError());
     }

@@ -31,12 +31,12 @@ __device__ __forceinline__ double sq_dist3(const double *__restrict__ p, const d
     return s;
 }
 
-template <int KQ>
+template <int KQ, int CAP>
 __device__ void tree_query(const PalDev &pal, const double x0, const double x1, const double x2, double *d2_out,
                            int *i_out)
 {
     const double xs[3] = {x0, x1, x2};
-    QItem q[kQueueCap];
+    QItem q[CAP];
     int qn = 0;
     double nb_prio[2];
     int nb_idx[2];
@@ -119,7 +119,7 @@ __device__ void tree_query(const PalDev &pal, const double x0, const double x1, 
                 far.side[1] = ns;
             else
                 far.side[2] = ns;
-            if (far.prio <= ub && qn < kQueueCap) {
+            if (far.prio <= ub && qn < CAP) {
                 int i = qn++;
                 q[i] = far;
                 while (i > 0 && q[i].prio < q[(i - 1) / 2].prio) {

@@ -35,7 +35,7 @@ extern "C" {
 #define DP_ENOMEM 4
 #define DP_EWORKSPACE 5  /* workspace too small; see the *_workspace_bytes query */
 
-#define DP_MAX_COLORS 256
+#define DP_MAX_COLORS 1024
 
 #define DP_MODE_NEAREST 0 /* NoDitherStrategy                     dithering_lib.py:333-341 */
 #define DP_MODE_MATRIX 1  /* MatrixDitherStrategy (Bayer, blue)   dithering_lib.py:346-378 */

@@ -100,9 +100,9 @@ def test_frames_api_tiles_and_pickle(d, orc):
 
 def test_too_many_colours_is_reported(d, orc):
     from dither_pie_amd import DitherPieError
-    pal = orc.palr(300, 1)
+    pal = orc.palr(1100, 1)
     with pytest.raises(DitherPieError):
-        d.ImageDitherer(300, d.DitherMode.NONE, pal).apply_dithering(Image.fromarray(orc.rnd(8, 8, 1)))
+        d.ImageDitherer(1100, d.DitherMode.NONE, pal).apply_dithering(Image.fromarray(orc.rnd(8, 8, 1)))
 
 
 def test_kmeans_gpu_matches_sklearn_fixture_and_oracle(d, orc, gold, kat):

@@ -277,3 +277,19 @@ def test_full_size_properties_and_2g_pixel_chunking(be, orc):
     palset = torch.tensor([(r << 16) | (g << 8) | b for r, g, b in pal], device="cuda")
     assert bool(torch.isin(packed, palset).all())
     assert torch.equal(be.ordered(near, P, be.MODE_NEAREST), near)
+
+
+@pytest.mark.parametrize("K,seed", [(257, 1), (300, 2), (700, 3), (1024, 4)])
+def test_large_palettes(be, orc, K, seed):
+    """above 256 colours: brute-force kernels with the 10-bit index key and the large traversal queue"""
+    pal = orc.palr(K, seed)
+    for arr in (orc.rnd(40, 61, seed), orc.grad(64, 80)):
+        for mode, params in [("none", {}), ("bayer", {"size": "8x8"}), ("IGN", {}), ("blue_noise", {"size": 32, "seed": 2})]:
+            out = _run_case(be, orc, arr, pal, mode, params, False)
+            _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False), f"{mode} K={K}")
+    arr = orc.rnd(70, 45, seed)
+    for params in [{"variant": "floyd_steinberg", "serpentine": "false"}, {"variant": "atkinson", "serpentine": "true"}]:
+        out = _run_case(be, orc, arr, pal, "error_diffusion", params, False)
+        _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, False), f"ed K={K}")
+    out = _run_case(be, orc, orc.grad(33, 47), pal, "bayer", {"size": "4x4"}, True)
+    _assert_same(out, orc.apply_dithering(orc.grad(33, 47), pal, "bayer", {"size": "4x4"}, True), f"gamma K={K}")
