@@ -190,7 +190,7 @@ def main():
         extra["c5_note"] = "1000 frames total split into contiguous blocks per rank (strong scaling), compute only"
         del f5, o5
         # C3: Floyd-Steinberg, 16 colours, 4K, a batch of frames (one wave per frame)
-        nf3 = 128
+        nf3 = 256
         d3 = ImageDitherer(16, DitherMode.ERROR_DIFFUSION, ColorReducer.generate_uniform_palette(16), False,
                            {"variant": "floyd_steinberg", "serpentine": "false"})
         f3 = frames[:min(nf3, args.frames)].repeat((nf3 + args.frames - 1) // args.frames, 1, 1, 1)[:nf3]

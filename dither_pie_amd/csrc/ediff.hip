@@ -14,9 +14,12 @@
 //   earlier.  Bands of one frame are pipelined across the waves of the workgroup: band b+1 behaves
 //   like "lanes 64.." of band b, trailing it by 63*skew+3 steps; it spins on a progress word in LDS
 //   that the producing wave publishes after its stores are acknowledged.  Nothing on the dependency
-//   chain touches HBM latency: errors live in an 8-deep per-row LDS ring, the two rows that cross a
-//   band boundary travel through a global row buffer (L2) and are prefetched one step ahead into a
-//   small LDS ring, and input pixels are prefetched two steps ahead into an LDS ring.
+//   chain touches global memory: all global traffic happens at 16-step period boundaries -- each lane
+//   fetches the 48 bytes of its next 16 pixels one full period ahead (unaligned dword loads), flushes
+//   the 48 output bytes of the finished period, rows 62/63 flush their staged errors to a global row
+//   buffer (L2) and lanes prefetch the previous band's two boundary rows into a 64-column LDS ring --
+//   so every wait is for operations issued a period earlier.  Errors of the band's own rows live in an
+//   8-deep per-row LDS ring.
 // ed_serial_kernel (any scan, used for serpentine): rows are strictly sequential under a
 //   serpentine scan (the first pixel of row y+1 needs the last pixel of row y), so parallelism
 //   comes from frames only: lane = frame, error rows interleaved across lanes in global memory.
@@ -34,8 +37,6 @@ namespace {
 
 constexpr int kMaxTaps = 16;
 constexpr int kRing = 8;    // per-row error ring depth (positions): skew*dy+dx <= 8 for every supported tap set
-constexpr int kVRing = 16;  // ring of the two boundary rows prefetched from the previous band
-constexpr int kPixRing = 8;
 constexpr int kMaxWaves = 16;
 
 struct Taps {
@@ -94,17 +95,20 @@ __device__ __forceinline__ int nearest_color(const PalDev &pal, const float o0, 
 
 __device__ __forceinline__ float clamp255(const float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
 
+// 16-step I/O period of the wavefront kernel: all global traffic happens at period boundaries
+constexpr int kPeriod = 16;
+
 template <int CAP>
 __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
                                                                       float *__restrict__ bnd_all)
 {
-    __shared__ float s_ring[kMaxWaves][64][kRing][3];   // errors of the band's own rows
-    __shared__ float s_vring[kMaxWaves][2][kVRing][3];  // errors of the two rows above the band
-    __shared__ uint32_t s_pix[kMaxWaves][64][kPixRing]; // prefetched input pixels (r | g<<8 | b<<16)
+    __shared__ float s_ring[kMaxWaves][64][kRing][3];    // errors of the band's own rows (last 8 columns)
+    __shared__ float s_vring[kMaxWaves][2][64][3];       // errors of the two rows above the band (64-column ring)
+    __shared__ float s_bout[kMaxWaves][2][kPeriod][3];   // this period's errors of rows 62/63, flushed to global
     __shared__ uint8_t s_lut[256];
-    __shared__ volatile uint32_t s_prog[kMaxWaves];     // (band << 16) | steps whose stores are acknowledged
+    __shared__ volatile uint32_t s_prog[kMaxWaves];      // (band << 16) | (acknowledged column of row 63 + 1024)
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     if (threadIdx.x < kMaxWaves) s_prog[threadIdx.x] = 0;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
+    const long frame_bytes = (long)h * w * 3;
     float *bnd = bnd_all + f * (size_t)4 * w * 3;  // [2 buffers][2 rows][w][3]
     const int skew = taps.skew;
     const int n_bands = (h + 63) / 64;
@@ -126,98 +131,176 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
         const int steps = w + skew * (rows_here - 1);
         const int pw = (wv + NW - 1) % NW;  // wave that owns band-1
         const bool row_ok = r < h;
-        uint32_t pf_pix = 0;    // pixel loaded in the previous step, to be parked in s_pix
-        int pf_pix_x = -1;
-        float pv0 = 0.f, pv1 = 0.f, pv2 = 0.f;  // boundary errors loaded in the previous step (lanes 0,1)
-        int pf_b_x = -1;
-        for (int t = -3; t < steps; ++t) {
-            const int x = t - skew * L;
-            // ---- park what the previous step fetched (its latency was hidden behind that step's compute)
-            if (pf_pix_x >= 0) s_pix[wv][L][pf_pix_x & (kPixRing - 1)] = pf_pix;
-            if (pf_b_x >= 0 && L < 2) {
-                s_vring[wv][L][pf_b_x & (kVRing - 1)][0] = pv0;
-                s_vring[wv][L][pf_b_x & (kVRing - 1)][1] = pv1;
-                s_vring[wv][L][pf_b_x & (kVRing - 1)][2] = pv2;
-            }
-            // every store of the previous steps is acknowledged (the loads above were waited for, and
-            // vmcnt retires in order): publish progress for the wave that owns the next band
+        const long row_byte = (long)r * w * 3;
+
+        uint32_t pix[12], cur[13], outb[13];  // 16 pixels in flight / being consumed / being produced (raw bytes)
+        float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;  // boundary errors in flight (one column per lane)
+        int pb_col = -1;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pix[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) cur[k] = outb[k] = 0;
+
+        for (int t0 = -kPeriod; t0 < steps + kPeriod; t0 += kPeriod) {
+            // ================= period boundary: everything issued one period ago has landed =================
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (L == 0 && t >= 0) s_prog[wv] = ((uint32_t)band << 16) | (uint32_t)t;
-            // ---- fetch ahead: the pixel two steps ahead, the boundary errors three columns ahead
-            pf_pix_x = -1;
-            if (row_ok && x + 2 >= 0 && x + 2 < w) {
-                const uint8_t *p = fin + ((size_t)r * w + (x + 2)) * 3;
-                pf_pix = (uint32_t)s_lut[p[0]] | ((uint32_t)s_lut[p[1]] << 8) | ((uint32_t)s_lut[p[2]] << 16);
-                pf_pix_x = x + 2;
+            if (L == 0) {
+                // boundary columns produced in steps < t0 - kPeriod are acknowledged
+                int ack = t0 - kPeriod - 63 * skew + 1024;
+                ack = ack < 0 ? 0 : ack;
+                s_prog[wv] = ((uint32_t)band << 16) | (uint32_t)ack;
             }
-            pf_b_x = -1;
+            // park the boundary errors fetched during the previous period
+            if (pb_col >= 0) {
+                float *dst = &s_vring[wv][L >> 5][pb_col & 63][0];
+                dst[0] = pb0;
+                dst[1] = pb1;
+                dst[2] = pb2;
+            }
+            // ---- flush the outputs of the period that just ended: columns [xs, xs+16) of row r
+            {
+                const int xs = (t0 - kPeriod) - skew * L;
+                const int lo = xs < 0 ? 0 : xs, hi = xs + kPeriod > w ? w : xs + kPeriod;
+                if (row_ok && hi > lo) {
+                    const long B = row_byte + (long)xs * 3;
+                    if (lo == xs && hi == xs + kPeriod) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) *reinterpret_cast<uint32_t *>(fout + B + 4 * k) = outb[k];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < kPeriod; ++i) {
+                            if (xs + i >= 0 && xs + i < w) {
+                                const int bo = 3 * i;
+                                const uint32_t c = __funnelshift_r(outb[bo >> 2], outb[(bo >> 2) + 1], (bo & 3) * 8);
+                                uint8_t *o = fout + B + bo;
+                                o[0] = (uint8_t)c;
+                                o[1] = (uint8_t)(c >> 8);
+                                o[2] = (uint8_t)(c >> 16);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 13; ++k) outb[k] = 0;
+                // rows 62/63: this band's boundary errors of the same period go to the global row buffer
+                if (L >= 62 && row_ok && hi > lo) {
+                    for (int i = lo - xs; i < hi - xs; ++i) {
+                        float *b = bnext + ((size_t)(L - 62) * w + (xs + i)) * 3;
+                        b[0] = s_bout[wv][L - 62][i][0];
+                        b[1] = s_bout[wv][L - 62][i][1];
+                        b[2] = s_bout[wv][L - 62][i][2];
+                    }
+                }
+            }
+            // ---- the pixels fetched during the previous period become current; fetch the next 16
+#pragma unroll
+            for (int k = 0; k < 12; ++k) cur[k] = pix[k];
+            {
+                const int xn = (t0 + kPeriod) - skew * L;  // first column of the NEXT period
+                const long B = row_byte + (long)xn * 3;
+                if (row_ok && xn + kPeriod > 0 && xn < w) {
+                    if (B >= 0 && B + 48 <= frame_bytes) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) pix[k] = *reinterpret_cast<const uint32_t *>(fin + B + 4 * k);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) {
+                            uint32_t v = 0;
+#pragma unroll
+                            for (int bb = 0; bb < 4; ++bb) {
+                                const long a = B + 4 * k + bb;
+                                if (a >= 0 && a < frame_bytes) v |= (uint32_t)fin[a] << (8 * bb);
+                            }
+                            pix[k] = v;
+                        }
+                    }
+                }
+            }
+            // ---- boundary rows of the band above: columns [x0n-14, x0n+18) around lane 0's next period
+            pb_col = -1;
             if (band > 0) {
-                const int pb = t + 3;  // wave-uniform column
-                if (pb < w) {
-                    // row band*64-1 (lane 63 of band-1) finishes column pb in its step pb+63*skew
-                    const uint32_t need = (uint32_t)(pb + 63 * skew + 1);
+                const int x0n = t0 + kPeriod;      // lane 0's first column of the next period (wave-uniform)
+                int need = x0n + 18;               // one past the last column fetched
+                need = need > w ? w : need;
+                if (x0n - 14 < w && need > 0) {
+                    const uint32_t want = (uint32_t)(need + 1024);
                     for (;;) {
                         const uint32_t v = s_prog[pw];
-                        if ((int)(v >> 16) > band - 1 || ((int)(v >> 16) == band - 1 && (v & 0xffffu) >= need)) break;
-                        __builtin_amdgcn_s_sleep(2);
+                        if ((int)(v >> 16) > band - 1 || ((int)(v >> 16) == band - 1 && (v & 0xffffu) >= want)) break;
+                        __builtin_amdgcn_s_sleep(4);
                     }
-                    if (L < 2) {
-                        // lane 0 -> row -2 (lane 62 of band-1), lane 1 -> row -1 (lane 63); bypass L1: the
-                        // buffer was written by another wave of this workgroup and is reused every 2 bands
-                        const float *b = bprev + ((size_t)L * w + pb) * 3;
-                        pv0 = __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        pv1 = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        pv2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        pf_b_x = pb;
+                    const int col = x0n - 14 + (L & 31);
+                    if (col >= 0 && col < w) {
+                        // lanes 0..31 -> row -2 (lane 62 of band-1), lanes 32..63 -> row -1 (lane 63); the buffer was
+                        // written by another wave of this workgroup and is reused every 2 bands: bypass L1
+                        const float *b = bprev + ((size_t)(L >> 5) * w + col) * 3;
+                        pb0 = __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pb1 = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pb2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pb_col = col;
                     }
-                }
-            }
-            // ---- this step's pixel
-            const bool act = row_ok && x >= 0 && x < w;
-            float e0 = 0.f, e1 = 0.f, e2 = 0.f;
-            if (act) {
-                const uint32_t pxv = s_pix[wv][L][x & (kPixRing - 1)];
-                float a0 = (float)(pxv & 255u), a1 = (float)((pxv >> 8) & 255u), a2 = (float)(pxv >> 16);
-                for (int k = 0; k < taps.n; ++k) {
-                    const int sxp = x - taps.dx[k];
-                    const int sr = r - taps.dy[k];
-                    if (sxp < 0 || sxp >= w || sr < 0) continue;
-                    const int rel = L - taps.dy[k];
-                    const float *src = rel >= 0 ? &s_ring[wv][rel][sxp & (kRing - 1)][0]
-                                                : &s_vring[wv][rel + 2][sxp & (kVRing - 1)][0];
-                    const float wq = taps.wq[k];
-                    a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
-                    a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
-                    a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
-                }
-                const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-                const int j = nearest_color<CAP>(pal, o0, o1, o2);
-                e0 = __fsub_rn(o0, pal.pts_f32[3 * j]);
-                e1 = __fsub_rn(o1, pal.pts_f32[3 * j + 1]);
-                e2 = __fsub_rn(o2, pal.pts_f32[3 * j + 2]);
-                const uint32_t c = pal.out_rgb[j];
-                uint8_t *o = fout + ((size_t)r * w + x) * 3;
-                o[0] = (uint8_t)c;
-                o[1] = (uint8_t)(c >> 8);
-                o[2] = (uint8_t)(c >> 16);
-            }
-            // every pull of this step precedes the ring writes below (slot x&7 still holds column x-8, which the
-            // row two below reads in this very step for a dx=+2 tap)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (act) {
-                s_ring[wv][L][x & (kRing - 1)][0] = e0;
-                s_ring[wv][L][x & (kRing - 1)][1] = e1;
-                s_ring[wv][L][x & (kRing - 1)][2] = e2;
-                if (L >= 62) {
-                    float *b = bnext + ((size_t)(L - 62) * w + x) * 3;
-                    b[0] = e0;
-                    b[1] = e1;
-                    b[2] = e2;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+
+            // ================= 16 steps that touch LDS and registers only =================
+            for (int i = 0; i < kPeriod; ++i) {
+                const int t = t0 + i;
+                const int x = t - skew * L;
+                const bool act = row_ok && x >= 0 && x < w && t >= 0 && t < steps;
+                float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+                uint32_t cbytes = 0;
+                if (act) {
+                    const uint32_t pxv = cur[0];  // this step's pixel sits in the low 3 bytes (see the rotation below)
+                    float a0 = (float)s_lut[pxv & 255u], a1 = (float)s_lut[(pxv >> 8) & 255u],
+                          a2 = (float)s_lut[(pxv >> 16) & 255u];
+                    for (int k = 0; k < taps.n; ++k) {
+                        const int sxp = x - taps.dx[k];
+                        const int sr = r - taps.dy[k];
+                        if (sxp < 0 || sxp >= w || sr < 0) continue;
+                        const int rel = L - taps.dy[k];
+                        const float *src = rel >= 0 ? &s_ring[wv][rel][sxp & (kRing - 1)][0]
+                                                    : &s_vring[wv][rel + 2][sxp & 63][0];
+                        const float wq = taps.wq[k];
+                        a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
+                        a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
+                        a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
+                    }
+                    const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
+                    const int j = nearest_color<CAP>(pal, o0, o1, o2);
+                    e0 = __fsub_rn(o0, pal.pts_f32[3 * j]);
+                    e1 = __fsub_rn(o1, pal.pts_f32[3 * j + 1]);
+                    e2 = __fsub_rn(o2, pal.pts_f32[3 * j + 2]);
+                    cbytes = pal.out_rgb[j];
+                }
+                // rotate both 48-byte period buffers by one pixel (static register indices only): the next pixel
+                // moves into the low bytes of cur[], this step's colour enters outb[] at bytes 45..47 and will have
+                // travelled down to byte 3*i by the time the period is flushed
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    cur[k] = __funnelshift_r(cur[k], cur[k + 1], 24);
+                    outb[k] = __funnelshift_r(outb[k], outb[k + 1], 24);
+                }
+                cur[11] >>= 24;
+                outb[11] = (outb[11] >> 24) | (cbytes << 8);
+                // every pull of this step precedes the ring writes below (slot x&7 still holds column x-8, which
+                // the row two below reads in this very step for a dx=+2 tap)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (act) {
+                    s_ring[wv][L][x & (kRing - 1)][0] = e0;
+                    s_ring[wv][L][x & (kRing - 1)][1] = e1;
+                    s_ring[wv][L][x & (kRing - 1)][2] = e2;
+                    if (L >= 62) {
+                        s_bout[wv][L - 62][i][0] = e0;
+                        s_bout[wv][L - 62][i][1] = e1;
+                        s_bout[wv][L - 62][i][2] = e2;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         // band finished: once its boundary stores are acknowledged the next band may read any column
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -322,7 +405,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         t.wq[i] = 0.f;
     }
     ProfMark *pm = prof_begin(s);
-    if (!serpentine && skew * 2 + 2 <= kRing && w + 64 * skew < 65000) {
+    if (!serpentine && skew * 2 + 2 <= kRing && w < 60000) {
         if (n_frames > 0x7fffffff) {
             set_error("dp_error_diffusion_u8: too many frames for one launch");
             return DP_EINVAL;
