@@ -20,8 +20,11 @@ namespace dp {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kListCap = 24576;           // LDS pixel list of the fix-up pass (96 KiB)
+constexpr int kListCap = 16384;           // LDS pixel list of the fix-up pass (64 KiB) = one full batch
+constexpr int kLdsTreeK = 256;            // palettes up to this size (and kLdsTreeNodes nodes) get their tree staged in LDS
+constexpr int kLdsTreeNodes = 512;
 constexpr int kDrainAt = kListCap - kBlock * 64;
+constexpr int kQueueTiles = 4096;          // wave tiles (256 px) with a flagged pixel that the fix-up visits directly
 
 struct Geo {
     uint32_t n_px;   // pixels in this launch (< 2^31)
@@ -32,6 +35,7 @@ struct Geo {
     int aligned;     // in/out are 4-byte aligned
     int neg2;        // -(2 << kLocalBits), kept in a register on purpose (see cand8)
     uint32_t adv_y, adv_x;  // (tile stride in pixels) mod hw, split into rows and columns (persistent kernel)
+    uint32_t *dirty;        // workspace word: number of waves that flagged a pixel (zeroed per launch)
 };
 
 __device__ __forceinline__ int med3i(const int a, const int b, const int c)
@@ -130,15 +134,23 @@ __device__ __forceinline__ void store4(uint8_t *__restrict__ out, const Geo &g, 
     }
 }
 
-__device__ __forceinline__ void store_flags(unsigned long long *__restrict__ flags, const uint32_t gidx,
-                                            const bool slow[4])
+__device__ __forceinline__ void store_flags(unsigned long long *__restrict__ flags, uint32_t *__restrict__ dirty,
+                                            const uint32_t gidx, const bool slow[4])
 {
     const uint32_t tile = gidx >> 6;
     const int lane = threadIdx.x & 63;
+    unsigned long long any = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const unsigned long long b = __ballot(slow[q]);
+        any |= b;
         if (lane == q) flags[(size_t)tile * 4 + q] = b;
+    }
+    // rare: queue this wave tile for the fix-up pass (dirty[0] = count, dirty[1..] = tile indices; when the
+    // count exceeds the queue the fix-up pass scans the whole bitmap instead)
+    if (any != 0ull && lane == 0) {
+        const uint32_t slot = atomicAdd(dirty, 1u);
+        if (slot < (uint32_t)kQueueTiles) dirty[1 + slot] = tile;
     }
 }
 
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void ordered_int_kernel(const uint8_t *__re
         cursor_next(g, thr, cur);
     }
     store4(out, g, gidx, col);
-    store_flags(flags, gidx, slow);
+    store_flags(flags, g.dirty, gidx, slow);
 }
 
 
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
             if (!(MODE == 1 && same_row) && MODE != 0) cursor_next(g, thr, cur);
         }
         store4(out, g, gidx, col);
-        store_flags(flags, gidx, slow);
+        store_flags(flags, g.dirty, gidx, slow);
 
         // advance this lane's coordinates to its group in the next tile (no division)
         fx += g.adv_x;
@@ -538,19 +550,54 @@ __global__ __launch_bounds__(kBlock) void ordered_f64_kernel(const uint8_t *__re
         cursor_next(g, thr, cur);
     }
     store4(out, g, gidx, col);
-    store_flags(flags, gidx, slow);
+    store_flags(flags, g.dirty, gidx, slow);
 }
 
 // Pass 2: resolve flagged pixels in scipy's order.
 template <int MODE, int CAP>  // MODE: 0 nearest, 2 matrix (f32 thresholds), 3 IGN; CAP: traversal queue entries
 __global__ __launch_bounds__(kBlock) void fixup_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                        const unsigned long long *__restrict__ flags,
-                                                       const uint32_t n_words, const Geo g, const PalDev pal,
+                                                       const uint32_t n_words, const Geo g, const PalDev pal_in,
                                                        const ThrDev thr, const float sx, const float sy,
                                                        const float sc)
 {
     __shared__ uint32_t s_list[kListCap];
     __shared__ uint32_t s_count;
+    const uint32_t n_dirty = *g.dirty;
+    if (n_dirty == 0u) return;  // nothing was flagged in pass 1
+    // The traversal is a chain of dependent reads (node -> child -> leaf -> point): from global memory one
+    // query costs tens of microseconds, which is the whole pass when only a few hundred pixels are flagged.
+    // Stage the tree in LDS and point a private copy of the palette descriptor at it.
+    __shared__ double s_pts[kLdsTreeK * 3];
+    __shared__ double s_split[kLdsTreeNodes];
+    __shared__ int32_t s_indices[kLdsTreeK];
+    __shared__ int32_t s_nodes[5][kLdsTreeNodes];  // split_dim, start, end, less, greater
+    __shared__ uint32_t s_outrgb[kLdsTreeK];
+    PalDev pal = pal_in;
+    if (pal_in.K <= kLdsTreeK && pal_in.n_nodes <= kLdsTreeNodes) {
+        for (int i = threadIdx.x; i < pal_in.K * 3; i += kBlock) s_pts[i] = pal_in.pts[i];
+        for (int i = threadIdx.x; i < pal_in.K; i += kBlock) {
+            s_indices[i] = pal_in.indices[i];
+            s_outrgb[i] = pal_in.out_rgb[i];
+        }
+        for (int i = threadIdx.x; i < pal_in.n_nodes; i += kBlock) {
+            s_split[i] = pal_in.split[i];
+            s_nodes[0][i] = pal_in.split_dim[i];
+            s_nodes[1][i] = pal_in.start[i];
+            s_nodes[2][i] = pal_in.end[i];
+            s_nodes[3][i] = pal_in.less[i];
+            s_nodes[4][i] = pal_in.greater[i];
+        }
+        pal.pts = s_pts;
+        pal.split = s_split;
+        pal.indices = s_indices;
+        pal.split_dim = s_nodes[0];
+        pal.start = s_nodes[1];
+        pal.end = s_nodes[2];
+        pal.less = s_nodes[3];
+        pal.greater = s_nodes[4];
+        pal.out_rgb = s_outrgb;
+    }
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
 
@@ -595,21 +642,61 @@ __global__ __launch_bounds__(kBlock) void fixup_kernel(const uint8_t *__restrict
         __syncthreads();
     };
 
-    for (uint32_t base = blockIdx.x * kBlock; base < n_words; base += gridDim.x * kBlock) {
-        const uint32_t wi = base + threadIdx.x;
-        unsigned long long word = (wi < n_words) ? flags[wi] : 0ull;
-        if (word) {
-            const int n = __popcll(word);
-            uint32_t pos = atomicAdd(&s_count, (uint32_t)n);
-            const uint32_t tile = wi >> 2, q = wi & 3u;
-            while (word) {
-                const int lane = __ffsll((long long)word) - 1;
-                word &= word - 1;
-                s_list[pos++] = ((tile * 64u + (uint32_t)lane) << 2) + q;
+    if (n_dirty <= (uint32_t)kQueueTiles) {
+        // few flagged wave tiles: visit exactly those (4 flag words each), 64 tiles per iteration
+        for (uint32_t base = blockIdx.x * 64u; base < n_dirty; base += gridDim.x * 64u) {
+            const uint32_t e = base + (threadIdx.x >> 2), q = threadIdx.x & 3u;
+            unsigned long long wd = 0;
+            uint32_t tile = 0;
+            if (e < n_dirty) {
+                tile = g.dirty[1 + e];
+                wd = flags[(size_t)tile * 4 + q];
             }
+            if (wd) {
+                const int n = __popcll(wd);
+                uint32_t pos = atomicAdd(&s_count, (uint32_t)n);
+                while (wd) {
+                    const int lane = __ffsll((long long)wd) - 1;
+                    wd &= wd - 1;
+                    s_list[pos++] = ((tile * 64u + (uint32_t)lane) << 2) + q;
+                }
+            }
+            __syncthreads();
+            if (s_count > (uint32_t)kDrainAt) drain();
         }
-        __syncthreads();
-        if (s_count > (uint32_t)kDrainAt) drain();  // uniform: every thread reads the same s_count
+        drain();
+        return;
+    }
+    // stream the bitmap 8 x 256 words per iteration; blocks without any flag (almost all of them once the
+    // tie codes are in use) cost one coalesced 8-byte load per lane and one barrier
+    constexpr int kWordsPerIter = 8;
+    for (uint32_t base = blockIdx.x * kBlock * kWordsPerIter; base < n_words; base += gridDim.x * kBlock * kWordsPerIter) {
+        unsigned long long word[kWordsPerIter];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int k = 0; k < kWordsPerIter; ++k) {
+            const uint32_t wi = base + k * kBlock + threadIdx.x;
+            word[k] = (wi < n_words) ? flags[wi] : 0ull;
+            any |= word[k];
+        }
+        if (!__syncthreads_or(any != 0ull)) continue;  // wave- and block-uniform
+#pragma unroll
+        for (int k = 0; k < kWordsPerIter; ++k) {
+            const uint32_t wi = base + k * kBlock + threadIdx.x;
+            unsigned long long wd = word[k];
+            if (wd) {
+                const int n = __popcll(wd);
+                uint32_t pos = atomicAdd(&s_count, (uint32_t)n);
+                const uint32_t tile = wi >> 2, q = wi & 3u;
+                while (wd) {
+                    const int lane = __ffsll((long long)wd) - 1;
+                    wd &= wd - 1;
+                    s_list[pos++] = ((tile * 64u + (uint32_t)lane) << 2) + q;
+                }
+            }
+            __syncthreads();
+            if (s_count > (uint32_t)kDrainAt) drain();  // uniform: every thread reads the same s_count
+        }
     }
     drain();
 }
@@ -714,6 +801,8 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
     // frames per launch so that pixel indices stay below 2^31
     const int64_t max_frames = std::max<int64_t>(1, ((int64_t)1 << 31) / hw - 1);
     unsigned long long *flags = reinterpret_cast<unsigned long long *>(ws);
+    // the dirty word lives in the slack behind the largest possible bitmap of this call
+    const size_t dirty_off = ((size_t)((std::min(max_frames, n_frames) * hw + 255) / 256) * 32 + 768) & ~size_t(7);
 
     for (int64_t f0 = 0; f0 < n_frames; f0 += max_frames) {
         const int64_t nf = std::min(max_frames, n_frames - f0);
@@ -733,6 +822,8 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         g.aligned = (((uintptr_t)in_c | (uintptr_t)out_c) & 3) == 0;
         g.neg2 = -(2 << kLocalBits);
         g.adv_y = g.adv_x = 0;
+        g.dirty = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ws) + dirty_off);
+        DP_HIP(hipMemsetAsync(g.dirty, 0, sizeof(uint32_t), s));  // the count; queue entries need no reset
         const uint32_t groups = (g.n_px + 3) / 4;
         const uint32_t blocks = (groups + kBlock - 1) / kBlock;
         uint32_t n_words = blocks * (kBlock / 64) * 4;
@@ -782,7 +873,8 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         }
         DP_HIP(hipGetLastError());
         prof_mid(pm, s);
-        const uint32_t fgrid = std::min<uint32_t>((n_words + kBlock - 1) / kBlock, 2048u);
+        // one resident workgroup per CU (the 96 KB LDS list admits no more): a persistent grid avoids queueing
+        const uint32_t fgrid = std::min<uint32_t>((n_words + kBlock * 8 - 1) / (kBlock * 8), (uint32_t)num_cus());
 #define DP_FIX(M, C) hipLaunchKernelGGL((fixup_kernel<M, C>), dim3(fgrid), dim3(kBlock), 0, s, in_c, out_c, fl, n_words, g, pal, thr, sx, sy, ign_scale)
         const bool big_q = pal.n_inner > kQueueSmall;
         if (fix_mode == 0) {
