@@ -61,9 +61,22 @@ def cpu_baseline(n_frames=16):
         orc.apply_dithering(arr, pal, "bayer", {"size": "8x8"})
         dt += time.perf_counter() - t0
         px += arr.shape[0] * arr.shape[1]
-    return {"value": round(px / dt / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
-            "sample": f"{n_frames} full 3840x2160 frames rnd(2160,3840,1234+i), Bayer 8x8, 256 colours; C oracle "
-                      f"(scipy-order KD-tree query per pixel), OpenMP over rows on {threads} threads, {dt:.2f} s"}
+    res = {"value": round(px / dt / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
+           "sample": f"{n_frames} full 3840x2160 frames rnd(2160,3840,1234+i), Bayer 8x8, 256 colours; C oracle "
+                     f"(scipy-order KD-tree query per pixel), OpenMP over rows on {threads} threads, {dt:.2f} s"}
+    try:  # the same math stated with the reference's own third-party calls (scipy KDTree.query(k=2) + numpy)
+        arr = orc.rnd(H4K, W4K, 1234)
+        t0 = time.perf_counter()
+        out = orc.ordered_scipy(arr, pal, orc.bayer_matrix("8x8"), False, workers=threads)
+        dt2 = time.perf_counter() - t0
+        import hashlib
+        res["alt"] = {"value": round(H4K * W4K / dt2 / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
+                      "sample": f"1 frame, scipy.spatial.KDTree.query(k=2, workers={threads}) + single-threaded numpy "
+                                f"post-processing as in dithering_lib.py:355-378, {dt2:.2f} s",
+                      "kat_ok": hashlib.sha256(out.tobytes()).hexdigest()[:16] == "7041bd52fdea90b5"}
+    except Exception as e:  # noqa: BLE001  (scipy missing on the box)
+        res["alt"] = {"error": str(e)}
+    return res
 
 
 def main():

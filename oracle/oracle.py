@@ -410,3 +410,26 @@ def palr(K, seed=7):
 def H(a):
     import hashlib
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------- scipy statement
+def ordered_scipy(arr, palette, thr, use_gamma=False, workers=-1):
+    """The matrix strategy stated directly with the third-party calls the reference makes
+    (dithering_lib.py:355-378 inside the uint8 wrapper :1952-1992): scipy.spatial.KDTree.query(k=2,
+    workers=-1) + numpy.  Independent of dp_oracle.c; used as a cross-check of the C restatement and as the
+    multi-core CPU baseline of BASELINE.md section 3 (item 2)."""
+    from scipy.spatial import KDTree
+    arr = np.asarray(arr, dtype=np.uint8)
+    h, w, _ = arr.shape
+    pal_f32, out_colors, lut_in = prepare_palette(palette, use_gamma)
+    src = lut_in[arr] if lut_in is not None else arr
+    px = src.reshape(-1, 3).astype(np.float32)
+    d, idx = KDTree(pal_f32).query(px, k=2, workers=workers)
+    s = d ** 2
+    tot = s[:, 0] + s[:, 1]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        f = np.where(tot == 0, 0.0, s[:, 0] / tot)
+    th_h, th_w = thr.shape
+    tiled = np.tile(thr, ((h + th_h - 1) // th_h, (w + th_w - 1) // th_w))[:h, :w].reshape(-1)
+    pick = np.where(f <= tiled, idx[:, 0], idx[:, 1])
+    return out_colors[pick].reshape(h, w, 3)

@@ -153,3 +153,15 @@ def test_kmeans_lloyd_matches_sklearn_from_same_init(orc, gold, kat, nm):
     pal = centers.astype(int)
     diff = np.abs(pal - gold[f"{nm}_palette"])
     assert diff.max() <= 1 and (diff > 0).mean() <= 0.05  # rounding noise at integer boundaries
+
+
+def test_scipy_statement_agrees_with_golden_and_c_oracle(orc, gold):
+    """three-way agreement: reference output (golden) == C restatement == scipy/numpy statement"""
+    pytest.importorskip("scipy.spatial")
+    for name, size in [("bayer8_p256_rnd_small", "8x8"), ("bayer8_p256_grad_small", "8x8"), ("bayer4_U16_grad", "4x4"),
+                       ("bayer8_p256_gamma_grad", "8x8")]:
+        case = next(c for c in _CASES if c["name"] == name)
+        arr = case_input(orc, case["input"])
+        pal = case_palette(orc, case["palette"])
+        out = orc.ordered_scipy(arr, pal, orc.bayer_matrix(size), case["gamma"], workers=2)
+        assert np.array_equal(out, gold["out_" + name]), name
