@@ -176,6 +176,40 @@ def error_diffusion(frames, pal: Palette, taps, divisor, serpentine=False, out=N
     return out if frames.dim() == 4 else out[0]
 
 
+DIFFUSER_PERCEPTUAL, DIFFUSER_HYBRID, DIFFUSER_ADAPTIVE_VARIANCE, DIFFUSER_OSTROMOUKHOV = 1, 2, 3, 4
+
+
+def variance_gate(frames, pal: Palette, var_threshold=300.0, window_radius=1):
+    """uint8 gate map [N,H,W] of AdaptiveVarianceDitherStrategy (local variance >= threshold)."""
+    f = _frames(frames)
+    n, h, w, _ = f.shape
+    gate = torch.empty((n, h, w), dtype=torch.uint8, device=f.device)
+    L = _lib.load()
+    ws_bytes = L.dp_variance_gate_workspace_bytes(n, h, w)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f.device)
+    with torch.cuda.device(f.device):
+        check(L.dp_variance_gate_u8(f.data_ptr(), gate.data_ptr(), n, h, w, pal._h, float(var_threshold),
+                                    int(window_radius), ws.data_ptr(), ws.numel(), _stream()))
+    return gate
+
+
+def variable_diffusion(frames, pal: Palette, model, p0=0.0, p1=0.0, serpentine=False, gate=None, coef=None, out=None):
+    """Perceptual / hybrid / adaptive-variance / Ostromoukhov diffusion of uint8 frames in HBM."""
+    f = _frames(frames)
+    n, h, w, _ = f.shape
+    if out is None:
+        out = torch.empty_like(f)
+    L = _lib.load()
+    ws_bytes = L.dp_error_diffusion_workspace_bytes(n, h, w)
+    ws = _workspace(ws_bytes, f.device)
+    with torch.cuda.device(f.device):
+        check(L.dp_variable_diffusion_u8(f.data_ptr(), out.data_ptr(), n, h, w, pal._h, int(model), float(p0), float(p1),
+                                         1 if serpentine else 0, gate.data_ptr() if gate is not None else None,
+                                         coef.data_ptr() if coef is not None else None, ws.data_ptr(), ws.numel(),
+                                         _stream()))
+    return out if frames.dim() == 4 else out[0]
+
+
 def ign_thresholds(h, w, scale=1.0, seed=0, y0=0, x0=0, device="cuda"):
     require_gpu()
     out = torch.empty((h, w), dtype=torch.float32, device=device)

@@ -121,6 +121,12 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
 size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w);
 int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int K, int64_t *sums, int64_t *counts,
                        int64_t *sumsq, hipStream_t s);
+int launch_variance_gate(const uint8_t *in, uint8_t *gate, int64_t n_frames, int h, int w, const PalDev &pal, float thr,
+                         int radius, void *ws, hipStream_t s);
+size_t variance_gate_ws_bytes(int64_t n_frames, int h, int w);
+int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal, int model,
+                              float p0, float p1, int serpentine, const uint8_t *gate, const float *coef, void *ws,
+                              hipStream_t s);
 int launch_resize_nearest(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int oh, int ow,
                           hipStream_t s);
 }  // namespace dp

@@ -598,6 +598,49 @@ int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_fra
                                   workspace_dev, workspace_bytes, (hipStream_t)stream);
 }
 
+int dp_variable_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
+                             const dp_palette *pal, int model, float p0, float p1, int serpentine,
+                             const uint8_t *gate_dev, const float *coef_dev, void *workspace_dev,
+                             size_t workspace_bytes, void *stream)
+{
+    if (n_frames == 0 && pal && h >= 1 && w >= 1) return DP_OK;
+    if (!in_dev || !out_dev || !pal || n_frames < 0 || h < 1 || w < 1 || model < 1 || model > 4 ||
+        (model == DP_DIFFUSER_ADAPTIVE_VARIANCE && !gate_dev) || (model == DP_DIFFUSER_OSTROMOUKHOV && !coef_dev)) {
+        set_error("dp_variable_diffusion_u8: bad argument");
+        return DP_EINVAL;
+    }
+    if (!workspace_dev || workspace_bytes < dp_error_diffusion_workspace_bytes(n_frames, h, w)) {
+        set_error("dp_variable_diffusion_u8: workspace too small (need %zu bytes)",
+                  dp_error_diffusion_workspace_bytes(n_frames, h, w));
+        return DP_EWORKSPACE;
+    }
+    return launch_variable_diffusion(in_dev, out_dev, n_frames, h, w, pal->dev, model, p0, p1, serpentine ? 1 : 0,
+                                     gate_dev, coef_dev, workspace_dev, (hipStream_t)stream);
+}
+
+size_t dp_variance_gate_workspace_bytes(int64_t n_frames, int h, int w)
+{
+    if (n_frames < 0 || h < 0 || w < 0) return 0;
+    return variance_gate_ws_bytes(n_frames, h, w);
+}
+
+int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_frames, int h, int w, const dp_palette *pal,
+                        float var_threshold, int window_radius, void *workspace_dev, size_t workspace_bytes,
+                        void *stream)
+{
+    if (n_frames == 0 && pal && h >= 1 && w >= 1) return DP_OK;
+    if (!in_dev || !gate_dev || !pal || n_frames < 0 || h < 1 || w < 1 || window_radius < 0 || window_radius > 64) {
+        set_error("dp_variance_gate_u8: bad argument");
+        return DP_EINVAL;
+    }
+    if (!workspace_dev || workspace_bytes < variance_gate_ws_bytes(n_frames, h, w)) {
+        set_error("dp_variance_gate_u8: workspace too small (need %zu bytes)", variance_gate_ws_bytes(n_frames, h, w));
+        return DP_EWORKSPACE;
+    }
+    return launch_variance_gate(in_dev, gate_dev, n_frames, h, w, pal->dev, var_threshold, window_radius, workspace_dev,
+                                (hipStream_t)stream);
+}
+
 int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
                       int64_t *counts_dev, int64_t *sumsq_dev, void *stream)
 {

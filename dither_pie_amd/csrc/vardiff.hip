@@ -1,0 +1,281 @@
+// Variable-weight error diffusers of the reference, frame-parallel version:
+//   model 1  PerceptualDitherStrategy        dithering_lib.py:1030-1066   weight_k * (0.5 + 0.5*lum/255) of the SOURCE pixel
+//   model 2  HybridDitherStrategy            dithering_lib.py:1111-1155   the error is split into luminance/colour parts
+//   model 3  AdaptiveVarianceDitherStrategy  dithering_lib.py:984-1017    sources diffuse only where the local variance is high
+//   model 4  OstromoukhovDitherStrategy      dithering_lib.py:1229-1266   3 taps, coefficients from a 256-entry table indexed by
+//                                                                          the source's luminance; clamps; optional serpentine
+// Same pull formulation as ediff.hip (pixel + sum of fl32(err_src * coefficient) in the reference's visiting
+// order), with a fourth float per stored error that carries what the coefficient depends on (sensitivity, gate or
+// table row).  lane = frame: these scans run one frame per lane (batches fill the GPU); porting them to the
+// anti-diagonal wavefront kernel is the next step.
+//
+// variance_gate: scipy.ndimage.uniform_filter(size, mode='nearest') restated (float32 passes along axis 0 then
+// axis 1, each a double running sum `tmp += entering - leaving`, out = tmp/size) on gray and gray^2, then
+// max(0, mean_sq - sq_mean^2) >= threshold  (dithering_lib.py:988-992, 1019-1025).
+#include "dp_internal.h"
+#include "tree_query.cuh"
+
+namespace dp {
+namespace {
+
+__device__ __forceinline__ float clamp255f(const float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
+
+template <int CAP>
+__device__ __forceinline__ int nearest_any(const PalDev &pal, const float o0, const float o1, const float o2)
+{
+    // float32 prefilter with a relative AND absolute margin (values are not clamped here, distances can be tiny)
+    float b0 = __int_as_float(0x7f800000), b1 = b0;
+    int i0 = 0;
+    const int K = pal.K;
+    for (int j = 0; j < K; ++j) {
+        const float a = pal.pts_f32[3 * j] - o0, b = pal.pts_f32[3 * j + 1] - o1, c = pal.pts_f32[3 * j + 2] - o2;
+        const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, c * c));
+        const bool lt0 = d < b0;
+        b1 = lt0 ? b0 : (d < b1 ? d : b1);
+        i0 = lt0 ? j : i0;
+        b0 = lt0 ? d : b0;
+    }
+    if (b1 > b0 * 1.000002f) return i0;
+    const double x0 = (double)o0, x1 = (double)o1, x2 = (double)o2;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double e0 = inf, e1 = inf;
+    for (int j = 0; j < K; ++j) {
+        const double d = sq_dist3(pal.pts + 3 * j, x0, x1, x2);
+        if (d < e0) {
+            e1 = e0;
+            e0 = d;
+            i0 = j;
+        } else if (d < e1) {
+            e1 = d;
+        }
+    }
+    if (e0 == e1 && K > kLeafSize) {
+        double d2[1];
+        int ii[1];
+        tree_query<1, CAP>(pal, x0, x1, x2, d2, ii);
+        i0 = ii[0];
+    }
+    return i0;
+}
+
+struct VarParams {
+    int model;
+    int serpentine;
+    float lum_factor, col_factor;
+    const uint8_t *gate;   // model 3: n_frames*h*w bytes
+    const float *coef;     // model 4: 256*3 float32
+};
+
+// taps in the reference's visiting order of the SOURCES (earlier row first, inside a row dx descending)
+__constant__ int kFsDx[4] = {1, 0, -1, 1};
+__constant__ int kFsDy[4] = {1, 1, 1, 0};
+__constant__ float kFsW[4] = {1.0f / 16, 5.0f / 16, 3.0f / 16, 7.0f / 16};
+// Ostromoukhov: (dx,dy) relative to the scan direction and the table column of each tap
+__constant__ int kOsDx[3] = {0, -1, 1};
+__constant__ int kOsDy[3] = {1, 1, 0};
+__constant__ int kOsCol[3] = {2, 1, 0};
+
+template <int CAP>
+__global__ __launch_bounds__(64) void var_serial_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                        const int64_t n_frames, const int h, const int w,
+                                                        const PalDev pal, const VarParams vp, float *__restrict__ ring)
+{
+    const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (f >= n_frames) return;
+    const uint8_t *fin = in + (size_t)f * h * w * 3;
+    uint8_t *fout = out + (size_t)f * h * w * 3;
+    const size_t nf = (size_t)n_frames;
+    const int model = vp.model;
+    const int ntaps = model == 4 ? 3 : 4;
+    for (int y = 0; y < h; ++y) {
+        const bool rev = model == 4 && vp.serpentine && (y & 1);
+        for (int step = 0; step < w; ++step) {
+            const int x = rev ? (w - 1 - step) : step;
+            const uint8_t *p = fin + ((size_t)y * w + x) * 3;
+            uint32_t c0 = p[0], c1 = p[1], c2 = p[2];
+            if (pal.lut_in) {
+                c0 = pal.lut_in[c0];
+                c1 = pal.lut_in[c1];
+                c2 = pal.lut_in[c2];
+            }
+            const float g0 = (float)c0, g1 = (float)c1, g2 = (float)c2;  // the original (linearised) pixel
+            float a0 = g0, a1 = g1, a2 = g2;
+            for (int k = 0; k < ntaps; ++k) {
+                const int dy = model == 4 ? kOsDy[k] : kFsDy[k];
+                const int sr = y - dy;
+                if (sr < 0) continue;
+                const int sdir = (model == 4 && vp.serpentine && (sr & 1)) ? -1 : 1;
+                const int dx = model == 4 ? kOsDx[k] : kFsDx[k];
+                const int sxp = x - dx * sdir;
+                if (sxp < 0 || sxp >= w) continue;
+                const float *e = ring + (((size_t)(sr % 3) * w + sxp) * 4) * nf + f;
+                const float aux = e[3 * nf];
+                float wk;
+                if (model == 1)
+                    wk = __fmul_rn(kFsW[k], aux);
+                else if (model == 3) {
+                    if (aux == 0.0f) continue;
+                    wk = kFsW[k];
+                } else if (model == 4)
+                    wk = vp.coef[3 * (int)aux + kOsCol[k]];
+                else
+                    wk = kFsW[k];
+                a0 = __fadd_rn(a0, __fmul_rn(e[0], wk));
+                a1 = __fadd_rn(a1, __fmul_rn(e[nf], wk));
+                a2 = __fadd_rn(a2, __fmul_rn(e[2 * nf], wk));
+            }
+            float o0 = a0, o1 = a1, o2 = a2;
+            if (model == 4) {
+                o0 = clamp255f(o0);
+                o1 = clamp255f(o1);
+                o2 = clamp255f(o2);
+            }
+            const int j = nearest_any<CAP>(pal, o0, o1, o2);
+            float e0 = __fsub_rn(o0, pal.pts_f32[3 * j]), e1 = __fsub_rn(o1, pal.pts_f32[3 * j + 1]),
+                  e2 = __fsub_rn(o2, pal.pts_f32[3 * j + 2]);
+            float aux = 1.0f;
+            if (model == 1) {
+                const float lum = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, g0), __fmul_rn(0.587f, g1)), __fmul_rn(0.114f, g2));
+                aux = __fadd_rn(0.5f, __fmul_rn(0.5f, __fdiv_rn(lum, 255.0f)));
+            } else if (model == 2) {
+                const float lv = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, e0), __fmul_rn(0.587f, e1)), __fmul_rn(0.114f, e2));
+                const float l0 = __fmul_rn(0.299f, lv), l1 = __fmul_rn(0.587f, lv), l2 = __fmul_rn(0.114f, lv);
+                e0 = __fadd_rn(__fmul_rn(vp.lum_factor, l0), __fmul_rn(vp.col_factor, __fsub_rn(e0, l0)));
+                e1 = __fadd_rn(__fmul_rn(vp.lum_factor, l1), __fmul_rn(vp.col_factor, __fsub_rn(e1, l1)));
+                e2 = __fadd_rn(__fmul_rn(vp.lum_factor, l2), __fmul_rn(vp.col_factor, __fsub_rn(e2, l2)));
+            } else if (model == 3) {
+                aux = vp.gate[((size_t)f * h + y) * w + x] ? 1.0f : 0.0f;
+            } else if (model == 4) {
+                float lum = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, o0), __fmul_rn(0.587f, o1)), __fmul_rn(0.114f, o2));
+                lum = clamp255f(lum);
+                aux = (float)(int)lum;
+            }
+            float *e = ring + (((size_t)(y % 3) * w + x) * 4) * nf + f;
+            e[0] = e0;
+            e[nf] = e1;
+            e[2 * nf] = e2;
+            e[3 * nf] = aux;
+            const uint32_t c = pal.out_rgb[j];
+            uint8_t *o = fout + ((size_t)y * w + x) * 3;
+            o[0] = (uint8_t)c;
+            o[1] = (uint8_t)(c >> 8);
+            o[2] = (uint8_t)(c >> 16);
+        }
+    }
+}
+
+// ---- variance gate -------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gray_of(const uint8_t *p, const uint8_t *lut)
+{
+    uint32_t c0 = p[0], c1 = p[1], c2 = p[2];
+    if (lut) {
+        c0 = lut[c0];
+        c1 = lut[c1];
+        c2 = lut[c2];
+    }
+    return __fadd_rn(__fadd_rn(__fmul_rn(0.299f, (float)c0), __fmul_rn(0.587f, (float)c1)), __fmul_rn(0.114f, (float)c2));
+}
+
+// pass 1: along axis 0 (one thread per frame x column), on gray^2 (t_sq) and gray (t_g)
+__global__ void var_axis0_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ lut, float *__restrict__ t_sq,
+                                 float *__restrict__ t_g, const int64_t n_frames, const int h, const int w, const int size)
+{
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_frames * w) return;
+    const int64_t f = id / w;
+    const int x = (int)(id - f * w);
+    const uint8_t *fin = in + (size_t)f * h * w * 3;
+    const int s1 = size / 2;
+    auto G = [&](int k) {
+        k = k < 0 ? 0 : (k >= h ? h - 1 : k);
+        return gray_of(fin + ((size_t)k * w + x) * 3, lut);
+    };
+    double tg = 0.0, ts = 0.0;
+    for (int i = 0; i < size; ++i) {
+        const float g = G(i - s1);
+        tg = __dadd_rn(tg, (double)g);
+        ts = __dadd_rn(ts, (double)__fmul_rn(g, g));
+    }
+    float *og = t_g + (size_t)f * h * w + x, *os = t_sq + (size_t)f * h * w + x;
+    og[0] = (float)__ddiv_rn(tg, (double)size);
+    os[0] = (float)__ddiv_rn(ts, (double)size);
+    for (int i = 1; i < h; ++i) {
+        const float ge = G(i + size - 1 - s1), gl = G(i - 1 - s1);
+        tg = __dadd_rn(tg, __dsub_rn((double)ge, (double)gl));
+        ts = __dadd_rn(ts, __dsub_rn((double)__fmul_rn(ge, ge), (double)__fmul_rn(gl, gl)));
+        og[(size_t)i * w] = (float)__ddiv_rn(tg, (double)size);
+        os[(size_t)i * w] = (float)__ddiv_rn(ts, (double)size);
+    }
+}
+
+// pass 2: along axis 1 (one thread per frame x row) on the float32 results of pass 1, then the gate
+__global__ void var_axis1_kernel(const float *__restrict__ t_sq, const float *__restrict__ t_g, uint8_t *__restrict__ gate,
+                                 const int64_t n_frames, const int h, const int w, const int size, const float thr)
+{
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_frames * h) return;
+    const float *rs = t_sq + (size_t)id * w, *rg = t_g + (size_t)id * w;
+    uint8_t *go = gate + (size_t)id * w;
+    const int s1 = size / 2;
+    auto C = [&](int k) { return k < 0 ? 0 : (k >= w ? w - 1 : k); };
+    double tg = 0.0, ts = 0.0;
+    for (int i = 0; i < size; ++i) {
+        tg = __dadd_rn(tg, (double)rg[C(i - s1)]);
+        ts = __dadd_rn(ts, (double)rs[C(i - s1)]);
+    }
+    for (int i = 0; i < w; ++i) {
+        if (i > 0) {
+            tg = __dadd_rn(tg, __dsub_rn((double)rg[C(i + size - 1 - s1)], (double)rg[C(i - 1 - s1)]));
+            ts = __dadd_rn(ts, __dsub_rn((double)rs[C(i + size - 1 - s1)], (double)rs[C(i - 1 - s1)]));
+        }
+        const float mean_sq = (float)__ddiv_rn(ts, (double)size), mean = (float)__ddiv_rn(tg, (double)size);
+        float var = __fsub_rn(mean_sq, __fmul_rn(mean, mean));
+        var = var > 0.0f ? var : 0.0f;
+        go[i] = var >= thr ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+size_t variance_gate_ws_bytes(int64_t n_frames, int h, int w) { return (size_t)n_frames * h * w * sizeof(float) * 2 + 256; }
+
+int launch_variance_gate(const uint8_t *in, uint8_t *gate, int64_t n_frames, int h, int w, const PalDev &pal, float thr,
+                         int radius, void *ws, hipStream_t s)
+{
+    const int size = 2 * radius + 1;
+    float *t_sq = reinterpret_cast<float *>(ws);
+    float *t_g = t_sq + (size_t)n_frames * h * w;
+    const int64_t n0 = n_frames * w, n1 = n_frames * h;
+    hipLaunchKernelGGL(var_axis0_kernel, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, in, pal.lut_in, t_sq, t_g,
+                       n_frames, h, w, size);
+    hipLaunchKernelGGL(var_axis1_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, t_sq, t_g, gate, n_frames, h, w,
+                       size, thr);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
+int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal, int model,
+                              float p0, float p1, int serpentine, const uint8_t *gate, const float *coef, void *ws,
+                              hipStream_t s)
+{
+    VarParams vp;
+    vp.model = model;
+    vp.serpentine = serpentine;
+    vp.lum_factor = p0;
+    vp.col_factor = p1;
+    vp.gate = gate;
+    vp.coef = coef;
+    const int64_t blocks = (n_frames + 63) / 64;
+    ProfMark *pm = prof_begin(s);
+    if (pal.n_inner > kQueueSmall)
+        hipLaunchKernelGGL(var_serial_kernel<kQueueLarge>, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h, w,
+                           pal, vp, reinterpret_cast<float *>(ws));
+    else
+        hipLaunchKernelGGL(var_serial_kernel<kQueueSmall>, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h, w,
+                           pal, vp, reinterpret_cast<float *>(ws));
+    prof_end(pm, s);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
+}  // namespace dp

@@ -7,8 +7,8 @@ dither_pie_gui.py / video_processor.py.  Pixel work happens in libditherpie_hip.
 file is host plumbing only (palette preparation, parameter handling, tensor hand-off).  There is no
 CPU fallback: without the shared library or a HIP device the calls raise DitherPieError.
 
-In scope: none, bayer, blue_noise, IGN, error_diffusion, polka_dot; k-means /
-uniform / median-cut palettes.  The other DitherMode members exist for configuration compatibility and raise
+In scope: none, bayer, blue_noise, IGN, error_diffusion, polka_dot, perceptual,
+hybrid, adaptive_variance, ostromoukhov; k-means / uniform / median-cut palettes.  The other DitherMode members exist for configuration compatibility and raise
 NotImplementedError when used.
 
 Extras that the reference does not have (all optional): ImageDitherer.apply_dithering_frames() for
@@ -29,7 +29,8 @@ __all__ = [
     "DitherMode", "PixelizeMethod", "PaletteSource", "ImageDitherer", "ColorReducer", "DitherUtils",
     "BaseDitherStrategy", "ErrorDiffusionKernel", "NoDitherStrategy", "MatrixDitherStrategy",
     "BayerDitherStrategy", "BlueNoiseDitherStrategy", "InterleavedGradientNoiseDitherStrategy",
-    "ErrorDiffusionDitherStrategy", "PolkaDotDitherStrategy", "generate_blue_noise",
+    "ErrorDiffusionDitherStrategy", "PolkaDotDitherStrategy", "PerceptualDitherStrategy", "HybridDitherStrategy",
+    "AdaptiveVarianceDitherStrategy", "OstromoukhovDitherStrategy", "generate_blue_noise",
 ]
 
 
@@ -67,10 +68,7 @@ class PaletteSource(Enum):
     FROM_FILE = "file"
 
 
-_OUT_OF_SCOPE = {
-    DitherMode.RIEMERSMA, DitherMode.WAVELET, DitherMode.ADAPTIVE_VARIANCE,
-    DitherMode.PERCEPTUAL, DitherMode.HYBRID, DitherMode.HALFTONE, DitherMode.OSTROMOUKHOV,
-}
+_OUT_OF_SCOPE = {DitherMode.RIEMERSMA, DitherMode.WAVELET, DitherMode.HALFTONE}
 
 
 # ------------------------------------------------------------------------------------- tap tables
@@ -504,6 +502,122 @@ class ErrorDiffusionDitherStrategy(BaseDitherStrategy):
         return _decode(out, palette_arr)
 
 
+class _VariableDiffuser(BaseDitherStrategy):
+    """Floyd-Steinberg-shaped scans whose coefficients depend on the source pixel."""
+
+    def _run(self, frames, pal, y0=0, x0=0, out=None):
+        if y0 or x0:
+            raise ValueError("error diffusion carries state across the whole raster and cannot be tiled")
+        return self._diffuse(frames, pal, out)
+
+    def dither(self, pixels, palette_arr, image_size):
+        out = self._run(_pixels_to_frame(pixels, image_size), _index_palette(palette_arr))
+        return _decode(out, palette_arr)
+
+
+class PerceptualDitherStrategy(_VariableDiffuser):
+    """Floyd-Steinberg weights scaled by 0.5 + 0.5*luminance/255 of the diffusing pixel (dithering_lib.py:1030-1066;
+    the reference's optional base_weights argument is not exposed by any caller and is not supported)."""
+
+    def _diffuse(self, frames, pal, out):
+        from . import backend
+        return backend.variable_diffusion(frames, pal, backend.DIFFUSER_PERCEPTUAL, out=out)
+
+
+class HybridDitherStrategy(_VariableDiffuser):
+    """Luminance part of the error diffused at lum_factor, colour part at col_factor (dithering_lib.py:1071-1155,
+    pure-Python branch)."""
+
+    @staticmethod
+    def get_parameter_info() -> Dict[str, Any]:
+        return {
+            "lum_factor": {
+                "type": "float", "default": 1.0, "min": 0.0, "max": 2.0, "step": 0.1, "label": "Luminance Factor",
+                "description": "Strength of luminance error diffusion (1.0 = full, 0.0 = none)",
+            },
+            "col_factor": {
+                "type": "float", "default": 0.2, "min": 0.0, "max": 2.0, "step": 0.1, "label": "Color Factor",
+                "description": "Strength of color error diffusion (lower = less color noise)",
+            },
+        }
+
+    def __init__(self, lum_factor: float = 1.0, col_factor: float = 0.2):
+        self.lum_factor = lum_factor
+        self.col_factor = col_factor
+        self.fs_offsets = [(1, 0, 7 / 16), (-1, 1, 3 / 16), (0, 1, 5 / 16), (1, 1, 1 / 16)]
+
+    def get_current_parameters(self) -> Dict[str, Any]:
+        return {"lum_factor": self.lum_factor, "col_factor": self.col_factor}
+
+    def _diffuse(self, frames, pal, out):
+        from . import backend
+        return backend.variable_diffusion(frames, pal, backend.DIFFUSER_HYBRID, self.lum_factor, self.col_factor, out=out)
+
+
+class AdaptiveVarianceDitherStrategy(_VariableDiffuser):
+    """Floyd-Steinberg diffusion only from pixels whose local grayscale variance reaches var_threshold
+    (dithering_lib.py:946-1025); the variance map reproduces scipy.ndimage.uniform_filter on the device."""
+
+    @staticmethod
+    def get_parameter_info() -> Dict[str, Any]:
+        return {
+            "var_threshold": {
+                "type": "float", "default": 300.0, "min": 0.0, "max": 1000.0, "step": 10.0, "label": "Variance Threshold",
+                "description": "Threshold for local variance to trigger error diffusion",
+            },
+            "window_radius": {
+                "type": "int", "default": 1, "min": 1, "max": 5, "label": "Window Radius",
+                "description": "Radius of window for computing local variance",
+            },
+        }
+
+    def __init__(self, var_threshold: float = 300.0, window_radius: int = 1):
+        self.var_threshold = var_threshold
+        self.window_radius = window_radius
+
+    def get_current_parameters(self) -> Dict[str, Any]:
+        return {"var_threshold": self.var_threshold, "window_radius": self.window_radius}
+
+    def _diffuse(self, frames, pal, out):
+        from . import backend
+        gate = backend.variance_gate(frames, pal, self.var_threshold, self.window_radius)
+        return backend.variable_diffusion(frames, pal, backend.DIFFUSER_ADAPTIVE_VARIANCE, gate=gate, out=out)
+
+
+class OstromoukhovDitherStrategy(_VariableDiffuser):
+    """Ostromoukhov's intensity-dependent three-tap diffusion (dithering_lib.py:1160-1269)."""
+
+    COEFFS_TABLE = [tuple(int(v) for v in row) for row in _tables.OSTROMOUKHOV]
+    _coef_cache: Dict[int, Any] = {}
+
+    @staticmethod
+    def get_parameter_info() -> Dict[str, Any]:
+        return {
+            "serpentine": {
+                "type": "choice", "default": "false", "choices": ["true", "false"], "label": "Serpentine Scan",
+                "description": "Alternates direction each row to reduce artifacts",
+            }
+        }
+
+    def __init__(self, serpentine: str = "false"):
+        self.serpentine = (serpentine == "true")
+
+    def get_current_parameters(self) -> Dict[str, Any]:
+        return {"serpentine": "true" if self.serpentine else "false"}
+
+    def _diffuse(self, frames, pal, out):
+        import torch
+        from . import backend
+        dev = _device_index()
+        coef = OstromoukhovDitherStrategy._coef_cache.get(dev)
+        if coef is None:
+            t = _tables.OSTROMOUKHOV
+            coef = torch.from_numpy((t / t.sum(1, keepdims=True)).astype(np.float32)).cuda()  # f32(c_k / divisor)
+            OstromoukhovDitherStrategy._coef_cache[dev] = coef
+        return backend.variable_diffusion(frames, pal, backend.DIFFUSER_OSTROMOUKHOV, serpentine=self.serpentine,
+                                          coef=coef, out=out)
+
+
 # ------------------------------------------------------------------------------------- palettes
 class ColorReducer:
     """Palette producers (dithering_lib.py:1807-1872)."""
@@ -570,6 +684,10 @@ class ImageDitherer:
         DitherMode.INTERLEAVED_GRADIENT_NOISE: InterleavedGradientNoiseDitherStrategy,
         DitherMode.ERROR_DIFFUSION: ErrorDiffusionDitherStrategy,
         DitherMode.POLKA_DOT: PolkaDotDitherStrategy,
+        DitherMode.PERCEPTUAL: PerceptualDitherStrategy,
+        DitherMode.HYBRID: HybridDitherStrategy,
+        DitherMode.ADAPTIVE_VARIANCE: AdaptiveVarianceDitherStrategy,
+        DitherMode.OSTROMOUKHOV: OstromoukhovDitherStrategy,
     }
 
     def __init__(self, num_colors: int = 16, dither_mode: Optional[DitherMode] = DitherMode.BAYER,
@@ -586,8 +704,8 @@ class ImageDitherer:
         """Parameter metadata for the GUI/CLI (dithering_lib.py:1893-1911); None for modes without
         parameters and for the modes this backend does not implement."""
         cls = ImageDitherer._STRATEGIES.get(mode)
-        if cls is None or cls is NoDitherStrategy:
-            return None
+        if cls is None or cls in (NoDitherStrategy, PerceptualDitherStrategy):
+            return None  # the reference lists no parameters for these modes either
         return cls.get_parameter_info()
 
     @staticmethod
@@ -600,7 +718,8 @@ class ImageDitherer:
         if mode in _OUT_OF_SCOPE:
             raise NotImplementedError(
                 f"dither mode {mode.value!r} is outside the MI355X backend's scope "
-                "(none, bayer, blue_noise, IGN, error_diffusion, polka_dot)")
+                "(none, bayer, blue_noise, IGN, polka_dot, error_diffusion, perceptual, hybrid, "
+                "adaptive_variance, ostromoukhov)")
         cls = self._STRATEGIES.get(mode)
         if cls is None:
             raise ValueError(f"Unrecognized DitherMode: {mode}")

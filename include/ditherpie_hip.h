@@ -122,6 +122,28 @@ int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_fra
                           int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
                           void *stream);
 
+/* variable-weight diffusers -------------------------------------------------------
+ * Replaces the pure-Python branches of PerceptualDitherStrategy.dither (dithering_lib.py:1030-1066, model 1),
+ * HybridDitherStrategy.dither (:1111-1155, model 2; p0 = lum_factor, p1 = col_factor),
+ * AdaptiveVarianceDitherStrategy.dither (:984-1017, model 3; gate_dev from dp_variance_gate_u8) and
+ * OstromoukhovDitherStrategy.dither (:1229-1266, model 4; coef_dev = 256 x 3 float32 c_k/(c0+c1+c2),
+ * serpentine 0/1).  Workspace: dp_error_diffusion_workspace_bytes(n_frames, h, w). */
+#define DP_DIFFUSER_PERCEPTUAL 1
+#define DP_DIFFUSER_HYBRID 2
+#define DP_DIFFUSER_ADAPTIVE_VARIANCE 3
+#define DP_DIFFUSER_OSTROMOUKHOV 4
+int dp_variable_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
+                             const dp_palette *pal, int model, float p0, float p1, int serpentine,
+                             const uint8_t *gate_dev, const float *coef_dev, void *workspace_dev,
+                             size_t workspace_bytes, void *stream);
+/* The variance gate of AdaptiveVarianceDitherStrategy (dithering_lib.py:988-992, 1019-1025): gate_dev[f][y][x] =
+ * (max(0, uniform_filter(gray^2) - uniform_filter(gray)^2) >= var_threshold), scipy.ndimage.uniform_filter's
+ * arithmetic (float32 passes, double running sums, mode 'nearest') on the palette's (LUT-mapped) input. */
+size_t dp_variance_gate_workspace_bytes(int64_t n_frames, int h, int w);
+int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_frames, int h, int w, const dp_palette *pal,
+                        float var_threshold, int window_radius, void *workspace_dev, size_t workspace_bytes,
+                        void *stream);
+
 /* k-means palette extraction ---------------------------------------------------------------------
  * One Lloyd pass of the KMeans fit at dithering_lib.py:1854-1856 over n uint8 RGB pixels: nearest
  * centre in float64 (lowest index on ties) and exact int64 per-cluster totals: channel sums

@@ -773,3 +773,137 @@ void orc_kmeans_step(const uint8_t *px, long n, const double *centers, int K, in
     }
     *inertia = tot;
 }
+
+/* ------------------------------------------------------------------ */
+/* variable-weight diffusers (pure-Python branches of the reference)   */
+/*   model 1  PerceptualDitherStrategy        dithering_lib.py:1030-1066 */
+/*   model 2  HybridDitherStrategy            dithering_lib.py:1111-1155 (p0 = lum_factor, p1 = col_factor) */
+/*   model 3  AdaptiveVarianceDitherStrategy  dithering_lib.py:984-1017 (gate[y*w+x] = var_map >= threshold) */
+/*   model 4  OstromoukhovDitherStrategy      dithering_lib.py:1229-1266 (coef[256][3] = f32(c_k/divisor)) */
+/* All are raster scans that push fl32(err * coefficient) into the      */
+/* not-yet-visited neighbours; only model 4 clamps before the search    */
+/* and supports serpentine.                                             */
+/* ------------------------------------------------------------------ */
+int orc_var_diffusion_u8(const uint8_t *in, uint8_t *out, int h, int w, const float *pal, int K,
+                         const uint8_t *out_colors, const uint8_t *lut_in, int model, double p0, double p1,
+                         int serpentine, const uint8_t *gate, const float *coef)
+{
+    static const int fs_dx[4] = {1, -1, 0, 1}, fs_dy[4] = {0, 1, 1, 1};
+    static const float fs_w[4] = {7.0f / 16, 3.0f / 16, 5.0f / 16, 1.0f / 16};
+    orc_tree *t = (orc_tree *)malloc(sizeof(orc_tree));
+    float *W = (float *)malloc(sizeof(float) * 3 * (size_t)h * w);
+    float *gray = (float *)malloc(sizeof(float) * (size_t)h * w);
+    int32_t *pick = (int32_t *)malloc(sizeof(int32_t) * (size_t)h * w);
+    double pts[ORC_KMAX * 3];
+    if (!t || !W || !gray || !pick || K < 1 || K > ORC_KMAX || model < 1 || model > 4) {
+        free(t); free(W); free(gray); free(pick);
+        return -1;
+    }
+    for (int i = 0; i < 3 * K; i++) pts[i] = (double)pal[i];
+    orc_tree_build(t, pts, K);
+    for (size_t i = 0; i < (size_t)h * w * 3; i++) W[i] = (float)(lut_in ? lut_in[in[i]] : in[i]);
+    for (size_t i = 0; i < (size_t)h * w; i++) {
+        /* 0.299*R + 0.587*G + 0.114*B in float32, left to right */
+        float a = 0.299f * W[3 * i], b = 0.587f * W[3 * i + 1], c = 0.114f * W[3 * i + 2];
+        gray[i] = (a + b) + c;
+    }
+    const float lf = (float)p0, cf = (float)p1;
+    for (int y = 0; y < h; y++) {
+        const int rev = (model == 4) && serpentine && (y & 1);
+        const int dir = rev ? -1 : 1;
+        for (int step = 0; step < w; step++) {
+            const int x = rev ? (w - 1 - step) : step;
+            float *p = W + ((size_t)y * w + x) * 3;
+            float old[3];
+            double q[3];
+            for (int c = 0; c < 3; c++) {
+                float v = p[c];
+                if (model == 4) v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+                old[c] = v;
+                q[c] = (double)v;
+            }
+            double d2[1];
+            int ii[1] = {0};
+            orc_tree_query(t, q, 1, d2, ii);
+            const int j = ii[0];
+            pick[(size_t)y * w + x] = j;
+            float err[3];
+            for (int c = 0; c < 3; c++) {
+                p[c] = pal[j * 3 + c];
+                err[c] = old[c] - pal[j * 3 + c];
+            }
+            if (model == 4) {
+                float lum = (0.299f * old[0] + 0.587f * old[1]) + 0.114f * old[2];
+                lum = lum < 0.0f ? 0.0f : (lum > 255.0f ? 255.0f : lum);
+                const float *ck = coef + 3 * (int)lum;
+                int nx = x + dir;
+                if (nx >= 0 && nx < w)
+                    for (int c = 0; c < 3; c++) p[3 * dir + c] = p[3 * dir + c] + err[c] * ck[0];
+                if (y + 1 < h) {
+                    nx = x - dir;
+                    float *r1 = W + ((size_t)(y + 1) * w) * 3;
+                    if (nx >= 0 && nx < w)
+                        for (int c = 0; c < 3; c++) r1[3 * nx + c] = r1[3 * nx + c] + err[c] * ck[1];
+                    for (int c = 0; c < 3; c++) r1[3 * x + c] = r1[3 * x + c] + err[c] * ck[2];
+                }
+                continue;
+            }
+            float fe[3] = {err[0], err[1], err[2]};
+            float scale = 1.0f;
+            if (model == 1) {
+                const float lum = gray[(size_t)y * w + x];
+                scale = 0.5f + 0.5f * (lum / 255.0f);
+            } else if (model == 2) {
+                const float lv = (0.299f * err[0] + 0.587f * err[1]) + 0.114f * err[2];
+                const float el[3] = {0.299f * lv, 0.587f * lv, 0.114f * lv};
+                for (int c = 0; c < 3; c++) {
+                    const float ec = err[c] - el[c];
+                    fe[c] = lf * el[c] + cf * ec;
+                }
+            } else if (model == 3) {
+                if (!gate[(size_t)y * w + x]) continue;
+            }
+            for (int k = 0; k < 4; k++) {
+                const int nx = x + fs_dx[k], ny = y + fs_dy[k];
+                if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
+                const float wk = (model == 1) ? fs_w[k] * scale : fs_w[k];
+                float *tp = W + ((size_t)ny * w + nx) * 3;
+                for (int c = 0; c < 3; c++) tp[c] = tp[c] + fe[c] * wk;
+            }
+        }
+    }
+    for (size_t i = 0; i < (size_t)h * w; i++) {
+        const int j = pick[i];
+        out[i * 3 + 0] = out_colors[j * 3 + 0];
+        out[i * 3 + 1] = out_colors[j * 3 + 1];
+        out[i * 3 + 2] = out_colors[j * 3 + 2];
+    }
+    free(t); free(W); free(gray); free(pick);
+    return 0;
+}
+
+/* scipy.ndimage.uniform_filter1d (NI_UniformFilter1D) along one axis, mode='nearest', origin 0:    */
+/* float32 in/out, double running sum tmp += (entering - leaving), out = tmp / size                  */
+void orc_uniform_filter1d_f32(const float *in, float *out, int n_lines, int length, long line_stride,
+                              long elem_stride, int size)
+{
+    const int s1 = size / 2;
+    double *buf = (double *)malloc(sizeof(double) * (size_t)(length + size));
+    for (int l = 0; l < n_lines; l++) {
+        const float *src = in + (size_t)l * line_stride;
+        float *dst = out + (size_t)l * line_stride;
+        for (int i = 0; i < length + size - 1; i++) {
+            int k = i - s1;
+            k = k < 0 ? 0 : (k >= length ? length - 1 : k);
+            buf[i] = (double)src[(size_t)k * elem_stride];
+        }
+        double tmp = 0.0;
+        for (int i = 0; i < size; i++) tmp += buf[i];
+        dst[0] = (float)(tmp / (double)size);
+        for (int i = 1; i < length; i++) {
+            tmp += buf[i + size - 1] - buf[i - 1];
+            dst[(size_t)i * elem_stride] = (float)(tmp / (double)size);
+        }
+    }
+    free(buf);
+}

@@ -56,6 +56,9 @@ def lib():
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int]
         L.orc_blue_noise.argtypes = [C.c_int, C.c_uint32, C.c_void_p]
+        L.orc_var_diffusion_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_uniform_filter1d_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int]
         L.orc_kmeans_step.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
         _LIB = L
@@ -236,6 +239,10 @@ def blue_noise(size=64, seed=42):
 
 # ----------------------------------------------------------------------------- dither
 MODE_DEFAULTS = {
+    "perceptual": {},
+    "hybrid": {"lum_factor": 1.0, "col_factor": 0.2},
+    "adaptive_variance": {"var_threshold": 300.0, "window_radius": 1},
+    "ostromoukhov": {"serpentine": "false"},
     "polka_dot": {"tile_size": 8, "gamma": 1.5},
     "bayer": {"size": "4x4"},
     "blue_noise": {"size": 64, "seed": 42},
@@ -289,6 +296,54 @@ def error_diffusion_u8(arr, pal_f32, out_colors, lut_in, variant="atkinson", ser
     return out
 
 
+def uniform_filter_f32(a, size):
+    """scipy.ndimage.uniform_filter(a, size, mode='nearest') for a 2-D float32 array, restated: axis 0 then
+    axis 1, each pass a double running sum written back as float32 (NI_UniformFilter1D)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    h, w = a.shape
+    t = np.empty_like(a)
+    lib().orc_uniform_filter1d_f32(_p(a), _p(t), w, h, 1, w, int(size))      # along axis 0: one line per column
+    o = np.empty_like(a)
+    lib().orc_uniform_filter1d_f32(_p(t), _p(o), h, w, w, 1, int(size))      # along axis 1: one line per row
+    return o
+
+
+def variance_gate(src_u8, var_threshold=300.0, window_radius=1):
+    """AdaptiveVarianceDitherStrategy: var_map >= threshold (dithering_lib.py:988-992, 1019-1025), uint8 map"""
+    px = src_u8.astype(np.float32)
+    gray = (np.float32(0.299) * px[:, :, 0] + np.float32(0.587) * px[:, :, 1]) + np.float32(0.114) * px[:, :, 2]
+    size = 2 * int(window_radius) + 1
+    mean_sq = uniform_filter_f32(gray * gray, size)
+    sq_mean = uniform_filter_f32(gray, size)
+    var = np.maximum(np.float32(0.0), mean_sq - sq_mean * sq_mean)
+    return np.ascontiguousarray((var >= np.float32(var_threshold)).astype(np.uint8)), var
+
+
+_OSTRO = None
+
+
+def ostromoukhov_coefficients():
+    """float32 c_k/(c0+c1+c2) per intensity (table data: tests/golden/small.npz 'ostro_table',
+    dithering_lib.py:1170-1203)."""
+    global _OSTRO
+    if _OSTRO is None:
+        t = np.load(os.path.join(_HERE, "..", "tests", "golden", "small.npz"))["ostro_table"].astype(np.int64)
+        _OSTRO = np.ascontiguousarray((t / t.sum(1, keepdims=True)).astype(np.float32))
+    return _OSTRO
+
+
+def var_diffusion_u8(arr, pal_f32, out_colors, lut_in, model, p0=0.0, p1=0.0, serpentine=False, gate=None):
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    h, w, _ = arr.shape
+    out = np.empty_like(arr)
+    coef = ostromoukhov_coefficients() if model == 4 else None
+    rc = lib().orc_var_diffusion_u8(_p(arr), _p(out), h, w, _p(pal_f32), pal_f32.shape[0], _p(out_colors), _p(lut_in),
+                                    model, float(p0), float(p1), 1 if serpentine else 0, _p(gate), _p(coef))
+    if rc != 0:
+        raise ValueError("oracle var_diffusion_u8 failed")
+    return out
+
+
 def apply_dithering(arr, palette, mode="bayer", params=None, use_gamma=False, y0=0, x0=0):
     """uint8 HWC -> uint8 HWC; mirrors ImageDitherer.apply_dithering (dithering_lib.py:1952-1992)
     for the in-scope modes.  (y0,x0) are the global coordinates of arr[0,0] for tile shards."""
@@ -310,6 +365,16 @@ def apply_dithering(arr, palette, mode="bayer", params=None, use_gamma=False, y0
                           y0=y0, x0=x0)
     if mode == "error_diffusion":
         return error_diffusion_u8(arr, pal_f32, out_colors, lut_in, p["variant"], p["serpentine"] == "true")
+    if mode == "perceptual":
+        return var_diffusion_u8(arr, pal_f32, out_colors, lut_in, 1)
+    if mode == "hybrid":
+        return var_diffusion_u8(arr, pal_f32, out_colors, lut_in, 2, p["lum_factor"], p["col_factor"])
+    if mode == "adaptive_variance":
+        src = lut_in[arr] if lut_in is not None else arr
+        gate, _ = variance_gate(src, p["var_threshold"], p["window_radius"])
+        return var_diffusion_u8(arr, pal_f32, out_colors, lut_in, 3, gate=gate)
+    if mode == "ostromoukhov":
+        return var_diffusion_u8(arr, pal_f32, out_colors, lut_in, 4, serpentine=(p["serpentine"] == "true"))
     raise ValueError(f"oracle: mode {mode!r} not in scope")
 
 

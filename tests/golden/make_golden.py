@@ -102,6 +102,17 @@ CASES = [
     ("polka_default_p32_grad", "polka_dot", {}, ("palr", 32), ("grad", 203, 317), False, True),
     ("polka_t5_g07_p256_rnd", "polka_dot", {"tile_size": 5, "gamma": 0.7}, ("palr", 256), ("rnd", 203, 317, 13), False, True),
     ("polka_t32_g3_U16_gamma_grad", "polka_dot", {"tile_size": 32, "gamma": 3.0}, ("U", 16), ("grad", 97, 131), True, True),
+    ("perceptual_p16_rnd", "perceptual", {}, ("palr", 16), ("rnd", 40, 56, 6), False, True),
+    ("perceptual_U16_grad", "perceptual", {}, ("U", 16), ("grad", 48, 64), False, True),
+    ("perceptual_p32_gamma_rnd", "perceptual", {}, ("palr", 32), ("rnd", 33, 47, 7), True, True),
+    ("hybrid_default_p16_rnd", "hybrid", {}, ("palr", 16), ("rnd", 40, 56, 6), False, True),
+    ("hybrid_l07_c13_U16_grad", "hybrid", {"lum_factor": 0.7, "col_factor": 1.3}, ("U", 16), ("grad", 48, 64), False, True),
+    ("adaptive_default_p16_rnd", "adaptive_variance", {}, ("palr", 16), ("rnd", 40, 56, 6), False, True),
+    ("adaptive_t50_r2_U16_grad", "adaptive_variance", {"var_threshold": 50.0, "window_radius": 2}, ("U", 16), ("grad", 48, 64), False, True),
+    ("adaptive_t900_r1_p32_gamma_rnd", "adaptive_variance", {"var_threshold": 900.0}, ("palr", 32), ("rnd", 33, 47, 7), True, True),
+    ("ostro_false_p16_rnd", "ostromoukhov", {"serpentine": "false"}, ("palr", 16), ("rnd", 40, 56, 6), False, True),
+    ("ostro_true_U16_grad", "ostromoukhov", {"serpentine": "true"}, ("U", 16), ("grad", 48, 64), False, True),
+    ("ostro_false_p64_gamma_grad", "ostromoukhov", {}, ("palr", 64), ("grad", 33, 47), True, True),
     ("ed_fs_p16_rnd", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 16), ("rnd", 120, 160, 5), False, True),
     ("ed_default_p256_grad", "error_diffusion", {}, ("palr", 256), ("grad", 64, 96), False, True),
     ("ed_fs_U16_gamma_grad", "error_diffusion", {"variant": "floyd_steinberg"}, ("U", 16), ("grad", 64, 96), True, True),
@@ -263,6 +274,11 @@ def main():
     npz["pixelize_regular_37x53_to16"] = np.array(vp.pixelize_regular(img, 16))
     npz["final_resize_37x53_x3"] = np.array(vp._apply_final_resize_to_frame(img, 3))
 
+    npz["ostro_table"] = np.array(dl.OstromoukhovDitherStrategy.COEFFS_TABLE, np.int32)
+    a = rnd(37, 53, 8).astype(np.float32)
+    g = 0.299 * a[:, :, 0] + 0.587 * a[:, :, 1] + 0.114 * a[:, :, 2]
+    for rad in (1, 2, 5):
+        npz[f"varmap_r{rad}"] = dl.AdaptiveVarianceDitherStrategy(300.0, rad)._compute_variance_map(g)
     npz["polka_8_15"] = dl.PolkaDotDitherStrategy(8, 1.5).threshold_matrix
     npz["polka_5_07"] = dl.PolkaDotDitherStrategy(5, 0.7).threshold_matrix
 

@@ -98,10 +98,13 @@ def test_parameter_metadata_matches_reference(kat):
     from dither_pie_amd import dithering_lib as d
     ref = kat["misc"]["mode_parameters"]
     for mode in (d.DitherMode.BAYER, d.DitherMode.BLUE_NOISE, d.DitherMode.INTERLEAVED_GRADIENT_NOISE,
-                 d.DitherMode.ERROR_DIFFUSION, d.DitherMode.POLKA_DOT):
+                 d.DitherMode.ERROR_DIFFUSION, d.DitherMode.POLKA_DOT, d.DitherMode.HYBRID,
+                 d.DitherMode.ADAPTIVE_VARIANCE, d.DitherMode.OSTROMOUKHOV):
         assert d.ImageDitherer.get_mode_parameters(mode) == ref[mode.value]
         assert d.ImageDitherer.mode_has_parameters(mode)
     assert d.ImageDitherer.get_mode_parameters(d.DitherMode.NONE) is None and ref["none"] is None
+    assert d.ImageDitherer.get_mode_parameters(d.DitherMode.PERCEPTUAL) is None and ref["perceptual"] is None
+    assert d.OstromoukhovDitherStrategy.COEFFS_TABLE[11] == (501, 224, 211)
 
 
 def test_strategy_construction_and_errors():

@@ -50,6 +50,17 @@ def _run_case(be, orc, arr, pal, mode, params, gamma, y0=0, x0=0, accel=True):
     elif mode == "error_diffusion":
         taps, div = orc.ed_kernel(p["variant"])
         out = be.error_diffusion(x, P, taps, div, p["serpentine"] == "true")
+    elif mode == "perceptual":
+        out = be.variable_diffusion(x, P, be.DIFFUSER_PERCEPTUAL)
+    elif mode == "hybrid":
+        out = be.variable_diffusion(x, P, be.DIFFUSER_HYBRID, p["lum_factor"], p["col_factor"])
+    elif mode == "adaptive_variance":
+        gate = be.variance_gate(x, P, p["var_threshold"], p["window_radius"])
+        out = be.variable_diffusion(x, P, be.DIFFUSER_ADAPTIVE_VARIANCE, gate=gate)
+    elif mode == "ostromoukhov":
+        import torch
+        coef = torch.from_numpy(orc.ostromoukhov_coefficients()).cuda()
+        out = be.variable_diffusion(x, P, be.DIFFUSER_OSTROMOUKHOV, serpentine=(p["serpentine"] == "true"), coef=coef)
     else:
         raise ValueError(mode)
     return out.cpu().numpy()
@@ -293,3 +304,32 @@ def test_large_palettes(be, orc, K, seed):
         _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, False), f"ed K={K}")
     out = _run_case(be, orc, orc.grad(33, 47), pal, "bayer", {"size": "4x4"}, True)
     _assert_same(out, orc.apply_dithering(orc.grad(33, 47), pal, "bayer", {"size": "4x4"}, True), f"gamma K={K}")
+
+
+@pytest.mark.parametrize("mode,params", [("perceptual", {}), ("hybrid", {"lum_factor": 1.4, "col_factor": 0.0}),
+                                         ("adaptive_variance", {"var_threshold": 120.0, "window_radius": 3}),
+                                         ("ostromoukhov", {"serpentine": "false"}), ("ostromoukhov", {"serpentine": "true"})])
+def test_variable_diffusers_vs_oracle(be, orc, mode, params):
+    for arr, pal in [(orc.rnd(70, 45, 4), orc.palr(16, 3)), (orc.grad(60, 90), orc.generate_uniform_palette(27)),
+                     (orc.rnd(33, 64, 5), orc.palr(300, 9))]:
+        out = _run_case(be, orc, arr, pal, mode, params, False)
+        _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False), f"{mode}")
+    frames = np.stack([orc.rnd(40, 50, s) for s in range(70)])  # more frames than lanes of one wave
+    import torch
+    P = be.Palette(*orc.prepare_palette(orc.palr(16, 3), False))
+    if mode == "perceptual":
+        out = be.variable_diffusion(_dev(frames), P, be.DIFFUSER_PERCEPTUAL).cpu().numpy()
+        for i in (0, 1, 63, 64, 69):
+            _assert_same(out[i], orc.apply_dithering(frames[i], orc.palr(16, 3), mode, params, False), f"frame {i}")
+
+
+def test_variance_gate_matches_scipy_restatement(be, orc):
+    arr = orc.rnd(77, 91, 3)
+    for gamma in (False, True):
+        pal_f32, oc, lut = orc.prepare_palette(orc.palr(16), gamma)
+        P = be.Palette(pal_f32, oc, lut)
+        src = lut[arr] if lut is not None else arr
+        for thr, rad in [(300.0, 1), (50.0, 2), (900.0, 5)]:
+            gate = be.variance_gate(_dev(arr), P, thr, rad).cpu().numpy()[0]
+            ref, _ = orc.variance_gate(src, thr, rad)
+            assert np.array_equal(gate, ref), (gamma, thr, rad)

@@ -165,3 +165,15 @@ def test_scipy_statement_agrees_with_golden_and_c_oracle(orc, gold):
         pal = case_palette(orc, case["palette"])
         out = orc.ordered_scipy(arr, pal, orc.bayer_matrix(size), case["gamma"], workers=2)
         assert np.array_equal(out, gold["out_" + name]), name
+
+
+def test_variance_map_restatement(orc, gold):
+    """scipy.ndimage.uniform_filter (third party) restated: float32 passes with a double running sum"""
+    a = orc.rnd(37, 53, 8)
+    for rad in (1, 2, 5):
+        _, var = orc.variance_gate(a, 300.0, rad)
+        assert np.array_equal(var, gold[f"varmap_r{rad}"]), rad
+    nd = pytest.importorskip("scipy.ndimage")
+    g = np.random.RandomState(3).rand(41, 29).astype(np.float32) * 255
+    for size in (3, 5, 11):
+        assert np.array_equal(orc.uniform_filter_f32(g, size), nd.uniform_filter(g, size=size, mode="nearest"))
