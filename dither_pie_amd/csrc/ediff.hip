@@ -364,8 +364,9 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
 size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w)
 {
     (void)h;
-    // wavefront: 4 boundary rows per frame; serial: 3 error rows per frame; take the larger
-    return (size_t)n_frames * (size_t)w * 3 * sizeof(float) * 4 + 256;
+    // wavefront: 4 boundary rows per frame; serial: 3 error rows per frame; 4 floats per column (the variable-weight
+    // diffusers of vardiff.hip carry an extra value per error)
+    return (size_t)n_frames * (size_t)w * 4 * sizeof(float) * 4 + 256;
 }
 
 int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal,

@@ -6,8 +6,8 @@
 //                                                                          the source's luminance; clamps; optional serpentine
 // Same pull formulation as ediff.hip (pixel + sum of fl32(err_src * coefficient) in the reference's visiting
 // order), with a fourth float per stored error that carries what the coefficient depends on (sensitivity, gate or
-// table row).  lane = frame: these scans run one frame per lane (batches fill the GPU); porting them to the
-// anti-diagonal wavefront kernel is the next step.
+// table row).  var_wavefront_kernel runs them on the anti-diagonal schedule of ediff.hip (serpentine off);
+// var_serial_kernel (lane = frame) covers Ostromoukhov's serpentine scan, whose rows are strictly sequential.
 //
 // variance_gate: scipy.ndimage.uniform_filter(size, mode='nearest') restated (float32 passes along axis 0 then
 // axis 1, each a double running sum `tmp += entering - leaving`, out = tmp/size) on gray and gray^2, then
@@ -164,6 +164,272 @@ __global__ __launch_bounds__(64) void var_serial_kernel(const uint8_t *__restric
     }
 }
 
+// ---- anti-diagonal wavefront version (serpentine off): same schedule as ed_wavefront_kernel in ediff.hip ------------
+// (one workgroup per frame, lane = row of a 64-row band, bands pipelined across the waves through a progress word,
+// global traffic in 16-step bursts), with four floats per stored error (the fourth is `aux`) and at most 12 waves so
+// that the wider rings fit LDS.  All four models have skew 2 (their only upward-left tap is dx=-1, dy=1).
+constexpr int kVWaves = 12;
+constexpr int kVRing = 8;
+constexpr int kVPeriod = 16;
+
+template <int CAP>
+__global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8_t *__restrict__ in,
+                                                                     uint8_t *__restrict__ out, const int h, const int w,
+                                                                     const PalDev pal, const VarParams vp,
+                                                                     float *__restrict__ bnd_all)
+{
+    __shared__ float s_ring[kVWaves][64][kVRing][4];
+    __shared__ float s_vring[kVWaves][2][64][4];
+    __shared__ float s_bout[kVWaves][2][kVPeriod][4];
+    __shared__ uint8_t s_lut[256];
+    __shared__ volatile uint32_t s_prog[kVWaves];
+    const int L = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const size_t f = blockIdx.x;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
+    if (threadIdx.x < kVWaves) s_prog[threadIdx.x] = 0;
+    const uint8_t *fin = in + f * (size_t)h * w * 3;
+    uint8_t *fout = out + f * (size_t)h * w * 3;
+    const uint8_t *fgate = vp.gate ? vp.gate + f * (size_t)h * w : nullptr;
+    const long frame_bytes = (long)h * w * 3;
+    const long gate_bytes = (long)h * w;
+    float *bnd = bnd_all + f * (size_t)4 * w * 4;  // [2 buffers][2 rows][w][4]
+    const int model = vp.model;
+    const int ntaps = model == 4 ? 3 : 4;
+    constexpr int skew = 2;
+    const int n_bands = (h + 63) / 64;
+    __syncthreads();
+
+    for (int band = wv; band < n_bands; band += NW) {
+        const int r = band * 64 + L;
+        const float *bprev = bnd + (size_t)((band + 1) & 1) * 2 * w * 4;
+        float *bnext = bnd + (size_t)(band & 1) * 2 * w * 4;
+        const int rows_here = min(64, h - band * 64);
+        const int steps = w + skew * (rows_here - 1);
+        const int pw = (wv + NW - 1) % NW;
+        const bool row_ok = r < h;
+        const long row_byte = (long)r * w * 3;
+        const long row_gate = (long)r * w;
+
+        uint32_t pix[12], cur[13], outb[13], gpx[4], gcur[5];
+        float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f, pb3 = 0.f;
+        int pb_col = -1;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pix[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) cur[k] = outb[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gpx[k] = gcur[k] = 0;
+        gcur[4] = 0;
+
+        for (int t0 = -kVPeriod; t0 < steps + kVPeriod; t0 += kVPeriod) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (L == 0) {
+                int ack = t0 - kVPeriod - 63 * skew + 1024;
+                ack = ack < 0 ? 0 : ack;
+                s_prog[wv] = ((uint32_t)band << 16) | (uint32_t)ack;
+            }
+            if (pb_col >= 0) {
+                float *dst = &s_vring[wv][L >> 5][pb_col & 63][0];
+                dst[0] = pb0;
+                dst[1] = pb1;
+                dst[2] = pb2;
+                dst[3] = pb3;
+            }
+            {
+                const int xs = (t0 - kVPeriod) - skew * L;
+                const int lo = xs < 0 ? 0 : xs, hi = xs + kVPeriod > w ? w : xs + kVPeriod;
+                if (row_ok && hi > lo) {
+                    const long B = row_byte + (long)xs * 3;
+                    if (lo == xs && hi == xs + kVPeriod) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) *reinterpret_cast<uint32_t *>(fout + B + 4 * k) = outb[k];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < kVPeriod; ++i) {
+                            if (xs + i >= 0 && xs + i < w) {
+                                const int bo = 3 * i;
+                                const uint32_t c = __funnelshift_r(outb[bo >> 2], outb[(bo >> 2) + 1], (bo & 3) * 8);
+                                uint8_t *o = fout + B + bo;
+                                o[0] = (uint8_t)c;
+                                o[1] = (uint8_t)(c >> 8);
+                                o[2] = (uint8_t)(c >> 16);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 13; ++k) outb[k] = 0;
+                if (L >= 62 && row_ok && hi > lo) {
+                    for (int i = lo - xs; i < hi - xs; ++i) {
+                        float *b = bnext + ((size_t)(L - 62) * w + (xs + i)) * 4;
+                        b[0] = s_bout[wv][L - 62][i][0];
+                        b[1] = s_bout[wv][L - 62][i][1];
+                        b[2] = s_bout[wv][L - 62][i][2];
+                        b[3] = s_bout[wv][L - 62][i][3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) cur[k] = pix[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gcur[k] = gpx[k];
+            {
+                const int xn = (t0 + kVPeriod) - skew * L;
+                const long B = row_byte + (long)xn * 3;
+                if (row_ok && xn + kVPeriod > 0 && xn < w) {
+                    if (B >= 0 && B + 48 <= frame_bytes) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) pix[k] = *reinterpret_cast<const uint32_t *>(fin + B + 4 * k);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) {
+                            uint32_t v = 0;
+#pragma unroll
+                            for (int bb = 0; bb < 4; ++bb) {
+                                const long a = B + 4 * k + bb;
+                                if (a >= 0 && a < frame_bytes) v |= (uint32_t)fin[a] << (8 * bb);
+                            }
+                            pix[k] = v;
+                        }
+                    }
+                    if (model == 3) {  // the next 16 gate bytes of this row
+                        const long G = row_gate + xn;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            uint32_t v = 0;
+#pragma unroll
+                            for (int bb = 0; bb < 4; ++bb) {
+                                const long a = G + 4 * k + bb;
+                                if (a >= 0 && a < gate_bytes) v |= (uint32_t)fgate[a] << (8 * bb);
+                            }
+                            gpx[k] = v;
+                        }
+                    }
+                }
+            }
+            pb_col = -1;
+            if (band > 0) {
+                const int x0n = t0 + kVPeriod;
+                int need = x0n + 18;
+                need = need > w ? w : need;
+                if (x0n - 14 < w && need > 0) {
+                    const uint32_t want = (uint32_t)(need + 1024);
+                    for (;;) {
+                        const uint32_t v = s_prog[pw];
+                        if ((int)(v >> 16) > band - 1 || ((int)(v >> 16) == band - 1 && (v & 0xffffu) >= want)) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    const int col = x0n - 14 + (L & 31);
+                    if (col >= 0 && col < w) {
+                        const float *b = bprev + ((size_t)(L >> 5) * w + col) * 4;
+                        pb0 = __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pb1 = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pb2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pb3 = __hip_atomic_load(b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pb_col = col;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            for (int i = 0; i < kVPeriod; ++i) {
+                const int t = t0 + i;
+                const int x = t - skew * L;
+                const bool act = row_ok && x >= 0 && x < w && t >= 0 && t < steps;
+                float e0 = 0.f, e1 = 0.f, e2 = 0.f, aux = 1.0f;
+                uint32_t cbytes = 0;
+                if (act) {
+                    const uint32_t pxv = cur[0];
+                    const float g0 = (float)s_lut[pxv & 255u], g1 = (float)s_lut[(pxv >> 8) & 255u],
+                                g2 = (float)s_lut[(pxv >> 16) & 255u];
+                    float a0 = g0, a1 = g1, a2 = g2;
+                    for (int k = 0; k < ntaps; ++k) {
+                        const int dx = model == 4 ? kOsDx[k] : kFsDx[k], dy = model == 4 ? kOsDy[k] : kFsDy[k];
+                        const int sxp = x - dx;
+                        const int sr = r - dy;
+                        if (sxp < 0 || sxp >= w || sr < 0) continue;
+                        const int rel = L - dy;
+                        const float *src = rel >= 0 ? &s_ring[wv][rel][sxp & (kVRing - 1)][0]
+                                                    : &s_vring[wv][rel + 2][sxp & 63][0];
+                        const float sa = src[3];
+                        float wk;
+                        if (model == 1)
+                            wk = __fmul_rn(kFsW[k], sa);
+                        else if (model == 3) {
+                            if (sa == 0.0f) continue;
+                            wk = kFsW[k];
+                        } else if (model == 4)
+                            wk = vp.coef[3 * (int)sa + kOsCol[k]];
+                        else
+                            wk = kFsW[k];
+                        a0 = __fadd_rn(a0, __fmul_rn(src[0], wk));
+                        a1 = __fadd_rn(a1, __fmul_rn(src[1], wk));
+                        a2 = __fadd_rn(a2, __fmul_rn(src[2], wk));
+                    }
+                    float o0 = a0, o1 = a1, o2 = a2;
+                    if (model == 4) {
+                        o0 = clamp255f(o0);
+                        o1 = clamp255f(o1);
+                        o2 = clamp255f(o2);
+                    }
+                    const int j = nearest_any<CAP>(pal, o0, o1, o2);
+                    e0 = __fsub_rn(o0, pal.pts_f32[3 * j]);
+                    e1 = __fsub_rn(o1, pal.pts_f32[3 * j + 1]);
+                    e2 = __fsub_rn(o2, pal.pts_f32[3 * j + 2]);
+                    if (model == 1) {
+                        const float lum = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, g0), __fmul_rn(0.587f, g1)), __fmul_rn(0.114f, g2));
+                        aux = __fadd_rn(0.5f, __fmul_rn(0.5f, __fdiv_rn(lum, 255.0f)));
+                    } else if (model == 2) {
+                        const float lv = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, e0), __fmul_rn(0.587f, e1)), __fmul_rn(0.114f, e2));
+                        const float l0 = __fmul_rn(0.299f, lv), l1 = __fmul_rn(0.587f, lv), l2 = __fmul_rn(0.114f, lv);
+                        e0 = __fadd_rn(__fmul_rn(vp.lum_factor, l0), __fmul_rn(vp.col_factor, __fsub_rn(e0, l0)));
+                        e1 = __fadd_rn(__fmul_rn(vp.lum_factor, l1), __fmul_rn(vp.col_factor, __fsub_rn(e1, l1)));
+                        e2 = __fadd_rn(__fmul_rn(vp.lum_factor, l2), __fmul_rn(vp.col_factor, __fsub_rn(e2, l2)));
+                    } else if (model == 3) {
+                        aux = (gcur[0] & 255u) ? 1.0f : 0.0f;
+                    } else if (model == 4) {
+                        float lum = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, o0), __fmul_rn(0.587f, o1)), __fmul_rn(0.114f, o2));
+                        aux = (float)(int)clamp255f(lum);
+                    }
+                    cbytes = pal.out_rgb[j];
+                }
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    cur[k] = __funnelshift_r(cur[k], cur[k + 1], 24);
+                    outb[k] = __funnelshift_r(outb[k], outb[k + 1], 24);
+                }
+                cur[11] >>= 24;
+                outb[11] = (outb[11] >> 24) | (cbytes << 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gcur[k] = __funnelshift_r(gcur[k], gcur[k + 1], 8);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (act) {
+                    float *dst = &s_ring[wv][L][x & (kVRing - 1)][0];
+                    dst[0] = e0;
+                    dst[1] = e1;
+                    dst[2] = e2;
+                    dst[3] = aux;
+                    if (L >= 62) {
+                        float *bo = &s_bout[wv][L - 62][i][0];
+                        bo[0] = e0;
+                        bo[1] = e1;
+                        bo[2] = e2;
+                        bo[3] = aux;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (L == 0) s_prog[wv] = ((uint32_t)(band + 1) << 16);
+    }
+}
+
 // ---- variance gate -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gray_of(const uint8_t *p, const uint8_t *lut)
 {
@@ -265,8 +531,21 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
     vp.col_factor = p1;
     vp.gate = gate;
     vp.coef = coef;
-    const int64_t blocks = (n_frames + 63) / 64;
     ProfMark *pm = prof_begin(s);
+    if (!(model == 4 && serpentine) && w < 60000 && n_frames <= 0x7fffffff) {
+        const int n_bands = (h + 63) / 64;
+        const int nw = n_bands < kVWaves ? n_bands : kVWaves;
+        if (pal.n_inner > kQueueSmall)
+            hipLaunchKernelGGL(var_wavefront_kernel<kQueueLarge>, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h,
+                               w, pal, vp, reinterpret_cast<float *>(ws));
+        else
+            hipLaunchKernelGGL(var_wavefront_kernel<kQueueSmall>, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h,
+                               w, pal, vp, reinterpret_cast<float *>(ws));
+        prof_end(pm, s);
+        DP_HIP(hipGetLastError());
+        return DP_OK;
+    }
+    const int64_t blocks = (n_frames + 63) / 64;
     if (pal.n_inner > kQueueSmall)
         hipLaunchKernelGGL(var_serial_kernel<kQueueLarge>, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h, w,
                            pal, vp, reinterpret_cast<float *>(ws));
