@@ -442,63 +442,54 @@ __device__ __forceinline__ float gray_of(const uint8_t *p, const uint8_t *lut)
     return __fadd_rn(__fadd_rn(__fmul_rn(0.299f, (float)c0), __fmul_rn(0.587f, (float)c1)), __fmul_rn(0.114f, (float)c2));
 }
 
-// pass 1: along axis 0 (one thread per frame x column), on gray^2 (t_sq) and gray (t_g)
+// scipy accumulates each line as a double running sum (tmp += entering - leaving).  Every term is a float32 in
+// [0, 65025] whose bits span less than 53 binary places together with the partial sums (gray = f32 sums of
+// 0.299*r etc.: >= 2^-27 granularity, <= 2^8; gray^2: >= 2^-30, <= 2^16; windows of <= 129 terms), so every partial
+// sum is exact and the running sum equals the plain window sum in any order: one thread per pixel reproduces it.
+// pass 1: along axis 0 on gray^2 (t_sq) and gray (t_g), float32 results as scipy stores them between the axes
 __global__ void var_axis0_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ lut, float *__restrict__ t_sq,
                                  float *__restrict__ t_g, const int64_t n_frames, const int h, const int w, const int size)
 {
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_frames * w) return;
-    const int64_t f = id / w;
-    const int x = (int)(id - f * w);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int64_t f = blockIdx.z;
+    if (x >= w) return;
     const uint8_t *fin = in + (size_t)f * h * w * 3;
     const int s1 = size / 2;
-    auto G = [&](int k) {
-        k = k < 0 ? 0 : (k >= h ? h - 1 : k);
-        return gray_of(fin + ((size_t)k * w + x) * 3, lut);
-    };
     double tg = 0.0, ts = 0.0;
     for (int i = 0; i < size; ++i) {
-        const float g = G(i - s1);
+        int k = y + i - s1;
+        k = k < 0 ? 0 : (k >= h ? h - 1 : k);
+        const float g = gray_of(fin + ((size_t)k * w + x) * 3, lut);
         tg = __dadd_rn(tg, (double)g);
         ts = __dadd_rn(ts, (double)__fmul_rn(g, g));
     }
-    float *og = t_g + (size_t)f * h * w + x, *os = t_sq + (size_t)f * h * w + x;
-    og[0] = (float)__ddiv_rn(tg, (double)size);
-    os[0] = (float)__ddiv_rn(ts, (double)size);
-    for (int i = 1; i < h; ++i) {
-        const float ge = G(i + size - 1 - s1), gl = G(i - 1 - s1);
-        tg = __dadd_rn(tg, __dsub_rn((double)ge, (double)gl));
-        ts = __dadd_rn(ts, __dsub_rn((double)__fmul_rn(ge, ge), (double)__fmul_rn(gl, gl)));
-        og[(size_t)i * w] = (float)__ddiv_rn(tg, (double)size);
-        os[(size_t)i * w] = (float)__ddiv_rn(ts, (double)size);
-    }
+    const size_t o = ((size_t)f * h + y) * w + x;
+    t_g[o] = (float)__ddiv_rn(tg, (double)size);
+    t_sq[o] = (float)__ddiv_rn(ts, (double)size);
 }
 
-// pass 2: along axis 1 (one thread per frame x row) on the float32 results of pass 1, then the gate
+// pass 2: along axis 1 on the float32 results of pass 1, then the gate
 __global__ void var_axis1_kernel(const float *__restrict__ t_sq, const float *__restrict__ t_g, uint8_t *__restrict__ gate,
                                  const int64_t n_frames, const int h, const int w, const int size, const float thr)
 {
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_frames * h) return;
-    const float *rs = t_sq + (size_t)id * w, *rg = t_g + (size_t)id * w;
-    uint8_t *go = gate + (size_t)id * w;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int64_t f = blockIdx.z;
+    if (x >= w) return;
+    const size_t row = ((size_t)f * h + y) * w;
     const int s1 = size / 2;
-    auto C = [&](int k) { return k < 0 ? 0 : (k >= w ? w - 1 : k); };
     double tg = 0.0, ts = 0.0;
     for (int i = 0; i < size; ++i) {
-        tg = __dadd_rn(tg, (double)rg[C(i - s1)]);
-        ts = __dadd_rn(ts, (double)rs[C(i - s1)]);
+        int k = x + i - s1;
+        k = k < 0 ? 0 : (k >= w ? w - 1 : k);
+        tg = __dadd_rn(tg, (double)t_g[row + k]);
+        ts = __dadd_rn(ts, (double)t_sq[row + k]);
     }
-    for (int i = 0; i < w; ++i) {
-        if (i > 0) {
-            tg = __dadd_rn(tg, __dsub_rn((double)rg[C(i + size - 1 - s1)], (double)rg[C(i - 1 - s1)]));
-            ts = __dadd_rn(ts, __dsub_rn((double)rs[C(i + size - 1 - s1)], (double)rs[C(i - 1 - s1)]));
-        }
-        const float mean_sq = (float)__ddiv_rn(ts, (double)size), mean = (float)__ddiv_rn(tg, (double)size);
-        float var = __fsub_rn(mean_sq, __fmul_rn(mean, mean));
-        var = var > 0.0f ? var : 0.0f;
-        go[i] = var >= thr ? 1 : 0;
-    }
+    const float mean_sq = (float)__ddiv_rn(ts, (double)size), mean = (float)__ddiv_rn(tg, (double)size);
+    float var = __fsub_rn(mean_sq, __fmul_rn(mean, mean));
+    var = var > 0.0f ? var : 0.0f;
+    gate[row + x] = var >= thr ? 1 : 0;
 }
 
 }  // namespace
@@ -511,11 +502,13 @@ int launch_variance_gate(const uint8_t *in, uint8_t *gate, int64_t n_frames, int
     const int size = 2 * radius + 1;
     float *t_sq = reinterpret_cast<float *>(ws);
     float *t_g = t_sq + (size_t)n_frames * h * w;
-    const int64_t n0 = n_frames * w, n1 = n_frames * h;
-    hipLaunchKernelGGL(var_axis0_kernel, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, in, pal.lut_in, t_sq, t_g,
-                       n_frames, h, w, size);
-    hipLaunchKernelGGL(var_axis1_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, t_sq, t_g, gate, n_frames, h, w,
-                       size, thr);
+    if (h > 65535 || n_frames > 65535) {
+        set_error("dp_variance_gate_u8: h or n_frames > 65535 not supported");
+        return DP_EUNSUPPORTED;
+    }
+    const dim3 grid((w + 255) / 256, h, (unsigned)n_frames);
+    hipLaunchKernelGGL(var_axis0_kernel, grid, dim3(256), 0, s, in, pal.lut_in, t_sq, t_g, n_frames, h, w, size);
+    hipLaunchKernelGGL(var_axis1_kernel, grid, dim3(256), 0, s, t_sq, t_g, gate, n_frames, h, w, size, thr);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }
