@@ -15,14 +15,15 @@
 //                each with its own 8-entry block; only a single colour with more than 8 equidistant
 //                candidates is marked "slow" (its pixels go to the generic fix-up pass).
 //                The whole table (128 KB + ~64 words per split) lives in LDS in the dither kernel.
-//   tie codes    2 bits per colour and per query kind (k=1, k=2): for colours whose three smallest
-//                distances contain a tie, the outcome of scipy's traversal (tree_query) expressed
-//                relative to the candidates sorted by (distance, index):
-//                  k=2: 0 -> (c0,c1)  1 -> (c1,c0)  2 -> (c0,c2)  3 -> none of these (rare; the
-//                       dither kernel flags the pixel for the generic fix-up pass)
-//                  k=1: 0 -> c0  1 -> c1  2 -> c2  3 -> other
+//   tie codes    per colour and per query kind: for colours whose three smallest distances contain a
+//                tie, the outcome of scipy's traversal (tree_query) expressed relative to the
+//                candidates sorted by (distance, index):
+//                  k=2 (4 bits): 0 -> (c0,c1)  1 -> (c1,c0)  2 -> (c0,c2)  3 -> (c2,c0)  4 -> (c1,c2)
+//                       5 -> (c2,c1)  15 -> none of these (four-way ties; the dither kernel flags the
+//                       pixel for the generic fix-up pass)
+//                  k=1 (2 bits): 0 -> c0  1 -> c1  2 -> c2  3 -> other
 //                "equal" is judged on the output colour, so duplicate palette entries never need the
-//                fix-up pass.  4 MB per kind, touched only by tied pixels (~0.2 %).
+//                fix-up pass.  8 MB + 4 MB, touched only by tied pixels (~0.3 %).
 #include <algorithm>
 #include <vector>
 
@@ -37,8 +38,11 @@ __device__ __forceinline__ int med3i(const int a, const int b, const int c)
     return max(min(a, b), min(max(a, b), c));
 }
 
+constexpr int kExcCap = 1 << 16;  // colours with an outcome outside the codes (four-way ties); normally a few dozen
+
 __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint32_t *__restrict__ masks,
-                                                         uint32_t *__restrict__ code1, uint32_t *__restrict__ code2)
+                                                         uint32_t *__restrict__ code1, uint32_t *__restrict__ code2,
+                                                         uint4 *__restrict__ exc, uint32_t *__restrict__ exc_count)
 {
     __shared__ uint32_t s_mask[9][8];  // [0] the whole cell, [1+s] its 8x8x8 sub-cell s
     if (threadIdx.x < 72) (&s_mask[0][0])[threadIdx.x] = 0;
@@ -87,16 +91,23 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
         if (!(tie01 || tie12)) continue;
         const uint32_t o0 = pal.out_rgb[c0], o1 = pal.out_rgb[c1], o2 = K > 2 ? pal.out_rgb[c2] : 0xffffffffu;
         double dd[2];
-        int ii[2];
+        int ii[2], i1 = 0;
+        bool other = false;
         {
             tree_query<2, kQueueSmall>(pal, (double)r, (double)g, (double)b, dd, ii);
             const uint32_t on = pal.out_rgb[ii[0]], os = pal.out_rgb[ii[1]];
-            uint32_t code = 3;
+            uint32_t code = 15;
             if (on == o0 && os == o1) code = 0;
             else if (on == o1 && os == o0) code = 1;
             else if (on == o0 && os == o2) code = 2;
-            if (code) atomicOr(&code2[x4 >> 4], code << ((x4 & 15u) * 2));
+            else if (on == o2 && os == o0) code = 3;
+            else if (on == o1 && os == o2) code = 4;
+            else if (on == o2 && os == o1) code = 5;
+            if (code) atomicOr(&code2[x4 >> 3], code << ((x4 & 7u) * 4));
+            other = code == 15;
+            i1 = ii[0];  // the k=1 answer unless the two nearest tie
         }
+        const uint32_t pair = (uint32_t)ii[0] | ((uint32_t)ii[1] << 16);
         if (tie01) {
             tree_query<1, kQueueSmall>(pal, (double)r, (double)g, (double)b, dd, ii);
             const uint32_t on = pal.out_rgb[ii[0]];
@@ -105,6 +116,12 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
             else if (on == o1) code = 1;
             else if (on == o2) code = 2;
             if (code) atomicOr(&code1[x4 >> 4], code << ((x4 & 15u) * 2));
+            other |= code == 3;
+            i1 = ii[0];
+        }
+        if (other) {  // spell the outcome out
+            const uint32_t slot = atomicAdd(exc_count, 1u);
+            if (slot < (uint32_t)kExcCap) exc[slot] = make_uint4(x4, pair, (uint32_t)i1, 0u);
         }
     }
     __syncthreads();
@@ -167,16 +184,16 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     *blob_out = nullptr;
     *blob_bytes = 0;
     const int K = dev.K;
-    constexpr size_t kCodeWords = (size_t)1 << 20;  // 2^24 colours x 2 bits
+    constexpr size_t kCodeWords = (size_t)1 << 20;  // 2^24 colours x 2 bits (k=1); the k=2 table has twice as many
     constexpr int kCells = 4096;
     constexpr int kTabCapWords = (160 * 1024 - 2048) / 4;  // LDS budget of the dither kernel
     uint32_t *d_masks = nullptr;
     uint8_t *blob = nullptr;
     // layout: code1 | code2 | table[cap]
-    const size_t bytes = sizeof(uint32_t) * (2 * kCodeWords + kTabCapWords);
+    const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16;
     DP_HIP(hipMalloc((void **)&blob, bytes));
     hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 72);
-    if (e == hipSuccess) e = hipMemset(blob, 0, sizeof(uint32_t) * 2 * kCodeWords);
+    if (e == hipSuccess) e = hipMemset(blob, 0, sizeof(uint32_t) * 3 * kCodeWords);
     if (e != hipSuccess) {
         (void)hipFree(blob);
         if (d_masks) (void)hipFree(d_masks);
@@ -184,8 +201,16 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     }
     uint32_t *code1 = reinterpret_cast<uint32_t *>(blob);
     uint32_t *code2 = code1 + kCodeWords;
-    uint32_t *d_tab = code2 + kCodeWords;
-    hipLaunchKernelGGL(accel_scan_kernel, dim3(kCells), dim3(256), 0, 0, dev, d_masks, code1, code2);
+    uint32_t *d_tab = code2 + 2 * kCodeWords;
+    uint4 *d_exc = reinterpret_cast<uint4 *>(d_tab + kTabCapWords);  // 16-byte aligned: every part is a multiple of 16
+    uint32_t *d_exc_count = reinterpret_cast<uint32_t *>(d_exc + kExcCap);
+    e = hipMemset(d_exc_count, 0, sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        (void)hipFree(d_masks);
+        return hip_fail(e, "accelerator allocation");
+    }
+    hipLaunchKernelGGL(accel_scan_kernel, dim3(kCells), dim3(256), 0, 0, dev, d_masks, code1, code2, d_exc, d_exc_count);
     std::vector<uint32_t> masks((size_t)kCells * 72);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(masks.data(), d_masks, sizeof(uint32_t) * masks.size(), hipMemcpyDeviceToHost);
@@ -259,10 +284,11 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         const uint32_t *m = &masks[(size_t)cell * 72];
         const int r0 = (cell >> 8) * 16, g0 = ((cell >> 4) & 15) * 16, b0 = (cell & 15) * 16;
         uint32_t blk[8];
+        const size_t slot = (size_t)cell_slot(cell >> 8, (cell >> 4) & 15, cell & 15);
         if (make_block(m, r0 + 8, g0 + 8, b0 + 8, blk))
-            std::copy(blk, blk + 8, tab.begin() + (size_t)cell * 8);
+            std::copy(blk, blk + 8, tab.begin() + slot * 8);
         else
-            split((size_t)cell * 8, Box{r0, g0, b0, 16}, m + 8);
+            split(slot * 8, Box{r0, g0, b0, 16}, m + 8);
     }
     // deeper levels: boxes that still hold more than 8 members are split again (their children's
     // masks come from accel_box_kernel); a single colour that still overflows is left to the fix-up pass
@@ -327,6 +353,23 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     dev.max_cell = max_cnt;
     dev.code1 = code1;
     dev.code2 = code2;
+    {
+        // the exception list, sorted by colour for the kernels' binary search
+        uint32_t n_exc = 0;
+        e = hipMemcpy(&n_exc, d_exc_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_exc > 0 && n_exc <= (uint32_t)kExcCap) {
+            std::vector<uint4> ex(n_exc);
+            e = hipMemcpy(ex.data(), d_exc, sizeof(uint4) * n_exc, hipMemcpyDeviceToHost);
+            std::sort(ex.begin(), ex.end(), [](const uint4 &a, const uint4 &b) { return a.x < b.x; });
+            if (e == hipSuccess) e = hipMemcpy(d_exc, ex.data(), sizeof(uint4) * n_exc, hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) {
+            (void)hipFree(blob);
+            return hip_fail(e, "accelerator exception list");
+        }
+        dev.exc = d_exc;
+        dev.n_exc = n_exc <= (uint32_t)kExcCap ? (int)n_exc : -1;
+    }
     *blob_out = blob;
     *blob_bytes = bytes;
     return DP_OK;

@@ -64,7 +64,9 @@ struct PalDev {
     int n_slow_blocks;
     int max_cell;
     const uint32_t *code1;      // 2 bits per colour: tie outcome of the k=1 query
-    const uint32_t *code2;      //                     ... of the k=2 query
+    const uint32_t *code2;      // 4 bits per colour: ... of the k=2 query (accel.hip)
+    const uint4 *exc;           // colours whose outcome no code expresses, sorted by colour:
+    int n_exc;                  //   {colour, k=2 indices i0 | i1<<16, k=1 index, 0}; n_exc < 0: list overflowed
 };
 
 struct ThrDev {
@@ -72,7 +74,16 @@ struct ThrDev {
     const float *f32;     // th_h*th_w
     const uint32_t *m;    // integer form: t = m / 2^sh (nullptr when not representable)
     int sh;
+    // lean ordered kernel: the integer table as uint16 rows of tw4 = max(th_w, 4) entries (rows narrower than
+    // 4 are repeated), so that the 4 thresholds of a lane come from one 8-byte LDS read; only when th_h and
+    // th_w are powers of two (nullptr otherwise)
+    const uint16_t *m16;
+    int tw4, lg_tw4;
 };
+
+// Position of a 16x16x16 cell in the LDS table: the kernels form it as r' | b'<<4 | g'<<8 (x & 0xf0f0f0,
+// OR-ed with itself shifted left by 12, bits 16..27), three operations fewer than r'<<8 | g'<<4 | b'.
+inline int cell_slot(int rc, int gc, int bc) { return rc | (bc << 4) | (gc << 8); }
 
 }  // namespace dp
 
@@ -90,6 +101,7 @@ struct dp_palette {
 struct dp_thresholds {
     dp::ThrDev dev;
     void *blob;
+    void *blob16;  // dev.m16 (may be null)
     int device;
 };
 

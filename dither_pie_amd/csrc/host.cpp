@@ -334,6 +334,8 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.n_split = d.n_slow_blocks = 0;
     d.max_cell = 0;
     d.code1 = d.code2 = nullptr;
+    d.exc = nullptr;
+    d.n_exc = 0;
     p->accel_blob = nullptr;
     p->accel_bytes = 0;
     p->accel_tried = false;
@@ -412,6 +414,9 @@ static int thresholds_from_device_f32(float *dev_f32, int th_h, int th_w, const 
     t->dev.f32 = dev_f32;
     t->dev.m = nullptr;
     t->dev.sh = 0;
+    t->dev.m16 = nullptr;
+    t->dev.tw4 = t->dev.lg_tw4 = 0;
+    t->blob16 = nullptr;
     if (sh >= 0) {
         m.resize(n);
         for (int i = 0; i < n; ++i) m[i] = (uint32_t)((double)host_copy[i] * (double)(1u << sh));
@@ -424,6 +429,27 @@ static int thresholds_from_device_f32(float *dev_f32, int th_h, int th_w, const 
         }
         t->dev.m = dm;
         t->dev.sh = sh;
+        const bool pow2 = (th_h & (th_h - 1)) == 0 && (th_w & (th_w - 1)) == 0;
+        if (pow2 && (int64_t)th_h * std::max(th_w, 4) * 2 <= 32 * 1024) {
+            const int tw4 = std::max(th_w, 4);
+            std::vector<uint16_t> m16((size_t)th_h * tw4);
+            for (int y = 0; y < th_h; ++y)
+                for (int x = 0; x < tw4; ++x) m16[(size_t)y * tw4 + x] = (uint16_t)m[(size_t)y * th_w + (x % th_w)];
+            void *d16 = nullptr;
+            e = hipMalloc(&d16, sizeof(uint16_t) * m16.size());
+            if (e == hipSuccess) e = hipMemcpy(d16, m16.data(), sizeof(uint16_t) * m16.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                if (d16) (void)hipFree(d16);
+                delete t;
+                return hip_fail(e, "thresholds uint16 upload");
+            }
+            t->blob16 = d16;
+            t->dev.m16 = (const uint16_t *)d16;
+            t->dev.tw4 = tw4;
+            int lg = 0;
+            while ((1 << lg) < tw4) ++lg;
+            t->dev.lg_tw4 = lg;
+        }
     }
     *out = t;
     return DP_OK;
@@ -509,6 +535,7 @@ void dp_thresholds_destroy(dp_thresholds *t)
 {
     if (!t) return;
     if (t->blob) (void)hipFree(t->blob);
+    if (t->blob16) (void)hipFree(t->blob16);
     delete t;
 }
 

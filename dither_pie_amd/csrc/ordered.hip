@@ -326,6 +326,33 @@ __device__ __forceinline__ void cand8(const uint32_t x, const uint4 ca, const ui
           [c5] "v"(cb.y), [c6] "v"(cb.z), [c7] "v"(cb.w), [ng] "s"(neg2));
 }
 
+// Colours whose tie outcome no code expresses: binary search of the palette's exception list.
+// Returns false when the colour is not listed (or the list overflowed at build time).
+__device__ __forceinline__ bool find_exception(const PalDev &pal, const uint32_t x, uint32_t &pair, uint32_t &single)
+{
+    int lo = 0, hi = pal.n_exc - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint4 e = pal.exc[mid];
+        if (e.x == x) {
+            pair = e.y;
+            single = e.z;
+            return true;
+        }
+        if (e.x < x) lo = mid + 1;
+        else hi = mid - 1;
+    }
+    return false;
+}
+
+// byte offset of the block of x's cell: slot = r' | b'<<4 | g'<<8 (dp_internal.h cell_slot), times 32
+__device__ __forceinline__ uint32_t cell_offset(const uint32_t x)
+{
+    const uint32_t t = x & 0xf0f0f0u;
+    const uint32_t y = t | (t << 12);  // bits 16..27 = r', b', g'
+    return (y >> 11) & 0x1ffe0u;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t *__restrict__ in,
                                                                   uint8_t *__restrict__ out,
@@ -369,8 +396,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t x = xq[q];
-            // (r>>4)<<8 | (g>>4)<<4 | (b>>4), times 32 bytes
-            blk[q] = ((x & 0xf0u) << 9) | ((x & 0xf000u) >> 3) | ((x >> 15) & 0x1e0u);
+            blk[q] = cell_offset(x);
             ca[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q]);
             cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
         }
@@ -429,19 +455,32 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
                     const uint32_t code = (pal.code1[x >> 4] >> ((x & 15u) * 2)) & 3u;
                     if (code == 1) a = b;
                     else if (code == 2) a = *reinterpret_cast<const uint32_t *>(s_bytes + blk[q] + (m2 & 0xfc));
-                    else if (code == 3) s = true;
+                    else if (code == 3) {
+                        uint32_t pair, single;
+                        if (find_exception(pal, x, pair, single)) a = pal.out_rgb[single];
+                        else s = true;
+                    }
                 }
             } else {
                 if (a0 == a1 || a1 == a2) {
-                    const uint32_t code = (pal.code2[x >> 4] >> ((x & 15u) * 2)) & 3u;
-                    if (code == 1) {
-                        const uint32_t t = a;
-                        a = b;
-                        b = t;
-                    } else if (code == 2) {
-                        b = *reinterpret_cast<const uint32_t *>(s_bytes + blk[q] + (m2 & 0xfc));
-                    } else if (code == 3) {
-                        s = true;
+                    const uint32_t code = (pal.code2[x >> 3] >> ((x & 7u) * 4)) & 15u;
+                    if (code != 0u) {
+                        const uint32_t c0 = a, c1 = b;
+                        const uint32_t c2 = *reinterpret_cast<const uint32_t *>(s_bytes + blk[q] + (m2 & 0xfc));
+                        if (code == 1) { a = c1; b = c0; }
+                        else if (code == 2) { b = c2; }
+                        else if (code == 3) { a = c2; b = c0; }
+                        else if (code == 4) { a = c1; b = c2; }
+                        else if (code == 5) { a = c2; b = c1; }
+                        else {
+                            uint32_t pair, single;
+                            if (find_exception(pal, x, pair, single)) {
+                                a = pal.out_rgb[pair & 0xffffu];
+                                b = pal.out_rgb[pair >> 16];
+                            } else {
+                                s = true;
+                            }
+                        }
                     }
                 }
                 const uint32_t S = d0 + d1;
@@ -481,6 +520,242 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
             ++fy;
         }
         if (fy >= g.h) fy -= g.h;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lean variant of the fast path for the common geometry: width a multiple of 4 (a lane's four pixels
+// never straddle a row, the pixel count is a multiple of 4), dword-aligned buffers and -- for matrices --
+// power-of-two tables in integer form.  Same table, same candidate network, same decision, but the
+// main loop is branch-free: byte shuffles through v_perm, one 8-byte LDS read for the four thresholds,
+// one colour read per pixel (of the chosen candidate only).  Everything that is rare per pixel but not
+// per wave -- split cells (1.5 % of the pixels of the headline case, but ~100 % of its waves), distance
+// ties (0.3 % / 18 %), exact equality in the decision -- is deferred: the pixel index goes into a
+// wave-private LDS queue, and whenever 64 have gathered the wave resolves them densely, one pixel per
+// lane, with the complete code (lean_pixel_full) and overwrites their bytes.  Split cells need no test
+// of their own: a marker block holds the marker word and seven zero words, i.e. seven equal colours, so
+// its keys always contain a tie among the three smallest.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLeanLdsWords = 160 * 1024 / 4;
+constexpr int kLeanQueue = 128;                                         // entries per wave
+constexpr int kLeanQueueWords = (kCellBlock / 64) * kLeanQueue;         // 8 KB at the top of LDS
+constexpr int kLeanTabBytes = (kLeanLdsWords - kLeanQueueWords) * 4;    // table + thresholds must fit below
+
+// Complete handling of one pixel (split cells, tie codes, the float64 replay, fix-up flags).
+template <int MODE>
+__device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t *__restrict__ in,
+                                             uint8_t *__restrict__ out, unsigned long long *__restrict__ flags,
+                                             const Geo &g, const PalDev &pal, const ThrDev &thr,
+                                             const uint8_t *s_bytes, const uint32_t thr_base)
+{
+    const uint8_t *b = in + (size_t)p * 3;
+    const uint32_t x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+    uint32_t blk = cell_offset(x);
+    uint4 ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
+    bool slow = false;
+    // split cells: descend by one colour bit per level
+    for (int bit = 3; (ca.x >> 31) != 0; --bit) {
+        if ((ca.x & 0x40000000u) || bit < 0) {
+            slow = true;  // a single colour with more than 8 candidates: fix-up pass
+            break;
+        }
+        const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
+        blk = (4096u * 8u + ((ca.x & 0xffffffu) * 8u + sub) * 8u) * 4u;
+        ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
+    }
+    const uint4 cb = *reinterpret_cast<const uint4 *>(s_bytes + blk + 16);
+    int m0, m1, m2;
+    cand8(x, ca, cb, g.neg2, m0, m1, m2);
+    const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits, a2 = m2 >> kLocalBits;
+    int sel;
+    bool have_c = false;
+    uint32_t c = 0, exc_pair = 0;
+    if (MODE == 0) {
+        sel = m0;
+        if (a0 == a1) {
+            const uint32_t code = (pal.code1[x >> 4] >> ((x & 15u) * 2)) & 3u;
+            if (code == 1) sel = m1;
+            else if (code == 2) sel = m2;
+            else if (code == 3) {
+                uint32_t pair, single;
+                if (find_exception(pal, x, pair, single)) {
+                    have_c = true;
+                    c = pal.out_rgb[single];
+                } else {
+                    slow = true;
+                }
+            }
+        }
+    } else {
+        uint32_t fy, fx;
+        locate(g, p, fy, fx);
+        const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
+        const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.tw4 - 1);
+        const uint32_t mt = *reinterpret_cast<const uint16_t *>(s_bytes + thr_base + (((row << thr.lg_tw4) + col) << 1));
+        const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
+        const uint32_t d0 = (uint32_t)(a0 + xx), d1 = (uint32_t)(a1 + xx);
+        const uint32_t lhs = d0 << thr.sh;
+        const uint32_t rhs = __umul24(mt, d0 + d1);
+        bool nearest = lhs <= rhs;
+        int sa = m0, sb = m1;
+        if (a0 == a1 || a1 == a2) {
+            const uint32_t code = (pal.code2[x >> 3] >> ((x & 7u) * 4)) & 15u;
+            if (code == 1) { sa = m1; sb = m0; }
+            else if (code == 2) { sb = m2; }
+            else if (code == 3) { sa = m2; sb = m0; }
+            else if (code == 4) { sa = m1; sb = m2; }
+            else if (code == 5) { sa = m2; sb = m1; }
+            else if (code != 0u) {
+                uint32_t pair, single;
+                if (find_exception(pal, x, pair, single)) {
+                    have_c = true;
+                    exc_pair = pair;
+                } else {
+                    slow = true;
+                }
+            }
+        }
+        if (lhs == rhs)  // the literal float64 chain decides
+            nearest = ordered_use_nearest((double)d0, (double)d1, __fmul_rn((float)mt, 1.0f / (float)(1u << thr.sh)));
+        sel = nearest ? sa : sb;
+        if (have_c) c = pal.out_rgb[nearest ? (exc_pair & 0xffffu) : (exc_pair >> 16)];
+    }
+    if (!have_c) c = *reinterpret_cast<const uint32_t *>(s_bytes + (blk | ((uint32_t)sel & 0xfcu)));
+    uint8_t *o = out + (size_t)p * 3;
+    o[0] = (uint8_t)c;
+    o[1] = (uint8_t)(c >> 8);
+    o[2] = (uint8_t)(c >> 16);
+    if (slow) {
+        const uint32_t wtile = p >> 8;  // 64 lanes x 4 pixels
+        atomicOr(&flags[(size_t)wtile * 4 + (p & 3u)], 1ull << ((p >> 2) & 63u));
+        // queue the wave tile for the fix-up pass (a tile may appear more than once: re-resolving is idempotent)
+        const uint32_t slot = atomicAdd(g.dirty, 1u);
+        if (slot < (uint32_t)kQueueTiles) g.dirty[1 + slot] = wtile;
+    }
+}
+
+template <int MODE>  // 0 nearest, 1 integer matrix
+__global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t *__restrict__ in,
+                                                                  uint8_t *__restrict__ out,
+                                                                  unsigned long long *__restrict__ flags,
+                                                                  const Geo g, const PalDev pal, const ThrDev thr,
+                                                                  const uint32_t n_tiles, const uint32_t n_groups)
+{
+    __shared__ __align__(16) uint32_t smem[kLeanLdsWords];  // static: LDS addresses need no base register
+    for (int i = threadIdx.x * 4; i < pal.tab_words; i += kCellBlock * 4)
+        *reinterpret_cast<uint4 *>(&smem[i]) = *reinterpret_cast<const uint4 *>(&pal.cell_tab[i]);
+    const uint32_t thr_base = (uint32_t)pal.tab_words * 4u;  // byte offset of the uint16 threshold rows
+    if (MODE == 1) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(thr.m16);
+        const int n = (thr.th_h * thr.tw4) >> 1;
+        for (int i = threadIdx.x; i < n; i += kCellBlock) smem[pal.tab_words + i] = src[i];
+    }
+    __syncthreads();
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(smem);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *s_queue = smem + (kLeanLdsWords - kLeanQueueWords) + (threadIdx.x >> 6) * kLeanQueue;
+    uint32_t qcount = 0;  // wave-uniform
+    const uint3 *in3 = reinterpret_cast<const uint3 *>(in);
+    uint3 *out3 = reinterpret_cast<uint3 *>(out);
+
+    uint32_t tile = blockIdx.x;
+    uint32_t fy = 0, fx = 0;
+    uint3 wn = make_uint3(0u, 0u, 0u);
+    if (tile < n_tiles) {
+        const uint32_t gidx0 = tile * kCellBlock + threadIdx.x;
+        if (gidx0 < n_groups) {
+            wn = in3[gidx0];
+            locate(g, gidx0 * 4u, fy, fx);
+        }
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t gidx = tile * kCellBlock + threadIdx.x;
+        const uint3 wc = wn;
+        {
+            const uint32_t next = tile + gridDim.x;
+            const uint32_t gn = next * kCellBlock + threadIdx.x;
+            if (next < n_tiles && gn < n_groups) wn = in3[gn];  // prefetch the next tile
+        }
+        // all clear; lean_pixel_full ORs in the bits of the pixels it leaves to the fix-up pass later
+        if (lane < 4u) flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
+        bool rare[4] = {false, false, false, false};
+        if (gidx < n_groups) {
+            uint32_t xq[4];
+            xq[0] = wc.x & 0xffffffu;
+            xq[1] = __builtin_amdgcn_perm(wc.y, wc.x, 0x0c050403u);
+            xq[2] = __builtin_amdgcn_perm(wc.z, wc.y, 0x0c040302u);
+            xq[3] = wc.z >> 8;
+            uint32_t blk[4];
+            uint4 ca[4], cb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                blk[q] = cell_offset(xq[q]);
+                ca[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q]);
+                cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
+            }
+            uint2 t4 = make_uint2(0u, 0u);
+            if (MODE == 1) {
+                const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
+                const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.tw4 - 1);
+                t4 = *reinterpret_cast<const uint2 *>(s_bytes + thr_base + (((row << thr.lg_tw4) + col) << 1));
+            }
+            uint32_t col[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = xq[q];
+                int m0, m1, m2;
+                cand8(x, ca[q], cb[q], g.neg2, m0, m1, m2);
+                const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits;
+                const bool tie = (a0 == a1) | ((uint32_t)(m1 ^ m2) < (1u << kLocalBits));  // also: any split cell
+                int sel;
+                if (MODE == 0) {
+                    sel = m0;
+                    rare[q] = tie;
+                } else {
+                    const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
+                    const uint32_t d0 = (uint32_t)(a0 + xx);
+                    const uint32_t S = d0 + (uint32_t)a1 + (uint32_t)xx;
+                    const uint32_t tw = (q & 2) ? t4.y : t4.x;
+                    const uint32_t mt = (q & 1) ? (tw >> 16) : (tw & 0xffffu);
+                    const uint32_t lhs = d0 << thr.sh;
+                    const uint32_t rhs = __umul24(mt, S);
+                    rare[q] = tie | (lhs == rhs);
+                    sel = (lhs <= rhs) ? m0 : m1;
+                }
+                col[q] = *reinterpret_cast<const uint32_t *>(s_bytes + (blk[q] | ((uint32_t)sel & 0xfcu)));
+            }
+            uint3 wo;
+            wo.x = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);
+            wo.y = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);
+            wo.z = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);
+            out3[gidx] = wo;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long rb = __ballot(rare[q]);
+            if (rb != 0ull) {  // wave-uniform
+                if (rare[q])
+                    s_queue[__builtin_amdgcn_mbcnt_hi((uint32_t)(rb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rb, qcount))] =
+                        gidx * 4u + (uint32_t)q;
+                qcount += (uint32_t)__popcll(rb);
+                if (qcount >= 64u) {
+                    qcount -= 64u;
+                    __threadfence_block();  // the queue writes, and the group stores that are about to be overwritten
+                    lean_pixel_full<MODE>(s_queue[qcount + lane], in, out, flags, g, pal, thr, s_bytes, thr_base);
+                }
+            }
+        }
+        fx += g.adv_x;
+        fy += g.adv_y;
+        if (fx >= g.w) {
+            fx -= g.w;
+            ++fy;
+        }
+        if (fy >= g.h) fy -= g.h;
+    }
+    if (qcount != 0u) {
+        __threadfence_block();
+        if (lane < qcount) lean_pixel_full<MODE>(s_queue[lane], in, out, flags, g, pal, thr, s_bytes, thr_base);
     }
 }
 
@@ -792,6 +1067,8 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
     thr.f32 = nullptr;
     thr.m = nullptr;
     thr.sh = 0;
+    thr.m16 = nullptr;
+    thr.tw4 = thr.lg_tw4 = 0;
     if (mode == DP_MODE_MATRIX) thr = *thr_in;
     // a single colour: every pixel maps to it, and the k=2 query of the reference has no second entry
     if (pal.K == 1) mode = DP_MODE_NEAREST;
@@ -844,7 +1121,20 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
                 g.adv_x = (uint32_t)(adv % (uint64_t)w);
             }
             int rc;
-            if (mode == DP_MODE_NEAREST) {
+            const bool lean_geo = (w % 4) == 0 && g.aligned && (size_t)pal.tab_words * 4 <= (size_t)kLeanTabBytes;
+            const bool lean_thr = thr.m16 != nullptr && (x0 % 4) == 0 && x0 >= 0 && y0 >= 0 &&
+                                  (size_t)pal.tab_words * 4 + (size_t)thr.th_h * thr.tw4 * 2 <= (size_t)kLeanTabBytes;
+            if (lean_geo && mode == DP_MODE_NEAREST) {
+                hipLaunchKernelGGL(ordered_lean_kernel<0>, dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr,
+                                   n_tiles, groups);
+                rc = DP_OK;
+                fix_mode = 0;
+            } else if (lean_geo && mode == DP_MODE_MATRIX && lean_thr) {
+                hipLaunchKernelGGL(ordered_lean_kernel<1>, dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr,
+                                   n_tiles, groups);
+                rc = DP_OK;
+                fix_mode = 2;
+            } else if (mode == DP_MODE_NEAREST) {
                 rc = launch_cell<0>(cgrid, lds, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles);
                 fix_mode = 0;
             } else if (mode == DP_MODE_IGN) {

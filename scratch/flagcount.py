@@ -16,3 +16,6 @@ print("flagged pixels:", bits, "of", npx, f"= {bits/npx*100:.4f}%")
 P2=backend.Palette(*prepare_palette(pal,False), accel=False)
 out2=backend.ordered(f,P2,backend.MODE_MATRIX,thr=thr); torch.cuda.synchronize()
 print("accel == brute force:", bool(torch.equal(out,out2)))
+dirty_off=(( (npx+255)//256*32 + 768) & ~7)
+d=ws[dirty_off:dirty_off+8].view(torch.int32)
+print("dirty count (queued wave tiles):", int(d[0]))
