@@ -258,8 +258,8 @@ constexpr int kCellBlock = 1024;
 //   key = ((|p|^2 - 2 x.p) << 8) | (4*idx)      (4*idx = byte offset of the candidate inside its block)
 // Hand scheduled: hipcc neither fuses the shift/add/multiply into v_lshl_add + v_mad_i32_i24 nor keeps
 // med3 for the running top-3, and it has to pad DOT results with s_nop; here all eight v_dot4 pairs are
-// issued first (a DOT result must not be read for 3 issue slots), then 2 ops per key, then the insertion
-// network (0 + 2 + 3 + 5x3 ops).  `neg2` = -512 must sit in an SGPR (v_mad_i32_i24 takes no literal).
+// issued first (a DOT result must not be read for 3 issue slots), then 2 ops per key, then the three
+// smallest: sort the first three (min3/med3/max3), insert the other five (3 ops each).  `neg2` = -512 must sit in an SGPR (v_mad_i32_i24 takes no literal).
 __device__ __forceinline__ void cand8(const uint32_t x, const uint4 ca, const uint4 cb, const int neg2, int &m0,
                                       int &m1, int &m2)
 {
@@ -298,11 +298,9 @@ __device__ __forceinline__ void cand8(const uint32_t x, const uint4 ca, const ui
         "v_mad_i32_i24 %[n6], %[p6], %[ng], %[n6]\n\t"
         "v_mad_i32_i24 %[n7], %[p7], %[ng], %[n7]\n\t"
         // top-3 insertion network (m0 <= m1 <= m2)
-        "v_min_i32 %[m0], %[n0], %[n1]\n\t"
-        "v_max_i32 %[m1], %[n0], %[n1]\n\t"
-        "v_max_i32 %[m2], %[m1], %[n2]\n\t"
-        "v_med3_i32 %[m1], %[m0], %[m1], %[n2]\n\t"
-        "v_min_i32 %[m0], %[m0], %[n2]\n\t"
+        "v_min3_i32 %[m0], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[n0], %[n1], %[n2]\n\t"
+        "v_max3_i32 %[m2], %[n0], %[n1], %[n2]\n\t"
         "v_med3_i32 %[m2], %[m1], %[m2], %[n3]\n\t"
         "v_med3_i32 %[m1], %[m0], %[m1], %[n3]\n\t"
         "v_min_i32 %[m0], %[m0], %[n3]\n\t"
