@@ -74,11 +74,12 @@ struct ThrDev {
     const float *f32;     // th_h*th_w
     const uint32_t *m;    // integer form: t = m / 2^sh (nullptr when not representable)
     int sh;
-    // lean ordered kernel: the integer table as uint16 rows of tw4 = max(th_w, 4) entries (rows narrower than
-    // 4 are repeated), so that the 4 thresholds of a lane come from one 8-byte LDS read; only when th_h and
-    // th_w are powers of two (nullptr otherwise)
-    const uint16_t *m16;
-    int tw4, lg_tw4;
+    // lean ordered kernel (power-of-two tables only, nullptr otherwise): rows of tw_pad = th_w + 3 entries, the
+    // last three repeating the row from its start, so that the 4 thresholds of a lane's pixels are 4 consecutive
+    // entries whatever the starting column.  fpad: the float32 values; mpad: the integer form (needs sh >= 0).
+    const float *fpad;
+    const uint32_t *mpad;
+    int tw_pad;
 };
 
 // Position of a 16x16x16 cell in the LDS table: the kernels form it as r' | b'<<4 | g'<<8 (x & 0xf0f0f0,
@@ -101,7 +102,7 @@ struct dp_palette {
 struct dp_thresholds {
     dp::ThrDev dev;
     void *blob;
-    void *blob16;  // dev.m16 (may be null)
+    void *blob_pad;  // dev.fpad / dev.mpad (may be null)
     int device;
 };
 

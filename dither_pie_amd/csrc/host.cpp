@@ -414,9 +414,10 @@ static int thresholds_from_device_f32(float *dev_f32, int th_h, int th_w, const 
     t->dev.f32 = dev_f32;
     t->dev.m = nullptr;
     t->dev.sh = 0;
-    t->dev.m16 = nullptr;
-    t->dev.tw4 = t->dev.lg_tw4 = 0;
-    t->blob16 = nullptr;
+    t->dev.fpad = nullptr;
+    t->dev.mpad = nullptr;
+    t->dev.tw_pad = 0;
+    t->blob_pad = nullptr;
     if (sh >= 0) {
         m.resize(n);
         for (int i = 0; i < n; ++i) m[i] = (uint32_t)((double)host_copy[i] * (double)(1u << sh));
@@ -429,27 +430,29 @@ static int thresholds_from_device_f32(float *dev_f32, int th_h, int th_w, const 
         }
         t->dev.m = dm;
         t->dev.sh = sh;
-        const bool pow2 = (th_h & (th_h - 1)) == 0 && (th_w & (th_w - 1)) == 0;
-        if (pow2 && (int64_t)th_h * std::max(th_w, 4) * 2 <= 32 * 1024) {
-            const int tw4 = std::max(th_w, 4);
-            std::vector<uint16_t> m16((size_t)th_h * tw4);
-            for (int y = 0; y < th_h; ++y)
-                for (int x = 0; x < tw4; ++x) m16[(size_t)y * tw4 + x] = (uint16_t)m[(size_t)y * th_w + (x % th_w)];
-            void *d16 = nullptr;
-            e = hipMalloc(&d16, sizeof(uint16_t) * m16.size());
-            if (e == hipSuccess) e = hipMemcpy(d16, m16.data(), sizeof(uint16_t) * m16.size(), hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                if (d16) (void)hipFree(d16);
-                delete t;
-                return hip_fail(e, "thresholds uint16 upload");
+    }
+    if ((th_h & (th_h - 1)) == 0 && (th_w & (th_w - 1)) == 0 && (int64_t)th_h * (th_w + 3) <= (1 << 18)) {
+        const int twp = th_w + 3;
+        const size_t np = (size_t)th_h * twp;
+        std::vector<uint32_t> pad(2 * np);  // float32 bit patterns, then the integer form
+        for (int y = 0; y < th_h; ++y)
+            for (int x = 0; x < twp; ++x) {
+                const size_t src = (size_t)y * th_w + (x % th_w);
+                std::memcpy(&pad[(size_t)y * twp + x], &host_copy[src], sizeof(float));
+                pad[np + (size_t)y * twp + x] = sh >= 0 ? m[src] : 0u;
             }
-            t->blob16 = d16;
-            t->dev.m16 = (const uint16_t *)d16;
-            t->dev.tw4 = tw4;
-            int lg = 0;
-            while ((1 << lg) < tw4) ++lg;
-            t->dev.lg_tw4 = lg;
+        void *dp = nullptr;
+        hipError_t e = hipMalloc(&dp, sizeof(uint32_t) * pad.size());
+        if (e == hipSuccess) e = hipMemcpy(dp, pad.data(), sizeof(uint32_t) * pad.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (dp) (void)hipFree(dp);
+            delete t;
+            return hip_fail(e, "thresholds padded upload");
         }
+        t->blob_pad = dp;
+        t->dev.fpad = (const float *)dp;
+        t->dev.mpad = sh >= 0 ? (const uint32_t *)dp + np : nullptr;
+        t->dev.tw_pad = twp;
     }
     *out = t;
     return DP_OK;
@@ -535,7 +538,7 @@ void dp_thresholds_destroy(dp_thresholds *t)
 {
     if (!t) return;
     if (t->blob) (void)hipFree(t->blob);
-    if (t->blob16) (void)hipFree(t->blob16);
+    if (t->blob_pad) (void)hipFree(t->blob_pad);
     delete t;
 }
 

@@ -522,30 +522,54 @@ __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Lean variant of the fast path for the common geometry: width a multiple of 4 (a lane's four pixels
-// never straddle a row, the pixel count is a multiple of 4), dword-aligned buffers and -- for matrices --
-// power-of-two tables in integer form.  Same table, same candidate network, same decision, but the
-// main loop is branch-free: byte shuffles through v_perm, one 8-byte LDS read for the four thresholds,
-// one colour read per pixel (of the chosen candidate only).  Everything that is rare per pixel but not
-// per wave -- split cells (1.5 % of the pixels of the headline case, but ~100 % of its waves), distance
-// ties (0.3 % / 18 %), exact equality in the decision -- is deferred: the pixel index goes into a
-// wave-private LDS queue, and whenever 64 have gathered the wave resolves them densely, one pixel per
-// lane, with the complete code (lean_pixel_full) and overwrites their bytes.  Split cells need no test
-// of their own: a marker block holds the marker word and seven zero words, i.e. seven equal colours, so
-// its keys always contain a tie among the three smallest.
+// Lean variant of the fast path: dword-aligned buffers, and for matrices power-of-two tables.  Same
+// cell table, same candidate network, same decision, but the main loop is branch-free: byte shuffles
+// through v_perm, the four thresholds of a lane from one padded table row, one colour read per pixel
+// (of the chosen candidate only).  Everything that is rare per pixel but not per wave -- split cells
+// (1.5 % of the pixels of the headline case, but ~100 % of its waves), distance ties (0.3 % / 18 %),
+// exact equality in the decision, the one group per image row that straddles its end when the width is
+// not a multiple of 4, a partial last group -- is deferred: the pixel index goes into a wave-private
+// LDS queue, and whenever 64 have gathered the wave resolves them densely, one pixel per lane, with
+// the complete code (lean_pixel_full) and overwrites their bytes.  Split cells need no test of their
+// own: a marker block holds the marker word and seven zero words, i.e. seven equal colours, so its
+// keys always contain a tie among the three smallest.
+// MODE: 0 nearest only; 1 matrix in integer form (table in LDS); 2 matrix float32 (table read from
+// global memory, it stays in L1); 3 IGN.
 // ---------------------------------------------------------------------------------------------
 constexpr int kLeanLdsWords = 160 * 1024 / 4;
 constexpr int kLeanQueue = 128;                                         // entries per wave
 constexpr int kLeanQueueWords = (kCellBlock / 64) * kLeanQueue;         // 8 KB at the top of LDS
 constexpr int kLeanTabBytes = (kLeanLdsWords - kLeanQueueWords) * 4;    // table + thresholds must fit below
 
+struct LeanThr {  // what the decision needs besides the distances
+    uint32_t mt;  // MODE 1
+    float t;      // MODE 2, 3
+};
+
+// nearest?  `eq` reports exact equality of the two sides (the float64 replay then decides)
+template <int MODE>
+__device__ __forceinline__ bool lean_decide(const uint32_t d0, const uint32_t S, const LeanThr &th, const int sh, bool &eq)
+{
+    if (MODE == 1) {
+        const uint32_t lhs = d0 << sh;
+        const uint32_t rhs = __umul24(th.mt, S);
+        eq = lhs == rhs;
+        return lhs <= rhs;
+    }
+    // exact: a 24-bit significand times a 19-bit integer fits a double
+    const double lhs = (double)d0, rhs = __dmul_rn((double)th.t, (double)S);
+    eq = lhs == rhs;
+    return lhs <= rhs;
+}
+
 // Complete handling of one pixel (split cells, tie codes, the float64 replay, fix-up flags).
 template <int MODE>
 __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t *__restrict__ in,
-                                             uint8_t *__restrict__ out, unsigned long long *__restrict__ flags,
-                                             const Geo &g, const PalDev &pal, const ThrDev &thr,
-                                             const uint8_t *s_bytes, const uint32_t thr_base)
+                                                uint8_t *__restrict__ out, unsigned long long *__restrict__ flags,
+                                                const Geo &g, const PalDev &pal, const ThrDev &thr,
+                                                const uint32_t *s_words, const float sx, const float sy, const float sc)
 {
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_words);
     const uint8_t *b = in + (size_t)p * 3;
     const uint32_t x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
     uint32_t blk = cell_offset(x);
@@ -587,14 +611,25 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     } else {
         uint32_t fy, fx;
         locate(g, p, fy, fx);
-        const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
-        const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.tw4 - 1);
-        const uint32_t mt = *reinterpret_cast<const uint16_t *>(s_bytes + thr_base + (((row << thr.lg_tw4) + col) << 1));
+        LeanThr th;
+        th.mt = 0;
+        th.t = 0.0f;
+        if (MODE == 3) {
+            th.t = ign_threshold(g.x0 + (int)fx, g.y0 + (int)fy, sx, sy, sc);
+        } else {
+            const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
+            const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.th_w - 1);
+            if (MODE == 1) {
+                th.mt = s_words[pal.tab_words + row * thr.tw_pad + col];
+                th.t = __fmul_rn((float)th.mt, 1.0f / (float)(1u << thr.sh));
+            } else {
+                th.t = thr.fpad[row * thr.tw_pad + col];
+            }
+        }
         const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
         const uint32_t d0 = (uint32_t)(a0 + xx), d1 = (uint32_t)(a1 + xx);
-        const uint32_t lhs = d0 << thr.sh;
-        const uint32_t rhs = __umul24(mt, d0 + d1);
-        bool nearest = lhs <= rhs;
+        bool eq;
+        bool nearest = lean_decide<MODE>(d0, d0 + d1, th, thr.sh, eq);
         int sa = m0, sb = m1;
         if (a0 == a1 || a1 == a2) {
             const uint32_t code = (pal.code2[x >> 3] >> ((x & 7u) * 4)) & 15u;
@@ -613,8 +648,7 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
                 }
             }
         }
-        if (lhs == rhs)  // the literal float64 chain decides
-            nearest = ordered_use_nearest((double)d0, (double)d1, __fmul_rn((float)mt, 1.0f / (float)(1u << thr.sh)));
+        if (eq) nearest = ordered_use_nearest((double)d0, (double)d1, th.t);  // the literal float64 chain decides
         sel = nearest ? sa : sb;
         if (have_c) c = pal.out_rgb[nearest ? (exc_pair & 0xffffu) : (exc_pair >> 16)];
     }
@@ -632,21 +666,20 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     }
 }
 
-template <int MODE>  // 0 nearest, 1 integer matrix
+template <int MODE>
 __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t *__restrict__ in,
                                                                   uint8_t *__restrict__ out,
                                                                   unsigned long long *__restrict__ flags,
                                                                   const Geo g, const PalDev pal, const ThrDev thr,
-                                                                  const uint32_t n_tiles, const uint32_t n_groups)
+                                                                  const float sx, const float sy, const float sc,
+                                                                  const uint32_t n_tiles)
 {
     __shared__ __align__(16) uint32_t smem[kLeanLdsWords];  // static: LDS addresses need no base register
     for (int i = threadIdx.x * 4; i < pal.tab_words; i += kCellBlock * 4)
         *reinterpret_cast<uint4 *>(&smem[i]) = *reinterpret_cast<const uint4 *>(&pal.cell_tab[i]);
-    const uint32_t thr_base = (uint32_t)pal.tab_words * 4u;  // byte offset of the uint16 threshold rows
     if (MODE == 1) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(thr.m16);
-        const int n = (thr.th_h * thr.tw4) >> 1;
-        for (int i = threadIdx.x; i < n; i += kCellBlock) smem[pal.tab_words + i] = src[i];
+        const int n = thr.th_h * thr.tw_pad;
+        for (int i = threadIdx.x; i < n; i += kCellBlock) smem[pal.tab_words + i] = thr.mpad[i];
     }
     __syncthreads();
     const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(smem);
@@ -655,16 +688,15 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
     uint32_t qcount = 0;  // wave-uniform
     const uint3 *in3 = reinterpret_cast<const uint3 *>(in);
     uint3 *out3 = reinterpret_cast<uint3 *>(out);
+    const uint32_t n_full = g.n_px >> 2;  // groups of four whole pixels; a partial last group goes through the queue
 
     uint32_t tile = blockIdx.x;
     uint32_t fy = 0, fx = 0;
     uint3 wn = make_uint3(0u, 0u, 0u);
     if (tile < n_tiles) {
         const uint32_t gidx0 = tile * kCellBlock + threadIdx.x;
-        if (gidx0 < n_groups) {
-            wn = in3[gidx0];
-            locate(g, gidx0 * 4u, fy, fx);
-        }
+        if (gidx0 < n_full) wn = in3[gidx0];
+        if (gidx0 * 4u < g.n_px) locate(g, gidx0 * 4u, fy, fx);
     }
     for (; tile < n_tiles; tile += gridDim.x) {
         const uint32_t gidx = tile * kCellBlock + threadIdx.x;
@@ -672,12 +704,12 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
         {
             const uint32_t next = tile + gridDim.x;
             const uint32_t gn = next * kCellBlock + threadIdx.x;
-            if (next < n_tiles && gn < n_groups) wn = in3[gn];  // prefetch the next tile
+            if (next < n_tiles && gn < n_full) wn = in3[gn];  // prefetch the next tile
         }
         // all clear; lean_pixel_full ORs in the bits of the pixels it leaves to the fix-up pass later
         if (lane < 4u) flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
         bool rare[4] = {false, false, false, false};
-        if (gidx < n_groups) {
+        if (gidx < n_full) {
             uint32_t xq[4];
             xq[0] = wc.x & 0xffffffu;
             xq[1] = __builtin_amdgcn_perm(wc.y, wc.x, 0x0c050403u);
@@ -691,12 +723,27 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                 ca[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q]);
                 cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
             }
-            uint2 t4 = make_uint2(0u, 0u);
-            if (MODE == 1) {
-                const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
-                const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.tw4 - 1);
-                t4 = *reinterpret_cast<const uint2 *>(s_bytes + thr_base + (((row << thr.lg_tw4) + col) << 1));
+            LeanThr th[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                th[q].mt = 0;
+                th[q].t = 0.0f;
             }
+            if (MODE == 1 || MODE == 2) {
+                const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
+                const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.th_w - 1);
+                const uint32_t at = row * (uint32_t)thr.tw_pad + col;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (MODE == 1) th[q].mt = smem[pal.tab_words + at + q];
+                    else th[q].t = thr.fpad[at + q];
+                }
+            } else if (MODE == 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) th[q].t = ign_threshold(g.x0 + (int)fx + q, g.y0 + (int)fy, sx, sy, sc);
+            }
+            // the group runs over the end of its row: all four through the queue (their positions differ)
+            const bool straddle = (MODE != 0) && (fx + 3u >= g.w);
             uint32_t col[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -713,12 +760,10 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                     const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
                     const uint32_t d0 = (uint32_t)(a0 + xx);
                     const uint32_t S = d0 + (uint32_t)a1 + (uint32_t)xx;
-                    const uint32_t tw = (q & 2) ? t4.y : t4.x;
-                    const uint32_t mt = (q & 1) ? (tw >> 16) : (tw & 0xffffu);
-                    const uint32_t lhs = d0 << thr.sh;
-                    const uint32_t rhs = __umul24(mt, S);
-                    rare[q] = tie | (lhs == rhs);
-                    sel = (lhs <= rhs) ? m0 : m1;
+                    bool eq;
+                    const bool nearest = lean_decide<MODE>(d0, S, th[q], thr.sh, eq);
+                    rare[q] = tie | eq | straddle;
+                    sel = nearest ? m0 : m1;
                 }
                 col[q] = *reinterpret_cast<const uint32_t *>(s_bytes + (blk[q] | ((uint32_t)sel & 0xfcu)));
             }
@@ -727,6 +772,9 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
             wo.y = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);
             wo.z = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);
             out3[gidx] = wo;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rare[q] = gidx * 4u + (uint32_t)q < g.n_px;  // the partial last group
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -739,7 +787,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                 if (qcount >= 64u) {
                     qcount -= 64u;
                     __threadfence_block();  // the queue writes, and the group stores that are about to be overwritten
-                    lean_pixel_full<MODE>(s_queue[qcount + lane], in, out, flags, g, pal, thr, s_bytes, thr_base);
+                    lean_pixel_full<MODE>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
                 }
             }
         }
@@ -753,7 +801,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
     }
     if (qcount != 0u) {
         __threadfence_block();
-        if (lane < qcount) lean_pixel_full<MODE>(s_queue[lane], in, out, flags, g, pal, thr, s_bytes, thr_base);
+        if (lane < qcount) lean_pixel_full<MODE>(s_queue[lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
     }
 }
 
@@ -1065,8 +1113,9 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
     thr.f32 = nullptr;
     thr.m = nullptr;
     thr.sh = 0;
-    thr.m16 = nullptr;
-    thr.tw4 = thr.lg_tw4 = 0;
+    thr.fpad = nullptr;
+    thr.mpad = nullptr;
+    thr.tw_pad = 0;
     if (mode == DP_MODE_MATRIX) thr = *thr_in;
     // a single colour: every pixel maps to it, and the k=2 query of the reference has no second entry
     if (pal.K == 1) mode = DP_MODE_NEAREST;
@@ -1119,19 +1168,27 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
                 g.adv_x = (uint32_t)(adv % (uint64_t)w);
             }
             int rc;
-            const bool lean_geo = (w % 4) == 0 && g.aligned && (size_t)pal.tab_words * 4 <= (size_t)kLeanTabBytes;
-            const bool lean_thr = thr.m16 != nullptr && (x0 % 4) == 0 && x0 >= 0 && y0 >= 0 &&
-                                  (size_t)pal.tab_words * 4 + (size_t)thr.th_h * thr.tw4 * 2 <= (size_t)kLeanTabBytes;
+            const bool lean_geo = g.aligned && (size_t)pal.tab_words * 4 <= (size_t)kLeanTabBytes && y0 >= 0 && x0 >= 0;
+            const bool int_lean = thr.mpad != nullptr &&
+                                  (size_t)pal.tab_words * 4 + (size_t)thr.th_h * thr.tw_pad * 4 <= (size_t)kLeanTabBytes;
+#define DP_LEAN(M) hipLaunchKernelGGL(ordered_lean_kernel<M>, dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles)
             if (lean_geo && mode == DP_MODE_NEAREST) {
-                hipLaunchKernelGGL(ordered_lean_kernel<0>, dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr,
-                                   n_tiles, groups);
+                DP_LEAN(0);
                 rc = DP_OK;
                 fix_mode = 0;
-            } else if (lean_geo && mode == DP_MODE_MATRIX && lean_thr) {
-                hipLaunchKernelGGL(ordered_lean_kernel<1>, dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr,
-                                   n_tiles, groups);
+            } else if (lean_geo && mode == DP_MODE_IGN) {
+                DP_LEAN(3);
+                rc = DP_OK;
+                fix_mode = 3;
+            } else if (lean_geo && mode == DP_MODE_MATRIX && int_lean) {
+                DP_LEAN(1);
                 rc = DP_OK;
                 fix_mode = 2;
+            } else if (lean_geo && mode == DP_MODE_MATRIX && thr.fpad != nullptr) {
+                DP_LEAN(2);
+                rc = DP_OK;
+                fix_mode = 2;
+#undef DP_LEAN
             } else if (mode == DP_MODE_NEAREST) {
                 rc = launch_cell<0>(cgrid, lds, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles);
                 fix_mode = 0;

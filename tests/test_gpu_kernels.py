@@ -333,3 +333,27 @@ def test_variance_gate_matches_scipy_restatement(be, orc):
             gate = be.variance_gate(_dev(arr), P, thr, rad).cpu().numpy()[0]
             ref, _ = orc.variance_gate(src, thr, rad)
             assert np.array_equal(gate, ref), (gamma, thr, rad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "8x8"}), ("bayer", {"size": "2x2"}),
+                                         ("blue_noise", {"size": 32, "seed": 3}), ("IGN", {"scale": 1.5, "seed": 4}),
+                                         ("polka_dot", {"tile_size": 8, "gamma": 1.5})])
+@pytest.mark.parametrize("w", [1003, 1004])
+def test_lean_kernel_queue_drains_and_row_straddles(be, orc, mode, params, w):
+    """The lean kernel defers split cells, ties and row-straddling groups to its wave-private queue; a frame
+    with many tie colours, an odd width and a tile origin makes every wave drain the queue several times.
+    Checked against the oracle and against the brute-force kernels (no accelerator)."""
+    rs = np.random.RandomState(77)
+    pal = orc.palr(256, seed=21)
+    arr = orc.rnd(611, w, 5)
+    # a third of the pixels are exact palette colours or midpoints of palette pairs (distance ties)
+    pick = rs.randint(0, 256, (611, w))
+    mid = (np.asarray(pal)[pick].astype(np.int64) + np.asarray(pal)[(pick + 1) % 256]) // 2
+    sel = rs.randint(0, 3, (611, w, 1))
+    arr = np.where(sel == 0, mid.astype(np.uint8), arr)
+    ref = orc.apply_dithering(arr, pal, mode, params, False, y0=5, x0=3)
+    out = _run_case(be, orc, arr, pal, mode, params, False, y0=5, x0=3)
+    _assert_same(out, ref, f"lean {mode} w={w}")
+    out2 = _run_case(be, orc, arr, pal, mode, params, False, y0=5, x0=3, accel=False)
+    _assert_same(out2, ref, f"brute {mode} w={w}")
