@@ -175,6 +175,225 @@ __global__ __launch_bounds__(64) void accel_box_kernel(const PalDev pal, const B
     if (threadIdx.x < 8) masks[blockIdx.x * 8 + threadIdx.x] = s_mask[threadIdx.x];
 }
 
+
+// ---- float (gamma) palettes ----------------------------------------------------------------------
+// Same cell lists for palettes whose coordinates are not integers (use_gamma: float32 linearised colours,
+// pixels looked up through lut_in first).  The dither kernel ranks a cell's candidates in float32 and
+// accepts the ranking only when neighbouring keys differ by more than 128 ulp (>= 7.6e-6 relative; its own
+// rounding error is < 1.5e-6), otherwise the pixel goes to the fix-up pass.  So a list must hold every entry
+// within that margin of the second smallest distance: T'(x) = { j : d_j <= d_(2) * (1 + 2^-14) }, d in
+// float64 exactly as scipy computes it.  Colours no pixel can take (values outside lut_in's image) are skipped.
+constexpr double kFloatListMargin = 1.0 + 6.103515625e-5;  // 1 + 2^-14
+
+__device__ __forceinline__ void float_members(const double *s_pts, const int K, const double r, const double g,
+                                              const double b, uint32_t *mask_a, uint32_t *mask_b)
+{
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double b0 = inf, b1 = inf;
+    for (int j = 0; j < K; ++j) {
+        const double d = sq_dist3(s_pts + 3 * j, r, g, b);
+        if (d < b1) {
+            if (d < b0) {
+                b1 = b0;
+                b0 = d;
+            } else {
+                b1 = d;
+            }
+        }
+    }
+    const double bound = __dmul_rn(b1, kFloatListMargin);
+    for (int j = 0; j < K; ++j) {
+        const double d = sq_dist3(s_pts + 3 * j, r, g, b);
+        if (d <= bound) {
+            atomicOr(&mask_a[j >> 5], 1u << (j & 31));
+            if (mask_b) atomicOr(&mask_b[j >> 5], 1u << (j & 31));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void accel_scan_float_kernel(const PalDev pal, const uint8_t *__restrict__ reach,
+                                                               uint32_t *__restrict__ masks)
+{
+    __shared__ uint32_t s_mask[9][8];
+    __shared__ double s_pts[256 * 3];
+    if (threadIdx.x < 72) (&s_mask[0][0])[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < pal.K * 3; i += 256) s_pts[i] = pal.pts[i];
+    __syncthreads();
+    const int cell = blockIdx.x;
+    const int rc = cell >> 8, gc = (cell >> 4) & 15, bc = cell & 15;
+    for (int t = 0; t < 16; ++t) {
+        const int id = threadIdx.x + 256 * t;
+        const int r = rc * 16 + (id >> 8), g = gc * 16 + ((id >> 4) & 15), b = bc * 16 + (id & 15);
+        if (!(reach[r] && reach[g] && reach[b])) continue;
+        const int sub = 1 + (((((id >> 8) >> 3) & 1) << 2) | (((((id >> 4) & 15) >> 3) & 1) << 1) | (((id & 15) >> 3) & 1));
+        float_members(s_pts, pal.K, (double)r, (double)g, (double)b, s_mask[0], s_mask[sub]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 72) masks[cell * 72 + threadIdx.x] = (&s_mask[0][0])[threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void accel_box_float_kernel(const PalDev pal, const uint8_t *__restrict__ reach,
+                                                             const Box *__restrict__ boxes, uint32_t *__restrict__ masks)
+{
+    __shared__ uint32_t s_mask[8];
+    __shared__ double s_pts[256 * 3];
+    if (threadIdx.x < 8) s_mask[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < pal.K * 3; i += 64) s_pts[i] = pal.pts[i];
+    __syncthreads();
+    const Box bx = boxes[blockIdx.x];
+    const int n = bx.size * bx.size * bx.size;
+    for (int id = threadIdx.x; id < n; id += 64) {
+        const int r = bx.r0 + id / (bx.size * bx.size), g = bx.g0 + (id / bx.size) % bx.size, b = bx.b0 + id % bx.size;
+        if (!(reach[r] && reach[g] && reach[b])) continue;
+        float_members(s_pts, pal.K, (double)r, (double)g, (double)b, s_mask, nullptr);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) masks[blockIdx.x * 8 + threadIdx.x] = s_mask[threadIdx.x];
+}
+
+}  // namespace
+
+namespace {
+
+constexpr int kCells = 4096;
+constexpr int kTabCapWords = (160 * 1024 - 2048) / 4;  // LDS budget of the dither kernels
+
+struct TableStats {
+    int n_split = 0, n_slow = 0, max_cnt = 0;
+    bool too_big = false;
+};
+
+// Turns the per-cell membership masks into the LDS table: [4096 cells][8 words], then [n_split][8 sub-cells][8].
+// coord4[j]: integer coordinates r | g<<8 | b<<16 of entry j (used to choose padding entries); word[j]: what a
+// block stores for entry j.  box_masks(boxes, out) computes the membership masks (8 words each) of further boxes.
+template <class BoxMasks>
+int assemble_table(const std::vector<uint32_t> &masks, const int K, const std::vector<uint32_t> &coord4,
+                   const std::vector<uint32_t> &word, BoxMasks box_masks, std::vector<uint32_t> &tab, TableStats &st)
+{
+    tab.assign((size_t)kCells * 8, 0u);
+    std::vector<int> list, extra;
+    std::vector<uint64_t> dkey;
+    // members of a mask, padded to 8 with the unused entries nearest to (cr,cg,cb); false if > 8
+    auto make_block = [&](const uint32_t *mask, int cr, int cg, int cb, uint32_t *out8) {
+        list.clear();
+        extra.clear();
+        for (int j = 0; j < K; ++j) ((mask[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
+        st.max_cnt = std::max(st.max_cnt, (int)list.size());
+        if (list.size() > 8) return false;
+        if (list.size() < 8) {
+            // pad with the unused entries nearest to the centre (any real entry is harmless); at most 7 picks
+            const size_t need = 8 - list.size();
+            dkey.resize(extra.size());
+            for (size_t q = 0; q < extra.size(); ++q) {
+                const uint32_t c = coord4[extra[q]];
+                const int r = c & 255, g = (c >> 8) & 255, b = (c >> 16) & 255;
+                dkey[q] = ((uint64_t)((r - cr) * (r - cr) + (g - cg) * (g - cg) + (b - cb) * (b - cb)) << 16) | (uint64_t)extra[q];
+            }
+            std::partial_sort(dkey.begin(), dkey.begin() + need, dkey.end());
+            for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
+            std::sort(list.begin(), list.end());  // key ties must break towards the lower palette index
+        }
+        for (int i = 0; i < 8; ++i) out8[i] = word[list[i]];
+        return true;
+    };
+    // pending splits below the 8^3 level: (block position in tab, box) resolved level by level
+    struct Pending {
+        size_t pos;
+        Box box;
+    };
+    std::vector<Pending> pending;
+    // turn the block at `pos` into a split node with 8 children of half size; children masks come
+    // either from `child_masks` (8 x 8 words) or, if null, are requested for the next round
+    auto split = [&](size_t pos, const Box &bx, const uint32_t *child_masks) {
+        const size_t base = tab.size();
+        if (base + 64 > (size_t)kTabCapWords) {
+            st.too_big = true;
+            return;
+        }
+        tab.resize(base + 64, 0u);
+        tab[pos] = 0x80000000u | (uint32_t)((base - (size_t)kCells * 8) / 64);
+        ++st.n_split;
+        const int hs = bx.size / 2;
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            Box c{bx.r0 + ((sidx >> 2) & 1) * hs, bx.g0 + ((sidx >> 1) & 1) * hs, bx.b0 + (sidx & 1) * hs, hs};
+            const size_t cpos = base + (size_t)sidx * 8;
+            if (child_masks) {
+                uint32_t blk[8];
+                if (make_block(child_masks + 8 * sidx, c.r0 + hs / 2, c.g0 + hs / 2, c.b0 + hs / 2, blk))
+                    std::copy(blk, blk + 8, tab.begin() + cpos);
+                else
+                    pending.push_back({cpos, c});
+            } else {
+                pending.push_back({cpos, c});
+            }
+        }
+    };
+    for (int cell = 0; cell < kCells && !st.too_big; ++cell) {
+        const uint32_t *m = &masks[(size_t)cell * 72];
+        const int r0 = (cell >> 8) * 16, g0 = ((cell >> 4) & 15) * 16, b0 = (cell & 15) * 16;
+        uint32_t blk[8];
+        const size_t slot = (size_t)cell_slot(cell >> 8, (cell >> 4) & 15, cell & 15);
+        if (make_block(m, r0 + 8, g0 + 8, b0 + 8, blk))
+            std::copy(blk, blk + 8, tab.begin() + slot * 8);
+        else
+            split(slot * 8, Box{r0, g0, b0, 16}, m + 8);
+    }
+    // deeper levels: boxes that still hold more than 8 members are split again; a single colour that still
+    // overflows is left to the fix-up pass
+    while (!pending.empty() && !st.too_big) {
+        std::vector<Pending> todo;
+        todo.swap(pending);
+        std::vector<Pending> kids;  // children whose masks we need this round
+        for (const Pending &pd : todo) {
+            if (pd.box.size == 1) {
+                tab[pd.pos] = 0xC0000000u;
+                ++st.n_slow;
+                continue;
+            }
+            const size_t before = pending.size();
+            split(pd.pos, pd.box, nullptr);
+            if (st.too_big) break;
+            for (size_t q = before; q < pending.size(); ++q) kids.push_back(pending[q]);
+            pending.resize(before);
+        }
+        if (st.too_big || kids.empty()) break;
+        std::vector<Box> boxes(kids.size());
+        for (size_t q = 0; q < kids.size(); ++q) boxes[q] = kids[q].box;
+        std::vector<uint32_t> bm(kids.size() * 8);
+        const int rc = box_masks(boxes, bm);
+        if (rc != DP_OK) return rc;
+        for (size_t q = 0; q < kids.size(); ++q) {
+            const Box &c = kids[q].box;
+            uint32_t blk[8];
+            if (make_block(&bm[q * 8], c.r0 + c.size / 2, c.g0 + c.size / 2, c.b0 + c.size / 2, blk))
+                std::copy(blk, blk + 8, tab.begin() + kids[q].pos);
+            else
+                pending.push_back(kids[q]);
+        }
+    }
+    return DP_OK;
+}
+
+// runs `launch(d_boxes, d_masks, n)` over a list of boxes and brings the masks back
+template <class Launch>
+int run_box_kernel(const std::vector<Box> &boxes, std::vector<uint32_t> &bm, Launch launch)
+{
+    Box *d_boxes = nullptr;
+    uint32_t *d_bm = nullptr;
+    hipError_t e = hipMalloc((void **)&d_boxes, sizeof(Box) * boxes.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&d_bm, sizeof(uint32_t) * bm.size());
+    if (e == hipSuccess) e = hipMemcpy(d_boxes, boxes.data(), sizeof(Box) * boxes.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch(d_boxes, d_bm, (unsigned)boxes.size());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(bm.data(), d_bm, sizeof(uint32_t) * bm.size(), hipMemcpyDeviceToHost);
+    if (d_boxes) (void)hipFree(d_boxes);
+    if (d_bm) (void)hipFree(d_bm);
+    if (e != hipSuccess) return hip_fail(e, "accelerator refinement");
+    return DP_OK;
+}
+
 }  // namespace
 
 // Builds the accelerator for an integer palette whose output colours equal its search colours.
@@ -185,11 +404,9 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     *blob_bytes = 0;
     const int K = dev.K;
     constexpr size_t kCodeWords = (size_t)1 << 20;  // 2^24 colours x 2 bits (k=1); the k=2 table has twice as many
-    constexpr int kCells = 4096;
-    constexpr int kTabCapWords = (160 * 1024 - 2048) / 4;  // LDS budget of the dither kernel
     uint32_t *d_masks = nullptr;
     uint8_t *blob = nullptr;
-    // layout: code1 | code2 | table[cap]
+    // layout: code1 | code2 | table[cap] | exceptions | exception count
     const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16;
     DP_HIP(hipMalloc((void **)&blob, bytes));
     hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 72);
@@ -220,124 +437,21 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         return hip_fail(e, "accelerator scan");
     }
 
-    std::vector<uint32_t> tab((size_t)kCells * 8, 0u);
-    std::vector<int> list, extra;
-    std::vector<uint64_t> dkey;
-    int n_split = 0, n_slow = 0, max_cnt = 0;
-    // members of a mask, padded to 8 with the unused entries nearest to (cr,cg,cb); false if > 8
-    auto make_block = [&](const uint32_t *mask, int cr, int cg, int cb, uint32_t *out8) {
-        list.clear();
-        extra.clear();
-        for (int j = 0; j < K; ++j) ((mask[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
-        max_cnt = std::max(max_cnt, (int)list.size());
-        if (list.size() > 8) return false;
-        if (list.size() < 8) {
-            // pad with the unused entries nearest to the centre (any real entry is harmless); at most 7 picks
-            const size_t need = 8 - list.size();
-            dkey.resize(extra.size());
-            for (size_t q = 0; q < extra.size(); ++q) {
-                const uint32_t c = p4_host[extra[q]];
-                const int r = c & 255, g = (c >> 8) & 255, b = (c >> 16) & 255;
-                dkey[q] = ((uint64_t)((r - cr) * (r - cr) + (g - cg) * (g - cg) + (b - cb) * (b - cb)) << 16) | (uint64_t)extra[q];
-            }
-            std::partial_sort(dkey.begin(), dkey.begin() + need, dkey.end());
-            for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
-            std::sort(list.begin(), list.end());  // key ties must break towards the lower palette index
-        }
-        for (int i = 0; i < 8; ++i) out8[i] = p4_host[list[i]];
-        return true;
-    };
-    // pending splits below the 8^3 level: (block position in tab, box) resolved level by level
-    struct Pending {
-        size_t pos;
-        Box box;
-    };
-    std::vector<Pending> pending;
-    bool too_big = false;
-    // turn the block at `pos` into a split node with 8 children of half size; children masks come
-    // either from `child_masks` (8 x 8 words) or, if null, are requested for the next round
-    auto split = [&](size_t pos, const Box &bx, const uint32_t *child_masks) {
-        const size_t base = tab.size();
-        if (base + 64 > (size_t)kTabCapWords) {
-            too_big = true;
-            return;
-        }
-        tab.resize(base + 64, 0u);
-        tab[pos] = 0x80000000u | (uint32_t)((base - (size_t)kCells * 8) / 64);
-        ++n_split;
-        const int hs = bx.size / 2;
-        for (int sidx = 0; sidx < 8; ++sidx) {
-            Box c{bx.r0 + ((sidx >> 2) & 1) * hs, bx.g0 + ((sidx >> 1) & 1) * hs, bx.b0 + (sidx & 1) * hs, hs};
-            const size_t cpos = base + (size_t)sidx * 8;
-            if (child_masks) {
-                uint32_t blk[8];
-                if (make_block(child_masks + 8 * sidx, c.r0 + hs / 2, c.g0 + hs / 2, c.b0 + hs / 2, blk))
-                    std::copy(blk, blk + 8, tab.begin() + cpos);
-                else
-                    pending.push_back({cpos, c});
-            } else {
-                pending.push_back({cpos, c});
-            }
-        }
-    };
-    for (int cell = 0; cell < kCells && !too_big; ++cell) {
-        const uint32_t *m = &masks[(size_t)cell * 72];
-        const int r0 = (cell >> 8) * 16, g0 = ((cell >> 4) & 15) * 16, b0 = (cell & 15) * 16;
-        uint32_t blk[8];
-        const size_t slot = (size_t)cell_slot(cell >> 8, (cell >> 4) & 15, cell & 15);
-        if (make_block(m, r0 + 8, g0 + 8, b0 + 8, blk))
-            std::copy(blk, blk + 8, tab.begin() + slot * 8);
-        else
-            split(slot * 8, Box{r0, g0, b0, 16}, m + 8);
+    std::vector<uint32_t> tab;
+    TableStats st;
+    const int rc = assemble_table(
+        masks, K, p4_host, p4_host,
+        [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
+            return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
+                hipLaunchKernelGGL(accel_box_kernel, dim3(n), dim3(64), 0, 0, dev, db, dm);
+            });
+        },
+        tab, st);
+    if (rc != DP_OK) {
+        (void)hipFree(blob);
+        return rc;
     }
-    // deeper levels: boxes that still hold more than 8 members are split again (their children's
-    // masks come from accel_box_kernel); a single colour that still overflows is left to the fix-up pass
-    while (!pending.empty() && !too_big) {
-        std::vector<Pending> todo;
-        todo.swap(pending);
-        std::vector<Pending> kids;  // children whose masks we need this round
-        for (const Pending &pd : todo) {
-            if (pd.box.size == 1) {
-                tab[pd.pos] = 0xC0000000u;
-                ++n_slow;
-                continue;
-            }
-            const size_t before = pending.size();
-            split(pd.pos, pd.box, nullptr);
-            if (too_big) break;
-            for (size_t q = before; q < pending.size(); ++q) kids.push_back(pending[q]);
-            pending.resize(before);
-        }
-        if (too_big || kids.empty()) break;
-        std::vector<Box> boxes(kids.size());
-        for (size_t q = 0; q < kids.size(); ++q) boxes[q] = kids[q].box;
-        Box *d_boxes = nullptr;
-        uint32_t *d_bm = nullptr;
-        std::vector<uint32_t> bm(kids.size() * 8);
-        e = hipMalloc((void **)&d_boxes, sizeof(Box) * boxes.size());
-        if (e == hipSuccess) e = hipMalloc((void **)&d_bm, sizeof(uint32_t) * bm.size());
-        if (e == hipSuccess) e = hipMemcpy(d_boxes, boxes.data(), sizeof(Box) * boxes.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(accel_box_kernel, dim3((unsigned)boxes.size()), dim3(64), 0, 0, dev, d_boxes, d_bm);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpy(bm.data(), d_bm, sizeof(uint32_t) * bm.size(), hipMemcpyDeviceToHost);
-        if (d_boxes) (void)hipFree(d_boxes);
-        if (d_bm) (void)hipFree(d_bm);
-        if (e != hipSuccess) {
-            (void)hipFree(blob);
-            return hip_fail(e, "accelerator refinement");
-        }
-        for (size_t q = 0; q < kids.size(); ++q) {
-            const Box &c = kids[q].box;
-            uint32_t blk[8];
-            if (make_block(&bm[q * 8], c.r0 + c.size / 2, c.g0 + c.size / 2, c.b0 + c.size / 2, blk))
-                std::copy(blk, blk + 8, tab.begin() + kids[q].pos);
-            else
-                pending.push_back(kids[q]);
-        }
-    }
-    if (too_big) {
+    if (st.too_big) {
         (void)hipFree(blob);
         return DP_OK;  // table would not fit in LDS: the brute-force kernel stays in charge
     }
@@ -348,9 +462,9 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     }
     dev.cell_tab = d_tab;
     dev.tab_words = (int)tab.size();
-    dev.n_split = n_split;
-    dev.n_slow_blocks = n_slow;
-    dev.max_cell = max_cnt;
+    dev.n_split = st.n_split;
+    dev.n_slow_blocks = st.n_slow;
+    dev.max_cell = st.max_cnt;
     dev.code1 = code1;
     dev.code2 = code2;
     {
@@ -364,12 +478,86 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
             if (e == hipSuccess) e = hipMemcpy(d_exc, ex.data(), sizeof(uint4) * n_exc, hipMemcpyHostToDevice);
         }
         if (e != hipSuccess) {
+            dev.cell_tab = nullptr;
             (void)hipFree(blob);
             return hip_fail(e, "accelerator exception list");
         }
         dev.exc = d_exc;
         dev.n_exc = n_exc <= (uint32_t)kExcCap ? (int)n_exc : -1;
     }
+    *blob_out = blob;
+    *blob_bytes = bytes;
+    return DP_OK;
+}
+
+// The same for a palette with float coordinates (use_gamma).  pal_f32: K x 3 as the tree sees them; lut_host:
+// the 256-entry input table or nullptr.  Table words are byte offsets (16 * j) into dev.fcand.
+int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host, void **blob_out, size_t *blob_bytes)
+{
+    *blob_out = nullptr;
+    *blob_bytes = 0;
+    const int K = dev.K;
+    std::vector<uint8_t> reach(256, lut_host ? 0 : 1);
+    if (lut_host)
+        for (int v = 0; v < 256; ++v) reach[lut_host[v]] = 1;
+    std::vector<uint32_t> coord4(K), word(K);
+    for (int j = 0; j < K; ++j) {
+        uint32_t c[3];
+        for (int k = 0; k < 3; ++k) {
+            const float v = pal_f32[3 * j + k];
+            c[k] = (uint32_t)std::min(255.0f, std::max(0.0f, std::nearbyint(v)));
+        }
+        coord4[j] = c[0] | (c[1] << 8) | (c[2] << 16);
+        word[j] = (uint32_t)j * 16u;
+    }
+    // layout: table[cap] | reach[256]
+    const size_t bytes = sizeof(uint32_t) * kTabCapWords + 256;
+    uint8_t *blob = nullptr;
+    uint32_t *d_masks = nullptr;
+    DP_HIP(hipMalloc((void **)&blob, bytes));
+    uint32_t *d_tab = reinterpret_cast<uint32_t *>(blob);
+    uint8_t *d_reach = blob + sizeof(uint32_t) * kTabCapWords;
+    hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 72);
+    if (e == hipSuccess) e = hipMemcpy(d_reach, reach.data(), 256, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        if (d_masks) (void)hipFree(d_masks);
+        return hip_fail(e, "float accelerator allocation");
+    }
+    hipLaunchKernelGGL(accel_scan_float_kernel, dim3(kCells), dim3(256), 0, 0, dev, d_reach, d_masks);
+    std::vector<uint32_t> masks((size_t)kCells * 72);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(masks.data(), d_masks, sizeof(uint32_t) * masks.size(), hipMemcpyDeviceToHost);
+    (void)hipFree(d_masks);
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        return hip_fail(e, "float accelerator scan");
+    }
+    // a cell none of whose colours can occur has an empty mask: it gets eight padding entries
+    std::vector<uint32_t> tab;
+    TableStats st;
+    const int rc = assemble_table(
+        masks, K, coord4, word,
+        [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
+            return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
+                hipLaunchKernelGGL(accel_box_float_kernel, dim3(n), dim3(64), 0, 0, dev, d_reach, db, dm);
+            });
+        },
+        tab, st);
+    if (rc != DP_OK || st.too_big) {
+        (void)hipFree(blob);
+        return rc;  // too big: the brute-force kernel stays in charge
+    }
+    e = hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        return hip_fail(e, "float accelerator upload");
+    }
+    dev.ftab = d_tab;
+    dev.ftab_words = (int)tab.size();
+    dev.n_split = st.n_split;
+    dev.n_slow_blocks = st.n_slow;
+    dev.max_cell = st.max_cnt;
     *blob_out = blob;
     *blob_bytes = bytes;
     return DP_OK;

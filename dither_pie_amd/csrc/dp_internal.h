@@ -65,6 +65,10 @@ struct PalDev {
     int max_cell;
     const uint32_t *code1;      // 2 bits per colour: tie outcome of the k=1 query
     const uint32_t *code2;      // 4 bits per colour: ... of the k=2 query (accel.hip)
+    // the same for float (gamma) palettes: blocks of 8 byte offsets (16 * j) into fcand
+    const uint32_t *ftab;
+    int ftab_words;
+    const float4 *fcand;        // K: {x, y, z, out_rgb bits}
     const uint4 *exc;           // colours whose outcome no code expresses, sorted by colour:
     int n_exc;                  //   {colour, k=2 indices i0 | i1<<16, k=1 index, 0}; n_exc < 0: list overflowed
 };
@@ -96,6 +100,9 @@ struct dp_palette {
     size_t accel_bytes;
     bool accel_tried, same_out;
     std::vector<uint32_t> p4_host;
+    std::vector<float> pal_host;   // K*3 as given (float palettes: for the accelerator build)
+    std::vector<uint8_t> lut_host; // 256 or empty
+    bool float_accel;              // a float palette the cell-table accelerator handles
     int device;
 };
 
@@ -122,6 +129,7 @@ void prof_end(ProfMark *m, hipStream_t s);
 // launchers (defined in the .hip files)
 namespace dp {
 int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_out, size_t *blob_bytes);
+int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host, void **blob_out, size_t *blob_bytes);
 int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int y0, int x0,
                    const PalDev &pal, int mode, const ThrDev *thr, float ign_scale, int ign_seed, void *ws,
                    size_t ws_bytes, hipStream_t s);

@@ -286,6 +286,14 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     const size_t o_pf = put(pal_f32, sizeof(float) * 3 * K);
     const size_t o_org = put(orgb.data(), sizeof(uint32_t) * K);
     const size_t o_lut = lut_in ? put(lut_in, 256) : 0;
+    std::vector<float> fcand((size_t)K * 4);
+    for (int j = 0; j < K; ++j) {
+        fcand[4 * j] = pal_f32[3 * j];
+        fcand[4 * j + 1] = pal_f32[3 * j + 1];
+        fcand[4 * j + 2] = pal_f32[3 * j + 2];
+        std::memcpy(&fcand[4 * j + 3], &orgb[j], sizeof(float));
+    }
+    const size_t o_fc = put(fcand.data(), sizeof(float) * 4 * K);
     const size_t o_idx = put(t.indices.data(), sizeof(int32_t) * K);
     const size_t o_sd = put(t.split_dim.data(), sizeof(int32_t) * nn);
     const size_t o_sp = put(t.split.data(), sizeof(double) * nn);
@@ -318,6 +326,9 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.pts_f32 = (const float *)(base + o_pf);
     d.out_rgb = (const uint32_t *)(base + o_org);
     d.lut_in = lut_in ? (base + o_lut) : nullptr;
+    d.fcand = (const float4 *)(base + o_fc);
+    d.ftab = nullptr;
+    d.ftab_words = 0;
     d.indices = (const int32_t *)(base + o_idx);
     d.split_dim = (const int32_t *)(base + o_sd);
     d.split = (const double *)(base + o_sp);
@@ -342,6 +353,13 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     p->p4_host = p4;
     p->same_out = integer && K >= 8 && K <= 256 && inner <= kQueueSmall;  // what the accelerator handles
     for (int j = 0; j < K && p->same_out; ++j) p->same_out = (orgb[j] == p4[j]);
+    // float palettes (use_gamma): coordinates within [0, 255], as the reference's clip guarantees
+    p->float_accel = !integer && K >= 8 && K <= 256;
+    for (int i = 0; i < 3 * K && p->float_accel; ++i) p->float_accel = pal_f32[i] >= 0.0f && pal_f32[i] <= 255.0f;
+    if (p->float_accel) {
+        p->pal_host.assign(pal_f32, pal_f32 + 3 * K);
+        if (lut_in) p->lut_host.assign(lut_in, lut_in + 256);
+    }
     *out = p;
     return DP_OK;
 }
@@ -372,8 +390,11 @@ int dp_palette_build_accel(dp_palette *p)
         set_error("dp_palette_build_accel: NULL palette");
         return DP_EINVAL;
     }
-    if (p->accel_tried || !p->same_out) return DP_OK;
+    if (p->accel_tried || !(p->same_out || p->float_accel)) return DP_OK;
     p->accel_tried = true;
+    if (p->float_accel)
+        return build_accel_float(p->dev, p->pal_host.data(), p->lut_host.empty() ? nullptr : p->lut_host.data(),
+                                 &p->accel_blob, &p->accel_bytes);
     // cell lists + tie codes: integer palettes whose output bytes are the palette colours themselves
     return build_accel(p->dev, p->p4_host, &p->accel_blob, &p->accel_bytes);
 }
@@ -384,8 +405,8 @@ int dp_palette_accel_info(const dp_palette *p, int *pool_entries, int *max_cell)
         set_error("dp_palette_accel_info: NULL palette");
         return DP_EINVAL;
     }
-    if (pool_entries) *pool_entries = p->dev.cell_tab ? p->dev.tab_words : 0;
-    if (max_cell) *max_cell = p->dev.cell_tab ? p->dev.max_cell : 0;
+    if (pool_entries) *pool_entries = p->dev.cell_tab ? p->dev.tab_words : (p->dev.ftab ? p->dev.ftab_words : 0);
+    if (max_cell) *max_cell = (p->dev.cell_tab || p->dev.ftab) ? p->dev.max_cell : 0;
     return DP_OK;
 }
 

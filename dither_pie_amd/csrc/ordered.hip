@@ -805,6 +805,164 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Float (gamma) palettes with a cell table (accel.hip, build_accel_float): blocks of 8 byte offsets into
+// the candidate table {x, y, z, out_rgb} held in LDS next to the cell table and lut_in.  Candidates are
+// ranked in float32 (key = distance bits with the block position in the low 3 bits); the ranking is
+// accepted only when neighbouring keys differ by more than 128 ulp -- the lists hold every entry within
+// 2^-14 of the second distance, the float32 evaluation is off by < 1.5e-6 -- and then the two winners'
+// distances are recomputed in float64 exactly as scipy does and the reference's float64 chain decides.
+// Anything else (near ties, a single colour with more than 8 candidates, groups straddling a row end)
+// is flagged for the fix-up pass.  MODE: 0 nearest only, 2 matrix (float32 thresholds), 3 IGN.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFloatKeyGap = 128;
+
+__device__ __forceinline__ int med3_i32(const int a, const int b, const int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const uint8_t *__restrict__ in,
+                                                                        uint8_t *__restrict__ out,
+                                                                        unsigned long long *__restrict__ flags,
+                                                                        const Geo g, const PalDev pal, const ThrDev thr,
+                                                                        const float sx, const float sy, const float sc,
+                                                                        const uint32_t n_tiles)
+{
+    __shared__ __align__(16) uint32_t smem[kLeanLdsWords];
+    for (int i = threadIdx.x * 4; i < pal.ftab_words; i += kCellBlock * 4)
+        *reinterpret_cast<uint4 *>(&smem[i]) = *reinterpret_cast<const uint4 *>(&pal.ftab[i]);
+    const uint32_t cand_base = (uint32_t)pal.ftab_words * 4u;  // bytes
+    const uint32_t lut_base = cand_base + (uint32_t)pal.K * 16u;
+    for (int i = threadIdx.x; i < pal.K; i += kCellBlock)
+        *reinterpret_cast<float4 *>(&smem[pal.ftab_words + 4 * i]) = pal.fcand[i];
+    if (threadIdx.x < 256)
+        reinterpret_cast<uint8_t *>(smem)[lut_base + threadIdx.x] = pal.lut_in ? pal.lut_in[threadIdx.x] : (uint8_t)threadIdx.x;
+    __syncthreads();
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(smem);
+    const uint8_t *s_lut = s_bytes + lut_base;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint3 *in3 = reinterpret_cast<const uint3 *>(in);
+    uint3 *out3 = reinterpret_cast<uint3 *>(out);
+    const uint32_t n_full = g.n_px >> 2;
+
+    uint32_t tile = blockIdx.x;
+    uint32_t fy = 0, fx = 0;
+    uint3 wn = make_uint3(0u, 0u, 0u);
+    if (tile < n_tiles) {
+        const uint32_t gidx0 = tile * kCellBlock + threadIdx.x;
+        if (gidx0 < n_full) wn = in3[gidx0];
+        if (gidx0 * 4u < g.n_px) locate(g, gidx0 * 4u, fy, fx);
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t gidx = tile * kCellBlock + threadIdx.x;
+        const uint3 wc = wn;
+        {
+            const uint32_t next = tile + gridDim.x;
+            const uint32_t gn = next * kCellBlock + threadIdx.x;
+            if (next < n_tiles && gn < n_full) wn = in3[gn];  // prefetch the next tile
+        }
+        bool slow[4] = {false, false, false, false};
+        if (gidx < n_full) {
+            uint32_t xs[4];
+            xs[0] = wc.x & 0xffffffu;
+            xs[1] = __builtin_amdgcn_perm(wc.y, wc.x, 0x0c050403u);
+            xs[2] = __builtin_amdgcn_perm(wc.z, wc.y, 0x0c040302u);
+            xs[3] = wc.z >> 8;
+            float tq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (MODE == 2) {
+                const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
+                const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.th_w - 1);
+                const uint32_t at = row * (uint32_t)thr.tw_pad + col;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tq[q] = thr.fpad[at + q];
+            } else if (MODE == 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tq[q] = ign_threshold(g.x0 + (int)fx + q, g.y0 + (int)fy, sx, sy, sc);
+            }
+            const bool straddle = (MODE != 0) && (fx + 3u >= g.w);
+            uint32_t col[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t r = s_lut[xs[q] & 255u], gg = s_lut[(xs[q] >> 8) & 255u], b = s_lut[xs[q] >> 16];
+                const uint32_t x = r | (gg << 8) | (b << 16);
+                uint32_t blk = cell_offset(x);
+                uint4 ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
+                bool s = straddle;
+                // split cells: descend by one colour bit per level
+                for (int bit = 3; (ca.x >> 31) != 0; --bit) {
+                    if ((ca.x & 0x40000000u) || bit < 0) {
+                        s = true;  // a single colour with more than 8 candidates: fix-up pass
+                        ca.x = 0u;
+                        break;
+                    }
+                    const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
+                    blk = (4096u * 8u + ((ca.x & 0xffffffu) * 8u + sub) * 8u) * 4u;
+                    ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
+                }
+                const uint4 cb = *reinterpret_cast<const uint4 *>(s_bytes + blk + 16);
+                const uint32_t off[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+                const float fr = (float)r, fg = (float)gg, fb = (float)b;
+                int key[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float4 cc = *reinterpret_cast<const float4 *>(s_bytes + cand_base + (off[c] & 0xffffu));
+                    const float dx = cc.x - fr, dy = cc.y - fg, dz = cc.z - fb;
+                    const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    key[c] = (int)((__float_as_uint(d) & ~7u) | (uint32_t)c);
+                }
+                int m0 = min(min(key[0], key[1]), key[2]);
+                int m1 = med3_i32(key[0], key[1], key[2]);
+                int m2 = max(max(key[0], key[1]), key[2]);
+#pragma unroll
+                for (int c = 3; c < 8; ++c) {
+                    m2 = med3_i32(m1, m2, key[c]);
+                    m1 = med3_i32(m0, m1, key[c]);
+                    m0 = min(m0, key[c]);
+                }
+                s |= (m1 - m0) <= kFloatKeyGap;
+                const uint32_t o0 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + 4u * ((uint32_t)m0 & 7u)) & 0xffffu;
+                const float4 c0 = *reinterpret_cast<const float4 *>(s_bytes + cand_base + o0);
+                uint32_t cpick = __float_as_uint(c0.w);
+                if (MODE != 0) {
+                    s |= (m2 - m1) <= kFloatKeyGap;
+                    const uint32_t o1 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + 4u * ((uint32_t)m1 & 7u)) & 0xffffu;
+                    const float4 c1 = *reinterpret_cast<const float4 *>(s_bytes + cand_base + o1);
+                    const double p0[3] = {(double)c0.x, (double)c0.y, (double)c0.z};
+                    const double p1[3] = {(double)c1.x, (double)c1.y, (double)c1.z};
+                    const double d0 = sq_dist3(p0, (double)r, (double)gg, (double)b);
+                    const double d1 = sq_dist3(p1, (double)r, (double)gg, (double)b);
+                    if (!ordered_use_nearest(d0, d1, tq[q])) cpick = __float_as_uint(c1.w);
+                }
+                slow[q] = s;
+                col[q] = cpick;
+            }
+            uint3 wo;
+            wo.x = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);
+            wo.y = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);
+            wo.z = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);
+            out3[gidx] = wo;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) slow[q] = gidx * 4u + (uint32_t)q < g.n_px;  // the partial last group
+        }
+        if (__ballot(slow[0] | slow[1] | slow[2] | slow[3]) != 0ull)
+            store_flags(flags, g.dirty, gidx, slow);
+        else if (lane < 4u)
+            flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
+        fx += g.adv_x;
+        fy += g.adv_y;
+        if (fx >= g.w) {
+            fx -= g.w;
+            ++fy;
+        }
+        if (fy >= g.h) fy -= g.h;
+    }
+}
+
 // General palettes (non-integer: gamma on) -- float64 brute force with the reference's arithmetic.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void ordered_f64_kernel(const uint8_t *__restrict__ in,
@@ -1203,6 +1361,28 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
                 fix_mode = 2;
             }
             if (rc != DP_OK) return rc;
+        } else if (!integer && pal.ftab != nullptr && g.aligned && y0 >= 0 && x0 >= 0 &&
+                   (size_t)pal.ftab_words * 4 + (size_t)pal.K * 16 + 256 <= sizeof(uint32_t) * kLeanLdsWords &&
+                   (mode != DP_MODE_MATRIX || thr.fpad != nullptr)) {
+            // float (gamma) palettes with a cell table
+            const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
+            n_words = n_tiles * (kCellBlock / 64) * 4;
+            const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus());
+            const uint64_t adv = ((uint64_t)cgrid * kCellBlock * 4u) % (uint64_t)hw;
+            g.adv_y = (uint32_t)(adv / (uint64_t)w);
+            g.adv_x = (uint32_t)(adv % (uint64_t)w);
+#define DP_LEANF(M) hipLaunchKernelGGL(ordered_lean_float_kernel<M>, dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles)
+            if (mode == DP_MODE_NEAREST) {
+                DP_LEANF(0);
+                fix_mode = 0;
+            } else if (mode == DP_MODE_IGN) {
+                DP_LEANF(3);
+                fix_mode = 3;
+            } else {
+                DP_LEANF(2);
+                fix_mode = 2;
+            }
+#undef DP_LEANF
         } else if (mode == DP_MODE_NEAREST) {
             launch_pass1<0>(integer, dim3(blocks), s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale);
             fix_mode = 0;

@@ -214,11 +214,13 @@ def test_resize_nearest_matches_pillow(be, orc):
         assert np.array_equal(out[i], np.array(Image.fromarray(frames[i]).resize((22, 16), Image.NEAREST)))
 
 
-def test_accelerator_is_built_for_integer_palettes(be, orc):
+def test_accelerator_is_built_for_integer_and_float_palettes(be, orc):
     P = be.Palette(*orc.prepare_palette(orc.palr(256), False), accel=True)
     assert P.is_integer and P.accel_entries > 0 and 4 <= P.accel_max_list <= 64
-    Pg = be.Palette(*orc.prepare_palette(orc.palr(256), True), accel=True)
-    assert not Pg.is_integer and Pg.accel_entries == 0
+    Pg = be.Palette(*orc.prepare_palette(orc.palr(256), True), accel=True)  # use_gamma: float coordinates + lut_in
+    assert not Pg.is_integer and Pg.accel_entries > 0 and 4 <= Pg.accel_max_list <= 64
+    Ps = be.Palette(*orc.prepare_palette(orc.palr(5), True), accel=True)     # too small to be worth a table
+    assert Ps.accel_entries == 0
 
 
 @pytest.mark.parametrize("K,seed", [(8, 1), (16, 2), (64, 3), (200, 4), (256, 5)])
@@ -357,3 +359,26 @@ def test_lean_kernel_queue_drains_and_row_straddles(be, orc, mode, params, w):
     _assert_same(out, ref, f"lean {mode} w={w}")
     out2 = _run_case(be, orc, arr, pal, mode, params, False, y0=5, x0=3, accel=False)
     _assert_same(out2, ref, f"brute {mode} w={w}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "8x8"}), ("blue_noise", {"size": 32, "seed": 3}),
+                                         ("IGN", {"scale": 1.5, "seed": 4})])
+@pytest.mark.parametrize("K,w", [(256, 1003), (64, 1004), (9, 640)])
+def test_float_palette_cell_table(be, orc, mode, params, K, w):
+    """use_gamma palettes (float32 coordinates, pixels through lut_in) on their own cell table: float32 ranking
+    with a 128-ulp certainty gap, float64 recomputation of the two winners; near ties go to the fix-up pass.
+    Checked against the oracle and the float64 brute-force kernel."""
+    rs = np.random.RandomState(78)
+    pal = orc.palr(K, seed=31)
+    arr = orc.rnd(411, w, 6)
+    pick = rs.randint(0, K, (411, w))
+    arr = np.where(rs.randint(0, 4, (411, w, 1)) == 0, np.asarray(pal, dtype=np.uint8)[pick], arr)  # exact palette hits
+    ref = orc.apply_dithering(arr, pal, mode, params, True, y0=2, x0=7)
+    pal_f32, oc, lut = orc.prepare_palette(pal, True)
+    P = be.Palette(pal_f32, oc, lut, accel=True)
+    assert P.accel_entries > 0, "the float accelerator should have been built"
+    out = _run_case(be, orc, arr, pal, mode, params, True, y0=2, x0=7)
+    _assert_same(out, ref, f"float table {mode} K={K} w={w}")
+    out2 = _run_case(be, orc, arr, pal, mode, params, True, y0=2, x0=7, accel=False)
+    _assert_same(out2, ref, f"float brute {mode} K={K} w={w}")
