@@ -14,6 +14,7 @@ namespace dp {
 constexpr int kLeafSize = 10;     // scipy.spatial.KDTree default (dithering_lib.py:339)
 constexpr int kQueueSmall = 64;   // traversal queue entries: every balanced tree of K <= 256 has <= 51 inner nodes
 constexpr int kQueueLarge = 256;  // ... larger palettes (K <= 1024) and degenerate trees use the large instantiation
+constexpr int kQueueTiles = 65536;  // wave tiles (256 px) with a flagged pixel that the fix-up pass visits directly (queue in the workspace)
 constexpr int kIdxBits = 10;      // palette index bits packed under the distance key (brute-force kernels)
 constexpr int kLocalBits = 8;     // byte offset of a candidate inside its block (cell-table kernel)
 

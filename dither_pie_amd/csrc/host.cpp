@@ -579,7 +579,7 @@ size_t dp_ordered_workspace_bytes(int64_t n_frames, int h, int w)
     // one flag bit per pixel, written as 4 x u64 per 256-pixel wave tile (+ slack for the tail)
     const int64_t npx = n_frames * (int64_t)h * w;
     const int64_t tiles = (npx + 255) / 256;
-    return (size_t)(tiles * 32 + 1024 + 4 * (4096 + 8));  // + dirty count and tile queue (ordered.hip)
+    return (size_t)(tiles * 32 + 1024 + 4 * ((size_t)dp::kQueueTiles + 8));  // + dirty count and tile queue (ordered.hip)
 }
 
 int dp_ordered_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int y0, int x0,

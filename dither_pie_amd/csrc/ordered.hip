@@ -24,7 +24,6 @@ constexpr int kListCap = 16384;           // LDS pixel list of the fix-up pass (
 constexpr int kLdsTreeK = 256;            // palettes up to this size (and kLdsTreeNodes nodes) get their tree staged in LDS
 constexpr int kLdsTreeNodes = 512;
 constexpr int kDrainAt = kListCap - kBlock * 64;
-constexpr int kQueueTiles = 4096;          // wave tiles (256 px) with a flagged pixel that the fix-up visits directly
 
 struct Geo {
     uint32_t n_px;   // pixels in this launch (< 2^31)
