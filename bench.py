@@ -153,12 +153,12 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
     # comes from the committed rocprofv3 --pmc pass of this same command (profiles/pmc_pass.sh)
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_final_pmc_ordered_cell.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01_final_pmc_ordered_lean.json")
     if args.frames == 24 and os.path.exists(pmc_file):
         try:
             with open(pmc_file) as f:
                 traffic = int(json.load(f)["derived"]["hbm_traffic_bytes_per_launch"])
-            traffic_src = "profiles/r01_final_pmc_ordered_cell.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+            traffic_src = "profiles/r01_final_pmc_ordered_lean.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
         except Exception:  # noqa: BLE001
             traffic = None
     result = {
@@ -172,7 +172,7 @@ def main():
                    "parallelism": f"frames x{world}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "ordered_cell_kernel<1>", "kernel_ms": round(k_ms, 4),
+                     "kernel": "ordered_lean_kernel<1>", "kernel_ms": round(k_ms, 4),
                      "fixup_ms": round(fix_ms / max(launches, 1), 4), "launches": launches,
                      "algorithmic_bytes_per_launch": BYTES_PER_PX * px_per_step},
         "parity_kat_4k": bool(kat_ok),
@@ -181,6 +181,25 @@ def main():
     # ---------------- secondary lines (same process, after the headline) -------------------------
     if not args.no_extra:
         extra = {}
+        # on-box streaming copy of the same 597 MB batch (3 B read + 3 B written per pixel, like the kernel)
+        tc = timed(lambda: out.copy_(frames), 10, 2) / 10
+        copy_gbs = BYTES_PER_PX * px_per_step / tc / 1e9
+        result["roofline"]["measured_copy_gbs"] = round(copy_gbs, 1)
+        result["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)
+        # C2 on the structured, tie-rich frame of SURVEY 8(d): every frame of the batch = grad(2160, 3840)
+        yy, xx = torch.meshgrid(torch.arange(H4K, device=dev), torch.arange(W4K, device=dev), indexing="ij")
+        gradf = torch.stack([xx % 256, yy % 256, ((xx + yy) // 2) % 256], -1).to(torch.uint8)
+        fg = gradf.unsqueeze(0).expand(args.frames, -1, -1, -1).contiguous()
+        del yy, xx, gradf
+        tg = timed(lambda: dith.apply_dithering_frames(fg, out=out), 5, 1) / 5
+        extra["c2_grad_frames_mpixel_per_s"] = round(world * px_per_step / tg / 1e6, 1)
+        extra["c2_grad_note"] = "same kernel on 24 copies of the structured frame grad(2160,3840) (0.36 % tied pixels)"
+        del fg
+        # C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in): the float cell table
+        dgam = ImageDitherer(256, DitherMode.BAYER, pal256, True, {"size": "8x8"})
+        dgam.apply_dithering_frames(frames, out=out)
+        tgm = timed(lambda: dgam.apply_dithering_frames(frames, out=out), 3, 1) / 3
+        extra["c2_use_gamma_mpixel_per_s"] = round(world * px_per_step / tgm / 1e6, 1)
         del out
         # C5: 1000 synthetic 1080p frames, Bayer 4x4, 16 uniform colours, frames sharded over the ranks
         from dither_pie_amd.dithering_lib import ColorReducer
