@@ -74,16 +74,107 @@ __device__ __forceinline__ int nearest_f64(const PalDev &pal, const float o0, co
 }
 
 // float32 prefilter: |d_f32 - d| <= ~3.6e-7 d (one rounding per subtract, square and add), so a gap of
-// 2e-6 (relative) between the two smallest float32 distances proves the float64 order
+// 2e-6 (relative) between the two smallest float32 distances proves the float64 order.
+// `cand`: the palette as {x, y, z, out_rgb bits} -- in LDS for the wavefront kernel (every lane reads the same
+// entry: one broadcast ds_read_b128 per colour, issued four at a time), in global memory for the serial one.
 template <int CAP>
-__device__ __forceinline__ int nearest_color(const PalDev &pal, const float o0, const float o1, const float o2)
+__device__ __forceinline__ int nearest_color(const PalDev &pal, const float4 *__restrict__ cand, const float o0,
+                                             const float o1, const float o2)
 {
     float b0 = __int_as_float(0x7f800000), b1 = b0;
     int i0 = 0;
     const int K = pal.K;
+    auto visit = [&](const float4 c, const int j) {
+        const float a = c.x - o0, b = c.y - o1, cc = c.z - o2;
+        const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, cc * cc));  // a filter only: any rounding within the margin
+        const bool lt0 = d < b0;
+        b1 = lt0 ? b0 : (d < b1 ? d : b1);
+        i0 = lt0 ? j : i0;
+        b0 = lt0 ? d : b0;
+    };
+    int j = 0;
+    for (; j + 4 <= K; j += 4) {
+        const float4 c0 = cand[j], c1 = cand[j + 1], c2 = cand[j + 2], c3 = cand[j + 3];
+        visit(c0, j);
+        visit(c1, j + 1);
+        visit(c2, j + 2);
+        visit(c3, j + 3);
+    }
+    for (; j < K; ++j) visit(cand[j], j);
+    if (b1 > b0 * 1.000002f) return i0;
+    return nearest_f64<CAP>(pal, o0, o1, o2);
+}
+
+__device__ __forceinline__ float clamp255(const float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
+
+// ---- candidate lists for the nearest-colour search (palettes of 9..256 colours) -------------------------
+// The query points of error diffusion are arbitrary float32 triples in [0,255]^3.  For every 8x8x8 cell of that
+// cube the table lists the entries that are nearest to at least one (real) point of the cell; a superset is
+// enough and is found geometrically: entry j qualifies if its smallest distance to the closed box does not exceed
+// the smallest of all entries' largest distances to the box.  Whatever the float32 scan below decides among the
+// listed entries is then validated exactly as in the full scan (the true nearest entry, and every entry tied with
+// it, is on the list).  ~3 entries per cell for 256 random colours, at most 15 stored.
+constexpr int kEdCells = 32 * 32 * 32;
+
+__global__ __launch_bounds__(256) void ed_cells_kernel(const PalDev pal, uint4 *__restrict__ cells)
+{
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= kEdCells) return;
+    const double lo[3] = {(double)((cell & 31) * 8), (double)(((cell >> 5) & 31) * 8), (double)((cell >> 10) * 8)};
+    const int K = pal.K;
+    double bound = __longlong_as_double(0x7ff0000000000000LL);
     for (int j = 0; j < K; ++j) {
-        const float a = pal.pts_f32[3 * j] - o0, b = pal.pts_f32[3 * j + 1] - o1, c = pal.pts_f32[3 * j + 2] - o2;
-        const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, c * c));  // a filter only: any rounding within the margin
+        double far2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double c = pal.pts[3 * j + k];
+            const double a = fabs(c - lo[k]), b = fabs(c - (lo[k] + 8.0));
+            const double m = a > b ? a : b;
+            far2 += m * m;
+        }
+        bound = far2 < bound ? far2 : bound;
+    }
+    bound = bound * (1.0 + 1e-12) + 1e-9;  // the sums above are rounded
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    int n = 0;
+    for (int j = 0; j < K; ++j) {
+        double near2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double c = pal.pts[3 * j + k];
+            double m = lo[k] - c;
+            const double m2 = c - (lo[k] + 8.0);
+            m = m > m2 ? m : m2;
+            m = m > 0.0 ? m : 0.0;
+            near2 += m * m;
+        }
+        if (near2 <= bound) {
+            ++n;
+            if (n <= 15) w[n >> 2] |= (uint32_t)j << (8 * (n & 3));
+        }
+    }
+    w[0] |= n <= 15 ? (uint32_t)n : 255u;
+    cells[cell] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// nearest_color restricted to the cell's list (same validation, same fallbacks)
+template <int CAP>
+__device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const float4 *__restrict__ cand, const float o0,
+                                                   const float o1, const float o2)
+{
+    const uint32_t ci = ((uint32_t)o0 >> 3) | (((uint32_t)o1 >> 3) << 5) | (((uint32_t)o2 >> 3) << 10);
+    uint4 blk = pal.ed_cells[ci];
+    int n = (int)(blk.x & 255u);
+    if (n > 15) return nearest_color<CAP>(pal, cand, o0, o1, o2);
+    float b0 = __int_as_float(0x7f800000), b1 = b0;
+    int i0 = 0;
+    for (; n > 0; --n) {
+        blk.x = __funnelshift_r(blk.x, blk.y, 8);
+        blk.y = __funnelshift_r(blk.y, blk.z, 8);
+        blk.z = __funnelshift_r(blk.z, blk.w, 8);
+        blk.w >>= 8;
+        const int j = (int)(blk.x & 255u);
+        const float4 c = cand[j];
+        const float a = c.x - o0, b = c.y - o1, cc = c.z - o2;
+        const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, cc * cc));
         const bool lt0 = d < b0;
         b1 = lt0 ? b0 : (d < b1 ? d : b1);
         i0 = lt0 ? j : i0;
@@ -93,12 +184,10 @@ __device__ __forceinline__ int nearest_color(const PalDev &pal, const float o0, 
     return nearest_f64<CAP>(pal, o0, o1, o2);
 }
 
-__device__ __forceinline__ float clamp255(const float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
-
 // 16-step I/O period of the wavefront kernel: all global traffic happens at period boundaries
 constexpr int kPeriod = 16;
 
-template <int CAP>
+template <int CAP, int NT>  // NT: tap slots compiled in (taps.n <= NT)
 __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
@@ -109,11 +198,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     __shared__ float s_bout[kMaxWaves][2][kPeriod][3];   // this period's errors of rows 62/63, flushed to global
     __shared__ uint8_t s_lut[256];
     __shared__ volatile uint32_t s_prog[kMaxWaves];      // (band << 16) | (acknowledged column of row 63 + 1024)
+    __shared__ float4 s_pal[DP_MAX_COLORS];              // {x, y, z, out_rgb bits}
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
     const size_t f = blockIdx.x;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
+    for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
     if (threadIdx.x < kMaxWaves) s_prog[threadIdx.x] = 0;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
@@ -255,24 +346,32 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                     const uint32_t pxv = cur[0];  // this step's pixel sits in the low 3 bytes (see the rotation below)
                     float a0 = (float)s_lut[pxv & 255u], a1 = (float)s_lut[(pxv >> 8) & 255u],
                           a2 = (float)s_lut[(pxv >> 16) & 255u];
-                    for (int k = 0; k < taps.n; ++k) {
-                        const int sxp = x - taps.dx[k];
-                        const int sr = r - taps.dy[k];
-                        if (sxp < 0 || sxp >= w || sr < 0) continue;
-                        const int rel = L - taps.dy[k];
-                        const float *src = rel >= 0 ? &s_ring[wv][rel][sxp & (kRing - 1)][0]
-                                                    : &s_vring[wv][rel + 2][sxp & 63][0];
-                        const float wq = taps.wq[k];
-                        a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
-                        a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
-                        a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
+                    // fully unrolled with constant indices: the tap parameters stay in scalar registers instead of
+                    // being re-read from the kernel arguments at every step
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        if (k < taps.n) {
+                            const int sxp = x - taps.dx[k];
+                            const int sr = r - taps.dy[k];
+                            if (sxp >= 0 && sxp < w && sr >= 0) {
+                                const int rel = L - taps.dy[k];
+                                const float *src = rel >= 0 ? &s_ring[wv][rel][sxp & (kRing - 1)][0]
+                                                            : &s_vring[wv][rel + 2][sxp & 63][0];
+                                const float wq = taps.wq[k];
+                                a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
+                                a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
+                                a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
+                            }
+                        }
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-                    const int j = nearest_color<CAP>(pal, o0, o1, o2);
-                    e0 = __fsub_rn(o0, pal.pts_f32[3 * j]);
-                    e1 = __fsub_rn(o1, pal.pts_f32[3 * j + 1]);
-                    e2 = __fsub_rn(o2, pal.pts_f32[3 * j + 2]);
-                    cbytes = pal.out_rgb[j];
+                    const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, s_pal, o0, o1, o2)
+                                               : nearest_color<CAP>(pal, s_pal, o0, o1, o2);
+                    const float4 pj = s_pal[j];
+                    e0 = __fsub_rn(o0, pj.x);
+                    e1 = __fsub_rn(o1, pj.y);
+                    e2 = __fsub_rn(o2, pj.z);
+                    cbytes = __float_as_uint(pj.w);
                 }
                 // rotate both 48-byte period buffers by one pixel (static register indices only): the next pixel
                 // moves into the low bytes of cur[], this step's colour enters outb[] at bytes 45..47 and will have
@@ -345,7 +444,8 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
                 a2 = __fadd_rn(a2, __fmul_rn(e[2 * nf], wq));
             }
             const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-            const int j = nearest_color<CAP>(pal, o0, o1, o2);
+            const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, o0, o1, o2)
+                                       : nearest_color<CAP>(pal, pal.fcand, o0, o1, o2);
             float *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
             e[0] = __fsub_rn(o0, (float)pal.pts[3 * j]);
             e[nf] = __fsub_rn(o1, (float)pal.pts[3 * j + 1]);
@@ -367,6 +467,23 @@ size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w)
     // wavefront: 4 boundary rows per frame; serial: 3 error rows per frame; 4 floats per column (the variable-weight
     // diffusers of vardiff.hip carry an extra value per error)
     return (size_t)n_frames * (size_t)w * 4 * sizeof(float) * 4 + 256;
+}
+
+int build_ed_cells(PalDev &dev, void **blob_out)
+{
+    *blob_out = nullptr;
+    uint4 *cells = nullptr;
+    DP_HIP(hipMalloc((void **)&cells, sizeof(uint4) * kEdCells));
+    hipLaunchKernelGGL(ed_cells_kernel, dim3(kEdCells / 256), dim3(256), 0, 0, dev, cells);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(cells);
+        return hip_fail(e, "error-diffusion candidate lists");
+    }
+    dev.ed_cells = cells;
+    *blob_out = cells;
+    return DP_OK;
 }
 
 int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal,
@@ -413,12 +530,16 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         }
         const int n_bands = (h + 63) / 64;
         const int nw = n_bands < kMaxWaves ? n_bands : kMaxWaves;
-        if (pal.n_inner > kQueueSmall)
-            hipLaunchKernelGGL(ed_wavefront_kernel<kQueueLarge>, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h,
-                               w, pal, t, reinterpret_cast<float *>(ws));
-        else
-            hipLaunchKernelGGL(ed_wavefront_kernel<kQueueSmall>, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h,
-                               w, pal, t, reinterpret_cast<float *>(ws));
+#define DP_EDW(C, N) hipLaunchKernelGGL((ed_wavefront_kernel<C, N>), dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws))
+        const bool big = pal.n_inner > kQueueSmall;
+        if (ntaps <= 4) {
+            if (big) DP_EDW(kQueueLarge, 4); else DP_EDW(kQueueSmall, 4);
+        } else if (ntaps <= 8) {
+            if (big) DP_EDW(kQueueLarge, 8); else DP_EDW(kQueueSmall, 8);
+        } else {
+            if (big) DP_EDW(kQueueLarge, kMaxTaps); else DP_EDW(kQueueSmall, kMaxTaps);
+        }
+#undef DP_EDW
     } else {
         const int64_t blocks = (n_frames + 63) / 64;
         if (pal.n_inner > kQueueSmall)

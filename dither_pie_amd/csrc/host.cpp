@@ -347,6 +347,8 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.code1 = d.code2 = nullptr;
     d.exc = nullptr;
     d.n_exc = 0;
+    d.ed_cells = nullptr;
+    p->ed_blob = nullptr;
     p->accel_blob = nullptr;
     p->accel_bytes = 0;
     p->accel_tried = false;
@@ -360,6 +362,14 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
         p->pal_host.assign(pal_f32, pal_f32 + 3 * K);
         if (lut_in) p->lut_host.assign(lut_in, lut_in + 256);
     }
+    if (K > 8 && K <= 256) {
+        // candidate lists of the error-diffusion kernels (a 512 KB table, one small kernel)
+        const int rc = build_ed_cells(p->dev, &p->ed_blob);
+        if (rc != DP_OK) {
+            dp_palette_destroy(p);
+            return rc;
+        }
+    }
     *out = p;
     return DP_OK;
 }
@@ -367,6 +377,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
 void dp_palette_destroy(dp_palette *p)
 {
     if (!p) return;
+    if (p->ed_blob) (void)hipFree(p->ed_blob);
     if (p->blob) (void)hipFree(p->blob);
     if (p->accel_blob) (void)hipFree(p->accel_blob);
     delete p;

@@ -382,3 +382,20 @@ def test_float_palette_cell_table(be, orc, mode, params, K, w):
     _assert_same(out, ref, f"float table {mode} K={K} w={w}")
     out2 = _run_case(be, orc, arr, pal, mode, params, True, y0=2, x0=7, accel=False)
     _assert_same(out2, ref, f"float brute {mode} K={K} w={w}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,gamma", [(256, False), (256, True), (97, False), (9, False), (200, True)])
+@pytest.mark.parametrize("variant,serp", [("floyd_steinberg", "false"), ("jjn", "false"), ("atkinson", "true")])
+def test_error_diffusion_candidate_lists(be, orc, K, gamma, variant, serp):
+    """Palettes of 9..256 colours search only the cell's candidate list (entries that can be nearest to some point
+    of the 8x8x8 cell); the result must stay bit-exact, including clustered palettes (long lists) and duplicates."""
+    rs = np.random.RandomState(K)
+    pal = orc.palr(K, seed=K + 5)
+    if K == 97:  # a tight cluster (lists longer than 15 -> full scan) plus duplicates
+        pal = pal[:60] + [(120 + int(a), 121 + int(b), 119 + int(c)) for a, b, c in rs.randint(0, 4, (30, 3))] + pal[:7]
+    arr = orc.rnd(96, 161, 11)
+    arr[20:60, 30:90] = np.asarray(pal, dtype=np.uint8)[rs.randint(0, len(pal), (40, 60))]
+    params = {"variant": variant, "serpentine": serp}
+    out = _run_case(be, orc, arr, pal, "error_diffusion", params, gamma)
+    _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, gamma), f"K={K} gamma={gamma} {variant}")
