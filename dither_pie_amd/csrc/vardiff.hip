@@ -21,20 +21,31 @@ namespace {
 __device__ __forceinline__ float clamp255f(const float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
 
 template <int CAP>
-__device__ __forceinline__ int nearest_any(const PalDev &pal, const float o0, const float o1, const float o2)
+__device__ __forceinline__ int nearest_any(const PalDev &pal, const float4 *__restrict__ cand, const float o0,
+                                           const float o1, const float o2)
 {
-    // float32 prefilter with a relative AND absolute margin (values are not clamped here, distances can be tiny)
+    // float32 prefilter with a relative AND absolute margin (values are not clamped here, distances can be tiny).
+    // `cand` = {x, y, z, out_rgb}: in LDS for the wavefront kernel (broadcast reads, four in flight), global otherwise
     float b0 = __int_as_float(0x7f800000), b1 = b0;
     int i0 = 0;
     const int K = pal.K;
-    for (int j = 0; j < K; ++j) {
-        const float a = pal.pts_f32[3 * j] - o0, b = pal.pts_f32[3 * j + 1] - o1, c = pal.pts_f32[3 * j + 2] - o2;
-        const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, c * c));
+    auto visit = [&](const float4 c, const int j) {
+        const float a = c.x - o0, b = c.y - o1, cc = c.z - o2;
+        const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, cc * cc));
         const bool lt0 = d < b0;
         b1 = lt0 ? b0 : (d < b1 ? d : b1);
         i0 = lt0 ? j : i0;
         b0 = lt0 ? d : b0;
+    };
+    int jj = 0;
+    for (; jj + 4 <= K; jj += 4) {
+        const float4 c0 = cand[jj], c1 = cand[jj + 1], c2 = cand[jj + 2], c3 = cand[jj + 3];
+        visit(c0, jj);
+        visit(c1, jj + 1);
+        visit(c2, jj + 2);
+        visit(c3, jj + 3);
     }
+    for (; jj < K; ++jj) visit(cand[jj], jj);
     if (b1 > b0 * 1.000002f) return i0;
     const double x0 = (double)o0, x1 = (double)o1, x2 = (double)o2;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(64) void var_serial_kernel(const uint8_t *__restric
                 o1 = clamp255f(o1);
                 o2 = clamp255f(o2);
             }
-            const int j = nearest_any<CAP>(pal, o0, o1, o2);
+            const int j = nearest_any<CAP>(pal, pal.fcand, o0, o1, o2);
             float e0 = __fsub_rn(o0, pal.pts_f32[3 * j]), e1 = __fsub_rn(o1, pal.pts_f32[3 * j + 1]),
                   e2 = __fsub_rn(o2, pal.pts_f32[3 * j + 2]);
             float aux = 1.0f;
@@ -183,11 +194,13 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     __shared__ float s_bout[kVWaves][2][kVPeriod][4];
     __shared__ uint8_t s_lut[256];
     __shared__ volatile uint32_t s_prog[kVWaves];
+    __shared__ float4 s_pal[DP_MAX_COLORS];  // {x, y, z, out_rgb bits}
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
     const size_t f = blockIdx.x;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
+    for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
     if (threadIdx.x < kVWaves) s_prog[threadIdx.x] = 0;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
@@ -375,10 +388,11 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                         o1 = clamp255f(o1);
                         o2 = clamp255f(o2);
                     }
-                    const int j = nearest_any<CAP>(pal, o0, o1, o2);
-                    e0 = __fsub_rn(o0, pal.pts_f32[3 * j]);
-                    e1 = __fsub_rn(o1, pal.pts_f32[3 * j + 1]);
-                    e2 = __fsub_rn(o2, pal.pts_f32[3 * j + 2]);
+                    const int j = nearest_any<CAP>(pal, s_pal, o0, o1, o2);
+                    const float4 pj = s_pal[j];
+                    e0 = __fsub_rn(o0, pj.x);
+                    e1 = __fsub_rn(o1, pj.y);
+                    e2 = __fsub_rn(o2, pj.z);
                     if (model == 1) {
                         const float lum = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, g0), __fmul_rn(0.587f, g1)), __fmul_rn(0.114f, g2));
                         aux = __fadd_rn(0.5f, __fmul_rn(0.5f, __fdiv_rn(lum, 255.0f)));
@@ -394,7 +408,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                         float lum = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, o0), __fmul_rn(0.587f, o1)), __fmul_rn(0.114f, o2));
                         aux = (float)(int)clamp255f(lum);
                     }
-                    cbytes = pal.out_rgb[j];
+                    cbytes = __float_as_uint(pj.w);
                 }
 #pragma unroll
                 for (int k = 0; k < 11; ++k) {
