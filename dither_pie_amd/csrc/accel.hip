@@ -40,12 +40,13 @@ __device__ __forceinline__ int med3i(const int a, const int b, const int c)
 
 constexpr int kExcCap = 1 << 16;  // colours with an outcome outside the codes (four-way ties); normally a few dozen
 
+template <int MW, int CAP>  // MW: mask words (32 palette entries each); CAP: traversal queue of the tie queries
 __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint32_t *__restrict__ masks,
                                                          uint32_t *__restrict__ code1, uint32_t *__restrict__ code2,
                                                          uint4 *__restrict__ exc, uint32_t *__restrict__ exc_count)
 {
-    __shared__ uint32_t s_mask[9][8];  // [0] the whole cell, [1+s] its 8x8x8 sub-cell s
-    if (threadIdx.x < 72) (&s_mask[0][0])[threadIdx.x] = 0;
+    __shared__ uint32_t s_mask[9][MW];  // [0] the whole cell, [1+s] its 8x8x8 sub-cell s
+    for (int i = threadIdx.x; i < 9 * MW; i += 256) (&s_mask[0][0])[i] = 0;
     __syncthreads();
     const int cell = blockIdx.x;
     const int rc = cell >> 8, gc = (cell >> 4) & 15, bc = cell & 15;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
         int ii[2], i1 = 0;
         bool other = false;
         {
-            tree_query<2, kQueueSmall>(pal, (double)r, (double)g, (double)b, dd, ii);
+            tree_query<2, CAP>(pal, (double)r, (double)g, (double)b, dd, ii);
             const uint32_t on = pal.out_rgb[ii[0]], os = pal.out_rgb[ii[1]];
             uint32_t code = 15;
             if (on == o0 && os == o1) code = 0;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
         }
         const uint32_t pair = (uint32_t)ii[0] | ((uint32_t)ii[1] << 16);
         if (tie01) {
-            tree_query<1, kQueueSmall>(pal, (double)r, (double)g, (double)b, dd, ii);
+            tree_query<1, CAP>(pal, (double)r, (double)g, (double)b, dd, ii);
             const uint32_t on = pal.out_rgb[ii[0]];
             uint32_t code = 3;
             if (on == o0) code = 0;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
         }
     }
     __syncthreads();
-    if (threadIdx.x < 72) masks[cell * 72 + threadIdx.x] = (&s_mask[0][0])[threadIdx.x];
+    for (int i = threadIdx.x; i < 9 * MW; i += 256) masks[(size_t)cell * 9 * MW + i] = (&s_mask[0][0])[i];
 }
 
 
@@ -134,11 +135,12 @@ struct Box {
     int r0, g0, b0, size;
 };
 
+template <int MW>
 __global__ __launch_bounds__(64) void accel_box_kernel(const PalDev pal, const Box *__restrict__ boxes,
                                                        uint32_t *__restrict__ masks)
 {
-    __shared__ uint32_t s_mask[8];
-    if (threadIdx.x < 8) s_mask[threadIdx.x] = 0;
+    __shared__ uint32_t s_mask[MW];
+    if (threadIdx.x < MW) s_mask[threadIdx.x] = 0;
     __syncthreads();
     const Box bx = boxes[blockIdx.x];
     const int K = pal.K;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(64) void accel_box_kernel(const PalDev pal, const B
             }
     }
     __syncthreads();
-    if (threadIdx.x < 8) masks[blockIdx.x * 8 + threadIdx.x] = s_mask[threadIdx.x];
+    if (threadIdx.x < MW) masks[(size_t)blockIdx.x * MW + threadIdx.x] = s_mask[threadIdx.x];
 }
 
 
@@ -267,7 +269,7 @@ struct TableStats {
 // coord4[j]: integer coordinates r | g<<8 | b<<16 of entry j (used to choose padding entries); word[j]: what a
 // block stores for entry j.  box_masks(boxes, out) computes the membership masks (8 words each) of further boxes.
 template <class BoxMasks>
-int assemble_table(const std::vector<uint32_t> &masks, const int K, const std::vector<uint32_t> &coord4,
+int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int K, const std::vector<uint32_t> &coord4,
                    const std::vector<uint32_t> &word, BoxMasks box_masks, std::vector<uint32_t> &tab, TableStats &st)
 {
     tab.assign((size_t)kCells * 8, 0u);
@@ -319,7 +321,7 @@ int assemble_table(const std::vector<uint32_t> &masks, const int K, const std::v
             const size_t cpos = base + (size_t)sidx * 8;
             if (child_masks) {
                 uint32_t blk[8];
-                if (make_block(child_masks + 8 * sidx, c.r0 + hs / 2, c.g0 + hs / 2, c.b0 + hs / 2, blk))
+                if (make_block(child_masks + (size_t)mw * sidx, c.r0 + hs / 2, c.g0 + hs / 2, c.b0 + hs / 2, blk))
                     std::copy(blk, blk + 8, tab.begin() + cpos);
                 else
                     pending.push_back({cpos, c});
@@ -329,14 +331,14 @@ int assemble_table(const std::vector<uint32_t> &masks, const int K, const std::v
         }
     };
     for (int cell = 0; cell < kCells && !st.too_big; ++cell) {
-        const uint32_t *m = &masks[(size_t)cell * 72];
+        const uint32_t *m = &masks[(size_t)cell * 9 * mw];
         const int r0 = (cell >> 8) * 16, g0 = ((cell >> 4) & 15) * 16, b0 = (cell & 15) * 16;
         uint32_t blk[8];
         const size_t slot = (size_t)cell_slot(cell >> 8, (cell >> 4) & 15, cell & 15);
         if (make_block(m, r0 + 8, g0 + 8, b0 + 8, blk))
             std::copy(blk, blk + 8, tab.begin() + slot * 8);
         else
-            split(slot * 8, Box{r0, g0, b0, 16}, m + 8);
+            split(slot * 8, Box{r0, g0, b0, 16}, m + mw);
     }
     // deeper levels: boxes that still hold more than 8 members are split again; a single colour that still
     // overflows is left to the fix-up pass
@@ -359,13 +361,13 @@ int assemble_table(const std::vector<uint32_t> &masks, const int K, const std::v
         if (st.too_big || kids.empty()) break;
         std::vector<Box> boxes(kids.size());
         for (size_t q = 0; q < kids.size(); ++q) boxes[q] = kids[q].box;
-        std::vector<uint32_t> bm(kids.size() * 8);
+        std::vector<uint32_t> bm(kids.size() * (size_t)mw);
         const int rc = box_masks(boxes, bm);
         if (rc != DP_OK) return rc;
         for (size_t q = 0; q < kids.size(); ++q) {
             const Box &c = kids[q].box;
             uint32_t blk[8];
-            if (make_block(&bm[q * 8], c.r0 + c.size / 2, c.g0 + c.size / 2, c.b0 + c.size / 2, blk))
+            if (make_block(&bm[q * (size_t)mw], c.r0 + c.size / 2, c.g0 + c.size / 2, c.b0 + c.size / 2, blk))
                 std::copy(blk, blk + 8, tab.begin() + kids[q].pos);
             else
                 pending.push_back(kids[q]);
@@ -406,10 +408,12 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     constexpr size_t kCodeWords = (size_t)1 << 20;  // 2^24 colours x 2 bits (k=1); the k=2 table has twice as many
     uint32_t *d_masks = nullptr;
     uint8_t *blob = nullptr;
+    const int mw = K <= 256 ? 8 : 32;               // mask words per (sub-)cell
+    const bool big_q = dev.n_inner > kQueueSmall;   // traversal queue of the tie queries
     // layout: code1 | code2 | table[cap] | exceptions | exception count
     const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16;
     DP_HIP(hipMalloc((void **)&blob, bytes));
-    hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 72);
+    hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 9 * mw);
     if (e == hipSuccess) e = hipMemset(blob, 0, sizeof(uint32_t) * 3 * kCodeWords);
     if (e != hipSuccess) {
         (void)hipFree(blob);
@@ -427,8 +431,14 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         (void)hipFree(d_masks);
         return hip_fail(e, "accelerator allocation");
     }
-    hipLaunchKernelGGL(accel_scan_kernel, dim3(kCells), dim3(256), 0, 0, dev, d_masks, code1, code2, d_exc, d_exc_count);
-    std::vector<uint32_t> masks((size_t)kCells * 72);
+#define DP_SCAN(MW, C) hipLaunchKernelGGL((accel_scan_kernel<MW, C>), dim3(kCells), dim3(256), 0, 0, dev, d_masks, code1, code2, d_exc, d_exc_count)
+    if (mw == 8) {
+        if (big_q) DP_SCAN(8, kQueueLarge); else DP_SCAN(8, kQueueSmall);
+    } else {
+        if (big_q) DP_SCAN(32, kQueueLarge); else DP_SCAN(32, kQueueSmall);
+    }
+#undef DP_SCAN
+    std::vector<uint32_t> masks((size_t)kCells * 9 * mw);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(masks.data(), d_masks, sizeof(uint32_t) * masks.size(), hipMemcpyDeviceToHost);
     (void)hipFree(d_masks);
@@ -440,10 +450,11 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     std::vector<uint32_t> tab;
     TableStats st;
     const int rc = assemble_table(
-        masks, K, p4_host, p4_host,
+        masks, mw, K, p4_host, p4_host,
         [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
             return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
-                hipLaunchKernelGGL(accel_box_kernel, dim3(n), dim3(64), 0, 0, dev, db, dm);
+                if (mw == 8) hipLaunchKernelGGL(accel_box_kernel<8>, dim3(n), dim3(64), 0, 0, dev, db, dm);
+                else hipLaunchKernelGGL(accel_box_kernel<32>, dim3(n), dim3(64), 0, 0, dev, db, dm);
             });
         },
         tab, st);
@@ -537,7 +548,7 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
     std::vector<uint32_t> tab;
     TableStats st;
     const int rc = assemble_table(
-        masks, K, coord4, word,
+        masks, 8, K, coord4, word,
         [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
             return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
                 hipLaunchKernelGGL(accel_box_float_kernel, dim3(n), dim3(64), 0, 0, dev, d_reach, db, dm);

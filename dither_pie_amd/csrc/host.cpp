@@ -353,7 +353,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     p->accel_bytes = 0;
     p->accel_tried = false;
     p->p4_host = p4;
-    p->same_out = integer && K >= 8 && K <= 256 && inner <= kQueueSmall;  // what the accelerator handles
+    p->same_out = integer && K >= 8 && K <= DP_MAX_COLORS;  // what the accelerator handles
     for (int j = 0; j < K && p->same_out; ++j) p->same_out = (orgb[j] == p4[j]);
     // float palettes (use_gamma): coordinates within [0, 255], as the reference's clip guarantees
     p->float_accel = !integer && K >= 8 && K <= 256;
