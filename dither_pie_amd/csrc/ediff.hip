@@ -536,6 +536,8 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
             if (big) DP_EDW(kQueueLarge, 4); else DP_EDW(kQueueSmall, 4);
         } else if (ntaps <= 8) {
             if (big) DP_EDW(kQueueLarge, 8); else DP_EDW(kQueueSmall, 8);
+        } else if (ntaps <= 12) {
+            if (big) DP_EDW(kQueueLarge, 12); else DP_EDW(kQueueSmall, 12);
         } else {
             if (big) DP_EDW(kQueueLarge, kMaxTaps); else DP_EDW(kQueueSmall, kMaxTaps);
         }
