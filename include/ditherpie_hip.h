@@ -65,13 +65,15 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
                       dp_palette **out);
 void dp_palette_destroy(dp_palette *p);
 int dp_palette_info(const dp_palette *p, int *K, int *is_integer, int *n_nodes);
-/* Search accelerator of an integer palette (accel.hip): per-cell candidate lists kept in LDS by the
- * dither kernel + per-colour tie codes.  Building it scans all 2^24 colours once (tens of
- * milliseconds, synchronous), which pays off from a few megapixels on; without it dp_ordered_u8 runs
- * the brute-force kernels.  dp_palette_build_accel is idempotent and returns DP_OK without building
- * when the palette does not qualify (non-integer colours, K < 8, output colours != palette colours,
- * or a table that would not fit LDS).  dp_palette_accel_info: size of the LDS table in 32-bit words
- * and the longest exact candidate list; both 0 when there is no accelerator. */
+/* Search accelerator (accel.hip): per-cell candidate lists kept in LDS by the dither kernels; for integer
+ * palettes (8..1024 colours whose output colours are the palette colours) also per-colour tie codes and an
+ * exception list, so that scipy's tie order needs no tree traversal; float palettes (use_gamma, 8..256
+ * colours) get the same table over the lut_in-mapped pixel values.  Building it scans all 2^24 colours once
+ * (a few milliseconds to tens of milliseconds, synchronous), which pays off from a few megapixels on; without
+ * it dp_ordered_u8 runs the brute-force kernels.  dp_palette_build_accel is idempotent and returns DP_OK
+ * without building when the palette does not qualify or the table would not fit LDS.
+ * dp_palette_accel_info: size of the LDS table in 32-bit words and the longest exact candidate list; both 0
+ * when there is no accelerator. */
 int dp_palette_build_accel(dp_palette *p);
 int dp_palette_accel_info(const dp_palette *p, int *pool_entries, int *max_cell);
 
