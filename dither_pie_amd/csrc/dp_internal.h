@@ -82,12 +82,15 @@ struct ThrDev {
     const float *f32;     // th_h*th_w
     const uint32_t *m;    // integer form: t = m / 2^sh (nullptr when not representable)
     int sh;
-    // lean ordered kernel (power-of-two tables only, nullptr otherwise): rows of tw_pad = th_w + 3 entries, the
-    // last three repeating the row from its start, so that the 4 thresholds of a lane's pixels are 4 consecutive
-    // entries whatever the starting column.  fpad: the float32 values; mpad: the integer form (needs sh >= 0).
+    // lean ordered kernels: rows of tw_pad = th_w + 3 entries, the last three repeating the row from its start, so
+    // that the 4 thresholds of a lane's pixels are 4 consecutive entries whatever the starting column.
+    // fpad: the float32 values; mpad: the integer form (needs sh >= 0).  pow2: both sizes are powers of two
+    // (positions by masking; otherwise by an exact float64 reciprocal, inv_h / inv_w).
     const float *fpad;
     const uint32_t *mpad;
     int tw_pad;
+    int pow2;
+    double inv_h, inv_w;
 };
 
 // Position of a 16x16x16 cell in the LDS table: the kernels form it as r' | b'<<4 | g'<<8 (x & 0xf0f0f0,

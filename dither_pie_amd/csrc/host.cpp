@@ -463,7 +463,10 @@ static int thresholds_from_device_f32(float *dev_f32, int th_h, int th_w, const 
         t->dev.m = dm;
         t->dev.sh = sh;
     }
-    if ((th_h & (th_h - 1)) == 0 && (th_w & (th_w - 1)) == 0 && (int64_t)th_h * (th_w + 3) <= (1 << 18)) {
+    t->dev.pow2 = ((th_h & (th_h - 1)) == 0 && (th_w & (th_w - 1)) == 0) ? 1 : 0;
+    t->dev.inv_h = 1.0 / (double)th_h;
+    t->dev.inv_w = 1.0 / (double)th_w;
+    if ((int64_t)th_h * (th_w + 3) <= (1 << 18)) {
         const int twp = th_w + 3;
         const size_t np = (size_t)th_h * twp;
         std::vector<uint32_t> pad(2 * np);  // float32 bit patterns, then the integer form

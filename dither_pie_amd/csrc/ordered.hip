@@ -540,6 +540,28 @@ constexpr int kLeanQueue = 128;                                         // entri
 constexpr int kLeanQueueWords = (kCellBlock / 64) * kLeanQueue;         // 8 KB at the top of LDS
 constexpr int kLeanTabBytes = (kLeanLdsWords - kLeanQueueWords) * 4;    // table + thresholds must fit below
 
+// x mod d for d > 0 with inv = 1.0/d (exact: the float64 quotient estimate is off by at most one)
+__device__ __forceinline__ uint32_t umod_inv(const uint32_t x, const uint32_t d, const double inv)
+{
+    const uint32_t q = (uint32_t)((double)x * inv);
+    int32_t r = (int32_t)(x - q * d);
+    if (r < 0) r += (int32_t)d;
+    else if ((uint32_t)r >= d) r -= (int32_t)d;
+    return (uint32_t)r;
+}
+
+// row / column of a pixel position in the threshold table
+__device__ __forceinline__ void thr_pos(const ThrDev &thr, const uint32_t gy, const uint32_t gx, uint32_t &row, uint32_t &col)
+{
+    if (thr.pow2) {
+        row = gy & (uint32_t)(thr.th_h - 1);
+        col = gx & (uint32_t)(thr.th_w - 1);
+    } else {
+        row = umod_inv(gy, (uint32_t)thr.th_h, thr.inv_h);
+        col = umod_inv(gx, (uint32_t)thr.th_w, thr.inv_w);
+    }
+}
+
 struct LeanThr {  // what the decision needs besides the distances
     uint32_t mt;  // MODE 1
     float t;      // MODE 2, 3
@@ -616,8 +638,8 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
         if (MODE == 3) {
             th.t = ign_threshold(g.x0 + (int)fx, g.y0 + (int)fy, sx, sy, sc);
         } else {
-            const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
-            const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.th_w - 1);
+            uint32_t row, col;
+            thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
             if (MODE == 1) {
                 th.mt = s_words[pal.tab_words + row * thr.tw_pad + col];
                 th.t = __fmul_rn((float)th.mt, 1.0f / (float)(1u << thr.sh));
@@ -729,8 +751,8 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                 th[q].t = 0.0f;
             }
             if (MODE == 1 || MODE == 2) {
-                const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
-                const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.th_w - 1);
+                uint32_t row, col;
+                thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
                 const uint32_t at = row * (uint32_t)thr.tw_pad + col;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -873,8 +895,8 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
             xs[3] = wc.z >> 8;
             float tq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (MODE == 2) {
-                const uint32_t row = ((uint32_t)g.y0 + fy) & (uint32_t)(thr.th_h - 1);
-                const uint32_t col = ((uint32_t)g.x0 + fx) & (uint32_t)(thr.th_w - 1);
+                uint32_t row, col;
+                thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
                 const uint32_t at = row * (uint32_t)thr.tw_pad + col;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) tq[q] = thr.fpad[at + q];
@@ -1273,6 +1295,8 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
     thr.fpad = nullptr;
     thr.mpad = nullptr;
     thr.tw_pad = 0;
+    thr.pow2 = 1;
+    thr.inv_h = thr.inv_w = 1.0;
     if (mode == DP_MODE_MATRIX) thr = *thr_in;
     // a single colour: every pixel maps to it, and the k=2 query of the reference has no second entry
     if (pal.K == 1) mode = DP_MODE_NEAREST;

@@ -340,7 +340,9 @@ def test_variance_gate_matches_scipy_restatement(be, orc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "8x8"}), ("bayer", {"size": "2x2"}),
                                          ("blue_noise", {"size": 32, "seed": 3}), ("IGN", {"scale": 1.5, "seed": 4}),
-                                         ("polka_dot", {"tile_size": 8, "gamma": 1.5})])
+                                         ("polka_dot", {"tile_size": 8, "gamma": 1.5}),
+                                         ("polka_dot", {"tile_size": 6, "gamma": 0.8}),   # not a power of two
+                                         ("blue_noise", {"size": 33, "seed": 5})])
 @pytest.mark.parametrize("w", [1003, 1004])
 def test_lean_kernel_queue_drains_and_row_straddles(be, orc, mode, params, w):
     """The lean kernel defers split cells, ties and row-straddling groups to its wave-private queue; a frame
@@ -363,7 +365,7 @@ def test_lean_kernel_queue_drains_and_row_straddles(be, orc, mode, params, w):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "8x8"}), ("blue_noise", {"size": 32, "seed": 3}),
-                                         ("IGN", {"scale": 1.5, "seed": 4})])
+                                         ("IGN", {"scale": 1.5, "seed": 4}), ("polka_dot", {"tile_size": 5, "gamma": 1.5})])
 @pytest.mark.parametrize("K,w", [(256, 1003), (64, 1004), (9, 640)])
 def test_float_palette_cell_table(be, orc, mode, params, K, w):
     """use_gamma palettes (float32 coordinates, pixels through lut_in) on their own cell table: float32 ranking
