@@ -102,7 +102,19 @@ def main():
     distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun even a single rank uses RCCL
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner to stdout when the first communicator comes up: keep stdout for the one
+        # JSON line by pointing fd 1 at stderr until that has happened
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from dither_pie_amd import backend
     from dither_pie_amd.dithering_lib import DitherMode, ImageDitherer
@@ -142,6 +154,11 @@ def main():
     import hashlib
     kat_ok = hashlib.sha256(out[0].cpu().numpy().tobytes()).hexdigest()[:16] == "7041bd52fdea90b5"
 
+    # untimed: bring the GPU clocks up and fault in every buffer before the contract's W warm-up steps, so that a
+    # short run (few steps) measures the same thing as a long one
+    for _ in range(30):
+        step()
+    torch.cuda.synchronize()
     backend.profile_enable(True)
     dt = timed(step, args.steps, args.warmup)
     main_ms, fix_ms, launches = backend.profile_read()
