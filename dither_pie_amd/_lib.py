@@ -78,6 +78,13 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise DitherPieError(-1, f"{LIB_PATH} is missing: build it with "
                                          f"`make -C {CSRC}` (or dither_pie_amd.build()); there is no CPU fallback")
+            # The library shares the process's HIP runtime with PyTorch (device memory and streams are torch's).
+            # torch ships its own libamdhip64: import it first so that ours binds to that copy -- loading the
+            # system runtime before torch's leaves two runtimes in the process and this one without a device.
+            try:
+                import torch  # noqa: F401
+            except ImportError:  # host-only use (dp_kdtree_build_host, symbol checks)
+                pass
             L = C.CDLL(LIB_PATH)
             for name, (res, args) in _SIGS.items():
                 fn = getattr(L, name)
