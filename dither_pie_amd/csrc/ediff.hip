@@ -105,7 +105,8 @@ __device__ __forceinline__ int nearest_color(const PalDev &pal, const float4 *__
     return nearest_f64<CAP>(pal, o0, o1, o2);
 }
 
-__device__ __forceinline__ float clamp255(const float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
+// min(max(v, 0), 255) for every non-NaN v, in one instruction
+__device__ __forceinline__ float clamp255(const float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f); }
 
 // ---- candidate lists for the nearest-colour search (palettes of 9..256 colours) -------------------------
 // The query points of error diffusion are arbitrary float32 triples in [0,255]^3.  For every 8x8x8 cell of that
@@ -459,6 +460,197 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Serpentine scans: one WAVE per frame.  Rows (and the pixels of a row) are strictly sequential, so the
+// only thing that matters is the latency of one pixel step; the lane = frame kernel above spends five
+// dependent global-memory round trips per step (~1.4 us).  Here everything on the chain stays in
+// registers: the three newest error rows live in LDS and are only read lane-parallel, 64 pixels ahead of
+// the walk (each lane prepares the pixel value plus all contributions from the rows above for "its"
+// pixel of the next 64-step block); the walk itself adds the two same-row taps from registers, evaluates
+// the palette lane-parallel (entry l + 64 m in lane l), reduces the two smallest distances with DPP row
+// shifts and picks the winner's colour up with v_readlane (or one LDS broadcast read when a lane holds
+// several entries).  Same float32 prefilter / float64 fallback / tie replay as everywhere else.
+// ---------------------------------------------------------------------------------------------
+// minimum of a non-negative float over the wave (as unsigned integers: same order, and v_min_u32 fuses with DPP)
+__device__ __forceinline__ float wave_min_to_all(const float vf)
+{
+    uint32_t v = __float_as_uint(vf);
+    // inclusive prefix minimum inside each row of 16 lanes, then across rows: lane 63 ends up with the minimum
+    // (a lane without a source, or outside the row mask, keeps its own value)
+    // one fused instruction per step; a VGPR written by a VALU op needs two wait states before a DPP read
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, 63));
+}
+
+template <int CAP, int M>  // M: palette entries per lane (K <= 64 * M)
+__global__ __launch_bounds__(64) void ed_rowserial_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                          const int h, const int w, const PalDev pal, const Taps taps,
+                                                          const int serpentine)
+{
+    extern __shared__ __align__(16) float s_dyn[];  // err[3][w][3], then (M > 1) K x {x, y, z, out_rgb}
+    __shared__ uint8_t s_lut[256];
+    float *s_err = s_dyn;
+    const float4 *s_pal = reinterpret_cast<const float4 *>(s_dyn + (((size_t)9 * w + 3) & ~(size_t)3));
+    const int lane = threadIdx.x;
+    const size_t f = blockIdx.x;
+    const uint8_t *fin = in + f * (size_t)h * w * 3;
+    uint8_t *fout = out + f * (size_t)h * w * 3;
+    const float inf = __int_as_float(0x7f800000);
+    const int K = pal.K;
+
+    float4 pc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int j = lane + 64 * m;
+        pc[m] = j < K ? pal.fcand[j] : make_float4(1e30f, 1e30f, 1e30f, 0.f);  // distance overflows to +inf
+    }
+    if (M > 1)
+        for (int j = lane; j < K; j += 64) const_cast<float4 *>(s_pal)[j] = pal.fcand[j];
+    for (int i = lane; i < 256; i += 64) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
+    __syncthreads();
+
+    // taps arrive sorted (dy descending, dx descending): the rows above first, then the same row (dx = 2, then 1)
+    int n_above = 0;
+    float w1 = 0.f, w2 = 0.f;
+    for (int k = 0; k < taps.n; ++k) {
+        if (taps.dy[k] > 0) n_above = k + 1;
+        else if (taps.dx[k] == 1) w1 = taps.wq[k];
+        else if (taps.dx[k] == 2) w2 = taps.wq[k];
+    }
+
+    // value of pixel (y, step) before the same-row taps: input (through lut_in) + contributions of the rows above,
+    // in the reference's order; `rev`: direction of row y
+    auto prepare = [&](const int y, const int step, const bool rev, float &p0, float &p1, float &p2) {
+        p0 = p1 = p2 = 0.f;
+        if (y >= h || step >= w) return;
+        const int x = rev ? (w - 1 - step) : step;
+        const uint8_t *px = fin + ((size_t)y * w + x) * 3;
+        float a0 = (float)s_lut[px[0]], a1 = (float)s_lut[px[1]], a2 = (float)s_lut[px[2]];
+        for (int k = 0; k < n_above; ++k) {
+            const int sr = y - taps.dy[k];
+            if (sr < 0) continue;
+            const int sdir = (serpentine && (sr & 1)) ? -1 : 1;
+            const int sxp = x - taps.dx[k] * sdir;
+            if (sxp < 0 || sxp >= w) continue;
+            const float *e = s_err + ((size_t)(sr % 3) * w + sxp) * 3;
+            const float wq = taps.wq[k];
+            a0 = __fadd_rn(a0, __fmul_rn(e[0], wq));
+            a1 = __fadd_rn(a1, __fmul_rn(e[1], wq));
+            a2 = __fadd_rn(a2, __fmul_rn(e[2], wq));
+        }
+        p0 = a0;
+        p1 = a1;
+        p2 = a2;
+    };
+
+    for (int y = 0; y < h; ++y) {
+        const bool rev = serpentine && (y & 1);
+        float e1x = 0.f, e1y = 0.f, e1z = 0.f, e2x = 0.f, e2y = 0.f, e2z = 0.f;  // errors of the previous two pixels
+        for (int step0 = 0; step0 < w; step0 += 64) {
+            // rows above are complete (their LDS writes precede this point in program order)
+            float p0, p1, p2;
+            prepare(y, step0 + lane, rev, p0, p1, p2);
+            float my_e0 = 0.f, my_e1 = 0.f, my_e2 = 0.f;
+            uint32_t my_c = 0;
+            const int nstep = min(64, w - step0);
+            for (int i = 0; i < nstep; ++i) {
+                float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), i));
+                float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1), i));
+                float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2), i));
+                // same-row taps (an absent source contributes fl(0*w) = 0, which leaves the sum unchanged)
+                a0 = __fadd_rn(__fadd_rn(a0, __fmul_rn(e2x, w2)), __fmul_rn(e1x, w1));
+                a1 = __fadd_rn(__fadd_rn(a1, __fmul_rn(e2y, w2)), __fmul_rn(e1y, w1));
+                a2 = __fadd_rn(__fadd_rn(a2, __fmul_rn(e2z, w2)), __fmul_rn(e1z, w1));
+                const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
+                // lane-parallel palette scan
+                float b0 = inf, b1 = inf;
+                int i0 = lane;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float da = pc[m].x - o0, db = pc[m].y - o1, dc = pc[m].z - o2;
+                    const float d = __fmaf_rn(da, da, __fmaf_rn(db, db, dc * dc));
+                    const bool lt0 = d < b0;
+                    b1 = lt0 ? b0 : (d < b1 ? d : b1);
+                    i0 = lt0 ? lane + 64 * m : i0;
+                    b0 = lt0 ? d : b0;
+                }
+                const float B0 = wave_min_to_all(b0);
+                const unsigned long long wm = __ballot(b0 == B0);
+                const int winner = __ffsll((long long)wm) - 1;
+                // the second smallest distance is only needed for the margin test "b1 > b0 * 1.000002": it fails iff
+                // some other entry lies within the margin, i.e. more than one lane passes, or a lane's own runner-up
+                const float lim = B0 * 1.000002f;
+                const unsigned long long close = __ballot(b0 <= lim);
+                const bool near_tie = (close & (close - 1ull)) != 0ull || (M > 1 && __ballot(b1 <= lim) != 0ull);
+                int j = M == 1 ? winner : __builtin_amdgcn_readlane(i0, winner);
+                float cx, cy, cz;
+                uint32_t cw;
+                if (!near_tie) {
+                    if (M == 1) {
+                        cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[0].x), winner));
+                        cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[0].y), winner));
+                        cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[0].z), winner));
+                        cw = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(pc[0].w), winner);
+                    } else {
+                        const float4 c = s_pal[j];
+                        cx = c.x;
+                        cy = c.y;
+                        cz = c.z;
+                        cw = __float_as_uint(c.w);
+                    }
+                } else {  // near tie: float64 scan, scipy's traversal on exact ties
+                    j = nearest_f64<CAP>(pal, o0, o1, o2);
+                    const float4 c = pal.fcand[j];
+                    cx = c.x;
+                    cy = c.y;
+                    cz = c.z;
+                    cw = __float_as_uint(c.w);
+                }
+                const float ex = __fsub_rn(o0, cx), ey = __fsub_rn(o1, cy), ez = __fsub_rn(o2, cz);
+                if (lane == i) {  // the lane that prepared this pixel keeps its error and colour for the block's stores
+                    my_e0 = ex;
+                    my_e1 = ey;
+                    my_e2 = ez;
+                    my_c = cw;
+                }
+                e2x = e1x;
+                e2y = e1y;
+                e2z = e1z;
+                e1x = ex;
+                e1y = ey;
+                e1z = ez;
+            }
+            if (lane < nstep) {
+                const int x = rev ? (w - 1 - (step0 + lane)) : (step0 + lane);
+                float *e = s_err + ((size_t)(y % 3) * w + x) * 3;
+                e[0] = my_e0;
+                e[1] = my_e1;
+                e[2] = my_e2;
+                uint8_t *o = fout + ((size_t)y * w + x) * 3;
+                o[0] = (uint8_t)my_c;
+                o[1] = (uint8_t)(my_c >> 8);
+                o[2] = (uint8_t)(my_c >> 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 }  // namespace
 
 size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w)
@@ -542,6 +734,26 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
             if (big) DP_EDW(kQueueLarge, kMaxTaps); else DP_EDW(kQueueSmall, kMaxTaps);
         }
 #undef DP_EDW
+    } else if (n_frames <= 0x7fffffff &&
+               ((size_t)9 * w + 4) * sizeof(float) + (pal.K > 64 ? (size_t)pal.K * 16 : 0) + 512 <= (size_t)158 * 1024) {
+        // any scan direction, one wave per frame (three error rows in LDS)
+        const size_t lds = ((((size_t)9 * w + 3) & ~(size_t)3)) * sizeof(float) + (pal.K > 64 ? (size_t)pal.K * 16 : 0);
+        const bool big = pal.n_inner > kQueueSmall;
+#define DP_EDR(C, MM)                                                                                                   \
+    do {                                                                                                               \
+        auto kern = ed_rowserial_kernel<C, MM>;                                                                        \
+        DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                   (int)lds));                                                                         \
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_frames), dim3(64), lds, s, in, out, h, w, pal, t, serpentine);        \
+    } while (0)
+        if (pal.K <= 64) {
+            if (big) DP_EDR(kQueueLarge, 1); else DP_EDR(kQueueSmall, 1);
+        } else if (pal.K <= 256) {
+            if (big) DP_EDR(kQueueLarge, 4); else DP_EDR(kQueueSmall, 4);
+        } else {
+            if (big) DP_EDR(kQueueLarge, 16); else DP_EDR(kQueueSmall, 16);
+        }
+#undef DP_EDR
     } else {
         const int64_t blocks = (n_frames + 63) / 64;
         if (pal.n_inner > kQueueSmall)

@@ -401,3 +401,15 @@ def test_error_diffusion_candidate_lists(be, orc, K, gamma, variant, serp):
     params = {"variant": variant, "serpentine": serp}
     out = _run_case(be, orc, arr, pal, "error_diffusion", params, gamma)
     _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, gamma), f"K={K} gamma={gamma} {variant}")
+
+
+@pytest.mark.gpu
+def test_serpentine_wide_rows_use_the_frame_parallel_kernel(be, orc):
+    """The one-wave-per-frame serpentine kernel keeps three error rows in LDS (rows up to ~4400 pixels); wider rows
+    fall back to the lane = frame kernel with its error rows in global memory.  Same bytes either way."""
+    pal = orc.palr(16, 3)
+    for w in (4300, 5001):
+        arr = orc.rnd(5, w, w)
+        params = {"variant": "sierra", "serpentine": "true"}
+        out = _run_case(be, orc, arr, pal, "error_diffusion", params, False)
+        _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, False), f"w={w}")
