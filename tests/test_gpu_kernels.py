@@ -413,3 +413,16 @@ def test_serpentine_wide_rows_use_the_frame_parallel_kernel(be, orc):
         params = {"variant": "sierra", "serpentine": "true"}
         out = _run_case(be, orc, arr, pal, "error_diffusion", params, False)
         _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, False), f"w={w}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_randomised_cases_against_oracle(be, orc, seed):
+    """150 random (mode, parameters, palette size, gamma, shape, tile origin, tie-rich content) cases per seed."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_scripts", "fuzz_ordered.py")
+    spec = importlib.util.spec_from_file_location("fuzz_ordered", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(seed, 150) == 0
