@@ -20,9 +20,11 @@
 //   buffer (L2) and lanes prefetch the previous band's two boundary rows into a 64-column LDS ring --
 //   so every wait is for operations issued a period earlier.  Errors of the band's own rows live in an
 //   8-deep per-row LDS ring.
-// ed_serial_kernel (any scan, used for serpentine): rows are strictly sequential under a
-//   serpentine scan (the first pixel of row y+1 needs the last pixel of row y), so parallelism
-//   comes from frames only: lane = frame, error rows interleaved across lanes in global memory.
+// ed_rowserial_kernel (any scan, used for serpentine): rows are strictly sequential under a serpentine
+//   scan (the first pixel of row y+1 needs the last pixel of row y), so only the latency of one pixel
+//   step counts: one wave per frame, error rows in LDS, lane-parallel palette scan (see the kernel).
+// ed_serial_kernel: lane = frame, error rows interleaved across lanes in global memory; the fallback for
+//   rows too wide for the LDS rows of ed_rowserial_kernel.
 //
 // Nearest colour: a float32 scan keeps the two smallest distances; if they are separated by more than
 // the float32 error margin the float32 winner is provably the float64 winner.  Otherwise (near ties)

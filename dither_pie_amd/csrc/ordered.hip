@@ -3,15 +3,23 @@
 // Replaces NoDitherStrategy.dither (dithering_lib.py:337-341), MatrixDitherStrategy.dither
 // (:355-378) and the IGN strategy (:551-568) for packed uint8 RGB frames.
 //
-// Pass 1 (ordered_int_kernel / ordered_f64_kernel): each lane owns 4 consecutive pixels = 12 bytes
-//   = three dword loads and three dword stores, fully coalesced across the wave (768 B per wave each
-//   way).  Integer palettes: exact squared distances through v_dot4_u32_u8, the three smallest
-//   (distance, index) keys kept with v_min/v_med3, and the reference's float64 decision
-//   `s0/(s0+s1) <= t` evaluated exactly in integers (d0 * 2^sh <= m * (d0+d1) for t = m/2^sh), which
-//   is provably the same decision except when both sides are equal.  Pixels whose result depends on
-//   scipy's visiting order (distance ties) or on float64 rounding (exact equality) only set a flag bit.
-// Pass 2 (fixup_kernel): the flagged pixels (~0.1-0.5 %) are compacted per workgroup into LDS and
-//   resolved densely through the scipy-order KD-tree emulation and the literal float64 chain.
+// Every kernel gives each lane 4 consecutive pixels = 12 bytes = one dwordx3 load and store, fully
+// coalesced across the wave (768 B per wave each way), finds the two (three) nearest palette entries
+// exactly and evaluates the reference's float64 decision `s0/(s0+s1) <= t` exactly (integer palettes:
+// d0 * 2^sh <= m * (d0+d1) for t = m/2^sh, provably the same decision except when both sides are equal).
+// Which kernel runs (launch_ordered):
+//   ordered_lean_kernel<MODE>        integer palettes with a cell table (accel.hip): the fast path -- LDS
+//                                    candidate blocks, branch-free main loop, rare pixels (split cells,
+//                                    distance ties, exact equality, row-straddling groups) deferred to a
+//                                    wave-private queue and resolved densely with tie codes / exceptions
+//   ordered_lean_float_kernel<MODE>  float (use_gamma) palettes with a cell table: float32 ranking with a
+//                                    certainty gap, float64 recomputation of the winners
+//   ordered_cell_kernel<MODE>        the previous generation of the fast path (inline rare paths); kept for
+//                                    buffers that are not dword-aligned
+//   ordered_int_kernel / ordered_f64_kernel   brute force over the whole palette (no accelerator)
+// Pixels whose result depends on scipy's visiting order in a way no table expresses, and near ties of the
+// float path, only set a flag bit; fixup_kernel compacts the flagged pixels per workgroup into LDS and
+// resolves them through the scipy-order KD-tree emulation (tree_query) and the literal float64 chain.
 #include "dp_internal.h"
 #include "tree_query.cuh"
 
