@@ -6,11 +6,12 @@ multiprocessing.Pool of <= 4 workers per 15-frame batch and pickles the ditherer
 (video_processor.py:304-346); a HIP context must not cross fork(), and frames are independent, so here
 frames are processed IN PROCESS in batches that stay resident in HBM between the stages
 (NEAREST down-scale -> dither -> NEAREST up-scale, all through libditherpie_hip.so).
-ffmpeg/ffprobe remain external subprocesses exactly as in the reference (frame extraction to PNG,
-libx264 re-encode with audio/subtitle copy); that I/O is outside the hot path.
-Failure policy kept: a frame that fails is retried twice, then copied from the nearest good frame;
-the whole call returns False on any other error; progress_callback(fraction, message) gets the same
-milestones (0.0, 0.05, 0.1 ... 0.9, 1.0).
+ffmpeg/ffprobe remain external subprocesses as in the reference (same libx264 re-encode with audio/subtitle
+copy), but frames travel as rawvideo rgb24 through pipes into pinned host buffers instead of PNG files on
+disk (PNG encode/decode dominates a processed frame in the reference); the PNG-file
+exchange of the reference remains available (`use_pipes=False`) with its failure policy: a frame that fails
+is retried twice, then copied from the nearest good frame.  Either way the call returns False on any other
+error and progress_callback(fraction, message) gets the same milestones (0.0, 0.05, 0.1 ... 0.9, 1.0).
 """
 from __future__ import annotations
 
@@ -207,10 +208,85 @@ class VideoProcessor:
                 failed.append(f)
         return failed
 
+    def _stream_through_pipes(self, input_path, output_path, ditherer, method, max_size, batch_size,
+                              final_resize_multiplier, info) -> int:
+        """decode -> GPU -> encode through two ffmpeg rawvideo pipes; returns the number of frames written."""
+        import torch
+        w, h, fps = int(info["width"]), int(info["height"]), info["fps"]
+        frame_bytes = w * h * 3
+        total_hint = info.get("frame_count") or 0
+        dec = subprocess.Popen(["ffmpeg", "-v", "error", "-i", input_path, "-f", "rawvideo", "-pix_fmt", "rgb24",
+                                "pipe:1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        enc = None
+        done = 0
+        stage = torch.empty(batch_size * frame_bytes, dtype=torch.uint8, pin_memory=True)
+        view = memoryview(stage.numpy())
+        out_host = None
+        try:
+            while True:
+                got = 0
+                while got < batch_size * frame_bytes:  # a pipe read returns at most 64 KiB at a time
+                    n = dec.stdout.readinto(view[got:])
+                    if not n:
+                        break
+                    got += n
+                n_frames = got // frame_bytes
+                if n_frames == 0:
+                    break
+                frames = stage[:n_frames * frame_bytes].view(n_frames, h, w, 3).cuda(non_blocking=True)
+                out = process_frames(frames, ditherer, method, max_size, final_resize_multiplier)
+                if enc is None:
+                    oh, ow = int(out.shape[1]), int(out.shape[2])
+                    enc = subprocess.Popen(
+                        ["ffmpeg", "-y", "-v", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{ow}x{oh}",
+                         "-framerate", f"{fps:.5f}", "-i", "pipe:0", "-i", input_path, "-map", "0:v:0", "-map", "1:a?",
+                         "-map", "1:s?", "-c:v", "libx264", "-preset", "medium", "-crf", "18", "-pix_fmt", "yuv420p",
+                         "-c:a", "copy", "-c:s", "copy", output_path],
+                        stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    out_host = torch.empty((batch_size,) + tuple(out.shape[1:]), dtype=torch.uint8, pin_memory=True)
+                out_host[:n_frames].copy_(out, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                enc.stdin.write(memoryview(out_host[:n_frames].numpy()).cast("B"))
+                done += n_frames
+                frac = done / total_hint if total_hint else 0.5
+                self._report_progress(0.1 + 0.8 * min(frac, 1.0), f"Processed {done}/{total_hint or '?'} frames")
+                if got < batch_size * frame_bytes:
+                    break
+        finally:
+            if dec.stdout:
+                dec.stdout.close()
+            rc_dec = dec.wait()
+            rc_enc = 0
+            if enc is not None:
+                enc.stdin.close()
+                rc_enc = enc.wait()
+        if rc_dec != 0 or rc_enc != 0:
+            raise RuntimeError(f"ffmpeg failed (decoder {rc_dec}, encoder {rc_enc})")
+        if done == 0:
+            raise ValueError("No frames extracted from video")
+        return done
+
     def process_video_streaming(self, input_path: str, output_path: str, ditherer: ImageDitherer,
                                 pixelize_func=None, batch_size: int = 15,
-                                final_resize_multiplier: Optional[int] = None) -> bool:
-        """video_processor.py:172-390; pixelize_func is the reference's tuple (method_str, max_size) or None."""
+                                final_resize_multiplier: Optional[int] = None, use_pipes: bool = True) -> bool:
+        """video_processor.py:172-390; pixelize_func is the reference's tuple (method_str, max_size) or None.
+        use_pipes (an addition): rawvideo pipes instead of the reference's PNG files on disk."""
+        if use_pipes:
+            try:
+                info = self.get_video_info(input_path)
+                self._report_progress(0.0, "Initializing video processing...")
+                self._report_progress(0.05, "Extracting frames...")
+                method, max_size = (None, 64) if pixelize_func is None else pixelize_func
+                self._report_progress(0.1, "Processing frames...")
+                self._stream_through_pipes(input_path, output_path, ditherer, method, max_size, max(1, batch_size),
+                                           final_resize_multiplier, info)
+                self._report_progress(0.9, "Encoding final video...")
+                self._report_progress(1.0, "Video processing complete!")
+                return True
+            except Exception as e:  # noqa: BLE001
+                self._report_progress(1.0, f"Error: {str(e)}")
+                print(f"Video processing error: {e}", file=sys.stderr)
+                return False
         try:
             info = self.get_video_info(input_path)
             fps = info["fps"]

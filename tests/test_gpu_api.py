@@ -173,3 +173,52 @@ def test_video_frame_pipeline(d, orc, gold, tmp_path):
     failed = v.VideoProcessor()._process_batch(files + [bad], it, None, 64, None)
     assert failed == [bad]
     assert np.array_equal(np.array(Image.open(files[1])), orc.apply_dithering(frames[1], pal, "bayer", {"size": "4x4"}))
+
+
+@pytest.mark.gpu
+def test_video_streaming_through_rawvideo_pipes(d, orc, tmp_path, monkeypatch):
+    """process_video_streaming with stand-ins for ffmpeg/ffprobe on PATH (there is no ffmpeg in the image): the
+    decoder stand-in emits 11 synthetic 64x48 rgb24 frames, the encoder stand-in stores what it receives; the
+    stored frames must equal process_frames() on the same input, including the partial last batch."""
+    import stat
+    import sys
+    import torch
+    from dither_pie_amd import video_processor as v
+    n, w, h = 11, 64, 48
+    rs = np.random.RandomState(5)
+    frames = rs.randint(0, 256, (n, h, w, 3)).astype(np.uint8)
+    raw = tmp_path / "input.raw"
+    raw.write_bytes(frames.tobytes())
+    fake_ffmpeg = tmp_path / "ffmpeg"
+    fake_ffmpeg.write_text(f"""#!{sys.executable}
+import sys
+a = sys.argv[1:]
+if "pipe:1" in a:      # decoder: raw frames to stdout
+    sys.stdout.buffer.write(open({str(raw)!r}, "rb").read())
+elif "pipe:0" in a:    # encoder: keep the size argument and the bytes
+    open(a[-1], "wb").write(a[a.index("-s") + 1].encode() + b"\\n" + sys.stdin.buffer.read())
+else:
+    sys.exit(2)
+""")
+    fake_ffprobe = tmp_path / "ffprobe"
+    fake_ffprobe.write_text(f"""#!{sys.executable}
+import sys
+e = sys.argv[sys.argv.index("-show_entries") + 1]
+print({{"stream=r_frame_rate": "25/1", "stream=width,height": "{w}\\n{h}", "stream=duration,nb_frames": "0.44\\n{n}"}}[e])
+""")
+    for f in (fake_ffmpeg, fake_ffprobe):
+        f.chmod(f.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv("PATH", str(tmp_path) + ":" + __import__("os").environ["PATH"])
+    it = d.ImageDitherer(16, d.DitherMode.BAYER, orc.palr(16, 3), False, {"size": "4x4"})
+    seen = []
+    vp = v.VideoProcessor(progress_callback=lambda f_, m: seen.append(f_))
+    out_path = tmp_path / "out.bin"
+    assert vp.process_video_streaming(str(tmp_path / "in.mp4"), str(out_path), it, ("regular", 32), batch_size=4,
+                                      final_resize_multiplier=2) is True
+    blob = out_path.read_bytes()
+    size, body = blob.split(b"\n", 1)
+    ref = v.process_frames(torch.from_numpy(frames).cuda(), it, "regular", 32, 2).cpu().numpy()
+    assert size.decode() == f"{ref.shape[2]}x{ref.shape[1]}"
+    got = np.frombuffer(body, np.uint8).reshape(ref.shape)
+    assert np.array_equal(got, ref)
+    assert seen[0] == 0.0 and seen[-1] == 1.0 and all(b >= a for a, b in zip(seen, seen[1:]))
