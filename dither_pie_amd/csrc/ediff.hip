@@ -33,6 +33,7 @@
 // (tree_query<1>) unless the palette fits one leaf (then the lowest index wins).
 #include "dp_internal.h"
 #include "tree_query.cuh"
+#include "wave_util.cuh"
 
 namespace dp {
 namespace {
@@ -473,31 +474,6 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
 // shifts and picks the winner's colour up with v_readlane (or one LDS broadcast read when a lane holds
 // several entries).  Same float32 prefilter / float64 fallback / tie replay as everywhere else.
 // ---------------------------------------------------------------------------------------------
-// minimum of a non-negative float over the wave (as unsigned integers: same order, and v_min_u32 fuses with DPP)
-__device__ __forceinline__ float wave_min_to_all(const float vf)
-{
-    uint32_t v = __float_as_uint(vf);
-    // inclusive prefix minimum inside each row of 16 lanes, then across rows: lane 63 ends up with the minimum
-    // (a lane without a source, or outside the row mask, keeps its own value)
-    // one fused instruction per step; a VGPR written by a VALU op needs two wait states before a DPP read
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 0"
-        : "+v"(v));
-    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, 63));
-}
-
 template <int CAP, int M>  // M: palette entries per lane (K <= 64 * M)
 __global__ __launch_bounds__(64) void ed_rowserial_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                           const int h, const int w, const PalDev pal, const Taps taps,

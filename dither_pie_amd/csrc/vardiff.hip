@@ -14,11 +14,40 @@
 // max(0, mean_sq - sq_mean^2) >= threshold  (dithering_lib.py:988-992, 1019-1025).
 #include "dp_internal.h"
 #include "tree_query.cuh"
+#include "wave_util.cuh"
 
 namespace dp {
 namespace {
 
 __device__ __forceinline__ float clamp255f(const float v) { return v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v); }
+
+// near ties of the float32 scan: float64 scan with the KD-tree's arithmetic, scipy's traversal on exact ties
+template <int CAP>
+__device__ __forceinline__ int nearest_any_f64(const PalDev &pal, const float o0, const float o1, const float o2)
+{
+    int i0 = 0;
+    const int K = pal.K;
+    const double x0 = (double)o0, x1 = (double)o1, x2 = (double)o2;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double e0 = inf, e1 = inf;
+    for (int j = 0; j < K; ++j) {
+        const double d = sq_dist3(pal.pts + 3 * j, x0, x1, x2);
+        if (d < e0) {
+            e1 = e0;
+            e0 = d;
+            i0 = j;
+        } else if (d < e1) {
+            e1 = d;
+        }
+    }
+    if (e0 == e1 && K > kLeafSize) {
+        double d2[1];
+        int ii[1];
+        tree_query<1, CAP>(pal, x0, x1, x2, d2, ii);
+        i0 = ii[0];
+    }
+    return i0;
+}
 
 template <int CAP>
 __device__ __forceinline__ int nearest_any(const PalDev &pal, const float4 *__restrict__ cand, const float o0,
@@ -47,26 +76,7 @@ __device__ __forceinline__ int nearest_any(const PalDev &pal, const float4 *__re
     }
     for (; jj < K; ++jj) visit(cand[jj], jj);
     if (b1 > b0 * 1.000002f) return i0;
-    const double x0 = (double)o0, x1 = (double)o1, x2 = (double)o2;
-    const double inf = __longlong_as_double(0x7ff0000000000000LL);
-    double e0 = inf, e1 = inf;
-    for (int j = 0; j < K; ++j) {
-        const double d = sq_dist3(pal.pts + 3 * j, x0, x1, x2);
-        if (d < e0) {
-            e1 = e0;
-            e0 = d;
-            i0 = j;
-        } else if (d < e1) {
-            e1 = d;
-        }
-    }
-    if (e0 == e1 && K > kLeafSize) {
-        double d2[1];
-        int ii[1];
-        tree_query<1, CAP>(pal, x0, x1, x2, d2, ii);
-        i0 = ii[0];
-    }
-    return i0;
+    return nearest_any_f64<CAP>(pal, o0, o1, o2);
 }
 
 struct VarParams {
@@ -171,6 +181,143 @@ __global__ __launch_bounds__(64) void var_serial_kernel(const uint8_t *__restric
             o[0] = (uint8_t)c;
             o[1] = (uint8_t)(c >> 8);
             o[2] = (uint8_t)(c >> 16);
+        }
+    }
+}
+
+// ---- Ostromoukhov with a serpentine scan: one wave per frame (the scheme of ed_rowserial_kernel, ediff.hip) --------
+// Rows are strictly sequential, so only the latency of one pixel step counts.  The two newest error rows {e0,e1,e2,
+// table row} live in LDS next to the coefficient table; each lane prepares, 64 pixels ahead of the walk, the input
+// plus the two contributions from the row above for "its" pixel; the walk adds the same-row tap (the previous
+// pixel's error, coefficient by its table row: one LDS broadcast read), evaluates the palette lane-parallel and
+// reduces with DPP.  ~250 ns per pixel step instead of ~2 us for the lane = frame kernel.
+template <int CAP, int M>  // M: palette entries per lane (K <= 64 * M)
+__global__ __launch_bounds__(64) void os_rowserial_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                          const int h, const int w, const PalDev pal, const VarParams vp)
+{
+    extern __shared__ __align__(16) float s_dyn[];  // err[2][w][4], coef[768], then (M > 1) K x {x, y, z, out_rgb}
+    __shared__ uint8_t s_lut[256];
+    float4 *s_err = reinterpret_cast<float4 *>(s_dyn);
+    float *s_coef = s_dyn + (size_t)8 * w;
+    const float4 *s_pal = reinterpret_cast<const float4 *>(s_coef + 768);
+    const int lane = threadIdx.x;
+    const size_t f = blockIdx.x;
+    const uint8_t *fin = in + f * (size_t)h * w * 3;
+    uint8_t *fout = out + f * (size_t)h * w * 3;
+    const float inf = __int_as_float(0x7f800000);
+    const int K = pal.K;
+    const bool serp = vp.serpentine != 0;
+
+    float4 pc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int j = lane + 64 * m;
+        pc[m] = j < K ? pal.fcand[j] : make_float4(1e30f, 1e30f, 1e30f, 0.f);  // distance overflows to +inf
+    }
+    if (M > 1)
+        for (int j = lane; j < K; j += 64) const_cast<float4 *>(s_pal)[j] = pal.fcand[j];
+    for (int i = lane; i < 768; i += 64) s_coef[i] = vp.coef[i];
+    for (int i = lane; i < 256; i += 64) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
+    __syncthreads();
+
+    for (int y = 0; y < h; ++y) {
+        const bool rev = serp && (y & 1);
+        float e1x = 0.f, e1y = 0.f, e1z = 0.f;  // error of the previous pixel of this row
+        int row1 = 0;                            // ... and its table row
+        for (int step0 = 0; step0 < w; step0 += 64) {
+            // input + the two taps from the row above (sources in the reference's visiting order), lane-parallel
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+            if (step0 + lane < w) {
+                const int x = rev ? (w - 1 - (step0 + lane)) : (step0 + lane);
+                const uint8_t *px = fin + ((size_t)y * w + x) * 3;
+                p0 = (float)s_lut[px[0]];
+                p1 = (float)s_lut[px[1]];
+                p2 = (float)s_lut[px[2]];
+                if (y > 0) {
+                    const int sdir = (serp && ((y - 1) & 1)) ? -1 : 1;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int sxp = x - kOsDx[k] * sdir;
+                        if (sxp < 0 || sxp >= w) continue;
+                        const float4 e = s_err[(size_t)((y - 1) & 1) * w + sxp];
+                        const float wk = s_coef[3 * (int)e.w + kOsCol[k]];
+                        p0 = __fadd_rn(p0, __fmul_rn(e.x, wk));
+                        p1 = __fadd_rn(p1, __fmul_rn(e.y, wk));
+                        p2 = __fadd_rn(p2, __fmul_rn(e.z, wk));
+                    }
+                }
+            }
+            float my_e0 = 0.f, my_e1 = 0.f, my_e2 = 0.f, my_aux = 0.f;
+            uint32_t my_c = 0;
+            const int nstep = min(64, w - step0);
+            for (int i = 0; i < nstep; ++i) {
+                float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), i));
+                float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1), i));
+                float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2), i));
+                // same-row tap: the previous pixel (none at the start of a row: its error is 0, which adds nothing)
+                const float w1 = s_coef[3 * row1 + kOsCol[2]];
+                a0 = __fadd_rn(a0, __fmul_rn(e1x, w1));
+                a1 = __fadd_rn(a1, __fmul_rn(e1y, w1));
+                a2 = __fadd_rn(a2, __fmul_rn(e1z, w1));
+                const float o0 = clamp255f(a0), o1 = clamp255f(a1), o2 = clamp255f(a2);
+                float b0 = inf, b1 = inf;
+                int i0 = lane;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float da = pc[m].x - o0, db = pc[m].y - o1, dc = pc[m].z - o2;
+                    const float d = __fmaf_rn(da, da, __fmaf_rn(db, db, dc * dc));
+                    const bool lt0 = d < b0;
+                    b1 = lt0 ? b0 : (d < b1 ? d : b1);
+                    i0 = lt0 ? lane + 64 * m : i0;
+                    b0 = lt0 ? d : b0;
+                }
+                const float B0 = wave_min_to_all(b0);
+                const unsigned long long wm = __ballot(b0 == B0);
+                const int winner = __ffsll((long long)wm) - 1;
+                const float lim = B0 * 1.000002f;
+                const unsigned long long close = __ballot(b0 <= lim);
+                const bool near_tie = (close & (close - 1ull)) != 0ull || (M > 1 && __ballot(b1 <= lim) != 0ull);
+                int j = M == 1 ? winner : __builtin_amdgcn_readlane(i0, winner);
+                float cx, cy, cz;
+                uint32_t cw;
+                if (!near_tie && M == 1) {
+                    cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[0].x), winner));
+                    cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[0].y), winner));
+                    cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[0].z), winner));
+                    cw = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(pc[0].w), winner);
+                } else {
+                    if (near_tie) j = nearest_any_f64<CAP>(pal, o0, o1, o2);
+                    const float4 c = (M > 1 && !near_tie) ? s_pal[j] : pal.fcand[j];
+                    cx = c.x;
+                    cy = c.y;
+                    cz = c.z;
+                    cw = __float_as_uint(c.w);
+                }
+                const float ex = __fsub_rn(o0, cx), ey = __fsub_rn(o1, cy), ez = __fsub_rn(o2, cz);
+                float lum = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, o0), __fmul_rn(0.587f, o1)), __fmul_rn(0.114f, o2));
+                const int row = (int)clamp255f(lum);
+                if (lane == i) {
+                    my_e0 = ex;
+                    my_e1 = ey;
+                    my_e2 = ez;
+                    my_aux = (float)row;
+                    my_c = cw;
+                }
+                e1x = ex;
+                e1y = ey;
+                e1z = ez;
+                row1 = row;
+            }
+            if (lane < nstep) {
+                const int x = rev ? (w - 1 - (step0 + lane)) : (step0 + lane);
+                s_err[(size_t)(y & 1) * w + x] = make_float4(my_e0, my_e1, my_e2, my_aux);
+                uint8_t *o = fout + ((size_t)y * w + x) * 3;
+                o[0] = (uint8_t)my_c;
+                o[1] = (uint8_t)(my_c >> 8);
+                o[2] = (uint8_t)(my_c >> 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -548,6 +695,30 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
         else
             hipLaunchKernelGGL(var_wavefront_kernel<kQueueSmall>, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h,
                                w, pal, vp, reinterpret_cast<float *>(ws));
+        prof_end(pm, s);
+        DP_HIP(hipGetLastError());
+        return DP_OK;
+    }
+    if (model == 4 && n_frames <= 0x7fffffff &&
+        ((size_t)8 * w + 768) * sizeof(float) + (pal.K > 64 ? (size_t)pal.K * 16 : 0) + 512 <= (size_t)158 * 1024) {
+        // Ostromoukhov, serpentine: one wave per frame (two error rows + the coefficient table in LDS)
+        const size_t lds = ((size_t)8 * w + 768) * sizeof(float) + (pal.K > 64 ? (size_t)pal.K * 16 : 0);
+        const bool big = pal.n_inner > kQueueSmall;
+#define DP_OSR(C, MM)                                                                                                   \
+    do {                                                                                                               \
+        auto kern = os_rowserial_kernel<C, MM>;                                                                        \
+        DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                   (int)lds));                                                                         \
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_frames), dim3(64), lds, s, in, out, h, w, pal, vp);                   \
+    } while (0)
+        if (pal.K <= 64) {
+            if (big) DP_OSR(kQueueLarge, 1); else DP_OSR(kQueueSmall, 1);
+        } else if (pal.K <= 256) {
+            if (big) DP_OSR(kQueueLarge, 4); else DP_OSR(kQueueSmall, 4);
+        } else {
+            if (big) DP_OSR(kQueueLarge, 16); else DP_OSR(kQueueSmall, 16);
+        }
+#undef DP_OSR
         prof_end(pm, s);
         DP_HIP(hipGetLastError());
         return DP_OK;

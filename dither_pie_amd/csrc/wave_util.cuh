@@ -1,0 +1,33 @@
+// Wave-level helpers shared by the one-wave-per-frame (serpentine) kernels of ediff.hip and vardiff.hip.
+#pragma once
+#include "dp_internal.h"
+
+namespace dp {
+
+// Minimum of a non-negative float over the 64 lanes, returned to every lane.  Non-negative floats order like
+// their bit patterns, so the reduction runs on unsigned integers with one fused v_min_u32_dpp per step: inclusive
+// prefix minimum inside each row of 16 lanes (row_shr 1, 2, 4, 8), then row_bcast:15 / row_bcast:31 across the
+// rows; lane 63 ends up with the minimum.  A lane without a source, or outside the row mask, keeps its value.
+// (A VGPR written by a VALU instruction needs two wait states before a DPP read.)
+__device__ __forceinline__ float wave_min_to_all(const float vf)
+{
+    uint32_t v = __float_as_uint(vf);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, 63));
+}
+
+}  // namespace dp
