@@ -3,7 +3,9 @@ import sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
 from oracle import oracle as orc
 from dither_pie_amd import backend as be
-modes = ["none", "bayer", "blue_noise", "IGN", "polka_dot", "error_diffusion"]
+modes = ["none", "bayer", "blue_noise", "IGN", "polka_dot", "error_diffusion", "perceptual", "hybrid",
+         "adaptive_variance", "ostromoukhov"]
+DIFFUSERS = ("error_diffusion", "perceptual", "hybrid", "adaptive_variance", "ostromoukhov")
 
 
 def run(seed, N):
@@ -30,7 +32,11 @@ def run(seed, N):
           params = {"variant": str(rs.choice(["floyd_steinberg", "jjn", "stucki", "burkes", "atkinson", "sierra", "sierra_two_row", "sierra_lite"])),
                     "serpentine": str(rs.choice(["true", "false"]))}
           if h * w > 40000: h, w = 40, 300
-      y0, x0 = (0, 0) if mode == "error_diffusion" else (int(rs.randint(0, 50)), int(rs.randint(0, 50)))
+      if mode == "hybrid": params = {"lum_factor": float(rs.choice([1.0, 1.4, 0.3])), "col_factor": float(rs.choice([0.2, 0.0, 1.0]))}
+      if mode == "adaptive_variance": params = {"var_threshold": float(rs.choice([300.0, 50.0, 2000.0])), "window_radius": int(rs.randint(1, 4))}
+      if mode == "ostromoukhov": params = {"serpentine": str(rs.choice(["true", "false"]))}
+      if mode in DIFFUSERS and h * w > 40000: h, w = 40, 300
+      y0, x0 = (0, 0) if mode in DIFFUSERS else (int(rs.randint(0, 50)), int(rs.randint(0, 50)))
       frames = rs.randint(0, 256, (nf, h, w, 3)).astype(np.uint8)
       if rs.rand() < 0.5:  # tie-rich content: palette colours and midpoints
           pa = np.asarray(pal, dtype=np.int64)
@@ -46,11 +52,18 @@ def run(seed, N):
       elif mode == "polka_dot": out = be.ordered(x, P, be.MODE_MATRIX, thr=be.Thresholds.from_matrix(orc.polka_dot_matrix(p["tile_size"], p["gamma"])), y0=y0, x0=x0)
       elif mode == "blue_noise": out = be.ordered(x, P, be.MODE_MATRIX, thr=be.Thresholds.blue_noise(p["size"], p["seed"]), y0=y0, x0=x0)
       elif mode == "IGN": out = be.ordered(x, P, be.MODE_IGN, ign_scale=p["scale"], ign_seed=p["seed"], y0=y0, x0=x0)
-      else:
+      elif mode == "error_diffusion":
           taps, div = orc.ed_kernel(p["variant"]); out = be.error_diffusion(x, P, taps, div, p["serpentine"] == "true")
+      elif mode == "perceptual": out = be.variable_diffusion(x, P, be.DIFFUSER_PERCEPTUAL)
+      elif mode == "hybrid": out = be.variable_diffusion(x, P, be.DIFFUSER_HYBRID, p["lum_factor"], p["col_factor"])
+      elif mode == "adaptive_variance":
+          out = be.variable_diffusion(x, P, be.DIFFUSER_ADAPTIVE_VARIANCE, gate=be.variance_gate(x, P, p["var_threshold"], p["window_radius"]))
+      else:
+          out = be.variable_diffusion(x, P, be.DIFFUSER_OSTROMOUKHOV, serpentine=(p["serpentine"] == "true"),
+                                      coef=torch.from_numpy(orc.ostromoukhov_coefficients()).cuda())
       out = out.cpu().numpy()
       for i in range(nf):
-          ref = orc.apply_dithering(frames[i], pal, mode, params, gamma, y0=y0, x0=x0) if mode != "error_diffusion" else orc.apply_dithering(frames[i], pal, mode, params, gamma)
+          ref = orc.apply_dithering(frames[i], pal, mode, params, gamma, y0=y0, x0=x0) if mode not in DIFFUSERS else orc.apply_dithering(frames[i], pal, mode, params, gamma)
           if not np.array_equal(out[i], ref):
               bad += 1
               print("MISMATCH", it, mode, params, "K", K, "gamma", gamma, (nf, h, w), "y0x0", (y0, x0), "accel", P.accel_entries, int((out[i] != ref).any(-1).sum()), "px", flush=True)
