@@ -510,14 +510,22 @@ __global__ __launch_bounds__(64) void ed_rowserial_kernel(const uint8_t *__restr
         else if (taps.dx[k] == 2) w2 = taps.wq[k];
     }
 
+    // raw bytes of this lane's pixel in block (y, step0): loaded one block ahead of the walk
+    auto load_px = [&](const int y, const int step0) -> uint32_t {
+        const int step = step0 + lane;
+        if (y >= h || step >= w) return 0u;
+        const bool rv = serpentine && (y & 1);
+        const int x = rv ? (w - 1 - step) : step;
+        const uint8_t *px = fin + ((size_t)y * w + x) * 3;
+        return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+    };
     // value of pixel (y, step) before the same-row taps: input (through lut_in) + contributions of the rows above,
     // in the reference's order; `rev`: direction of row y
-    auto prepare = [&](const int y, const int step, const bool rev, float &p0, float &p1, float &p2) {
+    auto prepare = [&](const uint32_t raw, const int y, const int step, const bool rev, float &p0, float &p1, float &p2) {
         p0 = p1 = p2 = 0.f;
         if (y >= h || step >= w) return;
         const int x = rev ? (w - 1 - step) : step;
-        const uint8_t *px = fin + ((size_t)y * w + x) * 3;
-        float a0 = (float)s_lut[px[0]], a1 = (float)s_lut[px[1]], a2 = (float)s_lut[px[2]];
+        float a0 = (float)s_lut[raw & 255u], a1 = (float)s_lut[(raw >> 8) & 255u], a2 = (float)s_lut[raw >> 16];
         for (int k = 0; k < n_above; ++k) {
             const int sr = y - taps.dy[k];
             if (sr < 0) continue;
@@ -535,13 +543,16 @@ __global__ __launch_bounds__(64) void ed_rowserial_kernel(const uint8_t *__restr
         p2 = a2;
     };
 
+    uint32_t raw_next = load_px(0, 0);
     for (int y = 0; y < h; ++y) {
         const bool rev = serpentine && (y & 1);
         float e1x = 0.f, e1y = 0.f, e1z = 0.f, e2x = 0.f, e2y = 0.f, e2z = 0.f;  // errors of the previous two pixels
         for (int step0 = 0; step0 < w; step0 += 64) {
+            const uint32_t raw = raw_next;
+            raw_next = step0 + 64 < w ? load_px(y, step0 + 64) : load_px(y + 1, 0);  // in flight during the walk
             // rows above are complete (their LDS writes precede this point in program order)
             float p0, p1, p2;
-            prepare(y, step0 + lane, rev, p0, p1, p2);
+            prepare(raw, y, step0 + lane, rev, p0, p1, p2);
             float my_e0 = 0.f, my_e1 = 0.f, my_e2 = 0.f;
             uint32_t my_c = 0;
             const int nstep = min(64, w - step0);
