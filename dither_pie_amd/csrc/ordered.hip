@@ -846,6 +846,10 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
 // ---------------------------------------------------------------------------------------------
 constexpr int kFloatKeyGap = 128;
 
+struct alignas(16) Cand3 {  // the coordinates of a candidate record: one ds_read_b96
+    float x, y, z;
+};
+
 __device__ __forceinline__ int med3_i32(const int a, const int b, const int c)
 {
     int r;
@@ -862,9 +866,17 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
                                                                         const uint32_t n_tiles)
 {
     __shared__ __align__(16) uint32_t smem[kLeanLdsWords];
-    for (int i = threadIdx.x * 4; i < pal.ftab_words; i += kCellBlock * 4)
-        *reinterpret_cast<uint4 *>(&smem[i]) = *reinterpret_cast<const uint4 *>(&pal.ftab[i]);
     const uint32_t cand_base = (uint32_t)pal.ftab_words * 4u;  // bytes
+    // table words are byte offsets into the candidate table: make them absolute LDS addresses while copying
+    // (markers have bit 31 set and stay as they are)
+    for (int i = threadIdx.x * 4; i < pal.ftab_words; i += kCellBlock * 4) {
+        uint4 v = *reinterpret_cast<const uint4 *>(&pal.ftab[i]);
+        v.x += (v.x >> 31) ? 0u : cand_base;
+        v.y += (v.y >> 31) ? 0u : cand_base;
+        v.z += (v.z >> 31) ? 0u : cand_base;
+        v.w += (v.w >> 31) ? 0u : cand_base;
+        *reinterpret_cast<uint4 *>(&smem[i]) = v;
+    }
     const uint32_t lut_base = cand_base + (uint32_t)pal.K * 16u;
     for (int i = threadIdx.x; i < pal.K; i += kCellBlock)
         *reinterpret_cast<float4 *>(&smem[pal.ftab_words + 4 * i]) = pal.fcand[i];
@@ -925,20 +937,21 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
                 for (int bit = 3; (ca.x >> 31) != 0; --bit) {
                     if ((ca.x & 0x40000000u) || bit < 0) {
                         s = true;  // a single colour with more than 8 candidates: fix-up pass
-                        ca.x = 0u;
+                        ca = make_uint4(cand_base, cand_base, cand_base, cand_base);  // any valid entry
                         break;
                     }
                     const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
                     blk = (4096u * 8u + ((ca.x & 0xffffffu) * 8u + sub) * 8u) * 4u;
                     ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
                 }
-                const uint4 cb = *reinterpret_cast<const uint4 *>(s_bytes + blk + 16);
+                uint4 cb = *reinterpret_cast<const uint4 *>(s_bytes + blk + 16);
+                if (s && (ca.x == cand_base)) cb = ca;  // the block of a slow marker holds no offsets
                 const uint32_t off[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
                 const float fr = (float)r, fg = (float)gg, fb = (float)b;
                 int key[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float4 cc = *reinterpret_cast<const float4 *>(s_bytes + cand_base + (off[c] & 0xffffu));
+                    const Cand3 cc = *reinterpret_cast<const Cand3 *>(s_bytes + off[c]);  // x, y, z: 12 of the 16 bytes
                     const float dx = cc.x - fr, dy = cc.y - fg, dz = cc.z - fb;
                     const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     key[c] = (int)((__float_as_uint(d) & ~7u) | (uint32_t)c);
@@ -953,13 +966,13 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
                     m0 = min(m0, key[c]);
                 }
                 s |= (m1 - m0) <= kFloatKeyGap;
-                const uint32_t o0 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + 4u * ((uint32_t)m0 & 7u)) & 0xffffu;
-                const float4 c0 = *reinterpret_cast<const float4 *>(s_bytes + cand_base + o0);
+                const uint32_t o0 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + 4u * ((uint32_t)m0 & 7u));
+                const float4 c0 = *reinterpret_cast<const float4 *>(s_bytes + (s ? cand_base : o0));
                 uint32_t cpick = __float_as_uint(c0.w);
                 if (MODE != 0) {
                     s |= (m2 - m1) <= kFloatKeyGap;
-                    const uint32_t o1 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + 4u * ((uint32_t)m1 & 7u)) & 0xffffu;
-                    const float4 c1 = *reinterpret_cast<const float4 *>(s_bytes + cand_base + o1);
+                    const uint32_t o1 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + 4u * ((uint32_t)m1 & 7u));
+                    const float4 c1 = *reinterpret_cast<const float4 *>(s_bytes + (s ? cand_base : o1));
                     const double p0[3] = {(double)c0.x, (double)c0.y, (double)c0.z};
                     const double p1[3] = {(double)c1.x, (double)c1.y, (double)c1.z};
                     const double d0 = sq_dist3(p0, (double)r, (double)gg, (double)b);
