@@ -25,6 +25,8 @@
 //                "equal" is judged on the output colour, so duplicate palette entries never need the
 //                fix-up pass.  8 MB + 4 MB, touched only by tied pixels (~0.3 %).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "dp_internal.h"
@@ -262,6 +264,7 @@ constexpr int kTabCapWords = (160 * 1024 - 2048) / 4;  // LDS budget of the dith
 
 struct TableStats {
     int n_split = 0, n_slow = 0, max_cnt = 0;
+    int n_split_cells = 0;  // 16^3 cells that are split (the pixels of these cells leave the main path of the kernels)
     bool too_big = false;
 };
 
@@ -269,22 +272,24 @@ struct TableStats {
 // coord4[j]: integer coordinates r | g<<8 | b<<16 of entry j (used to choose padding entries); word[j]: what a
 // block stores for entry j.  box_masks(boxes, out) computes the membership masks (8 words each) of further boxes.
 template <class BoxMasks>
-int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int K, const std::vector<uint32_t> &coord4,
-                   const std::vector<uint32_t> &word, BoxMasks box_masks, std::vector<uint32_t> &tab, TableStats &st)
+int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int bw, const int K,
+                   const std::vector<uint32_t> &coord4, const std::vector<uint32_t> &word, BoxMasks box_masks,
+                   std::vector<uint32_t> &tab, TableStats &st)
 {
-    tab.assign((size_t)kCells * 8, 0u);
+    // bw: entries per block (8, or 4 for small palettes); a split node is 8 child blocks
+    tab.assign((size_t)kCells * bw, 0u);
     std::vector<int> list, extra;
     std::vector<uint64_t> dkey;
-    // members of a mask, padded to 8 with the unused entries nearest to (cr,cg,cb); false if > 8
+    // members of a mask, padded to bw with the unused entries nearest to (cr,cg,cb); false if more than bw
     auto make_block = [&](const uint32_t *mask, int cr, int cg, int cb, uint32_t *out8) {
         list.clear();
         extra.clear();
         for (int j = 0; j < K; ++j) ((mask[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
         st.max_cnt = std::max(st.max_cnt, (int)list.size());
-        if (list.size() > 8) return false;
-        if (list.size() < 8) {
-            // pad with the unused entries nearest to the centre (any real entry is harmless); at most 7 picks
-            const size_t need = 8 - list.size();
+        if (list.size() > (size_t)bw) return false;
+        if (list.size() < (size_t)bw) {
+            // pad with the unused entries nearest to the centre (any real entry is harmless)
+            const size_t need = (size_t)bw - list.size();
             dkey.resize(extra.size());
             for (size_t q = 0; q < extra.size(); ++q) {
                 const uint32_t c = coord4[extra[q]];
@@ -295,7 +300,7 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int K
             for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
             std::sort(list.begin(), list.end());  // key ties must break towards the lower palette index
         }
-        for (int i = 0; i < 8; ++i) out8[i] = word[list[i]];
+        for (int i = 0; i < bw; ++i) out8[i] = word[list[i]];
         return true;
     };
     // pending splits below the 8^3 level: (block position in tab, box) resolved level by level
@@ -308,21 +313,21 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int K
     // either from `child_masks` (8 x 8 words) or, if null, are requested for the next round
     auto split = [&](size_t pos, const Box &bx, const uint32_t *child_masks) {
         const size_t base = tab.size();
-        if (base + 64 > (size_t)kTabCapWords) {
+        if (base + 8 * (size_t)bw > (size_t)kTabCapWords) {
             st.too_big = true;
             return;
         }
-        tab.resize(base + 64, 0u);
-        tab[pos] = 0x80000000u | (uint32_t)((base - (size_t)kCells * 8) / 64);
+        tab.resize(base + 8 * (size_t)bw, 0u);
+        tab[pos] = 0x80000000u | (uint32_t)((base - (size_t)kCells * bw) / (8 * (size_t)bw));
         ++st.n_split;
         const int hs = bx.size / 2;
         for (int sidx = 0; sidx < 8; ++sidx) {
             Box c{bx.r0 + ((sidx >> 2) & 1) * hs, bx.g0 + ((sidx >> 1) & 1) * hs, bx.b0 + (sidx & 1) * hs, hs};
-            const size_t cpos = base + (size_t)sidx * 8;
+            const size_t cpos = base + (size_t)sidx * bw;
             if (child_masks) {
                 uint32_t blk[8];
                 if (make_block(child_masks + (size_t)mw * sidx, c.r0 + hs / 2, c.g0 + hs / 2, c.b0 + hs / 2, blk))
-                    std::copy(blk, blk + 8, tab.begin() + cpos);
+                    std::copy(blk, blk + bw, tab.begin() + cpos);
                 else
                     pending.push_back({cpos, c});
             } else {
@@ -335,10 +340,12 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int K
         const int r0 = (cell >> 8) * 16, g0 = ((cell >> 4) & 15) * 16, b0 = (cell & 15) * 16;
         uint32_t blk[8];
         const size_t slot = (size_t)cell_slot(cell >> 8, (cell >> 4) & 15, cell & 15);
-        if (make_block(m, r0 + 8, g0 + 8, b0 + 8, blk))
-            std::copy(blk, blk + 8, tab.begin() + slot * 8);
-        else
-            split(slot * 8, Box{r0, g0, b0, 16}, m + mw);
+        if (make_block(m, r0 + 8, g0 + 8, b0 + 8, blk)) {
+            std::copy(blk, blk + bw, tab.begin() + slot * bw);
+        } else {
+            split(slot * bw, Box{r0, g0, b0, 16}, m + mw);
+            ++st.n_split_cells;
+        }
     }
     // deeper levels: boxes that still hold more than 8 members are split again; a single colour that still
     // overflows is left to the fix-up pass
@@ -368,7 +375,7 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int K
             const Box &c = kids[q].box;
             uint32_t blk[8];
             if (make_block(&bm[q * (size_t)mw], c.r0 + c.size / 2, c.g0 + c.size / 2, c.b0 + c.size / 2, blk))
-                std::copy(blk, blk + 8, tab.begin() + kids[q].pos);
+                std::copy(blk, blk + bw, tab.begin() + kids[q].pos);
             else
                 pending.push_back(kids[q]);
         }
@@ -410,8 +417,8 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     uint8_t *blob = nullptr;
     const int mw = K <= 256 ? 8 : 32;               // mask words per (sub-)cell
     const bool big_q = dev.n_inner > kQueueSmall;   // traversal queue of the tie queries
-    // layout: code1 | code2 | table[cap] | exceptions | exception count
-    const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16;
+    // layout: code1 | code2 | table[cap] | exceptions | exception count | table of 4-entry blocks [cap]
+    const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + 2 * kTabCapWords) + sizeof(uint4) * kExcCap + 16;
     DP_HIP(hipMalloc((void **)&blob, bytes));
     hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 9 * mw);
     if (e == hipSuccess) e = hipMemset(blob, 0, sizeof(uint32_t) * 3 * kCodeWords);
@@ -449,8 +456,33 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
 
     std::vector<uint32_t> tab;
     TableStats st;
+    auto box_masks = [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
+        return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
+            if (mw == 8) hipLaunchKernelGGL(accel_box_kernel<8>, dim3(n), dim3(64), 0, 0, dev, db, dm);
+            else hipLaunchKernelGGL(accel_box_kernel<32>, dim3(n), dim3(64), 0, 0, dev, db, dm);
+        });
+    };
+    // small palettes: most cells hold at most 4 candidates; a table of 4-entry blocks halves the work of the dither
+    // kernel as long as few cells overflow into splits (their pixels take the deferred path)
+    std::vector<uint32_t> tab4;
+    TableStats st4;
+    bool use4 = false;
+    if (K <= 64) {
+        const int rc4 = assemble_table(masks, mw, 4, K, p4_host, p4_host, box_masks, tab4, st4);
+        if (rc4 != DP_OK) {
+            (void)hipFree(blob);
+            return rc4;
+        }
+        // worth it while few pixels fall into split cells (they take the deferred path): up to 4 % of the cells.
+        // Single colours with more than 4 equidistant entries (marked slow; uniform grids have them) are resolved by
+        // the deferred path with a scan of the whole (small) palette.
+        use4 = !st4.too_big && st4.n_split_cells <= kCells * 4 / 100;
+        if (getenv("DP_DEBUG_ACCEL"))
+            fprintf(stderr, "accel K=%d: 4-entry table: %d split cells, %d split nodes, %d slow, %zu words, too_big=%d -> use=%d\n", K,
+                    st4.n_split_cells, st4.n_split, st4.n_slow, tab4.size(), (int)st4.too_big, (int)use4);
+    }
     const int rc = assemble_table(
-        masks, mw, K, p4_host, p4_host,
+        masks, mw, 8, K, p4_host, p4_host,
         [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
             return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
                 if (mw == 8) hipLaunchKernelGGL(accel_box_kernel<8>, dim3(n), dim3(64), 0, 0, dev, db, dm);
@@ -473,6 +505,19 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     }
     dev.cell_tab = d_tab;
     dev.tab_words = (int)tab.size();
+    dev.cell_tab4 = nullptr;
+    dev.tab4_words = 0;
+    if (use4) {
+        uint32_t *d_tab4 = d_exc_count + 4;
+        e = hipMemcpy(d_tab4, tab4.data(), sizeof(uint32_t) * tab4.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            dev.cell_tab = nullptr;
+            (void)hipFree(blob);
+            return hip_fail(e, "accelerator upload");
+        }
+        dev.cell_tab4 = d_tab4;
+        dev.tab4_words = (int)tab4.size();
+    }
     dev.n_split = st.n_split;
     dev.n_slow_blocks = st.n_slow;
     dev.max_cell = st.max_cnt;
@@ -548,7 +593,7 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
     std::vector<uint32_t> tab;
     TableStats st;
     const int rc = assemble_table(
-        masks, 8, K, coord4, word,
+        masks, 8, 8, K, coord4, word,
         [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
             return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
                 hipLaunchKernelGGL(accel_box_float_kernel, dim3(n), dim3(64), 0, 0, dev, d_reach, db, dm);

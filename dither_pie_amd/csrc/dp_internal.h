@@ -61,6 +61,10 @@ struct PalDev {
                                 // then [n_split][8 sub-cells][8]; word 0 of a block with bit 31 set is a marker:
                                 // 0x80000000|split index (cell is split) or 0xC0000000 (resolve in the fix-up pass)
     int tab_words;
+    // small palettes: the same table with 4-entry blocks (16 bytes per cell), nullptr when too many cells overflow;
+    // the lean kernel prefers it (half the candidate work)
+    const uint32_t *cell_tab4;
+    int tab4_words;
     int n_split;
     int n_slow_blocks;
     int max_cell;

@@ -358,6 +358,46 @@ __device__ __forceinline__ uint32_t cell_offset(const uint32_t x)
     return (y >> 11) & 0x1ffe0u;
 }
 
+// the same for the table of 4-entry blocks (16 bytes per cell)
+__device__ __forceinline__ uint32_t cell_offset4(const uint32_t x)
+{
+    const uint32_t t = x & 0xf0f0f0u;
+    const uint32_t y = t | (t << 12);
+    return (y >> 12) & 0xfff0u;
+}
+
+// Keys of the 4 candidates of a small block and the three smallest (see cand8)
+__device__ __forceinline__ void cand4(const uint32_t x, const uint4 ca, const int neg2, int &m0, int &m1, int &m2)
+{
+    int n0, n1, n2, n3, p0, p1, p2, p3;
+    asm volatile(
+        "v_dot4_u32_u8 %[n0], %[c0], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[p0], %[x], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[n1], %[c1], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[p1], %[x], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[n2], %[c2], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[p2], %[x], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[n3], %[c3], %[c3], 0\n\t"
+        "v_dot4_u32_u8 %[p3], %[x], %[c3], 0\n\t"
+        "v_lshl_add_u32 %[n0], %[n0], 8, 0\n\t"
+        "v_lshl_add_u32 %[n1], %[n1], 8, 4\n\t"
+        "v_lshl_add_u32 %[n2], %[n2], 8, 8\n\t"
+        "v_lshl_add_u32 %[n3], %[n3], 8, 12\n\t"
+        "v_mad_i32_i24 %[n0], %[p0], %[ng], %[n0]\n\t"
+        "v_mad_i32_i24 %[n1], %[p1], %[ng], %[n1]\n\t"
+        "v_mad_i32_i24 %[n2], %[p2], %[ng], %[n2]\n\t"
+        "v_mad_i32_i24 %[n3], %[p3], %[ng], %[n3]\n\t"
+        "v_min3_i32 %[m0], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[n0], %[n1], %[n2]\n\t"
+        "v_max3_i32 %[m2], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n3]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n3]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n3]\n\t"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2),
+          [p3] "=&v"(p3), [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2)
+        : [x] "v"(x), [c0] "v"(ca.x), [c1] "v"(ca.y), [c2] "v"(ca.z), [c3] "v"(ca.w), [ng] "s"(neg2));
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kCellBlock) void ordered_cell_kernel(const uint8_t *__restrict__ in,
                                                                   uint8_t *__restrict__ out,
@@ -592,7 +632,7 @@ __device__ __forceinline__ bool lean_decide(const uint32_t d0, const uint32_t S,
 }
 
 // Complete handling of one pixel (split cells, tie codes, the float64 replay, fix-up flags).
-template <int MODE>
+template <int MODE, int BW>  // BW: entries per block of the table in LDS (8, or 4: pal.cell_tab4)
 __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t *__restrict__ in,
                                                 uint8_t *__restrict__ out, unsigned long long *__restrict__ flags,
                                                 const Geo &g, const PalDev &pal, const ThrDev &thr,
@@ -601,40 +641,70 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_words);
     const uint8_t *b = in + (size_t)p * 3;
     const uint32_t x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
-    uint32_t blk = cell_offset(x);
+    uint32_t blk = BW == 8 ? cell_offset(x) : cell_offset4(x);
     uint4 ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
-    bool slow = false;
+    bool slow = false, scan = false;
     // split cells: descend by one colour bit per level
     for (int bit = 3; (ca.x >> 31) != 0; --bit) {
         if ((ca.x & 0x40000000u) || bit < 0) {
-            slow = true;  // a single colour with more than 8 candidates: fix-up pass
+            // a single colour with more candidates than a block holds: fix-up pass, or (small palettes) a scan
+            if (BW == 4) scan = true;
+            else slow = true;
             break;
         }
         const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
-        blk = (4096u * 8u + ((ca.x & 0xffffffu) * 8u + sub) * 8u) * 4u;
+        blk = (4096u * BW + ((ca.x & 0xffffffu) * 8u + sub) * BW) * 4u;
         ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
     }
-    const uint4 cb = *reinterpret_cast<const uint4 *>(s_bytes + blk + 16);
-    int m0, m1, m2;
-    cand8(x, ca, cb, g.neg2, m0, m1, m2);
-    const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits, a2 = m2 >> kLocalBits;
-    int sel;
-    bool have_c = false;
-    uint32_t c = 0, exc_pair = 0;
+    // the three nearest: distances (minus |x|^2) a0 <= a1 <= a2 and their colours, ordered by (distance, palette index)
+    int a0, a1, a2;
+    uint32_t c0, c1, c2;
+    if (BW == 4 && scan) {
+        constexpr int kBig = 0x7fffffff;
+        int m0 = kBig, m1 = kBig, m2 = kBig;
+        for (int j = 0; j < pal.K; ++j) {
+            const int dot = (int)__builtin_amdgcn_udot4(x, pal.p4[j], 0u, false);
+            const int key = pal.nkey[j] - (dot << (kIdxBits + 1));  // ((|p|^2 - 2 x.p) << kIdxBits) | j
+            const int n2 = med3i(m1, m2, key);
+            const int n1 = med3i(m0, m1, key);
+            m0 = min(m0, key);
+            m1 = n1;
+            m2 = n2;
+        }
+        constexpr int IM = (1 << kIdxBits) - 1;
+        a0 = m0 >> kIdxBits;
+        a1 = m1 >> kIdxBits;
+        a2 = m2 >> kIdxBits;
+        c0 = pal.out_rgb[m0 & IM];
+        c1 = pal.out_rgb[m1 & IM];
+        c2 = pal.K > 2 ? pal.out_rgb[m2 & IM] : c1;
+        if (pal.K < 3) a2 = kBig;
+    } else {
+        int m0, m1, m2;
+        if (BW == 8) {
+            const uint4 cb = *reinterpret_cast<const uint4 *>(s_bytes + blk + 16);
+            cand8(x, ca, cb, g.neg2, m0, m1, m2);
+        } else {
+            cand4(x, ca, g.neg2, m0, m1, m2);
+        }
+        a0 = m0 >> kLocalBits;
+        a1 = m1 >> kLocalBits;
+        a2 = m2 >> kLocalBits;
+        c0 = *reinterpret_cast<const uint32_t *>(s_bytes + (blk | ((uint32_t)m0 & 0xfcu)));
+        c1 = *reinterpret_cast<const uint32_t *>(s_bytes + (blk | ((uint32_t)m1 & 0xfcu)));
+        c2 = *reinterpret_cast<const uint32_t *>(s_bytes + (blk | ((uint32_t)m2 & 0xfcu)));
+    }
+    uint32_t c;
     if (MODE == 0) {
-        sel = m0;
+        c = c0;
         if (a0 == a1) {
             const uint32_t code = (pal.code1[x >> 4] >> ((x & 15u) * 2)) & 3u;
-            if (code == 1) sel = m1;
-            else if (code == 2) sel = m2;
+            if (code == 1) c = c1;
+            else if (code == 2) c = c2;
             else if (code == 3) {
                 uint32_t pair, single;
-                if (find_exception(pal, x, pair, single)) {
-                    have_c = true;
-                    c = pal.out_rgb[single];
-                } else {
-                    slow = true;
-                }
+                if (find_exception(pal, x, pair, single)) c = pal.out_rgb[single];
+                else slow = true;
             }
         }
     } else {
@@ -659,29 +729,27 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
         const uint32_t d0 = (uint32_t)(a0 + xx), d1 = (uint32_t)(a1 + xx);
         bool eq;
         bool nearest = lean_decide<MODE>(d0, d0 + d1, th, thr.sh, eq);
-        int sa = m0, sb = m1;
+        uint32_t ca_ = c0, cb_ = c1;  // reported nearest / second
         if (a0 == a1 || a1 == a2) {
             const uint32_t code = (pal.code2[x >> 3] >> ((x & 7u) * 4)) & 15u;
-            if (code == 1) { sa = m1; sb = m0; }
-            else if (code == 2) { sb = m2; }
-            else if (code == 3) { sa = m2; sb = m0; }
-            else if (code == 4) { sa = m1; sb = m2; }
-            else if (code == 5) { sa = m2; sb = m1; }
+            if (code == 1) { ca_ = c1; cb_ = c0; }
+            else if (code == 2) { cb_ = c2; }
+            else if (code == 3) { ca_ = c2; cb_ = c0; }
+            else if (code == 4) { ca_ = c1; cb_ = c2; }
+            else if (code == 5) { ca_ = c2; cb_ = c1; }
             else if (code != 0u) {
                 uint32_t pair, single;
                 if (find_exception(pal, x, pair, single)) {
-                    have_c = true;
-                    exc_pair = pair;
+                    ca_ = pal.out_rgb[pair & 0xffffu];
+                    cb_ = pal.out_rgb[pair >> 16];
                 } else {
                     slow = true;
                 }
             }
         }
         if (eq) nearest = ordered_use_nearest((double)d0, (double)d1, th.t);  // the literal float64 chain decides
-        sel = nearest ? sa : sb;
-        if (have_c) c = pal.out_rgb[nearest ? (exc_pair & 0xffffu) : (exc_pair >> 16)];
+        c = nearest ? ca_ : cb_;
     }
-    if (!have_c) c = *reinterpret_cast<const uint32_t *>(s_bytes + (blk | ((uint32_t)sel & 0xfcu)));
     uint8_t *o = out + (size_t)p * 3;
     o[0] = (uint8_t)c;
     o[1] = (uint8_t)(c >> 8);
@@ -695,7 +763,7 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     }
 }
 
-template <int MODE>
+template <int MODE, int BW>
 __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t *__restrict__ in,
                                                                   uint8_t *__restrict__ out,
                                                                   unsigned long long *__restrict__ flags,
@@ -748,9 +816,9 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
             uint4 ca[4], cb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                blk[q] = cell_offset(xq[q]);
+                blk[q] = BW == 8 ? cell_offset(xq[q]) : cell_offset4(xq[q]);
                 ca[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q]);
-                cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
+                if (BW == 8) cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
             }
             LeanThr th[4];
 #pragma unroll
@@ -778,7 +846,8 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
             for (int q = 0; q < 4; ++q) {
                 const uint32_t x = xq[q];
                 int m0, m1, m2;
-                cand8(x, ca[q], cb[q], g.neg2, m0, m1, m2);
+                if (BW == 8) cand8(x, ca[q], cb[q], g.neg2, m0, m1, m2);
+                else cand4(x, ca[q], g.neg2, m0, m1, m2);
                 const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits;
                 const bool tie = (a0 == a1) | ((uint32_t)(m1 ^ m2) < (1u << kLocalBits));  // also: any split cell
                 int sel;
@@ -816,7 +885,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                 if (qcount >= 64u) {
                     qcount -= 64u;
                     __threadfence_block();  // the queue writes, and the group stores that are about to be overwritten
-                    lean_pixel_full<MODE>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
+                    lean_pixel_full<MODE, BW>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
                 }
             }
         }
@@ -830,7 +899,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
     }
     if (qcount != 0u) {
         __threadfence_block();
-        if (lane < qcount) lean_pixel_full<MODE>(s_queue[lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
+        if (lane < qcount) lean_pixel_full<MODE, BW>(s_queue[lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
     }
 }
 
@@ -1373,7 +1442,20 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             const bool lean_geo = g.aligned && (size_t)pal.tab_words * 4 <= (size_t)kLeanTabBytes && y0 >= 0 && x0 >= 0;
             const bool int_lean = thr.mpad != nullptr &&
                                   (size_t)pal.tab_words * 4 + (size_t)thr.th_h * thr.tw_pad * 4 <= (size_t)kLeanTabBytes;
-#define DP_LEAN(M) hipLaunchKernelGGL(ordered_lean_kernel<M>, dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles)
+            // small palettes: the table of 4-entry blocks when the accelerator built one
+            PalDev pal4 = pal;
+            pal4.cell_tab = pal.cell_tab4;
+            pal4.tab_words = pal.tab4_words;
+            const bool small = pal.cell_tab4 != nullptr;
+#define DP_LEAN(M)                                                                                                        \
+    do {                                                                                                                 \
+        if (small)                                                                                                       \
+            hipLaunchKernelGGL((ordered_lean_kernel<M, 4>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, \
+                               sx, sy, ign_scale, n_tiles);                                                              \
+        else                                                                                                             \
+            hipLaunchKernelGGL((ordered_lean_kernel<M, 8>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr,  \
+                               sx, sy, ign_scale, n_tiles);                                                              \
+    } while (0)
             if (lean_geo && mode == DP_MODE_NEAREST) {
                 DP_LEAN(0);
                 rc = DP_OK;

@@ -426,3 +426,28 @@ def test_randomised_cases_against_oracle(be, orc, seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(seed, 150) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [8, 16, 27, 64])
+@pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "4x4"}), ("IGN", {})])
+def test_small_palettes_four_entry_blocks(be, orc, K, mode, params):
+    """Palettes of up to 64 colours get a table of 4-entry blocks when few cells overflow.  Uniform grids are the
+    hard case: colours equidistant from many entries (cube centres, face centres) overflow any block and are
+    resolved by a scan of the whole palette inside the deferred path.  Frames mix noise with exactly such points."""
+    pal = orc.generate_uniform_palette(K)
+    pa = np.asarray(pal, dtype=np.int64)
+    rs = np.random.RandomState(K)
+    h, w = 300, 404
+    arr = orc.rnd(h, w, K)
+    i, j, k = rs.randint(0, len(pal), (3, h, w))
+    mid2 = ((pa[i] + pa[j]) // 2).astype(np.uint8)
+    mid3 = ((pa[i] + pa[j] + pa[k]) // 3).astype(np.uint8)
+    cube = np.clip((pa[i] + 43) - (pa[i] + 43) % 85 + 42, 0, 255).astype(np.uint8)
+    pick = rs.randint(0, 4, (h, w, 1))
+    arr = np.where(pick == 0, mid2, np.where(pick == 1, mid3, np.where(pick == 2, cube, arr)))
+    out = _run_case(be, orc, arr, pal, mode, params, False, y0=1, x0=2)
+    _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False, y0=1, x0=2), f"uniform{K} {mode}")
+    pal2 = orc.palr(K, seed=K + 1)  # random palette of the same size
+    out = _run_case(be, orc, arr, pal2, mode, params, False)
+    _assert_same(out, orc.apply_dithering(arr, pal2, mode, params, False), f"random{K} {mode}")
