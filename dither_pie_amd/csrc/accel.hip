@@ -481,30 +481,32 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
             fprintf(stderr, "accel K=%d: 4-entry table: %d split cells, %d split nodes, %d slow, %zu words, too_big=%d -> use=%d\n", K,
                     st4.n_split_cells, st4.n_split, st4.n_slow, tab4.size(), (int)st4.too_big, (int)use4);
     }
-    const int rc = assemble_table(
-        masks, mw, 8, K, p4_host, p4_host,
-        [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
-            return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
-                if (mw == 8) hipLaunchKernelGGL(accel_box_kernel<8>, dim3(n), dim3(64), 0, 0, dev, db, dm);
-                else hipLaunchKernelGGL(accel_box_kernel<32>, dim3(n), dim3(64), 0, 0, dev, db, dm);
-            });
-        },
-        tab, st);
-    if (rc != DP_OK) {
-        (void)hipFree(blob);
-        return rc;
+    // the table of 8-entry blocks (palettes of fewer than 8 colours cannot fill a block: 4-entry blocks only)
+    const bool have8 = K >= 8;
+    if (have8) {
+        const int rc = assemble_table(masks, mw, 8, K, p4_host, p4_host, box_masks, tab, st);
+        if (rc != DP_OK) {
+            (void)hipFree(blob);
+            return rc;
+        }
     }
-    if (st.too_big) {
+    if ((!have8 || st.too_big) && !use4) {
         (void)hipFree(blob);
-        return DP_OK;  // table would not fit in LDS: the brute-force kernel stays in charge
+        return DP_OK;  // no table that fits LDS: the brute-force kernel stays in charge
     }
-    e = hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipFree(blob);
-        return hip_fail(e, "accelerator upload");
+    dev.cell_tab = nullptr;
+    dev.tab_words = 0;
+    if (have8 && !st.too_big) {
+        e = hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(blob);
+            return hip_fail(e, "accelerator upload");
+        }
+        dev.cell_tab = d_tab;
+        dev.tab_words = (int)tab.size();
+    } else {
+        st = st4;  // statistics of the table in use
     }
-    dev.cell_tab = d_tab;
-    dev.tab_words = (int)tab.size();
     dev.cell_tab4 = nullptr;
     dev.tab4_words = 0;
     if (use4) {

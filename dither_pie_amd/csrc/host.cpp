@@ -355,7 +355,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     p->accel_bytes = 0;
     p->accel_tried = false;
     p->p4_host = p4;
-    p->same_out = integer && K >= 8 && K <= DP_MAX_COLORS;  // what the accelerator handles
+    p->same_out = integer && K >= 4 && K <= DP_MAX_COLORS;  // what the accelerator handles
     for (int j = 0; j < K && p->same_out; ++j) p->same_out = (orgb[j] == p4[j]);
     // float palettes (use_gamma): coordinates within [0, 255], as the reference's clip guarantees
     p->float_accel = !integer && K >= 8 && K <= 256;
@@ -418,8 +418,10 @@ int dp_palette_accel_info(const dp_palette *p, int *pool_entries, int *max_cell)
         set_error("dp_palette_accel_info: NULL palette");
         return DP_EINVAL;
     }
-    if (pool_entries) *pool_entries = p->dev.cell_tab ? p->dev.tab_words : (p->dev.ftab ? p->dev.ftab_words : 0);
-    if (max_cell) *max_cell = (p->dev.cell_tab || p->dev.ftab) ? p->dev.max_cell : 0;
+    if (pool_entries)
+        *pool_entries = p->dev.cell_tab ? p->dev.tab_words
+                                        : (p->dev.cell_tab4 ? p->dev.tab4_words : (p->dev.ftab ? p->dev.ftab_words : 0));
+    if (max_cell) *max_cell = (p->dev.cell_tab || p->dev.cell_tab4 || p->dev.ftab) ? p->dev.max_cell : 0;
     return DP_OK;
 }
 

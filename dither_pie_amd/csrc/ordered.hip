@@ -1427,7 +1427,15 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         int fix_mode;
         ProfMark *pm = prof_begin(s);
         const bool int_thr_ok = thr.m != nullptr && thr.th_h * thr.th_w <= 256;
-        if (integer && pal.cell_tab != nullptr) {
+        // the table the lean kernels would stage: 4-entry blocks when the accelerator built them, else 8-entry blocks
+        const bool small = pal.cell_tab4 != nullptr;
+        const size_t lean_tab_bytes = 4 * (size_t)(small ? pal.tab4_words : pal.tab_words);
+        const bool lean_geo = integer && (small || pal.cell_tab != nullptr) && g.aligned && y0 >= 0 && x0 >= 0 &&
+                              lean_tab_bytes <= (size_t)kLeanTabBytes;
+        const bool int_lean = thr.mpad != nullptr && lean_tab_bytes + (size_t)thr.th_h * thr.tw_pad * 4 <= (size_t)kLeanTabBytes;
+        const bool lean_ok = lean_geo && (mode == DP_MODE_NEAREST || mode == DP_MODE_IGN ||
+                                          (mode == DP_MODE_MATRIX && (int_lean || thr.fpad != nullptr)));
+        if (integer && (lean_ok || pal.cell_tab != nullptr)) {
             // fast path: LDS cell table + tie codes, persistent 1024-lane workgroups over 4096-pixel tiles
             const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
             n_words = n_tiles * (kCellBlock / 64) * 4;
@@ -1439,14 +1447,9 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
                 g.adv_x = (uint32_t)(adv % (uint64_t)w);
             }
             int rc;
-            const bool lean_geo = g.aligned && (size_t)pal.tab_words * 4 <= (size_t)kLeanTabBytes && y0 >= 0 && x0 >= 0;
-            const bool int_lean = thr.mpad != nullptr &&
-                                  (size_t)pal.tab_words * 4 + (size_t)thr.th_h * thr.tw_pad * 4 <= (size_t)kLeanTabBytes;
-            // small palettes: the table of 4-entry blocks when the accelerator built one
             PalDev pal4 = pal;
             pal4.cell_tab = pal.cell_tab4;
             pal4.tab_words = pal.tab4_words;
-            const bool small = pal.cell_tab4 != nullptr;
 #define DP_LEAN(M)                                                                                                        \
     do {                                                                                                                 \
         if (small)                                                                                                       \

@@ -429,13 +429,14 @@ def test_randomised_cases_against_oracle(be, orc, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K", [8, 16, 27, 64])
+@pytest.mark.parametrize("K", [4, 5, 7, 8, 16, 27, 64])
 @pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "4x4"}), ("IGN", {})])
 def test_small_palettes_four_entry_blocks(be, orc, K, mode, params):
     """Palettes of up to 64 colours get a table of 4-entry blocks when few cells overflow.  Uniform grids are the
     hard case: colours equidistant from many entries (cube centres, face centres) overflow any block and are
     resolved by a scan of the whole palette inside the deferred path.  Frames mix noise with exactly such points."""
-    pal = orc.generate_uniform_palette(K)
+    pal = orc.generate_uniform_palette(K) if K >= 8 else [(0, 0, 0), (255, 255, 255), (255, 0, 0), (0, 255, 0), (0, 0, 255),
+                                                           (128, 128, 128), (64, 64, 64)][:K]
     pa = np.asarray(pal, dtype=np.int64)
     rs = np.random.RandomState(K)
     h, w = 300, 404
