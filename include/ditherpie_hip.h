@@ -66,7 +66,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
 void dp_palette_destroy(dp_palette *p);
 int dp_palette_info(const dp_palette *p, int *K, int *is_integer, int *n_nodes);
 /* Search accelerator (accel.hip): per-cell candidate lists kept in LDS by the dither kernels; for integer
- * palettes (8..1024 colours whose output colours are the palette colours) also per-colour tie codes and an
+ * palettes (4..1024 colours whose output colours are the palette colours) also per-colour tie codes and an
  * exception list, so that scipy's tie order needs no tree traversal; float palettes (use_gamma, 8..256
  * colours) get the same table over the lut_in-mapped pixel values.  Building it scans all 2^24 colours once
  * (a few milliseconds to tens of milliseconds, synchronous), which pays off from a few megapixels on; without
