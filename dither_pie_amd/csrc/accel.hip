@@ -261,6 +261,9 @@ namespace {
 
 constexpr int kCells = 4096;
 constexpr int kTabCapWords = (160 * 1024 - 2048) / 4;  // LDS budget of the dither kernels
+constexpr int kTabMaxWords = 1 << 20;                 // largest table built (4 MB); what exceeds LDS stays in global memory
+// words the lean kernels stage when the table is larger than LDS: the 4096 cell blocks + the first split nodes
+constexpr int kTabStageWords = 4096 * 8 + 88 * 64;
 
 struct TableStats {
     int n_split = 0, n_slow = 0, max_cnt = 0;
@@ -272,7 +275,7 @@ struct TableStats {
 // coord4[j]: integer coordinates r | g<<8 | b<<16 of entry j (used to choose padding entries); word[j]: what a
 // block stores for entry j.  box_masks(boxes, out) computes the membership masks (8 words each) of further boxes.
 template <class BoxMasks>
-int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int bw, const int K,
+int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int bw, const int cap_words, const int K,
                    const std::vector<uint32_t> &coord4, const std::vector<uint32_t> &word, BoxMasks box_masks,
                    std::vector<uint32_t> &tab, TableStats &st)
 {
@@ -313,7 +316,7 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int b
     // either from `child_masks` (8 x 8 words) or, if null, are requested for the next round
     auto split = [&](size_t pos, const Box &bx, const uint32_t *child_masks) {
         const size_t base = tab.size();
-        if (base + 8 * (size_t)bw > (size_t)kTabCapWords) {
+        if (base + 8 * (size_t)bw > (size_t)cap_words) {
             st.too_big = true;
             return;
         }
@@ -418,7 +421,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     const int mw = K <= 256 ? 8 : 32;               // mask words per (sub-)cell
     const bool big_q = dev.n_inner > kQueueSmall;   // traversal queue of the tie queries
     // layout: code1 | code2 | table[cap] | exceptions | exception count | table of 4-entry blocks [cap]
-    const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + 2 * kTabCapWords) + sizeof(uint4) * kExcCap + 16;
+    const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + kTabMaxWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16;
     DP_HIP(hipMalloc((void **)&blob, bytes));
     hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 9 * mw);
     if (e == hipSuccess) e = hipMemset(blob, 0, sizeof(uint32_t) * 3 * kCodeWords);
@@ -430,7 +433,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     uint32_t *code1 = reinterpret_cast<uint32_t *>(blob);
     uint32_t *code2 = code1 + kCodeWords;
     uint32_t *d_tab = code2 + 2 * kCodeWords;
-    uint4 *d_exc = reinterpret_cast<uint4 *>(d_tab + kTabCapWords);  // 16-byte aligned: every part is a multiple of 16
+    uint4 *d_exc = reinterpret_cast<uint4 *>(d_tab + kTabMaxWords);  // 16-byte aligned: every part is a multiple of 16
     uint32_t *d_exc_count = reinterpret_cast<uint32_t *>(d_exc + kExcCap);
     e = hipMemset(d_exc_count, 0, sizeof(uint32_t));
     if (e != hipSuccess) {
@@ -468,7 +471,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     TableStats st4;
     bool use4 = false;
     if (K <= 64) {
-        const int rc4 = assemble_table(masks, mw, 4, K, p4_host, p4_host, box_masks, tab4, st4);
+        const int rc4 = assemble_table(masks, mw, 4, kTabCapWords, K, p4_host, p4_host, box_masks, tab4, st4);
         if (rc4 != DP_OK) {
             (void)hipFree(blob);
             return rc4;
@@ -484,11 +487,15 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     // the table of 8-entry blocks (palettes of fewer than 8 colours cannot fill a block: 4-entry blocks only)
     const bool have8 = K >= 8;
     if (have8) {
-        const int rc = assemble_table(masks, mw, 8, K, p4_host, p4_host, box_masks, tab, st);
+        const int rc = assemble_table(masks, mw, 8, kTabMaxWords, K, p4_host, p4_host, box_masks, tab, st);
         if (rc != DP_OK) {
             (void)hipFree(blob);
             return rc;
         }
+        if (getenv("DP_DEBUG_ACCEL"))
+            fprintf(stderr, "accel K=%d: 8-entry table: %d split cells, %d split nodes, %d slow, %zu words (%s), longest list %d, too_big=%d\n",
+                    K, st.n_split_cells, st.n_split, st.n_slow, tab.size(), tab.size() <= (size_t)kTabCapWords ? "all in LDS" : "deep nodes in global memory",
+                    st.max_cnt, (int)st.too_big);
     }
     if ((!have8 || st.too_big) && !use4) {
         (void)hipFree(blob);
@@ -496,6 +503,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     }
     dev.cell_tab = nullptr;
     dev.tab_words = 0;
+    dev.tab_total = 0;
     if (have8 && !st.too_big) {
         e = hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -503,7 +511,8 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
             return hip_fail(e, "accelerator upload");
         }
         dev.cell_tab = d_tab;
-        dev.tab_words = (int)tab.size();
+        dev.tab_total = (int)tab.size();
+        dev.tab_words = tab.size() <= (size_t)kTabCapWords ? (int)tab.size() : std::min((int)tab.size(), kTabStageWords);
     } else {
         st = st4;  // statistics of the table in use
     }
@@ -595,7 +604,7 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
     std::vector<uint32_t> tab;
     TableStats st;
     const int rc = assemble_table(
-        masks, 8, 8, K, coord4, word,
+        masks, 8, 8, kTabCapWords, K, coord4, word,
         [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
             return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
                 hipLaunchKernelGGL(accel_box_float_kernel, dim3(n), dim3(64), 0, 0, dev, d_reach, db, dm);

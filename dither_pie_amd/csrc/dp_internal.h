@@ -60,7 +60,9 @@ struct PalDev {
     const uint32_t *cell_tab;   // [4096 cells][8] packed colours r | g<<8 | b<<16 (sorted by palette index),
                                 // then [n_split][8 sub-cells][8]; word 0 of a block with bit 31 set is a marker:
                                 // 0x80000000|split index (cell is split) or 0xC0000000 (resolve in the fix-up pass)
-    int tab_words;
+    int tab_words;              // words of cell_tab that the dither kernels stage in LDS ...
+    int tab_total;              // ... of tab_total: with clustered palettes the deepest split nodes stay in global memory
+                                // (only pixels of split cells, on the deferred path, ever read them)
     // small palettes: the same table with 4-entry blocks (16 bytes per cell), nullptr when too many cells overflow;
     // the lean kernel prefers it (half the candidate work)
     const uint32_t *cell_tab4;

@@ -342,6 +342,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     }
     d.cell_tab = nullptr;
     d.tab_words = 0;
+    d.tab_total = 0;
     d.cell_tab4 = nullptr;
     d.tab4_words = 0;
     d.n_split = d.n_slow_blocks = 0;

@@ -644,6 +644,9 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     uint32_t blk = BW == 8 ? cell_offset(x) : cell_offset4(x);
     uint4 ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
     bool slow = false, scan = false;
+    // blocks beyond the staged part of the table (deep split nodes of clustered palettes) are read from global memory
+    const uint32_t staged = (uint32_t)pal.tab_words * 4u;
+    const uint8_t *tab = s_bytes;
     // split cells: descend by one colour bit per level
     for (int bit = 3; (ca.x >> 31) != 0; --bit) {
         if ((ca.x & 0x40000000u) || bit < 0) {
@@ -654,7 +657,8 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
         }
         const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
         blk = (4096u * BW + ((ca.x & 0xffffffu) * 8u + sub) * BW) * 4u;
-        ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
+        tab = blk < staged ? s_bytes : reinterpret_cast<const uint8_t *>(pal.cell_tab);
+        ca = *reinterpret_cast<const uint4 *>(tab + blk);
     }
     // the three nearest: distances (minus |x|^2) a0 <= a1 <= a2 and their colours, ordered by (distance, palette index)
     int a0, a1, a2;
@@ -682,7 +686,7 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     } else {
         int m0, m1, m2;
         if (BW == 8) {
-            const uint4 cb = *reinterpret_cast<const uint4 *>(s_bytes + blk + 16);
+            const uint4 cb = *reinterpret_cast<const uint4 *>(tab + blk + 16);
             cand8(x, ca, cb, g.neg2, m0, m1, m2);
         } else {
             cand4(x, ca, g.neg2, m0, m1, m2);
@@ -690,9 +694,9 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
         a0 = m0 >> kLocalBits;
         a1 = m1 >> kLocalBits;
         a2 = m2 >> kLocalBits;
-        c0 = *reinterpret_cast<const uint32_t *>(s_bytes + (blk | ((uint32_t)m0 & 0xfcu)));
-        c1 = *reinterpret_cast<const uint32_t *>(s_bytes + (blk | ((uint32_t)m1 & 0xfcu)));
-        c2 = *reinterpret_cast<const uint32_t *>(s_bytes + (blk | ((uint32_t)m2 & 0xfcu)));
+        c0 = *reinterpret_cast<const uint32_t *>(tab + (blk | ((uint32_t)m0 & 0xfcu)));
+        c1 = *reinterpret_cast<const uint32_t *>(tab + (blk | ((uint32_t)m1 & 0xfcu)));
+        c2 = *reinterpret_cast<const uint32_t *>(tab + (blk | ((uint32_t)m2 & 0xfcu)));
     }
     uint32_t c;
     if (MODE == 0) {
@@ -1435,7 +1439,8 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         const bool int_lean = thr.mpad != nullptr && lean_tab_bytes + (size_t)thr.th_h * thr.tw_pad * 4 <= (size_t)kLeanTabBytes;
         const bool lean_ok = lean_geo && (mode == DP_MODE_NEAREST || mode == DP_MODE_IGN ||
                                           (mode == DP_MODE_MATRIX && (int_lean || thr.fpad != nullptr)));
-        if (integer && (lean_ok || pal.cell_tab != nullptr)) {
+        const bool whole_tab = pal.cell_tab != nullptr && pal.tab_total == pal.tab_words;  // the general kernel stages all of it
+        if (integer && (lean_ok || whole_tab)) {
             // fast path: LDS cell table + tie codes, persistent 1024-lane workgroups over 4096-pixel tiles
             const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
             n_words = n_tiles * (kCellBlock / 64) * 4;

@@ -452,3 +452,22 @@ def test_small_palettes_four_entry_blocks(be, orc, K, mode, params):
     pal2 = orc.palr(K, seed=K + 1)  # random palette of the same size
     out = _run_case(be, orc, arr, pal2, mode, params, False)
     _assert_same(out, orc.apply_dithering(arr, pal2, mode, params, False), f"random{K} {mode}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "8x8"}), ("blue_noise", {"size": 32, "seed": 1})])
+def test_clustered_palette_spills_split_nodes_to_global_memory(be, orc, mode, params):
+    """A palette as median cut produces it for smooth content: most of its 256 colours sit in a few 16^3 cells, which
+    need hundreds of split nodes -- more than LDS holds next to the 4096 cell blocks.  The deepest nodes then stay in
+    global memory and only the deferred path reads them.  Content concentrated in exactly those cells."""
+    rs = np.random.RandomState(9)
+    dense = [(int(60 + a), int(100 + b), int(150 + c)) for a, b, c in rs.randint(0, 40, (216, 3))]
+    pal = dense + orc.palr(40, seed=4)
+    P = be.Palette(*orc.prepare_palette(pal, False), accel=True)
+    assert P.accel_entries == 4096 * 8 + 88 * 64, "expected a table larger than LDS (staged part only)"
+    h, w = 200, 301
+    arr = np.clip(np.stack([60 + rs.randint(-8, 48, (h, w)), 100 + rs.randint(-8, 48, (h, w)), 150 + rs.randint(-8, 48, (h, w))], -1),
+                  0, 255).astype(np.uint8)
+    arr[:40] = orc.rnd(40, w, 3)
+    out = _run_case(be, orc, arr, pal, mode, params, False, y0=3, x0=1)
+    _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False, y0=3, x0=1), f"spilled table {mode}")
