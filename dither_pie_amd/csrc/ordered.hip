@@ -631,19 +631,16 @@ __device__ __forceinline__ bool lean_decide(const uint32_t d0, const uint32_t S,
     return lhs <= rhs;
 }
 
-// Complete handling of one pixel (split cells, tie codes, the float64 replay, fix-up flags).
+// Complete resolution of one pixel given its colour and threshold (split cells, tie codes, the float64 replay):
+// returns the output colour; `slow`: left to the fix-up pass; `hard`: needed more than the plain block of its cell.
 template <int MODE, int BW>  // BW: entries per block of the table in LDS (8, or 4: pal.cell_tab4)
-__device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t *__restrict__ in,
-                                                uint8_t *__restrict__ out, unsigned long long *__restrict__ flags,
-                                                const Geo &g, const PalDev &pal, const ThrDev &thr,
-                                                const uint32_t *s_words, const float sx, const float sy, const float sc)
+__device__ __forceinline__ uint32_t resolve_pixel(const uint32_t x, const LeanThr &th, const Geo &g, const PalDev &pal,
+                                                  const ThrDev &thr, const uint8_t *s_bytes, bool &slow_out, bool &hard)
 {
-    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_words);
-    const uint8_t *b = in + (size_t)p * 3;
-    const uint32_t x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
     uint32_t blk = BW == 8 ? cell_offset(x) : cell_offset4(x);
     uint4 ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
     bool slow = false, scan = false;
+    hard = (ca.x >> 31) != 0;
     // blocks beyond the staged part of the table (deep split nodes of clustered palettes) are read from global memory
     const uint32_t staged = (uint32_t)pal.tab_words * 4u;
     const uint8_t *tab = s_bytes;
@@ -702,6 +699,7 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     if (MODE == 0) {
         c = c0;
         if (a0 == a1) {
+            hard = true;
             const uint32_t code = (pal.code1[x >> 4] >> ((x & 15u) * 2)) & 3u;
             if (code == 1) c = c1;
             else if (code == 2) c = c2;
@@ -712,29 +710,13 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
             }
         }
     } else {
-        uint32_t fy, fx;
-        locate(g, p, fy, fx);
-        LeanThr th;
-        th.mt = 0;
-        th.t = 0.0f;
-        if (MODE == 3) {
-            th.t = ign_threshold(g.x0 + (int)fx, g.y0 + (int)fy, sx, sy, sc);
-        } else {
-            uint32_t row, col;
-            thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
-            if (MODE == 1) {
-                th.mt = s_words[pal.tab_words + row * thr.tw_pad + col];
-                th.t = __fmul_rn((float)th.mt, 1.0f / (float)(1u << thr.sh));
-            } else {
-                th.t = thr.fpad[row * thr.tw_pad + col];
-            }
-        }
         const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
         const uint32_t d0 = (uint32_t)(a0 + xx), d1 = (uint32_t)(a1 + xx);
         bool eq;
         bool nearest = lean_decide<MODE>(d0, d0 + d1, th, thr.sh, eq);
         uint32_t ca_ = c0, cb_ = c1;  // reported nearest / second
         if (a0 == a1 || a1 == a2) {
+            hard = true;
             const uint32_t code = (pal.code2[x >> 3] >> ((x & 7u) * 4)) & 15u;
             if (code == 1) { ca_ = c1; cb_ = c0; }
             else if (code == 2) { cb_ = c2; }
@@ -751,20 +733,57 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
                 }
             }
         }
-        if (eq) nearest = ordered_use_nearest((double)d0, (double)d1, th.t);  // the literal float64 chain decides
+        if (eq)  // the literal float64 chain decides
+            nearest = ordered_use_nearest((double)d0, (double)d1,
+                                          MODE == 1 ? __fmul_rn((float)th.mt, 1.0f / (float)(1u << thr.sh)) : th.t);
         c = nearest ? ca_ : cb_;
     }
+    slow_out = slow;
+    return c;
+}
+
+// fix-up bookkeeping of one pixel that stays unresolved
+__device__ __forceinline__ void flag_slow_pixel(const uint32_t p, unsigned long long *__restrict__ flags, const Geo &g)
+{
+    const uint32_t wtile = p >> 8;  // 64 lanes x 4 pixels
+    atomicOr(&flags[(size_t)wtile * 4 + (p & 3u)], 1ull << ((p >> 2) & 63u));
+    // queue the wave tile for the fix-up pass (a tile may appear more than once: re-resolving is idempotent)
+    const uint32_t slot = atomicAdd(g.dirty, 1u);
+    if (slot < (uint32_t)kQueueTiles) g.dirty[1 + slot] = wtile;
+}
+
+// The deferred path: one queued pixel per lane, from its bytes in memory to its bytes in memory.
+template <int MODE, int BW>
+__device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t *__restrict__ in,
+                                                uint8_t *__restrict__ out, unsigned long long *__restrict__ flags,
+                                                const Geo &g, const PalDev &pal, const ThrDev &thr,
+                                                const uint32_t *s_words, const float sx, const float sy, const float sc)
+{
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_words);
+    const uint8_t *b = in + (size_t)p * 3;
+    const uint32_t x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+    LeanThr th;
+    th.mt = 0;
+    th.t = 0.0f;
+    if (MODE != 0) {
+        uint32_t fy, fx;
+        locate(g, p, fy, fx);
+        if (MODE == 3) {
+            th.t = ign_threshold(g.x0 + (int)fx, g.y0 + (int)fy, sx, sy, sc);
+        } else {
+            uint32_t row, col;
+            thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
+            if (MODE == 1) th.mt = s_words[pal.tab_words + row * thr.tw_pad + col];
+            else th.t = thr.fpad[row * thr.tw_pad + col];
+        }
+    }
+    bool slow, hard;
+    const uint32_t c = resolve_pixel<MODE, BW>(x, th, g, pal, thr, s_bytes, slow, hard);
     uint8_t *o = out + (size_t)p * 3;
     o[0] = (uint8_t)c;
     o[1] = (uint8_t)(c >> 8);
     o[2] = (uint8_t)(c >> 16);
-    if (slow) {
-        const uint32_t wtile = p >> 8;  // 64 lanes x 4 pixels
-        atomicOr(&flags[(size_t)wtile * 4 + (p & 3u)], 1ull << ((p >> 2) & 63u));
-        // queue the wave tile for the fix-up pass (a tile may appear more than once: re-resolving is idempotent)
-        const uint32_t slot = atomicAdd(g.dirty, 1u);
-        if (slot < (uint32_t)kQueueTiles) g.dirty[1 + slot] = wtile;
-    }
+    if (slow) flag_slow_pixel(p, flags, g);
 }
 
 template <int MODE, int BW>
@@ -787,6 +806,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t *s_queue = smem + (kLeanLdsWords - kLeanQueueWords) + (threadIdx.x >> 6) * kLeanQueue;
     uint32_t qcount = 0;  // wave-uniform
+    bool deep = false;    // wave-uniform: resolve every pixel completely in place (see below)
     const uint3 *in3 = reinterpret_cast<const uint3 *>(in);
     uint3 *out3 = reinterpret_cast<uint3 *>(out);
     const uint32_t n_full = g.n_px >> 2;  // groups of four whole pixels; a partial last group goes through the queue
@@ -810,7 +830,56 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
         // all clear; lean_pixel_full ORs in the bits of the pixels it leaves to the fix-up pass later
         if (lane < 4u) flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
         bool rare[4] = {false, false, false, false};
-        if (gidx < n_full) {
+        uint32_t n_hard = 0;  // deep mode: pixels of this wave tile that needed more than their cell's block
+        if (deep && gidx < n_full) {
+            // Most recent pixels of this wave sat in split cells or on ties (palettes extracted from the image itself put
+            // their colours exactly where the pixels are): resolve the four pixels completely right here instead of
+            // computing a throw-away result and queueing them.
+            uint32_t xq[4];
+            xq[0] = wc.x & 0xffffffu;
+            xq[1] = __builtin_amdgcn_perm(wc.y, wc.x, 0x0c050403u);
+            xq[2] = __builtin_amdgcn_perm(wc.z, wc.y, 0x0c040302u);
+            xq[3] = wc.z >> 8;
+            LeanThr th[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                th[q].mt = 0;
+                th[q].t = 0.0f;
+            }
+            if (MODE == 1 || MODE == 2) {
+                uint32_t row, col;
+                thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
+                const uint32_t at = row * (uint32_t)thr.tw_pad + col;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (MODE == 1) th[q].mt = smem[pal.tab_words + at + q];
+                    else th[q].t = thr.fpad[at + q];
+                }
+            } else if (MODE == 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) th[q].t = ign_threshold(g.x0 + (int)fx + q, g.y0 + (int)fy, sx, sy, sc);
+            }
+            if ((MODE != 0) && (fx + 3u >= g.w)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rare[q] = true;  // the group straddles a row end: through the queue
+            } else {
+                uint32_t col[4];
+                uint32_t hard_bits = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bool slow, hard;
+                    col[q] = resolve_pixel<MODE, BW>(xq[q], th[q], g, pal, thr, s_bytes, slow, hard);
+                    if (slow) flag_slow_pixel(gidx * 4u + (uint32_t)q, flags, g);
+                    hard_bits += hard ? 1u : 0u;
+                }
+                uint3 wo;
+                wo.x = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);
+                wo.y = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);
+                wo.z = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);
+                out3[gidx] = wo;
+                n_hard = hard_bits;
+            }
+        } else if (gidx < n_full) {
             uint32_t xq[4];
             xq[0] = wc.x & 0xffffffu;
             xq[1] = __builtin_amdgcn_perm(wc.y, wc.x, 0x0c050403u);
@@ -878,9 +947,11 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
 #pragma unroll
             for (int q = 0; q < 4; ++q) rare[q] = gidx * 4u + (uint32_t)q < g.n_px;  // the partial last group
         }
+        uint32_t rare_px = 0;  // wave-uniform
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned long long rb = __ballot(rare[q]);
+            rare_px += (uint32_t)__popcll(rb);
             if (rb != 0ull) {  // wave-uniform
                 if (rare[q])
                     s_queue[__builtin_amdgcn_mbcnt_hi((uint32_t)(rb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rb, qcount))] =
@@ -892,6 +963,14 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                     lean_pixel_full<MODE, BW>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
                 }
             }
+        }
+        // adapt: more than a third of the last 256 pixels rare -> deep mode; fewer than an eighth hard -> back
+        if (deep) {
+            unsigned long long m1 = __ballot(n_hard & 1u), m2 = __ballot(n_hard & 2u), m4 = __ballot(n_hard & 4u);
+            const uint32_t hard_px = (uint32_t)__popcll(m1) + 2u * (uint32_t)__popcll(m2) + 4u * (uint32_t)__popcll(m4);
+            if (hard_px < 32u) deep = false;
+        } else if (rare_px > 96u) {
+            deep = true;
         }
         fx += g.adv_x;
         fy += g.adv_y;
