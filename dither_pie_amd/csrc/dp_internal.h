@@ -79,6 +79,7 @@ struct PalDev {
     // error diffusion: for each 8x8x8 cell of the cube the entries that can be nearest to some point of the cell
     // (count in byte 0, up to 15 indices; count 255 = more than that: scan the whole palette); nullptr if absent
     const uint4 *ed_cells;
+    const uint4 *ed_nodes;      // refinement of overflowing cells: 8 entries per node (count byte 254 = refined further)
     const uint4 *exc;           // colours whose outcome no code expresses, sorted by colour:
     int n_exc;                  //   {colour, k=2 indices i0 | i1<<16, k=1 index, 0}; n_exc < 0: list overflowed
 };
@@ -144,7 +145,7 @@ void prof_end(ProfMark *m, hipStream_t s);
 namespace dp {
 int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_out, size_t *blob_bytes);
 int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host, void **blob_out, size_t *blob_bytes);
-int build_ed_cells(PalDev &dev, void **blob_out);
+int build_ed_cells(PalDev &dev, const double *pts_host, void **blob_out);
 int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int y0, int x0,
                    const PalDev &pal, int mode, const ThrDev *thr, float ign_scale, int ign_seed, void *ws,
                    size_t ws_bytes, hipStream_t s);

@@ -31,6 +31,11 @@
 // brute force in float64 with the KD-tree's arithmetic, and an exact tie between the two smallest
 // distances (they do occur: diffused errors are dyadic) is resolved by replaying scipy's traversal
 // (tree_query<1>) unless the palette fits one leaf (then the lowest index wins).
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
 #include "dp_internal.h"
 #include "tree_query.cuh"
 #include "wave_util.cuh"
@@ -167,6 +172,14 @@ __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const floa
     const uint32_t ci = ((uint32_t)o0 >> 3) | (((uint32_t)o1 >> 3) << 5) | (((uint32_t)o2 >> 3) << 10);
     uint4 blk = pal.ed_cells[ci];
     int n = (int)(blk.x & 255u);
+    if (n == 254) {  // a crowded cell (clustered palettes): refined into 4^3, 2^3, 1^3 sub-cells
+        const uint32_t i0 = (uint32_t)o0, i1 = (uint32_t)o1, i2 = (uint32_t)o2;
+        for (int bit = 2; n == 254; --bit) {
+            const uint32_t sub = ((i0 >> bit) & 1u) | (((i1 >> bit) & 1u) << 1) | (((i2 >> bit) & 1u) << 2);
+            blk = pal.ed_nodes[(size_t)(blk.x >> 8) * 8 + sub];
+            n = (int)(blk.x & 255u);
+        }
+    }
     if (n > 15) return nearest_color<CAP>(pal, cand, o0, o1, o2);
     float b0 = __int_as_float(0x7f800000), b1 = b0;
     int i0 = 0;
@@ -650,19 +663,123 @@ size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w)
     return (size_t)n_frames * (size_t)w * 4 * sizeof(float) * 4 + 256;
 }
 
-int build_ed_cells(PalDev &dev, void **blob_out)
+int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
 {
     *blob_out = nullptr;
+    const int K = dev.K;
     uint4 *cells = nullptr;
     DP_HIP(hipMalloc((void **)&cells, sizeof(uint4) * kEdCells));
     hipLaunchKernelGGL(ed_cells_kernel, dim3(kEdCells / 256), dim3(256), 0, 0, dev, cells);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    std::vector<uint4> host(kEdCells);
+    if (e == hipSuccess) e = hipMemcpy(host.data(), cells, sizeof(uint4) * kEdCells, hipMemcpyDeviceToHost);
     if (e != hipSuccess) {
         (void)hipFree(cells);
         return hip_fail(e, "error-diffusion candidate lists");
     }
+    // Cells whose list overflowed (palettes extracted from an image crowd their colours into a few cells) are refined
+    // on the host: 8 children of half the size, down to unit cubes; a child's list is a subset of its parent's.
+    std::vector<uint4> nodes;
+    auto box_list = [&](const std::vector<int> &from, const double lo[3], const double size, std::vector<int> &list) {
+        double bound = std::numeric_limits<double>::infinity();
+        for (int j : from) {
+            double far2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double c = pts[3 * j + k];
+                const double m = std::max(std::fabs(c - lo[k]), std::fabs(c - (lo[k] + size)));
+                far2 += m * m;
+            }
+            bound = std::min(bound, far2);
+        }
+        bound = bound * (1.0 + 1e-12) + 1e-9;
+        list.clear();
+        for (int j : from) {
+            double near2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double c = pts[3 * j + k];
+                const double m = std::max(std::max(lo[k] - c, c - (lo[k] + size)), 0.0);
+                near2 += m * m;
+            }
+            if (near2 <= bound) list.push_back(j);
+        }
+    };
+    auto pack = [](const std::vector<int> &list) {
+        uint32_t w[4] = {(uint32_t)list.size(), 0u, 0u, 0u};
+        for (size_t n = 1; n <= list.size(); ++n) w[n >> 2] |= (uint32_t)list[n - 1] << (8 * (n & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    struct Work {
+        size_t slot;      // index into `nodes` (or, with top == true, into `host`)
+        bool top;
+        double lo[3];
+        double size;
+        std::vector<int> from;
+    };
+    std::vector<Work> stack;
+    std::vector<int> all(K), list;
+    for (int j = 0; j < K; ++j) all[j] = j;
+    for (int cell = 0; cell < kEdCells; ++cell)
+        if ((host[cell].x & 255u) == 255u) {
+            Work wk;
+            wk.slot = (size_t)cell;
+            wk.top = true;
+            wk.lo[0] = (double)((cell & 31) * 8);
+            wk.lo[1] = (double)(((cell >> 5) & 31) * 8);
+            wk.lo[2] = (double)((cell >> 10) * 8);
+            wk.size = 8.0;
+            box_list(all, wk.lo, 8.0, wk.from);  // the cell's full list
+            stack.push_back(std::move(wk));
+        }
+    bool give_up = false;
+    while (!stack.empty() && !give_up) {
+        Work wk = std::move(stack.back());
+        stack.pop_back();
+        uint4 entry;
+        if (wk.from.size() <= 15) {
+            entry = pack(wk.from);
+        } else if (wk.size <= 1.0) {
+            entry = make_uint4(255u, 0u, 0u, 0u);  // a unit cube that still sees more than 15 entries: scan the palette
+        } else {
+            const size_t node = nodes.size() / 8;
+            if (node >= (1u << 22)) {
+                give_up = true;
+                break;
+            }
+            nodes.resize(nodes.size() + 8, make_uint4(255u, 0u, 0u, 0u));
+            entry = make_uint4(254u | ((uint32_t)node << 8), 0u, 0u, 0u);
+            const double hs = wk.size * 0.5;
+            for (int sub = 0; sub < 8; ++sub) {
+                Work ch;
+                ch.slot = node * 8 + (size_t)sub;
+                ch.top = false;
+                ch.lo[0] = wk.lo[0] + ((sub & 1) ? hs : 0.0);
+                ch.lo[1] = wk.lo[1] + ((sub & 2) ? hs : 0.0);
+                ch.lo[2] = wk.lo[2] + ((sub & 4) ? hs : 0.0);
+                ch.size = hs;
+                box_list(wk.from, ch.lo, hs, ch.from);
+                stack.push_back(std::move(ch));
+            }
+        }
+        if (wk.top) host[wk.slot] = entry;
+        else nodes[wk.slot] = entry;
+    }
+    uint4 *d_nodes = nullptr;
+    if (!give_up && !nodes.empty()) {
+        // one allocation: cells, then the nodes
+        uint4 *both = nullptr;
+        e = hipMalloc((void **)&both, sizeof(uint4) * (kEdCells + nodes.size()));
+        if (e == hipSuccess) e = hipMemcpy(both, host.data(), sizeof(uint4) * kEdCells, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(both + kEdCells, nodes.data(), sizeof(uint4) * nodes.size(), hipMemcpyHostToDevice);
+        (void)hipFree(cells);
+        if (e != hipSuccess) {
+            if (both) (void)hipFree(both);
+            return hip_fail(e, "error-diffusion candidate lists");
+        }
+        cells = both;
+        d_nodes = both + kEdCells;
+    }
     dev.ed_cells = cells;
+    dev.ed_nodes = d_nodes;
     *blob_out = cells;
     return DP_OK;
 }

@@ -351,6 +351,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.exc = nullptr;
     d.n_exc = 0;
     d.ed_cells = nullptr;
+    d.ed_nodes = nullptr;
     p->ed_blob = nullptr;
     p->accel_blob = nullptr;
     p->accel_bytes = 0;
@@ -367,7 +368,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     }
     if (K > 8 && K <= 256) {
         // candidate lists of the error-diffusion kernels (a 512 KB table, one small kernel)
-        const int rc = build_ed_cells(p->dev, &p->ed_blob);
+        const int rc = build_ed_cells(p->dev, pts.data(), &p->ed_blob);
         if (rc != DP_OK) {
             dp_palette_destroy(p);
             return rc;

@@ -471,3 +471,20 @@ def test_clustered_palette_spills_split_nodes_to_global_memory(be, orc, mode, pa
     arr[:40] = orc.rnd(40, w, 3)
     out = _run_case(be, orc, arr, pal, mode, params, False, y0=3, x0=1)
     _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False, y0=3, x0=1), f"spilled table {mode}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,serp,gamma", [("floyd_steinberg", "false", False), ("stucki", "false", True), ("burkes", "true", False)])
+def test_error_diffusion_clustered_palette_refined_cells(be, orc, variant, serp, gamma):
+    """216 of 256 colours inside a 40^3 cube: the 8^3 candidate cells there overflow their 15 entries and are refined
+    down to unit cubes (host-built octree below each crowded cell); content inside and outside the crowded region."""
+    rs = np.random.RandomState(9)
+    dense = [(int(60 + a), int(100 + b), int(150 + c)) for a, b, c in rs.randint(0, 40, (216, 3))]
+    pal = dense + orc.palr(40, seed=4)
+    h, w = 70, 131
+    arr = np.clip(np.stack([60 + rs.randint(-8, 48, (h, w)), 100 + rs.randint(-8, 48, (h, w)), 150 + rs.randint(-8, 48, (h, w))], -1),
+                  0, 255).astype(np.uint8)
+    arr[:20] = orc.rnd(20, w, 3)
+    params = {"variant": variant, "serpentine": serp}
+    out = _run_case(be, orc, arr, pal, "error_diffusion", params, gamma)
+    _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, gamma), f"clustered {variant}")
