@@ -577,13 +577,13 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
         coord4[j] = c[0] | (c[1] << 8) | (c[2] << 16);
         word[j] = (uint32_t)j * 16u;
     }
-    // layout: table[cap] | reach[256]
-    const size_t bytes = sizeof(uint32_t) * kTabCapWords + 256;
+    // layout: table[max] | reach[256]
+    const size_t bytes = sizeof(uint32_t) * kTabMaxWords + 256;
     uint8_t *blob = nullptr;
     uint32_t *d_masks = nullptr;
     DP_HIP(hipMalloc((void **)&blob, bytes));
     uint32_t *d_tab = reinterpret_cast<uint32_t *>(blob);
-    uint8_t *d_reach = blob + sizeof(uint32_t) * kTabCapWords;
+    uint8_t *d_reach = blob + sizeof(uint32_t) * kTabMaxWords;
     hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 72);
     if (e == hipSuccess) e = hipMemcpy(d_reach, reach.data(), 256, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -604,7 +604,7 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
     std::vector<uint32_t> tab;
     TableStats st;
     const int rc = assemble_table(
-        masks, 8, 8, kTabCapWords, K, coord4, word,
+        masks, 8, 8, kTabMaxWords, K, coord4, word,
         [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
             return run_box_kernel(boxes, bm, [&](const Box *db, uint32_t *dm, unsigned n) {
                 hipLaunchKernelGGL(accel_box_float_kernel, dim3(n), dim3(64), 0, 0, dev, d_reach, db, dm);
@@ -613,7 +613,7 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
         tab, st);
     if (rc != DP_OK || st.too_big) {
         (void)hipFree(blob);
-        return rc;  // too big: the brute-force kernel stays in charge
+        return rc;  // too big even for global memory: the brute-force kernel stays in charge
     }
     e = hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -621,7 +621,11 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
         return hip_fail(e, "float accelerator upload");
     }
     dev.ftab = d_tab;
-    dev.ftab_words = (int)tab.size();
+    dev.ftab_total = (int)tab.size();
+    // staged in LDS next to the candidate table (16 bytes per colour) and lut_in: everything that fits, else the 4096
+    // cell blocks and the first split nodes
+    const int stage_cap = (160 * 1024 - K * 16 - 256) / 4;
+    dev.ftab_words = (int)tab.size() <= stage_cap ? (int)tab.size() : 4096 * 8 + ((stage_cap - 4096 * 8) / 64) * 64;
     dev.n_split = st.n_split;
     dev.n_slow_blocks = st.n_slow;
     dev.max_cell = st.max_cnt;

@@ -74,7 +74,8 @@ struct PalDev {
     const uint32_t *code2;      // 4 bits per colour: ... of the k=2 query (accel.hip)
     // the same for float (gamma) palettes: blocks of 8 byte offsets (16 * j) into fcand
     const uint32_t *ftab;
-    int ftab_words;
+    int ftab_words;             // words staged in LDS ...
+    int ftab_total;             // ... of ftab_total (deep split nodes of clustered palettes stay in global memory)
     const float4 *fcand;        // K: {x, y, z, out_rgb bits}
     // error diffusion: for each 8x8x8 cell of the cube the entries that can be nearest to some point of the cell
     // (count in byte 0, up to 15 indices; count 255 = more than that: scan the whole palette); nullptr if absent

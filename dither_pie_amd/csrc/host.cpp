@@ -329,6 +329,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.fcand = (const float4 *)(base + o_fc);
     d.ftab = nullptr;
     d.ftab_words = 0;
+    d.ftab_total = 0;
     d.indices = (const int32_t *)(base + o_idx);
     d.split_dim = (const int32_t *)(base + o_sd);
     d.split = (const double *)(base + o_sp);

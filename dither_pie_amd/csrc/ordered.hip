@@ -1085,19 +1085,38 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
                 uint32_t blk = cell_offset(x);
                 uint4 ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
                 bool s = straddle;
-                // split cells: descend by one colour bit per level
+                // split cells: descend by one colour bit per level; nodes beyond the staged part of the table (clustered
+                // palettes) are read from global memory, where the offsets are still relative to the candidate table
+                bool from_global = false;
                 for (int bit = 3; (ca.x >> 31) != 0; --bit) {
                     if ((ca.x & 0x40000000u) || bit < 0) {
                         s = true;  // a single colour with more than 8 candidates: fix-up pass
                         ca = make_uint4(cand_base, cand_base, cand_base, cand_base);  // any valid entry
+                        from_global = false;
+                        blk = 0u;
                         break;
                     }
                     const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
                     blk = (4096u * 8u + ((ca.x & 0xffffffu) * 8u + sub) * 8u) * 4u;
-                    ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
+                    from_global = blk >= cand_base;
+                    ca = from_global ? *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(pal.ftab) + blk)
+                                     : *reinterpret_cast<const uint4 *>(s_bytes + blk);
                 }
-                uint4 cb = *reinterpret_cast<const uint4 *>(s_bytes + blk + 16);
-                if (s && (ca.x == cand_base)) cb = ca;  // the block of a slow marker holds no offsets
+                uint4 cb;
+                if (from_global) {
+                    cb = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(pal.ftab) + blk + 16);
+                    ca.x += cand_base;  // a leaf block: eight offsets
+                    ca.y += cand_base;
+                    ca.z += cand_base;
+                    ca.w += cand_base;
+                    cb.x += cand_base;
+                    cb.y += cand_base;
+                    cb.z += cand_base;
+                    cb.w += cand_base;
+                } else {
+                    cb = *reinterpret_cast<const uint4 *>(s_bytes + blk + 16);
+                    if (s && (ca.x == cand_base)) cb = ca;  // the block of a slow marker holds no offsets
+                }
                 const uint32_t off[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
                 const float fr = (float)r, fg = (float)gg, fb = (float)b;
                 int key[8];
@@ -1118,12 +1137,16 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
                     m0 = min(m0, key[c]);
                 }
                 s |= (m1 - m0) <= kFloatKeyGap;
-                const uint32_t o0 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + 4u * ((uint32_t)m0 & 7u));
+                uint32_t o0 = off[0], o1 = off[0];
+#pragma unroll
+                for (int c = 1; c < 8; ++c) {
+                    o0 = ((uint32_t)m0 & 7u) == (uint32_t)c ? off[c] : o0;
+                    o1 = ((uint32_t)m1 & 7u) == (uint32_t)c ? off[c] : o1;
+                }
                 const float4 c0 = *reinterpret_cast<const float4 *>(s_bytes + (s ? cand_base : o0));
                 uint32_t cpick = __float_as_uint(c0.w);
                 if (MODE != 0) {
                     s |= (m2 - m1) <= kFloatKeyGap;
-                    const uint32_t o1 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + 4u * ((uint32_t)m1 & 7u));
                     const float4 c1 = *reinterpret_cast<const float4 *>(s_bytes + (s ? cand_base : o1));
                     const double p0[3] = {(double)c0.x, (double)c0.y, (double)c0.z};
                     const double p1[3] = {(double)c1.x, (double)c1.y, (double)c1.z};
@@ -1575,7 +1598,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             }
             if (rc != DP_OK) return rc;
         } else if (!integer && pal.ftab != nullptr && g.aligned && y0 >= 0 && x0 >= 0 &&
-                   (size_t)pal.ftab_words * 4 + (size_t)pal.K * 16 + 256 <= sizeof(uint32_t) * kLeanLdsWords &&
+                   (size_t)pal.ftab_words * 4 + (size_t)pal.K * 16 + 256 <= sizeof(uint32_t) * kLeanLdsWords &&  // staged part
                    (mode != DP_MODE_MATRIX || thr.fpad != nullptr)) {
             // float (gamma) palettes with a cell table
             const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;

@@ -488,3 +488,21 @@ def test_error_diffusion_clustered_palette_refined_cells(be, orc, variant, serp,
     params = {"variant": variant, "serpentine": serp}
     out = _run_case(be, orc, arr, pal, "error_diffusion", params, gamma)
     _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, gamma), f"clustered {variant}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "8x8"}), ("IGN", {})])
+def test_clustered_float_palette_spills_split_nodes(be, orc, mode, params):
+    """use_gamma with a clustered palette: the float cell table also keeps its deepest split nodes in global memory."""
+    rs = np.random.RandomState(10)
+    dense = [(int(90 + a), int(120 + b), int(160 + c)) for a, b, c in rs.randint(0, 44, (216, 3))]
+    pal = dense + orc.palr(40, seed=6)
+    pal_f32, oc, lut = orc.prepare_palette(pal, True)
+    P = be.Palette(pal_f32, oc, lut, accel=True)
+    assert P.accel_entries > 0
+    h, w = 160, 203
+    arr = np.clip(np.stack([90 + rs.randint(-10, 54, (h, w)), 120 + rs.randint(-10, 54, (h, w)), 160 + rs.randint(-10, 54, (h, w))], -1),
+                  0, 255).astype(np.uint8)
+    arr[:30] = orc.rnd(30, w, 3)
+    out = _run_case(be, orc, arr, pal, mode, params, True, y0=2, x0=5)
+    _assert_same(out, orc.apply_dithering(arr, pal, mode, params, True, y0=2, x0=5), f"float spilled {mode}")
