@@ -23,6 +23,11 @@ def run(seed, N):
       mode = modes[rs.randint(len(modes))]
       pal = orc.palr(K, seed=int(rs.randint(1 << 30)))
       if rs.rand() < 0.2: pal = pal[: K // 2] + pal[: K - K // 2]  # duplicates
+      clustered = K >= 16 and rs.rand() < 0.25
+      if clustered:  # as median cut produces for smooth content: most colours inside one small cube
+          c0 = rs.randint(20, 200, 3); span = int(rs.choice([6, 20, 40]))
+          nd = (K * 4) // 5
+          pal = [tuple(int(v) for v in c0 + rs.randint(0, span, 3)) for _ in range(nd)] + pal[: K - nd]
       params = {}
       if mode == "bayer": params = {"size": str(rs.choice(["2x2", "4x4", "8x8", "16x16"]))}
       if mode == "blue_noise": params = {"size": int(rs.choice([32, 33, 40])), "seed": int(rs.randint(100))}
@@ -38,6 +43,9 @@ def run(seed, N):
       if mode in DIFFUSERS and h * w > 40000: h, w = 40, 300
       y0, x0 = (0, 0) if mode in DIFFUSERS else (int(rs.randint(0, 50)), int(rs.randint(0, 50)))
       frames = rs.randint(0, 256, (nf, h, w, 3)).astype(np.uint8)
+      if clustered:  # content inside the crowded region
+          frames = np.where(rs.randint(0, 3, (nf, h, w, 1)) > 0,
+                            np.clip(c0 + rs.randint(-6, span + 6, (nf, h, w, 3)), 0, 255).astype(np.uint8), frames)
       if rs.rand() < 0.5:  # tie-rich content: palette colours and midpoints
           pa = np.asarray(pal, dtype=np.int64)
           pick = rs.randint(0, len(pal), (nf, h, w))
