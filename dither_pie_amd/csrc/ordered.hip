@@ -633,36 +633,90 @@ __device__ __forceinline__ bool lean_decide(const uint32_t d0, const uint32_t S,
 
 // Complete resolution of one pixel given its colour and threshold (split cells, tie codes, the float64 replay):
 // returns the output colour; `slow`: left to the fix-up pass; `hard`: needed more than the plain block of its cell.
-template <int MODE, int BW>  // BW: entries per block of the table in LDS (8, or 4: pal.cell_tab4)
-__device__ __forceinline__ uint32_t resolve_pixel(const uint32_t x, const LeanThr &th, const Geo &g, const PalDev &pal,
-                                                  const ThrDev &thr, const uint8_t *s_bytes, bool &slow_out, bool &hard)
+// The block that decides a pixel: its cell's, or -- split cells -- the leaf reached by one colour bit per level.
+struct Leaf {
+    uint32_t blk;        // byte offset of the block in the table
+    bool in_lds;         // the block is in the staged part of the table (else: read it from global memory)
+    uint4 ca;            // first 16 bytes of the block
+    bool stuck;          // ended on a "single colour with too many candidates" marker
+    bool split;          // the cell is split
+};
+
+// Reads from the table with the address space spelled out: the staged part through LDS instructions, deep split nodes
+// through global loads (a pointer that may be either turns every access into a flat load, and two plain branches get
+// merged into exactly that).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4_t lds_uint4_t;
+typedef const __attribute__((address_space(3))) uint32_t lds_uint32_t;
+typedef const __attribute__((address_space(1))) u32x4_t glb_uint4_t;
+typedef const __attribute__((address_space(1))) uint32_t glb_uint32_t;
+
+__device__ __forceinline__ uint4 leaf_read4(const Leaf &lf, const PalDev &pal, const uint8_t *s_bytes, const uint32_t off)
 {
-    uint32_t blk = BW == 8 ? cell_offset(x) : cell_offset4(x);
-    uint4 ca = *reinterpret_cast<const uint4 *>(s_bytes + blk);
-    bool slow = false, scan = false;
-    hard = (ca.x >> 31) != 0;
-    // blocks beyond the staged part of the table (deep split nodes of clustered palettes) are read from global memory
-    const uint32_t staged = (uint32_t)pal.tab_words * 4u;
-    const uint8_t *tab = s_bytes;
-    // split cells: descend by one colour bit per level
-    for (int bit = 3; (ca.x >> 31) != 0; --bit) {
-        if ((ca.x & 0x40000000u) || bit < 0) {
-            // a single colour with more candidates than a block holds: fix-up pass, or (small palettes) a scan
-            if (BW == 4) scan = true;
-            else slow = true;
-            break;
-        }
-        const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
-        blk = (4096u * BW + ((ca.x & 0xffffffu) * 8u + sub) * BW) * 4u;
-        tab = blk < staged ? s_bytes : reinterpret_cast<const uint8_t *>(pal.cell_tab);
-        ca = *reinterpret_cast<const uint4 *>(tab + blk);
+    u32x4_t v;
+    if (lf.in_lds) v = *(lds_uint4_t *)(s_bytes + off);
+    else v = *(glb_uint4_t *)(reinterpret_cast<const uint8_t *>(pal.cell_tab) + off);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t leaf_read1(const Leaf &lf, const PalDev &pal, const uint8_t *s_bytes, const uint32_t off)
+{
+    if (lf.in_lds) return *(lds_uint32_t *)(s_bytes + off);
+    return *(glb_uint32_t *)(reinterpret_cast<const uint8_t *>(pal.cell_tab) + off);
+}
+
+template <int BW>
+__device__ __forceinline__ void leaf_begin(const uint32_t x, const uint8_t *s_bytes, Leaf &lf)
+{
+    lf.blk = BW == 8 ? cell_offset(x) : cell_offset4(x);
+    lf.in_lds = true;
+    lf.ca = *reinterpret_cast<const uint4 *>(s_bytes + lf.blk);
+    lf.stuck = false;
+    lf.split = (lf.ca.x >> 31) != 0;
+}
+
+// one level down (call while leaf_pending); `bit`: 3 for the children of a 16^3 cell, then 2, 1, 0
+template <int BW>
+__device__ __forceinline__ void leaf_step(const uint32_t x, const int bit, const PalDev &pal, const uint8_t *s_bytes, Leaf &lf)
+{
+    if ((lf.ca.x & 0x40000000u) || bit < 0) {
+        lf.stuck = true;
+        return;
     }
-    // the three nearest: distances (minus |x|^2) a0 <= a1 <= a2 and their colours, ordered by (distance, palette index)
+    const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
+    lf.blk = (4096u * BW + ((lf.ca.x & 0xffffffu) * 8u + sub) * BW) * 4u;
+    // blocks beyond the staged part of the table (deep split nodes of clustered palettes) are read from global memory
+    // (two explicit paths: a pointer that may be either would turn every access into a flat load)
+    lf.in_lds = lf.blk < (uint32_t)pal.tab_words * 4u;
+    lf.ca = leaf_read4(lf, pal, s_bytes, lf.blk);
+}
+
+__device__ __forceinline__ bool leaf_pending(const Leaf &lf) { return (lf.ca.x >> 31) != 0 && !lf.stuck; }
+
+template <int BW>
+__device__ __forceinline__ void leaf_find(const uint32_t x, const PalDev &pal, const uint8_t *s_bytes, Leaf &lf)
+{
+    leaf_begin<BW>(x, s_bytes, lf);
+    for (int bit = 3; leaf_pending(lf); --bit) leaf_step<BW>(x, bit, pal, s_bytes, lf);
+}
+
+template <int MODE, int BW>  // BW: entries per block of the table in LDS (8, or 4: pal.cell_tab4)
+__device__ __forceinline__ uint32_t resolve_pixel(const uint32_t x, const LeanThr &th, const Leaf &lf, const Geo &g,
+                                                  const PalDev &pal, const ThrDev &thr, const uint8_t *s_bytes,
+                                                  bool &slow_out, bool &hard)
+{
+    const uint32_t blk = lf.blk;
+    const uint4 ca = lf.ca;
+    // a single colour with more candidates than a block holds: fix-up pass, or (small palettes) a scan
+    bool slow = lf.stuck && BW != 4;
+    const bool scan = lf.stuck && BW == 4;
+    hard = lf.split;
+    // the three nearest: distances (minus |x|^2) a0 <= a1 <= a2, ordered by (distance, palette index); their colours
+    // are fetched on demand: col(k) for the k-th nearest
     int a0, a1, a2;
-    uint32_t c0, c1, c2;
+    int m0, m1, m2;
     if (BW == 4 && scan) {
         constexpr int kBig = 0x7fffffff;
-        int m0 = kBig, m1 = kBig, m2 = kBig;
+        m0 = m1 = m2 = kBig;
         for (int j = 0; j < pal.K; ++j) {
             const int dot = (int)__builtin_amdgcn_udot4(x, pal.p4[j], 0u, false);
             const int key = pal.nkey[j] - (dot << (kIdxBits + 1));  // ((|p|^2 - 2 x.p) << kIdxBits) | j
@@ -672,18 +726,13 @@ __device__ __forceinline__ uint32_t resolve_pixel(const uint32_t x, const LeanTh
             m1 = n1;
             m2 = n2;
         }
-        constexpr int IM = (1 << kIdxBits) - 1;
         a0 = m0 >> kIdxBits;
         a1 = m1 >> kIdxBits;
-        a2 = m2 >> kIdxBits;
-        c0 = pal.out_rgb[m0 & IM];
-        c1 = pal.out_rgb[m1 & IM];
-        c2 = pal.K > 2 ? pal.out_rgb[m2 & IM] : c1;
-        if (pal.K < 3) a2 = kBig;
+        a2 = pal.K > 2 ? (m2 >> kIdxBits) : kBig;
+        if (pal.K < 3) m2 = m1;
     } else {
-        int m0, m1, m2;
         if (BW == 8) {
-            const uint4 cb = *reinterpret_cast<const uint4 *>(tab + blk + 16);
+            const uint4 cb = leaf_read4(lf, pal, s_bytes, blk + 16);
             cand8(x, ca, cb, g.neg2, m0, m1, m2);
         } else {
             cand4(x, ca, g.neg2, m0, m1, m2);
@@ -691,52 +740,59 @@ __device__ __forceinline__ uint32_t resolve_pixel(const uint32_t x, const LeanTh
         a0 = m0 >> kLocalBits;
         a1 = m1 >> kLocalBits;
         a2 = m2 >> kLocalBits;
-        c0 = *reinterpret_cast<const uint32_t *>(tab + (blk | ((uint32_t)m0 & 0xfcu)));
-        c1 = *reinterpret_cast<const uint32_t *>(tab + (blk | ((uint32_t)m1 & 0xfcu)));
-        c2 = *reinterpret_cast<const uint32_t *>(tab + (blk | ((uint32_t)m2 & 0xfcu)));
     }
+    auto col = [&](const int key) -> uint32_t {
+        if (BW == 4 && scan) return pal.out_rgb[key & ((1 << kIdxBits) - 1)];
+        return leaf_read1(lf, pal, s_bytes, blk | ((uint32_t)key & 0xfcu));
+    };
     uint32_t c;
     if (MODE == 0) {
-        c = c0;
+        int sel = m0;
+        bool direct = false;
+        c = 0;
         if (a0 == a1) {
             hard = true;
             const uint32_t code = (pal.code1[x >> 4] >> ((x & 15u) * 2)) & 3u;
-            if (code == 1) c = c1;
-            else if (code == 2) c = c2;
+            if (code == 1) sel = m1;
+            else if (code == 2) sel = m2;
             else if (code == 3) {
                 uint32_t pair, single;
-                if (find_exception(pal, x, pair, single)) c = pal.out_rgb[single];
-                else slow = true;
-            }
-        }
-    } else {
-        const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
-        const uint32_t d0 = (uint32_t)(a0 + xx), d1 = (uint32_t)(a1 + xx);
-        bool eq;
-        bool nearest = lean_decide<MODE>(d0, d0 + d1, th, thr.sh, eq);
-        uint32_t ca_ = c0, cb_ = c1;  // reported nearest / second
-        if (a0 == a1 || a1 == a2) {
-            hard = true;
-            const uint32_t code = (pal.code2[x >> 3] >> ((x & 7u) * 4)) & 15u;
-            if (code == 1) { ca_ = c1; cb_ = c0; }
-            else if (code == 2) { cb_ = c2; }
-            else if (code == 3) { ca_ = c2; cb_ = c0; }
-            else if (code == 4) { ca_ = c1; cb_ = c2; }
-            else if (code == 5) { ca_ = c2; cb_ = c1; }
-            else if (code != 0u) {
-                uint32_t pair, single;
                 if (find_exception(pal, x, pair, single)) {
-                    ca_ = pal.out_rgb[pair & 0xffffu];
-                    cb_ = pal.out_rgb[pair >> 16];
+                    c = pal.out_rgb[single];
+                    direct = true;
                 } else {
                     slow = true;
                 }
             }
         }
+        if (!direct) c = col(sel);
+    } else {
+        const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
+        const uint32_t d0 = (uint32_t)(a0 + xx), d1 = (uint32_t)(a1 + xx);
+        bool eq;
+        bool nearest = lean_decide<MODE>(d0, d0 + d1, th, thr.sh, eq);
+        int sa = m0, sb = m1;  // keys of the reported nearest / second
+        bool direct = false;
+        uint32_t exc_pair = 0;
+        if (a0 == a1 || a1 == a2) {
+            hard = true;
+            const uint32_t code = (pal.code2[x >> 3] >> ((x & 7u) * 4)) & 15u;
+            if (code == 1) { sa = m1; sb = m0; }
+            else if (code == 2) { sb = m2; }
+            else if (code == 3) { sa = m2; sb = m0; }
+            else if (code == 4) { sa = m1; sb = m2; }
+            else if (code == 5) { sa = m2; sb = m1; }
+            else if (code != 0u) {
+                uint32_t single;
+                if (find_exception(pal, x, exc_pair, single)) direct = true;
+                else slow = true;
+            }
+        }
         if (eq)  // the literal float64 chain decides
-            nearest = ordered_use_nearest((double)d0, (double)d1,
-                                          MODE == 1 ? __fmul_rn((float)th.mt, 1.0f / (float)(1u << thr.sh)) : th.t);
-        c = nearest ? ca_ : cb_;
+            nearest = ordered_use_nearest_call((double)d0, (double)d1,
+                                               MODE == 1 ? __fmul_rn((float)th.mt, 1.0f / (float)(1u << thr.sh)) : th.t);
+        if (direct) c = pal.out_rgb[nearest ? (exc_pair & 0xffffu) : (exc_pair >> 16)];
+        else c = col(nearest ? sa : sb);
     }
     slow_out = slow;
     return c;
@@ -778,7 +834,9 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
         }
     }
     bool slow, hard;
-    const uint32_t c = resolve_pixel<MODE, BW>(x, th, g, pal, thr, s_bytes, slow, hard);
+    Leaf lf;
+    leaf_find<BW>(x, pal, s_bytes, lf);
+    const uint32_t c = resolve_pixel<MODE, BW>(x, th, lf, g, pal, thr, s_bytes, slow, hard);
     uint8_t *o = out + (size_t)p * 3;
     o[0] = (uint8_t)c;
     o[1] = (uint8_t)(c >> 8);
@@ -865,10 +923,19 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
             } else {
                 uint32_t col[4];
                 uint32_t hard_bits = 0;
+                // the four descents advance level by level together, so that their reads are in flight at the same time
+                Leaf lf[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) leaf_begin<BW>(xq[q], s_bytes, lf[q]);
+                for (int bit = 3; (int)leaf_pending(lf[0]) | (int)leaf_pending(lf[1]) | (int)leaf_pending(lf[2]) | (int)leaf_pending(lf[3]); --bit) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (leaf_pending(lf[q])) leaf_step<BW>(xq[q], bit, pal, s_bytes, lf[q]);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     bool slow, hard;
-                    col[q] = resolve_pixel<MODE, BW>(xq[q], th[q], g, pal, thr, s_bytes, slow, hard);
+                    col[q] = resolve_pixel<MODE, BW>(xq[q], th[q], lf[q], g, pal, thr, s_bytes, slow, hard);
                     if (slow) flag_slow_pixel(gidx * 4u + (uint32_t)q, flags, g);
                     hard_bits += hard ? 1u : 0u;
                 }

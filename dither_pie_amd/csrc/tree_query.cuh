@@ -172,4 +172,11 @@ __device__ __forceinline__ float ign_threshold(const int gx, const int gy, const
     return __fsub_rn(v, floorf(v));
 }
 
+// The same as a real function (arguments and result in registers): for kernels that reach the float64 chain only on
+// exact equality of the integer decision and would otherwise carry a copy of its ~70 instructions at every inlined site.
+__device__ __noinline__ bool ordered_use_nearest_call(const double d2_0, const double d2_1, const float t)
+{
+    return ordered_use_nearest(d2_0, d2_1, t);
+}
+
 }  // namespace dp
