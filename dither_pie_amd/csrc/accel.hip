@@ -531,6 +531,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     }
     dev.n_split = st.n_split;
     dev.n_slow_blocks = st.n_slow;
+    dev.n_split_cells = st.n_split_cells;
     dev.max_cell = st.max_cnt;
     dev.code1 = code1;
     dev.code2 = code2;

@@ -69,6 +69,7 @@ struct PalDev {
     int tab4_words;
     int n_split;
     int n_slow_blocks;
+    int n_split_cells;          // 16^3 cells of cell_tab that are split (a palette crowded into few cells has many)
     int max_cell;
     const uint32_t *code1;      // 2 bits per colour: tie outcome of the k=1 query
     const uint32_t *code2;      // 4 bits per colour: ... of the k=2 query (accel.hip)

@@ -347,6 +347,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.cell_tab4 = nullptr;
     d.tab4_words = 0;
     d.n_split = d.n_slow_blocks = 0;
+    d.n_split_cells = 0;
     d.max_cell = 0;
     d.code1 = d.code2 = nullptr;
     d.exc = nullptr;

@@ -844,7 +844,9 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     if (slow) flag_slow_pixel(p, flags, g);
 }
 
-template <int MODE, int BW>
+// ADAPT: compiled with the deep mode (see below); the launcher picks it for palettes crowded into few cells, whose
+// pixels tend to sit in split cells -- the plain instantiation keeps its scalar registers for the lean loop
+template <int MODE, int BW, bool ADAPT>
 __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t *__restrict__ in,
                                                                   uint8_t *__restrict__ out,
                                                                   unsigned long long *__restrict__ flags,
@@ -889,7 +891,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
         if (lane < 4u) flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
         bool rare[4] = {false, false, false, false};
         uint32_t n_hard = 0;  // deep mode: pixels of this wave tile that needed more than their cell's block
-        if (deep && gidx < n_full) {
+        if (ADAPT && deep && gidx < n_full) {
             // Most recent pixels of this wave sat in split cells or on ties (palettes extracted from the image itself put
             // their colours exactly where the pixels are): resolve the four pixels completely right here instead of
             // computing a throw-away result and queueing them.
@@ -1032,7 +1034,8 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
             }
         }
         // adapt: more than a third of the last 256 pixels rare -> deep mode; fewer than an eighth hard -> back
-        if (deep) {
+        if (!ADAPT) {
+        } else if (deep) {
             unsigned long long m1 = __ballot(n_hard & 1u), m2 = __ballot(n_hard & 2u), m4 = __ballot(n_hard & 4u);
             const uint32_t hard_px = (uint32_t)__popcll(m1) + 2u * (uint32_t)__popcll(m2) + 4u * (uint32_t)__popcll(m4);
             if (hard_px < 32u) deep = false;
@@ -1624,14 +1627,19 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             PalDev pal4 = pal;
             pal4.cell_tab = pal.cell_tab4;
             pal4.tab_words = pal.tab4_words;
+            // crowded palettes (many split cells, or a table larger than LDS): the instantiation that adapts per wave
+            const bool adapt = !small && (pal.tab_total > pal.tab_words || pal.n_split_cells > 4096 * 3 / 100);
 #define DP_LEAN(M)                                                                                                        \
     do {                                                                                                                 \
         if (small)                                                                                                       \
-            hipLaunchKernelGGL((ordered_lean_kernel<M, 4>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, \
-                               sx, sy, ign_scale, n_tiles);                                                              \
+            hipLaunchKernelGGL((ordered_lean_kernel<M, 4, false>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g,     \
+                               pal4, thr, sx, sy, ign_scale, n_tiles);                                                   \
+        else if (adapt)                                                                                                  \
+            hipLaunchKernelGGL((ordered_lean_kernel<M, 8, true>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g,      \
+                               pal, thr, sx, sy, ign_scale, n_tiles);                                                    \
         else                                                                                                             \
-            hipLaunchKernelGGL((ordered_lean_kernel<M, 8>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr,  \
-                               sx, sy, ign_scale, n_tiles);                                                              \
+            hipLaunchKernelGGL((ordered_lean_kernel<M, 8, false>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g,     \
+                               pal, thr, sx, sy, ign_scale, n_tiles);                                                    \
     } while (0)
             if (lean_geo && mode == DP_MODE_NEAREST) {
                 DP_LEAN(0);
