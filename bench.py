@@ -212,6 +212,23 @@ def main():
         extra["c2_grad_frames_mpixel_per_s"] = round(world * px_per_step / tg / 1e6, 1)
         extra["c2_grad_note"] = "same kernel on 24 copies of the structured frame grad(2160,3840) (0.36 % tied pixels)"
         del fg
+        # C2-shaped, but content and palette as a user has them: smooth image-like frames (gradients + grain) and the
+        # 256-colour median-cut palette of that very content -- the palette crowds into the cells where the pixels are
+        from PIL import Image
+        from dither_pie_amd.dithering_lib import ColorReducer as _CR
+        rs = np.random.RandomState(3)
+        yy, xx = np.mgrid[0:540, 0:960]
+        img = np.clip(np.stack([80 + 60 * np.sin(xx / 300.0) + 40 * (yy / 540.0), 110 + 50 * np.cos(yy / 200.0) + 20 * np.sin(xx / 97.0),
+                                160 + 70 * (yy / 540.0) + 10 * np.sin((xx + yy) / 50.0)], -1) + rs.normal(0, 3, (540, 960, 3)), 0, 255).astype(np.uint8)
+        pal_mc = _CR.reduce_colors(Image.fromarray(img, "RGB"), 256)
+        fi = torch.from_numpy(img).to(dev).repeat(4, 4, 1).unsqueeze(0).repeat(args.frames, 1, 1, 1).contiguous()
+        dmc = ImageDitherer(256, DitherMode.BAYER, pal_mc, False, {"size": "8x8"})
+        dmc.apply_dithering_frames(fi, out=out)
+        ti = timed(lambda: dmc.apply_dithering_frames(fi, out=out), 3, 1) / 3
+        extra["c2_image_like_median_cut256_mpixel_per_s"] = round(world * px_per_step / ti / 1e6, 1)
+        extra["c2_image_like_note"] = ("smooth frames with grain + the 256-colour median-cut palette of that content: most pixels "
+                                       "fall into split cells of the table (deep split nodes in global memory, adaptive kernel)")
+        del fi, yy, xx
         # C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in): the float cell table
         dgam = ImageDitherer(256, DitherMode.BAYER, pal256, True, {"size": "8x8"})
         dgam.apply_dithering_frames(frames, out=out)
