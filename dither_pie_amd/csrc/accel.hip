@@ -267,6 +267,7 @@ constexpr int kTabStageWords = 4096 * 8 + 88 * 64;
 
 struct TableStats {
     int n_split = 0, n_slow = 0, max_cnt = 0;
+    std::vector<Box> node_box;  // the box each split node covers, by node index
     int n_split_cells = 0;  // 16^3 cells that are split (the pixels of these cells leave the main path of the kernels)
     bool too_big = false;
 };
@@ -323,6 +324,7 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int b
         tab.resize(base + 8 * (size_t)bw, 0u);
         tab[pos] = 0x80000000u | (uint32_t)((base - (size_t)kCells * bw) / (8 * (size_t)bw));
         ++st.n_split;
+        st.node_box.push_back(bx);
         const int hs = bx.size / 2;
         for (int sidx = 0; sidx < 8; ++sidx) {
             Box c{bx.r0 + ((sidx >> 2) & 1) * hs, bx.g0 + ((sidx >> 1) & 1) * hs, bx.b0 + (sidx & 1) * hs, hs};
@@ -384,6 +386,36 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int b
         }
     }
     return DP_OK;
+}
+
+// Tables larger than LDS: the kernels stage the cell blocks and the FIRST split nodes, the rest is read from global
+// memory.  Put the nodes of the most crowded boxes first -- a palette extracted from an image crowds its colours where
+// the image's pixels are, so those are the nodes the pixels visit.
+void crowded_nodes_first(std::vector<uint32_t> &tab, const TableStats &st, const int bw, const std::vector<uint32_t> &coord4)
+{
+    const size_t n = st.node_box.size();
+    if (n < 2) return;
+    std::vector<int> score(n, 0);
+    for (size_t k = 0; k < n; ++k) {
+        const Box &b = st.node_box[k];
+        for (const uint32_t c : coord4) {
+            const int r = c & 255, g = (c >> 8) & 255, bl = (c >> 16) & 255;
+            score[k] += (r >= b.r0 && r < b.r0 + b.size && g >= b.g0 && g < b.g0 + b.size && bl >= b.b0 && bl < b.b0 + b.size);
+        }
+    }
+    std::vector<uint32_t> order(n), where(n);
+    for (size_t k = 0; k < n; ++k) order[k] = (uint32_t)k;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
+    for (size_t k = 0; k < n; ++k) where[order[k]] = (uint32_t)k;
+    const size_t base = (size_t)kCells * bw, node_words = 8 * (size_t)bw;
+    std::vector<uint32_t> moved(tab.size());
+    std::copy(tab.begin(), tab.begin() + base, moved.begin());
+    for (size_t k = 0; k < n; ++k)
+        std::copy(tab.begin() + base + k * node_words, tab.begin() + base + (k + 1) * node_words,
+                  moved.begin() + base + where[k] * node_words);
+    for (uint32_t &w : moved)
+        if ((w >> 30) == 2u) w = 0x80000000u | where[w & 0xffffffu];  // split markers: the child node's new index
+    tab.swap(moved);
 }
 
 // runs `launch(d_boxes, d_masks, n)` over a list of boxes and brings the masks back
@@ -504,6 +536,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     dev.cell_tab = nullptr;
     dev.tab_words = 0;
     dev.tab_total = 0;
+    if (have8 && !st.too_big && tab.size() > (size_t)kTabCapWords) crowded_nodes_first(tab, st, 8, p4_host);
     if (have8 && !st.too_big) {
         e = hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -616,6 +649,7 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
         (void)hipFree(blob);
         return rc;  // too big even for global memory: the brute-force kernel stays in charge
     }
+    if ((int)tab.size() > (160 * 1024 - K * 16 - 256) / 4) crowded_nodes_first(tab, st, 8, coord4);
     e = hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(blob);
