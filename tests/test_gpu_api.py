@@ -222,3 +222,18 @@ print({{"stream=r_frame_rate": "25/1", "stream=width,height": "{w}\\n{h}", "stre
     got = np.frombuffer(body, np.uint8).reshape(ref.shape)
     assert np.array_equal(got, ref)
     assert seen[0] == 0.0 and seen[-1] == 1.0 and all(b >= a for a, b in zip(seen, seen[1:]))
+
+
+def test_distinct_colours_on_device_match_numpy():
+    """ColorReducer._distinct_in_order takes the GPU route for big images; it has to give the first-occurrence order the
+    numpy route gives (the set built from it, and so the median cut, depends on that order)."""
+    import torch
+    from dither_pie_amd.dithering_lib import ColorReducer
+    rs = np.random.RandomState(3)
+    for n, top in ((150_000, 256), (400_000, 12), (120_001, 40)):
+        arr = rs.randint(0, top, (n, 3)).astype(np.uint8)
+        got = ColorReducer._distinct_in_order(arr)
+        packed = (arr[:, 0].astype(np.uint32) << 16) | (arr[:, 1].astype(np.uint32) << 8) | arr[:, 2]
+        _, first = np.unique(packed, return_index=True)
+        assert np.array_equal(got, arr[np.sort(first)])
+    assert torch.cuda.is_available()
