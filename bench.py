@@ -226,8 +226,9 @@ def main():
         dmc.apply_dithering_frames(fi, out=out)
         ti = timed(lambda: dmc.apply_dithering_frames(fi, out=out), 3, 1) / 3
         extra["c2_image_like_median_cut256_mpixel_per_s"] = round(world * px_per_step / ti / 1e6, 1)
-        extra["c2_image_like_note"] = ("smooth frames with grain + the 256-colour median-cut palette of that content: most pixels "
-                                       "fall into split cells of the table (deep split nodes in global memory, adaptive kernel)")
+        extra["c2_image_like_note"] = ("smooth frames with grain + the 256-colour median-cut palette of that content: the palette "
+                                       "crowds a few cells of the colour cube (table over warped cells, adaptive kernel, deep split "
+                                       "nodes in global memory)")
         del fi, yy, xx
         # C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in): the float cell table
         dgam = ImageDitherer(256, DitherMode.BAYER, pal256, True, {"size": "8x8"})

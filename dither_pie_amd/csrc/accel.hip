@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "dp_internal.h"
@@ -177,6 +178,111 @@ __global__ __launch_bounds__(64) void accel_box_kernel(const PalDev pal, const B
     }
     __syncthreads();
     if (threadIdx.x < MW) masks[(size_t)blockIdx.x * MW + threadIdx.x] = s_mask[threadIdx.x];
+}
+
+
+// ---- warped cells ------------------------------------------------------------------------------------
+// A palette extracted from an image crowds its colours into a small part of the cube -- exactly where the image's
+// pixels are -- and the uniform 16^3 cells there hold far more than 8 candidates.  For such palettes the table is
+// built a second time over WARPED coordinates: per channel a monotone map u = lut[v] (0..255 -> 0..255) that gives
+// each sixteenth of the palette's coordinates (by rank) its own cell, with the 16 sub-positions of a cell spread
+// evenly over the cell's values.  Cells, sub-cells and the octree below them are defined on (lut_r[r], lut_g[g],
+// lut_b[b]) exactly as the plain table defines them on (r, g, b); a warped position may stand for several colours
+// (wide cells in empty regions) or for none.  The dither kernel looks the three bytes up in LDS.
+struct Range {
+    int r0, r1, g0, g1, b0, b1;  // the colours r0 <= r < r1, ...
+};
+
+template <int MW>
+__global__ __launch_bounds__(256) void accel_range_kernel(const PalDev pal, const Range *__restrict__ ranges,
+                                                          uint32_t *__restrict__ masks)
+{
+    __shared__ uint32_t s_mask[MW];
+    if (threadIdx.x < MW) s_mask[threadIdx.x] = 0;
+    __syncthreads();
+    const Range bx = ranges[blockIdx.x];
+    const int K = pal.K;
+    constexpr int kBig = 0x7fffffff;
+    constexpr int IM = (1 << kIdxBits) - 1;
+    const int ng = bx.g1 - bx.g0, nb = bx.b1 - bx.b0;
+    const int n = (bx.r1 - bx.r0) * ng * nb;
+    for (int id = threadIdx.x; id < n; id += 256) {
+        const uint32_t r = bx.r0 + id / (ng * nb), g = bx.g0 + (id / nb) % ng, b = bx.b0 + id % nb;
+        const uint32_t x4 = r | (g << 8) | (b << 16);
+        int m0 = kBig, m1 = kBig, m2 = kBig, m3 = kBig;
+        for (int j = 0; j < K; ++j) {
+            const int dot = (int)__builtin_amdgcn_udot4(x4, pal.p4[j], 0u, false);
+            const int key = pal.nkey[j] - (dot << (kIdxBits + 1));
+            const int n3 = med3i(m2, m3, key);
+            const int n2 = med3i(m1, m2, key);
+            const int n1 = med3i(m0, m1, key);
+            m0 = min(m0, key);
+            m1 = n1;
+            m2 = n2;
+            m3 = n3;
+        }
+        const int d1 = m1 >> kIdxBits, d2 = m2 >> kIdxBits, d3 = m3 >> kIdxBits;
+        atomicOr(&s_mask[(m0 & IM) >> 5], 1u << (m0 & 31));
+        if (K > 1) atomicOr(&s_mask[(m1 & IM) >> 5], 1u << (m1 & 31));
+        if (K > 2 && d2 == d1) atomicOr(&s_mask[(m2 & IM) >> 5], 1u << (m2 & 31));
+        if (K > 3 && d3 == d1)
+            for (int j = 0; j < K; ++j) {
+                const int dot = (int)__builtin_amdgcn_udot4(x4, pal.p4[j], 0u, false);
+                const int dj = (pal.nkey[j] - (dot << (kIdxBits + 1))) >> kIdxBits;
+                if (dj <= d1) atomicOr(&s_mask[j >> 5], 1u << (j & 31));
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x < MW) masks[(size_t)blockIdx.x * MW + threadIdx.x] = s_mask[threadIdx.x];
+}
+
+// T(x) of every colour, OR-ed into the masks of its WARPED cell and 8^3 sub-cell (masks zeroed by the caller; same
+// layout as accel_scan_kernel's: [cell = r'<<8 | g'<<4 | b'][9][MW]).  One block per plain cell of colours.
+template <int MW>
+__global__ __launch_bounds__(256) void accel_scan_warp_kernel(const PalDev pal, const uint8_t *__restrict__ lut,
+                                                              uint32_t *__restrict__ masks)
+{
+    const int cell = blockIdx.x;
+    const int rc = cell >> 8, gc = (cell >> 4) & 15, bc = cell & 15;
+    const int K = pal.K;
+    constexpr int kBig = 0x7fffffff;
+    constexpr int IM = (1 << kIdxBits) - 1;
+    for (int t = 0; t < 16; ++t) {
+        const int id = threadIdx.x + 256 * t;
+        const uint32_t r = rc * 16 + (id >> 8), g = gc * 16 + ((id >> 4) & 15), b = bc * 16 + (id & 15);
+        const uint32_t x4 = r | (g << 8) | (b << 16);
+        int m0 = kBig, m1 = kBig, m2 = kBig, m3 = kBig;
+        for (int j = 0; j < K; ++j) {
+            const int dot = (int)__builtin_amdgcn_udot4(x4, pal.p4[j], 0u, false);
+            const int key = pal.nkey[j] - (dot << (kIdxBits + 1));
+            const int n3 = med3i(m2, m3, key);
+            const int n2 = med3i(m1, m2, key);
+            const int n1 = med3i(m0, m1, key);
+            m0 = min(m0, key);
+            m1 = n1;
+            m2 = n2;
+            m3 = n3;
+        }
+        const int d1 = m1 >> kIdxBits, d2 = m2 >> kIdxBits, d3 = m3 >> kIdxBits;
+        const uint32_t ur = lut[r], ug = lut[256 + g], ub = lut[512 + b];
+        const uint32_t wcell = ((ur >> 4) << 8) | ((ug >> 4) << 4) | (ub >> 4);
+        const uint32_t sub = 1u + ((((ur >> 3) & 1u) << 2) | (((ug >> 3) & 1u) << 1) | ((ub >> 3) & 1u));
+        uint32_t *whole = masks + (size_t)wcell * 9 * MW, *part = whole + (size_t)sub * MW;
+        auto mark = [&](int j) {
+            const uint32_t bit = 1u << (j & 31);
+            if (!(whole[j >> 5] & bit)) atomicOr(&whole[j >> 5], bit);
+            if (!(part[j >> 5] & bit)) atomicOr(&part[j >> 5], bit);
+        };
+        mark(m0 & IM);
+        if (K > 1) mark(m1 & IM);
+        if (K > 2 && d2 == d1) mark(m2 & IM);
+        if (K > 3 && d3 == d1)
+            for (int j = 0; j < K; ++j) {
+                const int dot = (int)__builtin_amdgcn_udot4(x4, pal.p4[j], 0u, false);
+                const int dj = (pal.nkey[j] - (dot << (kIdxBits + 1))) >> kIdxBits;
+                if (dj <= d1) mark(j);
+            }
+    }
 }
 
 
@@ -418,15 +524,89 @@ void crowded_nodes_first(std::vector<uint32_t> &tab, const TableStats &st, const
     tab.swap(moved);
 }
 
-// runs `launch(d_boxes, d_masks, n)` over a list of boxes and brings the masks back
-template <class Launch>
-int run_box_kernel(const std::vector<Box> &boxes, std::vector<uint32_t> &bm, Launch launch)
+// The per-channel maps of a warped table (see accel_scan_warp_kernel).
+struct WarpMaps {
+    uint8_t lut[3][256];  // colour value -> warped coordinate
+    int lo[3][257];       // lo[c][u]: the smallest value whose warped coordinate is >= u (256 when there is none)
+};
+
+// 16 cells per channel, cell i starting at the palette's coordinate of rank K*i/16 (boundaries kept strictly
+// increasing); inside a cell of w values, value number k sits at sub-position k*16/w.
+void make_warp(const std::vector<uint32_t> &coord4, WarpMaps &wm)
 {
-    Box *d_boxes = nullptr;
+    const size_t K = coord4.size();
+    for (int c = 0; c < 3; ++c) {
+        std::vector<int> v(K);
+        for (size_t j = 0; j < K; ++j) v[j] = (coord4[j] >> (8 * c)) & 255;
+        std::sort(v.begin(), v.end());
+        int a[17];
+        a[0] = 0;
+        a[16] = 256;
+        for (int i = 1; i < 16; ++i) {
+            int q = v[K * (size_t)i / 16];
+            q = std::max(q, a[i - 1] + 1);
+            q = std::min(q, 256 - (16 - i));
+            a[i] = q;
+        }
+        for (int i = 0; i < 16; ++i) {
+            const int w = a[i + 1] - a[i];
+            for (int x = a[i]; x < a[i + 1]; ++x) wm.lut[c][x] = (uint8_t)(16 * i + ((x - a[i]) * 16) / w);
+        }
+        int x = 0;
+        for (int u = 0; u <= 256; ++u) {
+            while (x < 256 && (int)wm.lut[c][x] < u) ++x;
+            wm.lo[c][u] = x;
+        }
+    }
+}
+
+// the palette entries and, for each entry, the points a quarter and half of the way to its four nearest other entries
+std::vector<uint32_t> mass_points(const std::vector<uint32_t> &coord4)
+{
+    std::vector<uint32_t> out(coord4);
+    const size_t K = coord4.size();
+    constexpr int kNear = 4;
+    for (size_t j = 0; j < K && K > (size_t)kNear; ++j) {
+        const int r = coord4[j] & 255, g = (coord4[j] >> 8) & 255, b = (coord4[j] >> 16) & 255;
+        uint64_t best[kNear];
+        for (uint64_t &v : best) v = ~0ull;
+        for (size_t k = 0; k < K; ++k) {
+            if (k == j) continue;
+            const int dr = (int)(coord4[k] & 255) - r, dg = (int)((coord4[k] >> 8) & 255) - g, db = (int)((coord4[k] >> 16) & 255) - b;
+            uint64_t key = ((uint64_t)(dr * dr + dg * dg + db * db) << 32) | k;
+            for (uint64_t &v : best)
+                if (key < v) std::swap(key, v);
+        }
+        for (const uint64_t key : best) {
+            const uint32_t c = coord4[key & 0xffffffffu];
+            const int cr = c & 255, cg = (c >> 8) & 255, cb = (c >> 16) & 255;
+            for (const int q : {1, 2})  // quarters of the way
+                out.push_back((uint32_t)(r + (cr - r) * q / 4) | ((uint32_t)(g + (cg - g) * q / 4) << 8) | ((uint32_t)(b + (cb - b) * q / 4) << 16));
+        }
+    }
+    return out;
+}
+
+// how many of the given points (coordinates as the table sees them) sit in split cells
+int entries_in_split_cells(const std::vector<uint32_t> &tab, const int bw, const std::vector<uint32_t> &coord4)
+{
+    int n = 0;
+    for (const uint32_t c : coord4) {
+        const size_t slot = (size_t)cell_slot((c & 255) >> 4, ((c >> 8) & 255) >> 4, ((c >> 16) & 255) >> 4);
+        n += (int)(tab[slot * bw] >> 31);
+    }
+    return n;
+}
+
+// runs `launch(d_boxes, d_masks, n)` over a list of boxes and brings the masks back
+template <class B, class Launch>
+int run_box_kernel(const std::vector<B> &boxes, std::vector<uint32_t> &bm, Launch launch)
+{
+    B *d_boxes = nullptr;
     uint32_t *d_bm = nullptr;
-    hipError_t e = hipMalloc((void **)&d_boxes, sizeof(Box) * boxes.size());
+    hipError_t e = hipMalloc((void **)&d_boxes, sizeof(B) * boxes.size());
     if (e == hipSuccess) e = hipMalloc((void **)&d_bm, sizeof(uint32_t) * bm.size());
-    if (e == hipSuccess) e = hipMemcpy(d_boxes, boxes.data(), sizeof(Box) * boxes.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_boxes, boxes.data(), sizeof(B) * boxes.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         launch(d_boxes, d_bm, (unsigned)boxes.size());
         e = hipGetLastError();
@@ -452,14 +632,22 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     uint8_t *blob = nullptr;
     const int mw = K <= 256 ? 8 : 32;               // mask words per (sub-)cell
     const bool big_q = dev.n_inner > kQueueSmall;   // traversal queue of the tie queries
-    // layout: code1 | code2 | table[cap] | exceptions | exception count | table of 4-entry blocks [cap]
-    const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + kTabMaxWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16;
+    // layout: code1 | code2 | table[max] | exceptions | exception count | table of 4-entry blocks [cap] |
+    //         table over warped cells [max] | the three warp maps [768 bytes]
+    const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + 2 * kTabMaxWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16 + 768;
     DP_HIP(hipMalloc((void **)&blob, bytes));
+    struct DevFree {  // frees the scan masks on every way out
+        void *p = nullptr;
+        ~DevFree()
+        {
+            if (p) (void)hipFree(p);
+        }
+    } masks_guard;
     hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 9 * mw);
+    masks_guard.p = d_masks;
     if (e == hipSuccess) e = hipMemset(blob, 0, sizeof(uint32_t) * 3 * kCodeWords);
     if (e != hipSuccess) {
         (void)hipFree(blob);
-        if (d_masks) (void)hipFree(d_masks);
         return hip_fail(e, "accelerator allocation");
     }
     uint32_t *code1 = reinterpret_cast<uint32_t *>(blob);
@@ -470,7 +658,6 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     e = hipMemset(d_exc_count, 0, sizeof(uint32_t));
     if (e != hipSuccess) {
         (void)hipFree(blob);
-        (void)hipFree(d_masks);
         return hip_fail(e, "accelerator allocation");
     }
 #define DP_SCAN(MW, C) hipLaunchKernelGGL((accel_scan_kernel<MW, C>), dim3(kCells), dim3(256), 0, 0, dev, d_masks, code1, code2, d_exc, d_exc_count)
@@ -483,7 +670,6 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     std::vector<uint32_t> masks((size_t)kCells * 9 * mw);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(masks.data(), d_masks, sizeof(uint32_t) * masks.size(), hipMemcpyDeviceToHost);
-    (void)hipFree(d_masks);
     if (e != hipSuccess) {
         (void)hipFree(blob);
         return hip_fail(e, "accelerator scan");
@@ -532,6 +718,133 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     if ((!have8 || st.too_big) && !use4) {
         (void)hipFree(blob);
         return DP_OK;  // no table that fits LDS: the brute-force kernel stays in charge
+    }
+    // Where an image's pixels are when the palette was extracted from that image: at the palette entries and between
+    // neighbouring entries.  The share of these points that sits in split cells tells how many pixels would leave the
+    // main path of the dither kernel.
+    const std::vector<uint32_t> mass = mass_points(p4_host);
+    const int n_mass = (int)mass.size();
+    const bool ok8 = have8 && !st.too_big;
+    const bool u8_spilled = ok8 && tab.size() > (size_t)kTabCapWords;
+    const int m4 = use4 ? entries_in_split_cells(tab4, 4, mass) : n_mass;
+    const int m8 = ok8 ? entries_in_split_cells(tab, 8, mass) : n_mass;
+    // the 4-entry table loses its advantage when pixels crowd its split cells (more than 5 % of the mass) and the 8-entry
+    // table keeps them on the main path
+    if (use4 && ok8 && m4 * 20 > n_mass && m8 * 2 <= m4) use4 = false;
+    // experiments: DP_FORCE_TABLE = u4 | u8 | w4 | w8 picks the table regardless of the estimates (when it exists)
+    const char *force_env = getenv("DP_FORCE_TABLE");
+    const std::string force = force_env ? force_env : "";
+    if (force == "u4") use4 = K <= 64 && !st4.too_big;
+    else if (!force.empty() && ok8) use4 = false;
+    const int u_mass = use4 ? m4 : m8;
+    const int u_cells = use4 ? st4.n_split_cells : st.n_split_cells;
+    const bool u_spilled = !use4 && u8_spilled;
+    const bool u_crowded = u_spilled || u_cells > kCells * 3 / 100 || u_mass * 4 >= n_mass;
+    // worth a second table: the table in use is crowded, or more than 2 % of the mass sits in its split cells (a table over
+    // warped cells costs the kernel three more LDS reads per pixel, so it has to win something)
+    const bool try_warp = (u_crowded && !(use4 && m4 * 50 <= n_mass)) || u_mass * 50 > n_mass;
+    // Crowded palettes (extracted from an image: the colours sit where the pixels are, in a few cells that hold far more
+    // than a block): build the table a second time over warped cells and keep it when it leaves at most half as much
+    // of the mass in split cells.
+    std::vector<uint32_t> wtab;
+    TableStats wst;
+    WarpMaps wm;
+    int wbw = 0, w_mass = 0;
+    bool w_spilled = false;
+    uint32_t *d_wtab = d_exc_count + 4 + kTabCapWords;
+    uint8_t *d_lut = reinterpret_cast<uint8_t *>(d_wtab + kTabMaxWords);
+    if (K >= 8 && (try_warp || force[0] == 'w') && force[0] != 'u' && !getenv("DP_NO_WARP")) {
+        make_warp(p4_host, wm);
+        auto warped = [&](const uint32_t c) {
+            return (uint32_t)wm.lut[0][c & 255] | ((uint32_t)wm.lut[1][(c >> 8) & 255] << 8) | ((uint32_t)wm.lut[2][(c >> 16) & 255] << 16);
+        };
+        std::vector<uint32_t> coordw(K), massw(mass.size());
+        for (int j = 0; j < K; ++j) coordw[j] = warped(p4_host[j]);
+        for (size_t j = 0; j < mass.size(); ++j) massw[j] = warped(mass[j]);
+        e = hipMemcpy(d_lut, &wm.lut[0][0], 768, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(d_masks, 0, sizeof(uint32_t) * kCells * 9 * mw);
+        if (e == hipSuccess) {
+            if (mw == 8) hipLaunchKernelGGL(accel_scan_warp_kernel<8>, dim3(kCells), dim3(256), 0, 0, dev, d_lut, d_masks);
+            else hipLaunchKernelGGL(accel_scan_warp_kernel<32>, dim3(kCells), dim3(256), 0, 0, dev, d_lut, d_masks);
+            e = hipGetLastError();
+        }
+        std::vector<uint32_t> wmasks((size_t)kCells * 9 * mw);
+        if (e == hipSuccess) e = hipMemcpy(wmasks.data(), d_masks, sizeof(uint32_t) * wmasks.size(), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            (void)hipFree(blob);
+            return hip_fail(e, "accelerator scan (warped cells)");
+        }
+        auto box_masks_w = [&](const std::vector<Box> &boxes, std::vector<uint32_t> &bm) {
+            std::vector<Range> ranges(boxes.size());
+            for (size_t q = 0; q < boxes.size(); ++q) {
+                const Box &b = boxes[q];
+                ranges[q] = Range{wm.lo[0][b.r0], wm.lo[0][b.r0 + b.size], wm.lo[1][b.g0], wm.lo[1][b.g0 + b.size],
+                                  wm.lo[2][b.b0], wm.lo[2][b.b0 + b.size]};
+            }
+            return run_box_kernel(ranges, bm, [&](const Range *db, uint32_t *dm, unsigned n) {
+                if (mw == 8) hipLaunchKernelGGL(accel_range_kernel<8>, dim3(n), dim3(256), 0, 0, dev, db, dm);
+                else hipLaunchKernelGGL(accel_range_kernel<32>, dim3(n), dim3(256), 0, 0, dev, db, dm);
+            });
+        };
+        // (the warp maps take 768 bytes of the kernels' LDS)
+        int w4_mass = -1;
+        if (K <= 64 && force != "w8") {
+            TableStats s4;
+            std::vector<uint32_t> t4;
+            const int rc4 = assemble_table(wmasks, mw, 4, kTabCapWords - 192, K, coordw, p4_host, box_masks_w, t4, s4);
+            if (rc4 != DP_OK) {
+                (void)hipFree(blob);
+                return rc4;
+            }
+            w4_mass = s4.too_big ? n_mass : entries_in_split_cells(t4, 4, massw);
+            // 4-entry blocks only when practically nothing leaves the main path (else 8-entry blocks are the safer choice)
+            if (!s4.too_big && ((s4.n_split_cells <= kCells / 100 && s4.n_slow == 0 && w4_mass * 50 <= n_mass) || force == "w4")) {
+                wtab.swap(t4);
+                wst = s4;
+                wbw = 4;
+                w_mass = w4_mass;
+            }
+        }
+        if (wbw == 0) {
+            const int rc8 = assemble_table(wmasks, mw, 8, kTabMaxWords, K, coordw, p4_host, box_masks_w, wtab, wst);
+            if (rc8 != DP_OK) {
+                (void)hipFree(blob);
+                return rc8;
+            }
+            if (!wst.too_big) {
+                wbw = 8;
+                w_spilled = wtab.size() > (size_t)(kTabCapWords - 192);
+                w_mass = entries_in_split_cells(wtab, 8, massw);
+                if (w_spilled) crowded_nodes_first(wtab, wst, 8, coordw);
+            }
+        }
+        if (getenv("DP_DEBUG_ACCEL"))
+            fprintf(stderr, "accel K=%d: mass in split cells: plain 4-entry %d, plain 8-entry %d of %d (in use: %d-entry, %d cells%s); warped 4-entry %d, "
+                    "warped %d-entry table: %d, %d split cells, %d nodes, %d slow, %zu words%s\n",
+                    K, m4, m8, n_mass, use4 ? 4 : 8, u_cells, u_spilled ? ", spilled" : "", w4_mass, wbw, w_mass, wst.n_split_cells, wst.n_split,
+                    wst.n_slow, wtab.size(), w_spilled ? " (deep nodes in global memory)" : "");
+        // no real gain (less than half of the mass brought back, or less than 2 % of it): stay with the plain cells
+        if (wbw != 0 && (w_mass * 2 > u_mass || (u_mass - w_mass) * 50 < n_mass) && !(u_spilled && !w_spilled) && force.empty()) wbw = 0;
+    } else if (getenv("DP_DEBUG_ACCEL")) {
+        fprintf(stderr, "accel K=%d: mass in split cells: plain 4-entry %d, plain 8-entry %d of %d (in use: %d-entry, %d cells)\n", K, m4, m8, n_mass,
+                use4 ? 4 : 8, u_cells);
+    }
+    dev.warp_tab = nullptr;
+    dev.warp_lut = nullptr;
+    dev.warp_words = dev.warp_total = dev.warp_bw = dev.warp_adapt = 0;
+    dev.adapt = (!use4 && u_crowded) ? 1 : 0;
+    if (wbw != 0) {
+        e = hipMemcpy(d_wtab, wtab.data(), sizeof(uint32_t) * wtab.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(blob);
+            return hip_fail(e, "accelerator upload (warped cells)");
+        }
+        dev.warp_tab = d_wtab;
+        dev.warp_lut = d_lut;
+        dev.warp_bw = wbw;
+        dev.warp_total = (int)wtab.size();
+        dev.warp_words = w_spilled ? std::min((int)wtab.size(), kTabStageWords - 3 * 64) : (int)wtab.size();
+        dev.warp_adapt = (wbw == 8 && (w_spilled || wst.n_split_cells > kCells * 3 / 100 || w_mass * 4 >= n_mass)) ? 1 : 0;
     }
     dev.cell_tab = nullptr;
     dev.tab_words = 0;

@@ -67,6 +67,14 @@ struct PalDev {
     // the lean kernel prefers it (half the candidate work)
     const uint32_t *cell_tab4;
     int tab4_words;
+    int adapt;                  // the palette crowds a few cells of cell_tab: use the kernel instantiation that adapts per wave
+    // crowded palettes (extracted from an image): a table over WARPED cells -- cell coordinates are
+    // (warp_lut[r], warp_lut[256 + g], warp_lut[512 + b]) instead of (r, g, b) -- or nullptr.  Lean kernels only.
+    const uint32_t *warp_tab;   // blocks of warp_bw entries (4 or 8), same structure as cell_tab
+    const uint8_t *warp_lut;    // 768 bytes
+    int warp_words, warp_total; // staged / all words (as tab_words / tab_total)
+    int warp_bw;
+    int warp_adapt;
     int n_split;
     int n_slow_blocks;
     int n_split_cells;          // 16^3 cells of cell_tab that are split (a palette crowded into few cells has many)

@@ -346,6 +346,10 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.tab_total = 0;
     d.cell_tab4 = nullptr;
     d.tab4_words = 0;
+    d.adapt = 0;
+    d.warp_tab = nullptr;
+    d.warp_lut = nullptr;
+    d.warp_words = d.warp_total = d.warp_bw = d.warp_adapt = 0;
     d.n_split = d.n_slow_blocks = 0;
     d.n_split_cells = 0;
     d.max_cell = 0;

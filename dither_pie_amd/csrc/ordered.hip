@@ -587,6 +587,18 @@ constexpr int kLeanLdsWords = 160 * 1024 / 4;
 constexpr int kLeanQueue = 128;                                         // entries per wave
 constexpr int kLeanQueueWords = (kCellBlock / 64) * kLeanQueue;         // 8 KB at the top of LDS
 constexpr int kLeanTabBytes = (kLeanLdsWords - kLeanQueueWords) * 4;    // table + thresholds must fit below
+constexpr int kWarpLutBytes = 768;                                      // tables over warped cells: the three maps ...
+constexpr int kWarpLutAt = kLeanTabBytes - kWarpLutBytes;               // ... sit right below the queue
+
+// Cell coordinates of a colour: the colour itself, or (tables over warped cells, accel.hip) its three bytes mapped
+// through the per-channel tables staged in LDS.
+template <bool WARP>
+__device__ __forceinline__ uint32_t cell_coord(const uint32_t x, const uint8_t *s_bytes)
+{
+    if (!WARP) return x;
+    const uint8_t *lut = s_bytes + kWarpLutAt;
+    return (uint32_t)lut[x & 255u] | ((uint32_t)lut[256u + ((x >> 8) & 255u)] << 8) | ((uint32_t)lut[512u + (x >> 16)] << 16);
+}
 
 // x mod d for d > 0 with inv = 1.0/d (exact: the float64 quotient estimate is off by at most one)
 __device__ __forceinline__ uint32_t umod_inv(const uint32_t x, const uint32_t d, const double inv)
@@ -809,7 +821,7 @@ __device__ __forceinline__ void flag_slow_pixel(const uint32_t p, unsigned long 
 }
 
 // The deferred path: one queued pixel per lane, from its bytes in memory to its bytes in memory.
-template <int MODE, int BW>
+template <int MODE, int BW, bool WARP>
 __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t *__restrict__ in,
                                                 uint8_t *__restrict__ out, unsigned long long *__restrict__ flags,
                                                 const Geo &g, const PalDev &pal, const ThrDev &thr,
@@ -835,7 +847,7 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     }
     bool slow, hard;
     Leaf lf;
-    leaf_find<BW>(x, pal, s_bytes, lf);
+    leaf_find<BW>(cell_coord<WARP>(x, s_bytes), pal, s_bytes, lf);
     const uint32_t c = resolve_pixel<MODE, BW>(x, th, lf, g, pal, thr, s_bytes, slow, hard);
     uint8_t *o = out + (size_t)p * 3;
     o[0] = (uint8_t)c;
@@ -846,7 +858,7 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
 
 // ADAPT: compiled with the deep mode (see below); the launcher picks it for palettes crowded into few cells, whose
 // pixels tend to sit in split cells -- the plain instantiation keeps its scalar registers for the lean loop
-template <int MODE, int BW, bool ADAPT>
+template <int MODE, int BW, bool ADAPT, bool WARP>
 __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t *__restrict__ in,
                                                                   uint8_t *__restrict__ out,
                                                                   unsigned long long *__restrict__ flags,
@@ -861,6 +873,8 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
         const int n = thr.th_h * thr.tw_pad;
         for (int i = threadIdx.x; i < n; i += kCellBlock) smem[pal.tab_words + i] = thr.mpad[i];
     }
+    if (WARP && threadIdx.x < kWarpLutBytes / 4)
+        smem[kWarpLutAt / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(pal.warp_lut)[threadIdx.x];
     __syncthreads();
     const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(smem);
     const uint32_t lane = threadIdx.x & 63u;
@@ -927,12 +941,16 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                 uint32_t hard_bits = 0;
                 // the four descents advance level by level together, so that their reads are in flight at the same time
                 Leaf lf[4];
+                uint32_t xc[4];  // cell coordinates
 #pragma unroll
-                for (int q = 0; q < 4; ++q) leaf_begin<BW>(xq[q], s_bytes, lf[q]);
+                for (int q = 0; q < 4; ++q) {
+                    xc[q] = cell_coord<WARP>(xq[q], s_bytes);
+                    leaf_begin<BW>(xc[q], s_bytes, lf[q]);
+                }
                 for (int bit = 3; (int)leaf_pending(lf[0]) | (int)leaf_pending(lf[1]) | (int)leaf_pending(lf[2]) | (int)leaf_pending(lf[3]); --bit) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (leaf_pending(lf[q])) leaf_step<BW>(xq[q], bit, pal, s_bytes, lf[q]);
+                        if (leaf_pending(lf[q])) leaf_step<BW>(xc[q], bit, pal, s_bytes, lf[q]);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -958,7 +976,8 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
             uint4 ca[4], cb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                blk[q] = BW == 8 ? cell_offset(xq[q]) : cell_offset4(xq[q]);
+                const uint32_t xc = cell_coord<WARP>(xq[q], s_bytes);
+                blk[q] = BW == 8 ? cell_offset(xc) : cell_offset4(xc);
                 ca[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q]);
                 if (BW == 8) cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
             }
@@ -1029,7 +1048,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                 if (qcount >= 64u) {
                     qcount -= 64u;
                     __threadfence_block();  // the queue writes, and the group stores that are about to be overwritten
-                    lean_pixel_full<MODE, BW>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
+                    lean_pixel_full<MODE, BW, WARP>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
                 }
             }
         }
@@ -1052,7 +1071,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
     }
     if (qcount != 0u) {
         __threadfence_block();
-        if (lane < qcount) lean_pixel_full<MODE, BW>(s_queue[lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
+        if (lane < qcount) lean_pixel_full<MODE, BW, WARP>(s_queue[lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
     }
 }
 
@@ -1604,9 +1623,11 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         ProfMark *pm = prof_begin(s);
         const bool int_thr_ok = thr.m != nullptr && thr.th_h * thr.th_w <= 256;
         // the table the lean kernels would stage: 4-entry blocks when the accelerator built them, else 8-entry blocks
-        const bool small = pal.cell_tab4 != nullptr;
-        const size_t lean_tab_bytes = 4 * (size_t)(small ? pal.tab4_words : pal.tab_words);
-        const bool lean_geo = integer && (small || pal.cell_tab != nullptr) && g.aligned && y0 >= 0 && x0 >= 0 &&
+        // ... or, crowded palettes, the table over warped cells (with its maps)
+        const bool warp = pal.warp_tab != nullptr;
+        const bool small = warp ? pal.warp_bw == 4 : pal.cell_tab4 != nullptr;
+        const size_t lean_tab_bytes = warp ? 4 * (size_t)pal.warp_words + kWarpLutBytes : 4 * (size_t)(small ? pal.tab4_words : pal.tab_words);
+        const bool lean_geo = integer && (warp || small || pal.cell_tab != nullptr) && g.aligned && y0 >= 0 && x0 >= 0 &&
                               lean_tab_bytes <= (size_t)kLeanTabBytes;
         const bool int_lean = thr.mpad != nullptr && lean_tab_bytes + (size_t)thr.th_h * thr.tw_pad * 4 <= (size_t)kLeanTabBytes;
         const bool lean_ok = lean_geo && (mode == DP_MODE_NEAREST || mode == DP_MODE_IGN ||
@@ -1616,7 +1637,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             // fast path: LDS cell table + tie codes, persistent 1024-lane workgroups over 4096-pixel tiles
             const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
             n_words = n_tiles * (kCellBlock / 64) * 4;
-            const size_t lds = sizeof(uint32_t) * ((size_t)pal.tab_words + 256);
+            const size_t lds = sizeof(uint32_t) * ((size_t)pal.tab_words + 256);  // launch_cell (plain table) only
             const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus());
             {
                 const uint64_t adv = ((uint64_t)cgrid * kCellBlock * 4u) % (uint64_t)hw;
@@ -1624,22 +1645,29 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
                 g.adv_x = (uint32_t)(adv % (uint64_t)w);
             }
             int rc;
-            PalDev pal4 = pal;
-            pal4.cell_tab = pal.cell_tab4;
-            pal4.tab_words = pal.tab4_words;
+            PalDev pal4 = pal;  // the table the lean kernel stages, in the fields it reads
+            if (warp) {
+                pal4.cell_tab = pal.warp_tab;
+                pal4.tab_words = pal.warp_words;
+                pal4.tab_total = pal.warp_total;
+            } else if (small) {
+                pal4.cell_tab = pal.cell_tab4;
+                pal4.tab_words = pal.tab4_words;
+                pal4.tab_total = pal.tab4_words;
+            }
             // crowded palettes (many split cells, or a table larger than LDS): the instantiation that adapts per wave
-            const bool adapt = !small && (pal.tab_total > pal.tab_words || pal.n_split_cells > 4096 * 3 / 100);
+            const bool adapt = warp ? pal.warp_adapt != 0 : (!small && pal.adapt != 0);
+#define DP_LEAN_K(M, BW, AD, WP)                                                                                         \
+    hipLaunchKernelGGL((ordered_lean_kernel<M, BW, AD, WP>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, \
+                       sx, sy, ign_scale, n_tiles)
 #define DP_LEAN(M)                                                                                                        \
     do {                                                                                                                 \
-        if (small)                                                                                                       \
-            hipLaunchKernelGGL((ordered_lean_kernel<M, 4, false>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g,     \
-                               pal4, thr, sx, sy, ign_scale, n_tiles);                                                   \
-        else if (adapt)                                                                                                  \
-            hipLaunchKernelGGL((ordered_lean_kernel<M, 8, true>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g,      \
-                               pal, thr, sx, sy, ign_scale, n_tiles);                                                    \
-        else                                                                                                             \
-            hipLaunchKernelGGL((ordered_lean_kernel<M, 8, false>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g,     \
-                               pal, thr, sx, sy, ign_scale, n_tiles);                                                    \
+        if (warp && small) DP_LEAN_K(M, 4, false, true);                                                                 \
+        else if (warp && adapt) DP_LEAN_K(M, 8, true, true);                                                             \
+        else if (warp) DP_LEAN_K(M, 8, false, true);                                                                     \
+        else if (small) DP_LEAN_K(M, 4, false, false);                                                                   \
+        else if (adapt) DP_LEAN_K(M, 8, true, false);                                                                    \
+        else DP_LEAN_K(M, 8, false, false);                                                                              \
     } while (0)
             if (lean_geo && mode == DP_MODE_NEAREST) {
                 DP_LEAN(0);
@@ -1658,6 +1686,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
                 rc = DP_OK;
                 fix_mode = 2;
 #undef DP_LEAN
+#undef DP_LEAN_K
             } else if (mode == DP_MODE_NEAREST) {
                 rc = launch_cell<0>(cgrid, lds, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles);
                 fix_mode = 0;

@@ -506,3 +506,36 @@ def test_clustered_float_palette_spills_split_nodes(be, orc, mode, params):
     arr[:30] = orc.rnd(30, w, 3)
     out = _run_case(be, orc, arr, pal, mode, params, True, y0=2, x0=5)
     _assert_same(out, orc.apply_dithering(arr, pal, mode, params, True, y0=2, x0=5), f"float spilled {mode}")
+
+
+def _image_like(rs, h, w, kind):
+    y, x = np.mgrid[0:h, 0:w]
+    if kind == "dark":
+        chans = [20 + 25 * np.sin(x / 12.0) ** 2 + 15 * (y / h), 18 + 22 * np.cos(y / 9.0) ** 2, 25 + 30 * np.sin((x + y) / 15.0) ** 2]
+    else:
+        chans = [80 + 60 * np.sin(x / 30.0) + 40 * (y / h), 110 + 50 * np.cos(y / 20.0) + 20 * np.sin(x / 9.7),
+                 160 + 70 * (y / h) + 10 * np.sin((x + y) / 5.0)]
+    return np.clip(np.stack(chans, -1) + rs.normal(0, 3, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("table", ["", "u4", "u8", "w4", "w8"])
+@pytest.mark.parametrize("kind,K", [("dark", 8), ("dark", 16), ("smooth", 64), ("dark", 256), ("smooth", 256)])
+def test_image_derived_palettes_every_cell_table(be, orc, monkeypatch, table, kind, K):
+    """Palettes extracted from the image itself crowd a few cells of the plain 16^3 grid; the accelerator then builds its
+    table over warped cells (per-channel maps staged in LDS).  Every table variant the accelerator can choose -- plain or
+    warped cells, 4- or 8-entry blocks (DP_FORCE_TABLE; "" = its own choice) -- has to give the oracle's bytes, on the
+    image-like content the palette came from and on noise (which lands in the wide cells of the warped grid)."""
+    from PIL import Image
+    from dither_pie_amd.dithering_lib import ColorReducer
+    if table:
+        monkeypatch.setenv("DP_FORCE_TABLE", table)
+    rs = np.random.RandomState(K + len(kind))
+    h, w = 120, 203
+    arr = _image_like(rs, h, w, kind)
+    pal = ColorReducer.reduce_colors(Image.fromarray(arr, "RGB"), K)
+    arr[:24] = orc.rnd(24, w, K)  # noise rows
+    arr[24:30] = np.asarray(pal, dtype=np.uint8)[rs.randint(0, len(pal), (6, w))]  # exact palette colours
+    for mode, params in (("none", {}), ("bayer", {"size": "8x8"}), ("IGN", {}), ("blue_noise", {"size": 32, "seed": 2})):
+        out = _run_case(be, orc, arr, pal, mode, params, False, y0=2, x0=3)
+        _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False, y0=2, x0=3), f"{kind} K={K} table={table or 'auto'} {mode}")

@@ -20,7 +20,7 @@ g=torch.Generator(device='cuda'); g.manual_seed(1234)
 frames=torch.randint(0,256,(24,2160,3840,3),dtype=torch.uint8,device='cuda',generator=g); out=torch.empty_like(frames)
 for kind in ("smooth","dark","patches"):
     a=img(kind)
-    for K in (16,64,256):
+    for K in ((16,64,256) if len(sys.argv) < 2 else [int(v) for v in sys.argv[1:]]):
         for src,pal in (("median_cut",ColorReducer.reduce_colors(Image.fromarray(a,"RGB"),K)),("kmeans",ColorReducer.generate_kmeans_palette(Image.fromarray(a,"RGB"),K,random_state=42))):
             P=backend.Palette(*prepare_palette(pal,False),accel=True)
             big=torch.from_numpy(a).cuda().repeat(4,4,1).unsqueeze(0).repeat(24,1,1,1).contiguous()   # 24 frames of 2160x3840 image-like content
