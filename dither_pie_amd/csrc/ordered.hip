@@ -820,13 +820,17 @@ __device__ __forceinline__ void flag_slow_pixel(const uint32_t p, unsigned long 
     if (slot < (uint32_t)kQueueTiles) g.dirty[1 + slot] = wtile;
 }
 
-// The deferred path: one queued pixel per lane, from its bytes in memory to its bytes in memory.
+// The deferred path: one queue entry per lane -- (group of four pixels) << 4 | the group's deferred pixels -- whose
+// lowest pixel is resolved from its bytes in memory to its bytes in memory.  Returns the entry without that pixel
+// (0 when the group is done; the caller queues the rest again: two deferred pixels in one group are rare).
 template <int MODE, int BW, bool WARP>
-__device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t *__restrict__ in,
-                                                uint8_t *__restrict__ out, unsigned long long *__restrict__ flags,
-                                                const Geo &g, const PalDev &pal, const ThrDev &thr,
-                                                const uint32_t *s_words, const float sx, const float sy, const float sc)
+__device__ __forceinline__ uint32_t lean_pixel_full(const uint32_t entry, const uint8_t *__restrict__ in,
+                                                    uint8_t *__restrict__ out, unsigned long long *__restrict__ flags,
+                                                    const Geo &g, const PalDev &pal, const ThrDev &thr,
+                                                    const uint32_t *s_words, const float sx, const float sy, const float sc)
 {
+    const uint32_t mask = entry & 15u;
+    const uint32_t p = (entry >> 4) * 4u + (uint32_t)__builtin_ctz(mask | 16u);
     const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_words);
     const uint8_t *b = in + (size_t)p * 3;
     const uint32_t x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
@@ -854,6 +858,8 @@ __device__ __forceinline__ void lean_pixel_full(const uint32_t p, const uint8_t 
     o[1] = (uint8_t)(c >> 8);
     o[2] = (uint8_t)(c >> 16);
     if (slow) flag_slow_pixel(p, flags, g);
+    const uint32_t rest = mask & (mask - 1u);
+    return rest ? ((entry & ~15u) | rest) : 0u;
 }
 
 // ADAPT: compiled with the deep mode (see below); the launcher picks it for palettes crowded into few cells, whose
@@ -1036,19 +1042,26 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
             for (int q = 0; q < 4; ++q) rare[q] = gidx * 4u + (uint32_t)q < g.n_px;  // the partial last group
         }
         uint32_t rare_px = 0;  // wave-uniform
+        if (ADAPT) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned long long rb = __ballot(rare[q]);
-            rare_px += (uint32_t)__popcll(rb);
-            if (rb != 0ull) {  // wave-uniform
-                if (rare[q])
-                    s_queue[__builtin_amdgcn_mbcnt_hi((uint32_t)(rb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rb, qcount))] =
-                        gidx * 4u + (uint32_t)q;
-                qcount += (uint32_t)__popcll(rb);
-                if (qcount >= 64u) {
-                    qcount -= 64u;
-                    __threadfence_block();  // the queue writes, and the group stores that are about to be overwritten
-                    lean_pixel_full<MODE, BW, WARP>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
+            for (int q = 0; q < 4; ++q) rare_px += (uint32_t)__popcll(__ballot(rare[q]));
+        }
+        // one queue entry per group with deferred pixels: group << 4 | which of its four
+        const uint32_t rmask = (rare[0] ? 1u : 0u) | (rare[1] ? 2u : 0u) | (rare[2] ? 4u : 0u) | (rare[3] ? 8u : 0u);
+        const unsigned long long rb = __ballot(rmask != 0u);
+        if (rb != 0ull) {  // wave-uniform
+            if (rmask != 0u)
+                s_queue[__builtin_amdgcn_mbcnt_hi((uint32_t)(rb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rb, qcount))] = (gidx << 4) | rmask;
+            qcount += (uint32_t)__popcll(rb);
+            while (qcount >= 64u) {
+                qcount -= 64u;
+                __threadfence_block();  // the group stores that are about to be overwritten
+                const uint32_t rest = lean_pixel_full<MODE, BW, WARP>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
+                const unsigned long long mb = __ballot(rest != 0u);  // groups with a further deferred pixel go back
+                if (mb != 0ull) {
+                    if (rest != 0u)
+                        s_queue[__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, qcount))] = rest;
+                    qcount += (uint32_t)__popcll(mb);
                 }
             }
         }
@@ -1069,9 +1082,18 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
         }
         if (fy >= g.h) fy -= g.h;
     }
-    if (qcount != 0u) {
+    while (qcount != 0u) {
+        const uint32_t n = qcount < 64u ? qcount : 64u;
+        qcount -= n;
         __threadfence_block();
-        if (lane < qcount) lean_pixel_full<MODE, BW, WARP>(s_queue[lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
+        uint32_t rest = 0u;
+        if (lane < n) rest = lean_pixel_full<MODE, BW, WARP>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
+        const unsigned long long mb = __ballot(rest != 0u);
+        if (mb != 0ull) {
+            if (rest != 0u)
+                s_queue[__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, qcount))] = rest;
+            qcount += (uint32_t)__popcll(mb);
+        }
     }
 }
 
@@ -1588,8 +1610,9 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
 
     const float sx = (float)((double)ign_seed * 0.37), sy = (float)((double)ign_seed * 0.73);
     const int64_t hw = (int64_t)h * w;
-    // frames per launch so that pixel indices stay below 2^31
-    const int64_t max_frames = std::max<int64_t>(1, ((int64_t)1 << 31) / hw - 1);
+    // frames per launch so that pixel indices stay below 2^30
+    // (2^30: the lean kernels' queue entries keep the index of a group of four pixels in 28 bits)
+    const int64_t max_frames = std::max<int64_t>(1, ((int64_t)1 << 30) / hw - 1);
     unsigned long long *flags = reinterpret_cast<unsigned long long *>(ws);
     // the dirty word lives in the slack behind the largest possible bitmap of this call
     const size_t dirty_off = ((size_t)((std::min(max_frames, n_frames) * hw + 255) / 256) * 32 + 768) & ~size_t(7);
@@ -1628,7 +1651,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         const bool small = warp ? pal.warp_bw == 4 : pal.cell_tab4 != nullptr;
         const size_t lean_tab_bytes = warp ? 4 * (size_t)pal.warp_words + kWarpLutBytes : 4 * (size_t)(small ? pal.tab4_words : pal.tab_words);
         const bool lean_geo = integer && (warp || small || pal.cell_tab != nullptr) && g.aligned && y0 >= 0 && x0 >= 0 &&
-                              lean_tab_bytes <= (size_t)kLeanTabBytes;
+                              lean_tab_bytes <= (size_t)kLeanTabBytes && g.n_px <= (1u << 30);
         const bool int_lean = thr.mpad != nullptr && lean_tab_bytes + (size_t)thr.th_h * thr.tw_pad * 4 <= (size_t)kLeanTabBytes;
         const bool lean_ok = lean_geo && (mode == DP_MODE_NEAREST || mode == DP_MODE_IGN ||
                                           (mode == DP_MODE_MATRIX && (int_lean || thr.fpad != nullptr)));
