@@ -229,6 +229,12 @@ def main():
         extra["c2_image_like_note"] = ("smooth frames with grain + the 256-colour median-cut palette of that content: the palette "
                                        "crowds a few cells of the colour cube (table over warped cells, adaptive kernel, deep split "
                                        "nodes in global memory)")
+        # the same content with the reference's default palette size: 16 colours by median cut
+        pal_mc16 = _CR.reduce_colors(Image.fromarray(img, "RGB"), 16)
+        dmc16 = ImageDitherer(16, DitherMode.BAYER, pal_mc16, False, {"size": "8x8"})
+        dmc16.apply_dithering_frames(fi, out=out)
+        ti16 = timed(lambda: dmc16.apply_dithering_frames(fi, out=out), 3, 1) / 3
+        extra["c2_image_like_median_cut16_mpixel_per_s"] = round(world * px_per_step / ti16 / 1e6, 1)
         del fi, yy, xx
         # C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in): the float cell table
         dgam = ImageDitherer(256, DitherMode.BAYER, pal256, True, {"size": "8x8"})
@@ -264,6 +270,14 @@ def main():
         o3 = torch.empty_like(f3)
         t3 = timed(lambda: d3.apply_dithering_frames(f3, out=o3), 2, 1) / 2
         extra["c3_fs_k16_4k_mpixel_per_s"] = round(world * nf3 * H4K * W4K / t3 / 1e6, 2)
+        # the C3 batch as SURVEY 8(d) words it (the 24 frames of C2), and one frame: few frames in flight, each frame's
+        # bands spread over several workgroups
+        o24 = o3[:args.frames]
+        d3.apply_dithering_frames(frames, out=o24)
+        t24 = timed(lambda: d3.apply_dithering_frames(frames, out=o24), 2, 1) / 2
+        extra["c3_fs_k16_4k_24_frames_ms"] = round(t24 * 1e3, 2)
+        t1f = timed(lambda: d3.apply_dithering_frames(frames[:1], out=o24[:1]), 2, 1) / 2
+        extra["c3_fs_k16_4k_one_frame_ms"] = round(t1f * 1e3, 2)
         extra["c3_note"] = (f"{nf3} frames in flight per GPU (one workgroup of 16 waves per frame), "
                             "bit-exact float32 error accumulation")
         # C4: k-means 32-colour palette from a 7680x4320 image + blue-noise dither, the image split into row

@@ -32,6 +32,7 @@
 // distances (they do occur: diffused errors are dyadic) is resolved by replaying scipy's traversal
 // (tree_query<1>) unless the palette fits one leaf (then the lowest index wins).
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -203,13 +204,19 @@ __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const floa
 
 // 16-step I/O period of the wavefront kernel: all global traffic happens at period boundaries
 constexpr int kPeriod = 16;
+// progress words per frame when a frame's bands are spread over several workgroups (the last one: give-up flag)
+constexpr int kEdProgWords = 64;
 
 template <int CAP, int NT>  // NT: tap slots compiled in (taps.n <= NT)
 __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
-                                                                      float *__restrict__ bnd_all)
+                                                                      float *__restrict__ bnd_all, const int G,
+                                                                      uint32_t *__restrict__ gprog_all)
 {
+    // G > 1: a frame's bands are spread over G workgroups (few frames in flight: more CUs per frame, fewer waves per
+    // CU).  Waves of different workgroups then meet through progress words in global memory instead of s_prog, and the
+    // boundary rows are written with agent-scope stores (the workgroups may sit on different XCDs, i.e. L2s).
     __shared__ float s_ring[kMaxWaves][64][kRing][3];    // errors of the band's own rows (last 8 columns)
     __shared__ float s_vring[kMaxWaves][2][64][3];       // errors of the two rows above the band (64-column ring)
     __shared__ float s_bout[kMaxWaves][2][kPeriod][3];   // this period's errors of rows 62/63, flushed to global
@@ -219,7 +226,10 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
-    const size_t f = blockIdx.x;
+    const size_t f = blockIdx.x / (unsigned)G;
+    const int NWT = NW * G;                                // waves working on this frame
+    const int gw = (int)(blockIdx.x % (unsigned)G) * NW + wv;  // this wave's number among them
+    uint32_t *gprog = gprog_all + f * (size_t)kEdProgWords;   // [NWT] progress words + [kEdProgWords-1] give-up flag
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
     for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
     if (threadIdx.x < kMaxWaves) s_prog[threadIdx.x] = 0;
@@ -231,13 +241,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     const int n_bands = (h + 63) / 64;
     __syncthreads();  // the only workgroup barrier: from here on waves only meet through s_prog
 
-    for (int band = wv; band < n_bands; band += NW) {
+    for (int band = gw; band < n_bands; band += NWT) {
         const int r = band * 64 + L;
         const float *bprev = bnd + (size_t)((band + 1) & 1) * 2 * w * 3;  // written by band-1
         float *bnext = bnd + (size_t)(band & 1) * 2 * w * 3;
         const int rows_here = min(64, h - band * 64);
         const int steps = w + skew * (rows_here - 1);
-        const int pw = (wv + NW - 1) % NW;  // wave that owns band-1
+        const int pw = (gw + NWT - 1) % NWT;  // wave that owns band-1
         const bool row_ok = r < h;
         const long row_byte = (long)r * w * 3;
 
@@ -256,7 +266,9 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                 // boundary columns produced in steps < t0 - kPeriod are acknowledged
                 int ack = t0 - kPeriod - 63 * skew + 1024;
                 ack = ack < 0 ? 0 : ack;
-                s_prog[wv] = ((uint32_t)band << 16) | (uint32_t)ack;
+                const uint32_t word = ((uint32_t)band << 16) | (uint32_t)ack;
+                if (G == 1) s_prog[wv] = word;
+                else __hip_atomic_store(&gprog[gw], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // park the boundary errors fetched during the previous period
             if (pb_col >= 0) {
@@ -294,9 +306,15 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                 if (L >= 62 && row_ok && hi > lo) {
                     for (int i = lo - xs; i < hi - xs; ++i) {
                         float *b = bnext + ((size_t)(L - 62) * w + (xs + i)) * 3;
-                        b[0] = s_bout[wv][L - 62][i][0];
-                        b[1] = s_bout[wv][L - 62][i][1];
-                        b[2] = s_bout[wv][L - 62][i][2];
+                        if (G == 1) {
+                            b[0] = s_bout[wv][L - 62][i][0];
+                            b[1] = s_bout[wv][L - 62][i][1];
+                            b[2] = s_bout[wv][L - 62][i][2];
+                        } else {
+                            __hip_atomic_store(b, s_bout[wv][L - 62][i][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(b + 1, s_bout[wv][L - 62][i][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(b + 2, s_bout[wv][L - 62][i][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
             }
@@ -332,10 +350,17 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                 need = need > w ? w : need;
                 if (x0n - 14 < w && need > 0) {
                     const uint32_t want = (uint32_t)(need + 1024);
-                    for (;;) {
-                        const uint32_t v = s_prog[pw];
+                    for (uint32_t spins = 0;; ++spins) {
+                        const uint32_t v = G == 1 ? s_prog[pw] : __hip_atomic_load(&gprog[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((int)(v >> 16) > band - 1 || ((int)(v >> 16) == band - 1 && (v & 0xffffu) >= want)) break;
                         __builtin_amdgcn_s_sleep(4);
+                        // across workgroups the producer is another workgroup of the grid: never wait for it forever
+                        // (the host reports the flag as an error instead of the launch hanging)
+                        if (G != 1 && (spins > (1u << 24) || (spins % 1024u == 1023u &&
+                                                               __hip_atomic_load(&gprog[kEdProgWords - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))) {
+                            if (L == 0) __hip_atomic_store(&gprog[kEdProgWords - 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            return;
+                        }
                     }
                     const int col = x0n - 14 + (L & 31);
                     if (col >= 0 && col < w) {
@@ -420,7 +445,10 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
         }
         // band finished: once its boundary stores are acknowledged the next band may read any column
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (L == 0) s_prog[wv] = ((uint32_t)(band + 1) << 16);
+        if (L == 0) {
+            if (G == 1) s_prog[wv] = ((uint32_t)(band + 1) << 16);
+            else __hip_atomic_store(&gprog[gw], (uint32_t)(band + 1) << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -788,7 +816,6 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
                            const int32_t *dx, const int32_t *dy, const float *wq, int ntaps, int serpentine,
                            void *ws, size_t ws_bytes, hipStream_t s)
 {
-    (void)ws_bytes;
     Taps t;
     t.n = ntaps;
     // reference visiting order of the source pixels: earlier rows first (dy descending), and inside a
@@ -827,8 +854,28 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
             return DP_EINVAL;
         }
         const int n_bands = (h + 63) / 64;
-        const int nw = n_bands < kMaxWaves ? n_bands : kMaxWaves;
-#define DP_EDW(C, N) hipLaunchKernelGGL((ed_wavefront_kernel<C, N>), dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws))
+        int nw = n_bands < kMaxWaves ? n_bands : kMaxWaves;
+        // Few frames in flight: spread each frame's bands over G workgroups so that the batch covers the CUs (one
+        // workgroup per frame leaves all but n_frames CUs idle and packs 16 waves onto one CU's four SIMDs) and up to
+        // 32 bands of a frame advance together.  The workgroups of a frame meet through progress words in the workspace.
+        int G = 1;
+        int cus = 0, dev_id = 0;
+        if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
+        uint32_t *gprog = nullptr;
+        {
+            const size_t prog_off = ((size_t)n_frames * (size_t)w * 48 + 255) & ~(size_t)255;
+            const size_t prog_bytes = (size_t)n_frames * kEdProgWords * sizeof(uint32_t);
+            if (n_frames * 2 <= cus && n_bands >= 4 && w >= 64 && prog_off + prog_bytes <= ws_bytes && !getenv("DP_ED_ONE_WG")) {
+                const int nwt = n_bands < 32 ? n_bands : 32;
+                while (G * 2 <= 16 && n_frames * (G * 2) <= cus && G * 2 <= nwt) G *= 2;
+                if (G > 1) {
+                    nw = (nwt + G - 1) / G;
+                    gprog = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ws) + prog_off);
+                    DP_HIP(hipMemsetAsync(gprog, 0, prog_bytes, s));
+                }
+            }
+        }
+#define DP_EDW(C, N) hipLaunchKernelGGL((ed_wavefront_kernel<C, N>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws), G, gprog)
         const bool big = pal.n_inner > kQueueSmall;
         if (ntaps <= 4) {
             if (big) DP_EDW(kQueueLarge, 4); else DP_EDW(kQueueSmall, 4);

@@ -539,3 +539,30 @@ def test_image_derived_palettes_every_cell_table(be, orc, monkeypatch, table, ki
     for mode, params in (("none", {}), ("bayer", {"size": "8x8"}), ("IGN", {}), ("blue_noise", {"size": 32, "seed": 2})):
         out = _run_case(be, orc, arr, pal, mode, params, False, y0=2, x0=3)
         _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False, y0=2, x0=3), f"{kind} K={K} table={table or 'auto'} {mode}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,K,gamma", [("floyd_steinberg", 16, False), ("jjn", 40, False), ("atkinson", 256, True)])
+def test_error_diffusion_frame_spread_over_workgroups(be, orc, monkeypatch, variant, K, gamma):
+    """Few frames in flight and at least four 64-row bands: the bands of a frame are spread over several workgroups that
+    meet through progress words in global memory (agent-scope stores for the boundary rows).  Same bytes as the oracle and
+    as the one-workgroup-per-frame schedule (DP_ED_ONE_WG=1)."""
+    import torch
+    h, w = 333, 150  # 6 bands, the last one partial
+    arr = orc.rnd(h, w, K + 5)
+    pal = orc.generate_uniform_palette(16) if K == 16 else orc.palr(K, seed=K)
+    params = {"variant": variant, "serpentine": "false"}
+    ref = orc.apply_dithering(arr, pal, "error_diffusion", params, gamma)
+    out = _run_case(be, orc, arr, pal, "error_diffusion", params, gamma)
+    _assert_same(out, ref, f"spread {variant}")
+    monkeypatch.setenv("DP_ED_ONE_WG", "1")
+    out1 = _run_case(be, orc, arr, pal, "error_diffusion", params, gamma)
+    _assert_same(out1, ref, f"one workgroup {variant}")
+    monkeypatch.delenv("DP_ED_ONE_WG")
+    # a small batch: three different frames
+    taps, div = orc.ed_kernel(variant)
+    frames = np.stack([arr, orc.rnd(h, w, K + 6), orc.rnd(h, w, K + 7)])
+    P = be.Palette(*orc.prepare_palette(pal, gamma), accel=True)
+    got = be.error_diffusion(torch.from_numpy(frames).cuda(), P, taps, div, False).cpu().numpy()
+    for i in range(3):
+        _assert_same(got[i], orc.apply_dithering(frames[i], pal, "error_diffusion", params, gamma), f"batch frame {i}")
