@@ -165,38 +165,78 @@ __global__ __launch_bounds__(256) void ed_cells_kernel(const PalDev pal, uint4 *
     cells[cell] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// nearest_color restricted to the cell's list (same validation, same fallbacks)
+// nearest_color restricted to the cell's list (same validation, same fallbacks).
+// `coarse` (wavefront kernel, palettes of 9..16 colours; else nullptr): an LDS copy of the lists of the 16x16x16 cells,
+// count and up to 7 indices as nibbles of one word (count 15: longer than that) -- 99.8 % of the cells of a 16-colour
+// palette; a step then needs no load from global memory at all (the 8x8x8 lists live in L2: ~600 cycles of latency that
+// every step of the dependency chain would pay).
 template <int CAP>
-__device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const float4 *__restrict__ cand, const float o0,
-                                                   const float o1, const float o2)
+__device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const float4 *__restrict__ cand,
+                                                   const uint32_t *__restrict__ coarse, const float o0, const float o1,
+                                                   const float o2)
 {
-    const uint32_t ci = ((uint32_t)o0 >> 3) | (((uint32_t)o1 >> 3) << 5) | (((uint32_t)o2 >> 3) << 10);
-    uint4 blk = pal.ed_cells[ci];
-    int n = (int)(blk.x & 255u);
-    if (n == 254) {  // a crowded cell (clustered palettes): refined into 4^3, 2^3, 1^3 sub-cells
-        const uint32_t i0 = (uint32_t)o0, i1 = (uint32_t)o1, i2 = (uint32_t)o2;
-        for (int bit = 2; n == 254; --bit) {
-            const uint32_t sub = ((i0 >> bit) & 1u) | (((i1 >> bit) & 1u) << 1) | (((i2 >> bit) & 1u) << 2);
-            blk = pal.ed_nodes[(size_t)(blk.x >> 8) * 8 + sub];
-            n = (int)(blk.x & 255u);
-        }
-    }
-    if (n > 15) return nearest_color<CAP>(pal, cand, o0, o1, o2);
     float b0 = __int_as_float(0x7f800000), b1 = b0;
     int i0 = 0;
-    for (; n > 0; --n) {
-        blk.x = __funnelshift_r(blk.x, blk.y, 8);
-        blk.y = __funnelshift_r(blk.y, blk.z, 8);
-        blk.z = __funnelshift_r(blk.z, blk.w, 8);
-        blk.w >>= 8;
-        const int j = (int)(blk.x & 255u);
-        const float4 c = cand[j];
+    auto visit = [&](const float4 c, const int j, const bool ok) {
         const float a = c.x - o0, b = c.y - o1, cc = c.z - o2;
-        const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, cc * cc));
+        float d = __fmaf_rn(a, a, __fmaf_rn(b, b, cc * cc));
+        d = ok ? d : __int_as_float(0x7f800000);
         const bool lt0 = d < b0;
         b1 = lt0 ? b0 : (d < b1 ? d : b1);
         i0 = lt0 ? j : i0;
         b0 = lt0 ? d : b0;
+    };
+    bool listed = false;
+    if (coarse) {
+        const uint32_t e = coarse[((uint32_t)o0 >> 4) | (((uint32_t)o1 >> 4) << 4) | (((uint32_t)o2 >> 4) << 8)];
+        const int n = (int)(e & 15u);
+        if (n <= 7) {
+            const int j1 = (e >> 4) & 15, j2 = (e >> 8) & 15, j3 = (e >> 12) & 15, j4 = (e >> 16) & 15;
+            const float4 c1 = cand[j1], c2 = cand[j2], c3 = cand[j3], c4 = cand[j4];
+            visit(c1, j1, n >= 1);
+            visit(c2, j2, n >= 2);
+            visit(c3, j3, n >= 3);
+            visit(c4, j4, n >= 4);
+            if (n > 4) {
+                const int j5 = (e >> 20) & 15, j6 = (e >> 24) & 15, j7 = (e >> 28) & 15;
+                const float4 c5 = cand[j5], c6 = cand[j6], c7 = cand[j7];
+                visit(c5, j5, true);
+                visit(c6, j6, n >= 6);
+                visit(c7, j7, n >= 7);
+            }
+            listed = true;
+        }
+    }
+    if (!listed) {
+        const uint32_t ci = ((uint32_t)o0 >> 3) | (((uint32_t)o1 >> 3) << 5) | (((uint32_t)o2 >> 3) << 10);
+        uint4 blk = pal.ed_cells[ci];
+        int n = (int)(blk.x & 255u);
+        if (n == 254) {  // a crowded cell (clustered palettes): refined into 4^3, 2^3, 1^3 sub-cells
+            const uint32_t i0 = (uint32_t)o0, i1 = (uint32_t)o1, i2 = (uint32_t)o2;
+            for (int bit = 2; n == 254; --bit) {
+                const uint32_t sub = ((i0 >> bit) & 1u) | (((i1 >> bit) & 1u) << 1) | (((i2 >> bit) & 1u) << 2);
+                blk = pal.ed_nodes[(size_t)(blk.x >> 8) * 8 + sub];
+                n = (int)(blk.x & 255u);
+            }
+        }
+        if (n > 15) return nearest_color<CAP>(pal, cand, o0, o1, o2);
+        // four entries per round, their reads in flight together (unused slots hold index 0: a valid, ignored read)
+        blk.x = __funnelshift_r(blk.x, blk.y, 8);  // drop the count byte
+        blk.y = __funnelshift_r(blk.y, blk.z, 8);
+        blk.z = __funnelshift_r(blk.z, blk.w, 8);
+        blk.w >>= 8;
+        for (; n > 0; n -= 4) {
+            const int j1 = (int)(blk.x & 255u), j2 = (int)((blk.x >> 8) & 255u), j3 = (int)((blk.x >> 16) & 255u), j4 = (int)(blk.x >> 24);
+            const float4 c1 = cand[j1], c2 = cand[j2], c3 = cand[j3], c4 = cand[j4];
+            visit(c1, j1, true);
+            visit(c2, j2, n >= 2);
+            visit(c3, j3, n >= 3);
+            visit(c4, j4, n >= 4);
+            blk.x = blk.y;
+            blk.y = blk.z;
+            blk.z = blk.w;
+            blk.w = 0u;
+        }
     }
     if (b1 > b0 * 1.000002f) return i0;
     return nearest_f64<CAP>(pal, o0, o1, o2);
@@ -223,6 +263,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     __shared__ uint8_t s_lut[256];
     __shared__ volatile uint32_t s_prog[kMaxWaves];      // (band << 16) | (acknowledged column of row 63 + 1024)
     __shared__ float4 s_pal[DP_MAX_COLORS];              // {x, y, z, out_rgb bits}
+    __shared__ uint32_t s_coarse[4096];                  // candidate lists of the 16^3 cells (palettes of 9..16 colours)
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -232,6 +273,9 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     uint32_t *gprog = gprog_all + f * (size_t)kEdProgWords;   // [NWT] progress words + [kEdProgWords-1] give-up flag
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
     for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
+    if (pal.ed_coarse)
+        for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_coarse[i] = pal.ed_coarse[i];
+    const uint32_t *coarse = pal.ed_coarse ? s_coarse : nullptr;
     if (threadIdx.x < kMaxWaves) s_prog[threadIdx.x] = 0;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
@@ -407,7 +451,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                         }
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-                    const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, s_pal, o0, o1, o2)
+                    const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2)
                                                : nearest_color<CAP>(pal, s_pal, o0, o1, o2);
                     const float4 pj = s_pal[j];
                     e0 = __fsub_rn(o0, pj.x);
@@ -489,7 +533,7 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
                 a2 = __fadd_rn(a2, __fmul_rn(e[2 * nf], wq));
             }
             const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-            const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, o0, o1, o2)
+            const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, nullptr, o0, o1, o2)
                                        : nearest_color<CAP>(pal, pal.fcand, o0, o1, o2);
             float *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
             e[0] = __fsub_rn(o0, (float)pal.pts[3 * j]);
@@ -696,7 +740,8 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     *blob_out = nullptr;
     const int K = dev.K;
     uint4 *cells = nullptr;
-    DP_HIP(hipMalloc((void **)&cells, sizeof(uint4) * kEdCells));
+    constexpr size_t kCoarseQuads = 4096 / 4;  // room for the 16^3-cell table behind the lists (and the nodes)
+    DP_HIP(hipMalloc((void **)&cells, sizeof(uint4) * (kEdCells + kCoarseQuads)));
     hipLaunchKernelGGL(ed_cells_kernel, dim3(kEdCells / 256), dim3(256), 0, 0, dev, cells);
     hipError_t e = hipGetLastError();
     std::vector<uint4> host(kEdCells);
@@ -795,7 +840,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     if (!give_up && !nodes.empty()) {
         // one allocation: cells, then the nodes
         uint4 *both = nullptr;
-        e = hipMalloc((void **)&both, sizeof(uint4) * (kEdCells + nodes.size()));
+        e = hipMalloc((void **)&both, sizeof(uint4) * (kEdCells + nodes.size() + kCoarseQuads));
         if (e == hipSuccess) e = hipMemcpy(both, host.data(), sizeof(uint4) * kEdCells, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(both + kEdCells, nodes.data(), sizeof(uint4) * nodes.size(), hipMemcpyHostToDevice);
         (void)hipFree(cells);
@@ -808,6 +853,30 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     }
     dev.ed_cells = cells;
     dev.ed_nodes = d_nodes;
+    dev.ed_coarse = nullptr;
+    if (K <= 16) {
+        // lists of the 16x16x16 cells for the wavefront kernel's LDS: count | up to 7 indices, one nibble each
+        std::vector<uint32_t> coarse(4096);
+        for (int cell = 0; cell < 4096; ++cell) {
+            const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
+            box_list(all, lo, 16.0, list);
+            uint32_t word = 15u;
+            if (list.size() <= 7) {
+                word = (uint32_t)list.size();
+                for (size_t n = 0; n < list.size(); ++n) word |= (uint32_t)list[n] << (4 * (n + 1));
+            }
+            coarse[cell] = word;
+        }
+        uint32_t *d_coarse = reinterpret_cast<uint32_t *>(cells + kEdCells + nodes.size() * (d_nodes ? 1 : 0));
+        e = hipMemcpy(d_coarse, coarse.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(cells);
+            dev.ed_cells = nullptr;
+            dev.ed_nodes = nullptr;
+            return hip_fail(e, "error-diffusion candidate lists");
+        }
+        dev.ed_coarse = d_coarse;
+    }
     *blob_out = cells;
     return DP_OK;
 }
