@@ -399,7 +399,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                         if ((int)(v >> 16) > band - 1 || ((int)(v >> 16) == band - 1 && (v & 0xffffu) >= want)) break;
                         __builtin_amdgcn_s_sleep(4);
                         // across workgroups the producer is another workgroup of the grid: never wait for it forever
-                        // (the host reports the flag as an error instead of the launch hanging)
+                        // (a give-up flag stays in the workspace; the launch ends instead of hanging)
                         if (G != 1 && (spins > (1u << 24) || (spins % 1024u == 1023u &&
                                                                __hip_atomic_load(&gprog[kEdProgWords - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))) {
                             if (L == 0) __hip_atomic_store(&gprog[kEdProgWords - 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -422,14 +422,23 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
             __builtin_amdgcn_wave_barrier();
 
             // ================= 16 steps that touch LDS and registers only =================
-            for (int i = 0; i < kPeriod; ++i) {
+            // Four steps per round of the loop: the round's pixels are bytes 0..11 of cur[] and its colours become bytes
+            // 36..47 of outb[] at fixed positions, then both 48-byte buffers move down by three whole registers -- a
+            // per-step rotation by three bytes costs 24 funnel shifts per step.
+            for (int i4 = 0; i4 < kPeriod; i4 += 4) {
+              uint32_t cb[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int i = i4 + q;
                 const int t = t0 + i;
                 const int x = t - skew * L;
                 const bool act = row_ok && x >= 0 && x < w && t >= 0 && t < steps;
                 float e0 = 0.f, e1 = 0.f, e2 = 0.f;
                 uint32_t cbytes = 0;
                 if (act) {
-                    const uint32_t pxv = cur[0];  // this step's pixel sits in the low 3 bytes (see the rotation below)
+                    // this step's pixel: bytes 3q..3q+2 of the round's twelve
+                    const uint32_t pxv = q == 0 ? cur[0] : (q == 1 ? __funnelshift_r(cur[0], cur[1], 24)
+                                                               : (q == 2 ? __funnelshift_r(cur[1], cur[2], 16) : (cur[2] >> 8)));
                     float a0 = (float)s_lut[pxv & 255u], a1 = (float)s_lut[(pxv >> 8) & 255u],
                           a2 = (float)s_lut[(pxv >> 16) & 255u];
                     // fully unrolled with constant indices: the tap parameters stay in scalar registers instead of
@@ -459,16 +468,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                     e2 = __fsub_rn(o2, pj.z);
                     cbytes = __float_as_uint(pj.w);
                 }
-                // rotate both 48-byte period buffers by one pixel (static register indices only): the next pixel
-                // moves into the low bytes of cur[], this step's colour enters outb[] at bytes 45..47 and will have
-                // travelled down to byte 3*i by the time the period is flushed
-#pragma unroll
-                for (int k = 0; k < 11; ++k) {
-                    cur[k] = __funnelshift_r(cur[k], cur[k + 1], 24);
-                    outb[k] = __funnelshift_r(outb[k], outb[k + 1], 24);
-                }
-                cur[11] >>= 24;
-                outb[11] = (outb[11] >> 24) | (cbytes << 8);
+                cb[q] = cbytes;
                 // every pull of this step precedes the ring writes below (slot x&7 still holds column x-8, which
                 // the row two below reads in this very step for a dx=+2 tap)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -485,6 +485,18 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+              }
+              // the round's twelve bytes are consumed / produced: both buffers move down by three registers; the colour of
+              // step i will have travelled to byte 3*i by the time the period is flushed
+#pragma unroll
+              for (int k = 0; k < 9; ++k) {
+                  cur[k] = cur[k + 3];
+                  outb[k] = outb[k + 3];
+              }
+              cur[9] = cur[10] = cur[11] = 0u;
+              outb[9] = cb[0] | (cb[1] << 24);
+              outb[10] = (cb[1] >> 8) | (cb[2] << 16);
+              outb[11] = (cb[2] >> 16) | (cb[3] << 8);
             }
         }
         // band finished: once its boundary stores are acknowledged the next band may read any column
