@@ -264,6 +264,8 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     __shared__ volatile uint32_t s_prog[kMaxWaves];      // (band << 16) | (acknowledged column of row 63 + 1024)
     __shared__ float4 s_pal[DP_MAX_COLORS];              // {x, y, z, out_rgb bits}
     __shared__ uint32_t s_coarse[4096];                  // candidate lists of the 16^3 cells (palettes of 9..16 colours)
+    __shared__ float s_zero[4];                          // the "error" of pixels that do not exist
+    typedef const __attribute__((address_space(3))) float lds_float_t;
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_coarse[i] = pal.ed_coarse[i];
     const uint32_t *coarse = pal.ed_coarse ? s_coarse : nullptr;
     if (threadIdx.x < kMaxWaves) s_prog[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_zero[threadIdx.x] = 0.0f;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
     const long frame_bytes = (long)h * w * 3;
@@ -295,6 +298,19 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
         const bool row_ok = r < h;
         const long row_byte = (long)r * w * 3;
 
+        // Where each tap of this lane's row finds its source row: the ring of a row of the band (8 columns), the ring of
+        // the two rows above the band (64 columns), or -- the row does not exist (top of the image) -- the zero slot.
+        // Adding a zero error is exact, so the step needs no row test and one column test per tap.
+        lds_float_t *tbase[NT];
+        uint32_t tmask[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int rel = L - taps.dy[k];
+            const bool exists = k < taps.n && r - taps.dy[k] >= 0;
+            const float *row = rel >= 0 ? &s_ring[wv][rel & 63][0][0] : &s_vring[wv][(rel + 2) & 1][0][0];
+            tbase[k] = exists ? (lds_float_t *)row : (lds_float_t *)s_zero;
+            tmask[k] = exists ? (rel >= 0 ? (uint32_t)(kRing - 1) : 63u) : 0u;
+        }
         uint32_t pix[12], cur[13], outb[13];  // 16 pixels in flight / being consumed / being produced (raw bytes)
         float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;  // boundary errors in flight (one column per lane)
         int pb_col = -1;
@@ -447,16 +463,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                     for (int k = 0; k < NT; ++k) {
                         if (k < taps.n) {
                             const int sxp = x - taps.dx[k];
-                            const int sr = r - taps.dy[k];
-                            if (sxp >= 0 && sxp < w && sr >= 0) {
-                                const int rel = L - taps.dy[k];
-                                const float *src = rel >= 0 ? &s_ring[wv][rel][sxp & (kRing - 1)][0]
-                                                            : &s_vring[wv][rel + 2][sxp & 63][0];
-                                const float wq = taps.wq[k];
-                                a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
-                                a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
-                                a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
-                            }
+                            lds_float_t *src = (uint32_t)sxp < (uint32_t)w ? tbase[k] + (sxp & (int)tmask[k]) * 3 : (lds_float_t *)s_zero;
+                            const float wq = taps.wq[k];
+                            a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
+                            a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
+                            a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
                         }
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
