@@ -755,7 +755,8 @@ size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w)
     (void)h;
     // wavefront: 4 boundary rows per frame; serial: 3 error rows per frame; 4 floats per column (the variable-weight
     // diffusers of vardiff.hip carry an extra value per error)
-    return (size_t)n_frames * (size_t)w * 4 * sizeof(float) * 4 + 256;
+    // + 256 bytes per frame of progress words (few frames in flight: a frame's bands spread over workgroups)
+    return (size_t)n_frames * (size_t)w * 4 * sizeof(float) * 4 + 512 + (size_t)n_frames * 256;
 }
 
 int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)

@@ -12,6 +12,8 @@
 // variance_gate: scipy.ndimage.uniform_filter(size, mode='nearest') restated (float32 passes along axis 0 then
 // axis 1, each a double running sum `tmp += entering - leaving`, out = tmp/size) on gray and gray^2, then
 // max(0, mean_sq - sq_mean^2) >= threshold  (dithering_lib.py:988-992, 1019-1025).
+#include <cstdlib>
+
 #include "dp_internal.h"
 #include "tree_query.cuh"
 #include "wave_util.cuh"
@@ -329,13 +331,16 @@ __global__ __launch_bounds__(64) void os_rowserial_kernel(const uint8_t *__restr
 constexpr int kVWaves = 12;
 constexpr int kVRing = 8;
 constexpr int kVPeriod = 16;
+constexpr int kVProgWords = 64;  // progress words per frame when a frame's bands are spread over workgroups (ediff.hip)
 
 template <int CAP>
 __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                      uint8_t *__restrict__ out, const int h, const int w,
                                                                      const PalDev pal, const VarParams vp,
-                                                                     float *__restrict__ bnd_all)
+                                                                     float *__restrict__ bnd_all, const int G,
+                                                                     uint32_t *__restrict__ gprog_all)
 {
+    // G > 1: the bands of a frame are spread over G workgroups (few frames in flight), see ed_wavefront_kernel
     __shared__ float s_ring[kVWaves][64][kVRing][4];
     __shared__ float s_vring[kVWaves][2][64][4];
     __shared__ float s_bout[kVWaves][2][kVPeriod][4];
@@ -345,7 +350,10 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
-    const size_t f = blockIdx.x;
+    const size_t f = blockIdx.x / (unsigned)G;
+    const int NWT = NW * G;
+    const int gw = (int)(blockIdx.x % (unsigned)G) * NW + wv;
+    uint32_t *gprog = gprog_all + f * (size_t)kVProgWords;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
     for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
     if (threadIdx.x < kVWaves) s_prog[threadIdx.x] = 0;
@@ -361,13 +369,13 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     const int n_bands = (h + 63) / 64;
     __syncthreads();
 
-    for (int band = wv; band < n_bands; band += NW) {
+    for (int band = gw; band < n_bands; band += NWT) {
         const int r = band * 64 + L;
         const float *bprev = bnd + (size_t)((band + 1) & 1) * 2 * w * 4;
         float *bnext = bnd + (size_t)(band & 1) * 2 * w * 4;
         const int rows_here = min(64, h - band * 64);
         const int steps = w + skew * (rows_here - 1);
-        const int pw = (wv + NW - 1) % NW;
+        const int pw = (gw + NWT - 1) % NWT;
         const bool row_ok = r < h;
         const long row_byte = (long)r * w * 3;
         const long row_gate = (long)r * w;
@@ -388,7 +396,9 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
             if (L == 0) {
                 int ack = t0 - kVPeriod - 63 * skew + 1024;
                 ack = ack < 0 ? 0 : ack;
-                s_prog[wv] = ((uint32_t)band << 16) | (uint32_t)ack;
+                const uint32_t word = ((uint32_t)band << 16) | (uint32_t)ack;
+                if (G == 1) s_prog[wv] = word;
+                else __hip_atomic_store(&gprog[gw], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (pb_col >= 0) {
                 float *dst = &s_vring[wv][L >> 5][pb_col & 63][0];
@@ -424,10 +434,16 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                 if (L >= 62 && row_ok && hi > lo) {
                     for (int i = lo - xs; i < hi - xs; ++i) {
                         float *b = bnext + ((size_t)(L - 62) * w + (xs + i)) * 4;
-                        b[0] = s_bout[wv][L - 62][i][0];
-                        b[1] = s_bout[wv][L - 62][i][1];
-                        b[2] = s_bout[wv][L - 62][i][2];
-                        b[3] = s_bout[wv][L - 62][i][3];
+                        if (G == 1) {
+                            b[0] = s_bout[wv][L - 62][i][0];
+                            b[1] = s_bout[wv][L - 62][i][1];
+                            b[2] = s_bout[wv][L - 62][i][2];
+                            b[3] = s_bout[wv][L - 62][i][3];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                __hip_atomic_store(b + c, s_bout[wv][L - 62][i][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
             }
@@ -476,10 +492,16 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                 need = need > w ? w : need;
                 if (x0n - 14 < w && need > 0) {
                     const uint32_t want = (uint32_t)(need + 1024);
-                    for (;;) {
-                        const uint32_t v = s_prog[pw];
+                    for (uint32_t spins = 0;; ++spins) {
+                        const uint32_t v = G == 1 ? s_prog[pw] : __hip_atomic_load(&gprog[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((int)(v >> 16) > band - 1 || ((int)(v >> 16) == band - 1 && (v & 0xffffu) >= want)) break;
                         __builtin_amdgcn_s_sleep(4);
+                        // another workgroup produces this: never wait forever (a give-up flag stays in the workspace)
+                        if (G != 1 && (spins > (1u << 24) || (spins % 1024u == 1023u &&
+                                                               __hip_atomic_load(&gprog[kVProgWords - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))) {
+                            if (L == 0) __hip_atomic_store(&gprog[kVProgWords - 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            return;
+                        }
                     }
                     const int col = x0n - 14 + (L & 31);
                     if (col >= 0 && col < w) {
@@ -587,7 +609,10 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (L == 0) s_prog[wv] = ((uint32_t)(band + 1) << 16);
+        if (L == 0) {
+            if (G == 1) s_prog[wv] = ((uint32_t)(band + 1) << 16);
+            else __hip_atomic_store(&gprog[gw], (uint32_t)(band + 1) << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -688,13 +713,28 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
     ProfMark *pm = prof_begin(s);
     if (!(model == 4 && serpentine) && w < 60000 && n_frames <= 0x7fffffff) {
         const int n_bands = (h + 63) / 64;
-        const int nw = n_bands < kVWaves ? n_bands : kVWaves;
+        int nw = n_bands < kVWaves ? n_bands : kVWaves;
+        // few frames in flight: a frame's bands over G workgroups (see launch_error_diffusion); the progress words sit
+        // behind the boundary rows in the workspace (error_diffusion_ws_bytes reserves them)
+        int G = 1, cus = 0, dev_id = 0;
+        if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
+        uint32_t *gprog = nullptr;
+        if (n_frames * 2 <= cus && n_bands >= 4 && w >= 64 && !getenv("DP_ED_ONE_WG")) {
+            const int nwt = n_bands < 2 * kVWaves ? n_bands : 2 * kVWaves;
+            while (G * 2 <= 16 && n_frames * (G * 2) <= cus && G * 2 <= nwt) G *= 2;
+            if (G > 1) {
+                nw = (nwt + G - 1) / G;
+                const size_t prog_off = ((size_t)n_frames * (size_t)w * 64 + 255) & ~(size_t)255;
+                gprog = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ws) + prog_off);
+                DP_HIP(hipMemsetAsync(gprog, 0, (size_t)n_frames * kVProgWords * sizeof(uint32_t), s));
+            }
+        }
         if (pal.n_inner > kQueueSmall)
-            hipLaunchKernelGGL(var_wavefront_kernel<kQueueLarge>, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h,
-                               w, pal, vp, reinterpret_cast<float *>(ws));
+            hipLaunchKernelGGL(var_wavefront_kernel<kQueueLarge>, dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h,
+                               w, pal, vp, reinterpret_cast<float *>(ws), G, gprog);
         else
-            hipLaunchKernelGGL(var_wavefront_kernel<kQueueSmall>, dim3((unsigned)n_frames), dim3(64 * nw), 0, s, in, out, h,
-                               w, pal, vp, reinterpret_cast<float *>(ws));
+            hipLaunchKernelGGL(var_wavefront_kernel<kQueueSmall>, dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h,
+                               w, pal, vp, reinterpret_cast<float *>(ws), G, gprog);
         prof_end(pm, s);
         DP_HIP(hipGetLastError());
         return DP_OK;

@@ -566,3 +566,20 @@ def test_error_diffusion_frame_spread_over_workgroups(be, orc, monkeypatch, vari
     got = be.error_diffusion(torch.from_numpy(frames).cuda(), P, taps, div, False).cpu().numpy()
     for i in range(3):
         _assert_same(got[i], orc.apply_dithering(frames[i], pal, "error_diffusion", params, gamma), f"batch frame {i}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,params", [("perceptual", {}), ("hybrid", {"lum_factor": 1.4, "col_factor": 0.3}),
+                                         ("adaptive_variance", {"var_threshold": 200.0, "window_radius": 2}),
+                                         ("ostromoukhov", {"serpentine": "false"})])
+def test_variable_diffusers_frame_spread_over_workgroups(be, orc, monkeypatch, mode, params):
+    """The four variable-weight diffusers with few frames in flight and five 64-row bands: a frame's bands run in several
+    workgroups (progress words in global memory).  Same bytes as the oracle and as one workgroup per frame."""
+    h, w = 290, 130
+    arr = orc.rnd(h, w, 21)
+    pal = orc.palr(16, 8)
+    for gamma in (False, True):
+        ref = orc.apply_dithering(arr, pal, mode, params, gamma)
+        _assert_same(_run_case(be, orc, arr, pal, mode, params, gamma), ref, f"spread {mode} gamma={gamma}")
+    monkeypatch.setenv("DP_ED_ONE_WG", "1")
+    _assert_same(_run_case(be, orc, arr, pal, mode, params, False), orc.apply_dithering(arr, pal, mode, params, False), f"one workgroup {mode}")
