@@ -333,7 +333,7 @@ constexpr int kVRing = 8;
 constexpr int kVPeriod = 16;
 constexpr int kVProgWords = 64;  // progress words per frame when a frame's bands are spread over workgroups (ediff.hip)
 
-template <int CAP>
+template <int CAP, int MODEL>  // MODEL: 1 perceptual, 2 hybrid, 3 adaptive variance, 4 Ostromoukhov (vp.model)
 __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                      uint8_t *__restrict__ out, const int h, const int w,
                                                                      const PalDev pal, const VarParams vp,
@@ -363,8 +363,8 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     const long frame_bytes = (long)h * w * 3;
     const long gate_bytes = (long)h * w;
     float *bnd = bnd_all + f * (size_t)4 * w * 4;  // [2 buffers][2 rows][w][4]
-    const int model = vp.model;
-    const int ntaps = model == 4 ? 3 : 4;
+    constexpr int model = MODEL;
+    constexpr int ntaps = model == 4 ? 3 : 4;
     constexpr int skew = 2;
     const int n_bands = (h + 63) / 64;
     __syncthreads();
@@ -517,14 +517,20 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
-            for (int i = 0; i < kVPeriod; ++i) {
+            // four steps per round (see ed_wavefront_kernel): the period buffers move by whole registers
+            for (int i4 = 0; i4 < kVPeriod; i4 += 4) {
+              uint32_t cb[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int i = i4 + q;
                 const int t = t0 + i;
                 const int x = t - skew * L;
                 const bool act = row_ok && x >= 0 && x < w && t >= 0 && t < steps;
                 float e0 = 0.f, e1 = 0.f, e2 = 0.f, aux = 1.0f;
                 uint32_t cbytes = 0;
                 if (act) {
-                    const uint32_t pxv = cur[0];
+                    const uint32_t pxv = q == 0 ? cur[0] : (q == 1 ? __funnelshift_r(cur[0], cur[1], 24)
+                                                               : (q == 2 ? __funnelshift_r(cur[1], cur[2], 16) : (cur[2] >> 8)));
                     const float g0 = (float)s_lut[pxv & 255u], g1 = (float)s_lut[(pxv >> 8) & 255u],
                                 g2 = (float)s_lut[(pxv >> 16) & 255u];
                     float a0 = g0, a1 = g1, a2 = g2;
@@ -572,22 +578,14 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                         e1 = __fadd_rn(__fmul_rn(vp.lum_factor, l1), __fmul_rn(vp.col_factor, __fsub_rn(e1, l1)));
                         e2 = __fadd_rn(__fmul_rn(vp.lum_factor, l2), __fmul_rn(vp.col_factor, __fsub_rn(e2, l2)));
                     } else if (model == 3) {
-                        aux = (gcur[0] & 255u) ? 1.0f : 0.0f;
+                        aux = ((gcur[0] >> (8 * q)) & 255u) ? 1.0f : 0.0f;
                     } else if (model == 4) {
                         float lum = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, o0), __fmul_rn(0.587f, o1)), __fmul_rn(0.114f, o2));
                         aux = (float)(int)clamp255f(lum);
                     }
                     cbytes = __float_as_uint(pj.w);
                 }
-#pragma unroll
-                for (int k = 0; k < 11; ++k) {
-                    cur[k] = __funnelshift_r(cur[k], cur[k + 1], 24);
-                    outb[k] = __funnelshift_r(outb[k], outb[k + 1], 24);
-                }
-                cur[11] >>= 24;
-                outb[11] = (outb[11] >> 24) | (cbytes << 8);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) gcur[k] = __funnelshift_r(gcur[k], gcur[k + 1], 8);
+                cb[q] = cbytes;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (act) {
@@ -606,6 +604,18 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+              }
+#pragma unroll
+              for (int k = 0; k < 9; ++k) {
+                  cur[k] = cur[k + 3];
+                  outb[k] = outb[k + 3];
+              }
+              cur[9] = cur[10] = cur[11] = 0u;
+              outb[9] = cb[0] | (cb[1] << 24);
+              outb[10] = (cb[1] >> 8) | (cb[2] << 16);
+              outb[11] = (cb[2] >> 16) | (cb[3] << 8);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) gcur[k] = gcur[k + 1];  // four gate bytes consumed
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -729,12 +739,18 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
                 DP_HIP(hipMemsetAsync(gprog, 0, (size_t)n_frames * kVProgWords * sizeof(uint32_t), s));
             }
         }
-        if (pal.n_inner > kQueueSmall)
-            hipLaunchKernelGGL(var_wavefront_kernel<kQueueLarge>, dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h,
-                               w, pal, vp, reinterpret_cast<float *>(ws), G, gprog);
-        else
-            hipLaunchKernelGGL(var_wavefront_kernel<kQueueSmall>, dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h,
-                               w, pal, vp, reinterpret_cast<float *>(ws), G, gprog);
+#define DP_VARW(C, M) hipLaunchKernelGGL((var_wavefront_kernel<C, M>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, vp, reinterpret_cast<float *>(ws), G, gprog)
+#define DP_VARW_M(C)                   \
+    do {                               \
+        if (model == 1) DP_VARW(C, 1); \
+        else if (model == 2) DP_VARW(C, 2); \
+        else if (model == 3) DP_VARW(C, 3); \
+        else DP_VARW(C, 4);            \
+    } while (0)
+        if (pal.n_inner > kQueueSmall) DP_VARW_M(kQueueLarge);
+        else DP_VARW_M(kQueueSmall);
+#undef DP_VARW_M
+#undef DP_VARW
         prof_end(pm, s);
         DP_HIP(hipGetLastError());
         return DP_OK;
