@@ -1254,16 +1254,29 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
                     o0 = ((uint32_t)m0 & 7u) == (uint32_t)c ? off[c] : o0;
                     o1 = ((uint32_t)m1 & 7u) == (uint32_t)c ? off[c] : o1;
                 }
-                const float4 c0 = *reinterpret_cast<const float4 *>(s_bytes + (s ? cand_base : o0));
-                uint32_t cpick = __float_as_uint(c0.w);
+                const uint32_t a0 = s ? cand_base : o0;
+                uint32_t cpick = *reinterpret_cast<const uint32_t *>(s_bytes + a0 + 12);  // the winner's output colour
                 if (MODE != 0) {
                     s |= (m2 - m1) <= kFloatKeyGap;
-                    const float4 c1 = *reinterpret_cast<const float4 *>(s_bytes + (s ? cand_base : o1));
-                    const double p0[3] = {(double)c0.x, (double)c0.y, (double)c0.z};
-                    const double p1[3] = {(double)c1.x, (double)c1.y, (double)c1.z};
-                    const double d0 = sq_dist3(p0, (double)r, (double)gg, (double)b);
-                    const double d1 = sq_dist3(p1, (double)r, (double)gg, (double)b);
-                    if (!ordered_use_nearest(d0, d1, tq[q])) cpick = __float_as_uint(c1.w);
+                    const uint32_t a1 = s ? cand_base : o1;
+                    const uint32_t cnext = *reinterpret_cast<const uint32_t *>(s_bytes + a1 + 12);
+                    // The decision s0/(s0+s1) <= t in float32 first: the keys hold the two distances to within 8 ulp on
+                    // top of the < 1.5e-6 of their float32 evaluation, so the quotient (<= 0.5) is off by < 3e-6 absolute
+                    // while the reference's float64 chain is off by < 1e-15; a gap of more than 2e-5 to the threshold
+                    // settles it.  Only pixels closer than that (about one in 10^4) replay the float64 chain.
+                    const float s0f = __uint_as_float((uint32_t)m0 & ~7u), s1f = __uint_as_float((uint32_t)m1 & ~7u);
+                    const float gap = __fdividef(s0f, s0f + s1f) - tq[q];
+                    bool use_nearest = gap <= 0.0f;
+                    if (fabsf(gap) <= 2e-5f && !s) {
+                        const float4 c0 = *reinterpret_cast<const float4 *>(s_bytes + a0);
+                        const float4 c1 = *reinterpret_cast<const float4 *>(s_bytes + a1);
+                        const double p0[3] = {(double)c0.x, (double)c0.y, (double)c0.z};
+                        const double p1[3] = {(double)c1.x, (double)c1.y, (double)c1.z};
+                        const double d0 = sq_dist3(p0, (double)r, (double)gg, (double)b);
+                        const double d1 = sq_dist3(p1, (double)r, (double)gg, (double)b);
+                        use_nearest = ordered_use_nearest(d0, d1, tq[q]);
+                    }
+                    if (!use_nearest) cpick = cnext;
                 }
                 slow[q] = s;
                 col[q] = cpick;
