@@ -41,6 +41,7 @@ def run(seed, N):
       if mode == "adaptive_variance": params = {"var_threshold": float(rs.choice([300.0, 50.0, 2000.0])), "window_radius": int(rs.randint(1, 4))}
       if mode == "ostromoukhov": params = {"serpentine": str(rs.choice(["true", "false"]))}
       if mode in DIFFUSERS and h * w > 40000: h, w = 40, 300
+      if mode in DIFFUSERS and rs.rand() < 0.3: h, w, nf = int(rs.randint(193, 420)), int(rs.randint(64, 180)), int(rs.randint(1, 3))  # several 64-row bands: a frame spread over workgroups
       y0, x0 = (0, 0) if mode in DIFFUSERS else (int(rs.randint(0, 50)), int(rs.randint(0, 50)))
       frames = rs.randint(0, 256, (nf, h, w, 3)).astype(np.uint8)
       if clustered:  # content inside the crowded region
