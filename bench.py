@@ -169,13 +169,15 @@ def main():
     achieved = BYTES_PER_PX * px_per_step / (k_ms * 1e-3) / 1e9
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
     # comes from the committed rocprofv3 --pmc pass of this same command (profiles/pmc_pass.sh)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_per_launch = None, None, None
     pmc_file = os.path.join(ROOT, "profiles", "r01_final_pmc_ordered_lean.json")
     if args.frames == 24 and os.path.exists(pmc_file):
         try:
             with open(pmc_file) as f:
-                traffic = int(json.load(f)["derived"]["hbm_traffic_bytes_per_launch"])
+                pmc = json.load(f)
+            traffic = int(pmc["derived"]["hbm_traffic_bytes_per_launch"])
             traffic_src = "profiles/r01_final_pmc_ordered_lean.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+            valu_per_launch = [v["SQ_INSTS_VALU"] for k, v in pmc["counters_mean_per_launch"].items() if "ordered_lean" in k][0]
         except Exception:  # noqa: BLE001
             traffic = None
     result = {
@@ -194,6 +196,11 @@ def main():
                      "algorithmic_bytes_per_launch": BYTES_PER_PX * px_per_step},
         "parity_kat_4k": bool(kat_ok),
     }
+    if valu_per_launch:
+        # what actually bounds the kernel: wave64 VALU instructions of one launch (same PMC file) against
+        # the issue rate of 1024 SIMDs, one instruction per 4 cycles, at the 2.4 GHz peak clock
+        result["roofline"]["valu_issue_frac"] = round(valu_per_launch * 4 / (1024 * 2.4e9 * k_ms * 1e-3), 4)
+        result["roofline"]["valu_wave_instructions_per_launch"] = int(valu_per_launch)
 
     # ---------------- secondary lines (same process, after the headline) -------------------------
     if not args.no_extra:
