@@ -468,6 +468,20 @@ def grad(h, w):
     return np.stack([x % 256, y % 256, ((x + y) // 2) % 256], -1).astype(np.uint8)
 
 
+def imgl(h, w, seed, kind="smooth"):
+    """Image-like content without transcendental functions (identical on every machine): ramps, a little structure and
+    grain; "dark" keeps every channel within ~45 levels.  A palette extracted from it crowds a small part of the cube."""
+    y, x = np.mgrid[0:h, 0:w]
+    rs = np.random.RandomState(seed)
+    if kind == "dark":
+        chans = [20 + (35 * x) // w + (10 * y) // h, 18 + (25 * y) // h + (x // 9) % 3, 25 + (30 * ((x + 2 * y) % w)) // w]
+        grain = rs.randint(-2, 3, (h, w, 3))
+    else:
+        chans = [60 + (100 * x) // w + (30 * y) // h, 90 + (80 * y) // h + (x // 7) % 9, 150 + (60 * (x + y)) // (w + h) - (y // 5) % 7]
+        grain = rs.randint(-3, 4, (h, w, 3))
+    return np.clip(np.stack(chans, -1) + grain, 0, 255).astype(np.uint8)
+
+
 def palr(K, seed=7):
     return [tuple(int(v) for v in c) for c in np.random.RandomState(seed).randint(0, 256, (K, 3))]
 

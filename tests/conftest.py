@@ -39,6 +39,8 @@ def case_input(orc, spec):
         return orc.rnd(spec[1], spec[2], spec[3])
     if spec[0] == "grad":
         return orc.grad(spec[1], spec[2])
+    if spec[0] == "imgl":
+        return orc.imgl(spec[1], spec[2], spec[3], spec[4])
     raise ValueError(spec)
 
 

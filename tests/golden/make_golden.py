@@ -30,7 +30,7 @@ import dithering_lib as dl  # noqa: E402  (the reference)
 from PIL import Image  # noqa: E402
 
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
-from oracle.oracle import grad, palr, rnd  # noqa: E402  (input formulas only)
+from oracle.oracle import grad, imgl, palr, rnd  # noqa: E402  (input formulas only)
 
 
 def H(a):
@@ -43,6 +43,8 @@ def make_input(spec):
         return rnd(spec[1], spec[2], spec[3])
     if kind == "grad":
         return grad(spec[1], spec[2])
+    if kind == "imgl":
+        return imgl(spec[1], spec[2], spec[3], spec[4])
     raise ValueError(spec)
 
 
@@ -121,10 +123,50 @@ CASES = [
     ("ed_fs_p16_tiny_w1", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 16), ("rnd", 17, 1, 2), False, True),
     ("ed_stucki_p16_tiny_h1", "error_diffusion", {"variant": "stucki"}, ("palr", 16), ("rnd", 1, 23, 2), False, True),
 ]
+# Palettes extracted from the image itself (the reference's default: palette=None => median cut, dithering_lib.py:1960-1966):
+# the palette spec ("mc", K) is resolved with the REFERENCE's reduce_colors and recorded as a plain list.
+CASES += [
+    ("bayer8_mc64_smooth", "bayer", {"size": "8x8"}, ("mc", 64), ("imgl", 240, 320, 5, "smooth"), False, True),
+    ("bayer8_mc256_dark", "bayer", {"size": "8x8"}, ("mc", 256), ("imgl", 240, 320, 6, "dark"), False, True),
+    ("none_mc16_dark", "none", {}, ("mc", 16), ("imgl", 200, 301, 7, "dark"), False, True),
+    ("ign_mc128_smooth", "IGN", {}, ("mc", 128), ("imgl", 200, 301, 8, "smooth"), False, True),
+    ("blue32_mc256_smooth", "blue_noise", {"size": 32, "seed": 7}, ("mc", 256), ("imgl", 200, 301, 9, "smooth"), False, True),
+    ("bayer8_mc64_gamma_smooth", "bayer", {"size": "8x8"}, ("mc", 64), ("imgl", 120, 160, 10, "smooth"), True, True),
+    ("ed_fs_mc16_smooth", "error_diffusion", {"variant": "floyd_steinberg"}, ("mc", 16), ("imgl", 96, 128, 11, "smooth"), False, True),
+    ("ed_jjn_mc256_dark", "error_diffusion", {"variant": "jjn"}, ("mc", 256), ("imgl", 64, 96, 12, "dark"), False, True),
+]
 for v in ED_VARIANTS:
     for s in ("false", "true"):
         CASES.append((f"ed_{v}_{s}_U16_grad", "error_diffusion", {"variant": v, "serpentine": s},
                       ("U", 16), ("grad", 64, 96), False, True))
+
+
+def append_new():
+    """Adds the cases of CASES that kat.json does not hold yet (and their median-cut palettes) without touching the rest."""
+    with open(os.path.join(HERE, "kat.json")) as f:
+        kat = json.load(f)
+    npz = dict(np.load(os.path.join(HERE, "small.npz")))
+    have = {c["name"] for c in kat["cases"]}
+    for name, mode, params, pspec, ispec, gamma, keep in CASES:
+        if name in have:
+            continue
+        arr = make_input(ispec)
+        if pspec[0] == "mc":
+            pal = [tuple(int(v) for v in c) for c in dl.ColorReducer.reduce_colors(Image.fromarray(arr), pspec[1])]
+            kat["misc"]["median_cut"][f"{ispec[0]}:{':'.join(str(v) for v in ispec[1:])}_{pspec[1]}"] = [list(c) for c in pal]
+            pspec = ("list", [list(c) for c in pal])
+        else:
+            pal = make_palette(pspec)
+        out = run_ref(arr, pal, mode, params, gamma)
+        kat["cases"].append(dict(name=name, mode=mode, params=params, palette=list(pspec), input=list(ispec),
+                                 gamma=gamma, h_in=H(arr), h_out=H(out), full=keep))
+        if keep:
+            npz["out_" + name] = out
+        print(name, H(arr), H(out), flush=True)
+    np.savez_compressed(os.path.join(HERE, "small.npz"), **npz)
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, indent=1, sort_keys=True)
+    print("now", len(npz), "arrays,", len(kat["cases"]), "cases")
 
 
 def main():
@@ -175,7 +217,12 @@ def main():
     # ---- dither cases
     for name, mode, params, pspec, ispec, gamma, keep in CASES:
         arr = make_input(ispec)
-        pal = make_palette(pspec)
+        if pspec[0] == "mc":  # resolved by the reference, recorded as a list
+            pal = [tuple(int(v) for v in c) for c in dl.ColorReducer.reduce_colors(Image.fromarray(arr), pspec[1])]
+            kat["misc"].setdefault("median_cut_cases", {})[f"{ispec[0]}:{':'.join(str(v) for v in ispec[1:])}_{pspec[1]}"] = [list(c) for c in pal]
+            pspec = ("list", [list(c) for c in pal])
+        else:
+            pal = make_palette(pspec)
         out = run_ref(arr, pal, mode, params, gamma)
         kat["cases"].append(dict(name=name, mode=mode, params=params, palette=list(pspec), input=list(ispec),
                                  gamma=gamma, h_in=H(arr), h_out=H(out), full=keep))
@@ -258,6 +305,7 @@ def main():
     for nm, arr in {"rnd40x50": rnd(40, 50, 41), "grad64x96": grad(64, 96)}.items():
         for n in (1, 2, 8, 16, 20):
             mc[f"{nm}_{n}"] = [list(map(int, c)) for c in dl.ColorReducer.reduce_colors(Image.fromarray(arr), n)]
+    mc.update(kat["misc"].pop("median_cut_cases", {}))
     kat["misc"]["median_cut"] = mc
     for gamma in (False, True):
         d = dl.ImageDitherer(8, dl.DitherMode.BAYER, None, gamma, {"size": "4x4"})
@@ -297,4 +345,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--append" in sys.argv:
+        append_new()
+    else:
+        main()
