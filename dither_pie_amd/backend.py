@@ -202,6 +202,10 @@ def variable_diffusion(frames, pal: Palette, model, p0=0.0, p1=0.0, serpentine=F
     L = _lib.load()
     ws_bytes = L.dp_error_diffusion_workspace_bytes(n, h, w)
     ws = _workspace(ws_bytes, f.device)
+    if gate is not None and n * h * w >= Palette.ACCEL_MIN_PIXELS:
+        # adaptive variance: gated-off (flat) regions query the palette with the pixels themselves; exact ties at integer
+        # points are then resolved from the accelerator's tie codes instead of a traversal replay per pixel
+        pal.build_accel()
     with torch.cuda.device(f.device):
         check(L.dp_variable_diffusion_u8(f.data_ptr(), out.data_ptr(), n, h, w, pal._h, int(model), float(p0), float(p1),
                                          1 if serpentine else 0, gate.data_ptr() if gate is not None else None,

@@ -1,0 +1,187 @@
+// Nearest palette entry of an arbitrary float32 point, as scipy's KD-tree query (k=1) reports it: float32 prefilter,
+// float64 validation, tree replay for exact ties; optionally restricted to the candidate list of the point's cell
+// (ediff.hip: build_ed_cells).  Shared by the error-diffusion kernels (ediff.hip) and the variable-weight diffusers
+// (vardiff.hip).
+#pragma once
+#include "dp_internal.h"
+#include "tree_query.cuh"
+
+namespace dp {
+namespace {
+
+template <int CAP>
+__device__ __forceinline__ int nearest_f64(const PalDev &pal, const float o0, const float o1, const float o2)
+{
+    const double x0 = (double)o0, x1 = (double)o1, x2 = (double)o2;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double b0 = inf, b1 = inf;
+    int i0 = 0;
+    const int K = pal.K;
+    for (int j = 0; j < K; ++j) {
+        const double d = sq_dist3(pal.pts + 3 * j, x0, x1, x2);
+        if (d < b0) {
+            b1 = b0;
+            b0 = d;
+            i0 = j;
+        } else if (d < b1) {
+            b1 = d;
+        }
+    }
+    if (b0 == b1 && K > kLeafSize) {
+        double d2[1];
+        int ii[1];
+        tree_query<1, CAP>(pal, x0, x1, x2, d2, ii);
+        i0 = ii[0];
+    }
+    return i0;
+}
+
+// An exact tie at an integer point of the cube, integer palette with tie codes (accel.hip): the float32 distances are
+// exact there, and which of several entries at the smallest distance scipy's traversal reports is tabulated (k=1 code:
+// 0 / 1 / 2 = the first / second / third of them in index order).  Flat image regions under the adaptive-variance gate
+// are exactly this case (no error arrives, the query is the pixel itself), and lattice or image-derived palettes tie on
+// 5-20 % of such pixels; the generic answer (float64 scan + traversal replay with its heaps in scratch memory) costs
+// microseconds per occurrence.  Returns -1 when the shortcut does not apply or the code says "other".
+__device__ __forceinline__ int integer_tie_choice(const PalDev &pal, const float4 *__restrict__ cand, const float o0,
+                                                  const float o1, const float o2, const float b0, const int i0)
+{
+    if (!pal.is_integer || pal.code1 == nullptr) return -1;
+    if (!(o0 >= 0.0f && o0 <= 255.0f && o1 >= 0.0f && o1 <= 255.0f && o2 >= 0.0f && o2 <= 255.0f)) return -1;
+    const uint32_t r = (uint32_t)o0, g = (uint32_t)o1, b = (uint32_t)o2;
+    if ((float)r != o0 || (float)g != o1 || (float)b != o2) return -1;
+    const uint32_t x = r | (g << 8) | (b << 16);
+    const uint32_t code = (pal.code1[x >> 4] >> ((x & 15u) * 2)) & 3u;
+    if (code == 0u) return i0;  // the lowest index among the tied entries (candidates are visited in index order)
+    if (code == 3u) return -1;
+    uint32_t seen = 0;
+    for (int j = 0; j < pal.K; ++j) {
+        const float4 c = cand[j];
+        const float a = c.x - o0, bb = c.y - o1, cc = c.z - o2;
+        const float d = __fmaf_rn(a, a, __fmaf_rn(bb, bb, cc * cc));
+        if (d == b0) {
+            if (seen == code) return j;
+            ++seen;
+        }
+    }
+    return -1;
+}
+
+// float32 prefilter: |d_f32 - d| <= ~3.6e-7 d (one rounding per subtract, square and add), so a gap of
+// 2e-6 (relative) between the two smallest float32 distances proves the float64 order.
+// `cand`: the palette as {x, y, z, out_rgb bits} -- in LDS for the wavefront kernel (every lane reads the same
+// entry: one broadcast ds_read_b128 per colour, issued four at a time), in global memory for the serial one.
+template <int CAP>
+__device__ __forceinline__ int nearest_color(const PalDev &pal, const float4 *__restrict__ cand, const float o0,
+                                             const float o1, const float o2)
+{
+    float b0 = __int_as_float(0x7f800000), b1 = b0;
+    int i0 = 0;
+    const int K = pal.K;
+    auto visit = [&](const float4 c, const int j) {
+        const float a = c.x - o0, b = c.y - o1, cc = c.z - o2;
+        const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, cc * cc));  // a filter only: any rounding within the margin
+        const bool lt0 = d < b0;
+        b1 = lt0 ? b0 : (d < b1 ? d : b1);
+        i0 = lt0 ? j : i0;
+        b0 = lt0 ? d : b0;
+    };
+    int j = 0;
+    for (; j + 4 <= K; j += 4) {
+        const float4 c0 = cand[j], c1 = cand[j + 1], c2 = cand[j + 2], c3 = cand[j + 3];
+        visit(c0, j);
+        visit(c1, j + 1);
+        visit(c2, j + 2);
+        visit(c3, j + 3);
+    }
+    for (; j < K; ++j) visit(cand[j], j);
+    if (b1 > b0 * 1.000002f) return i0;
+    if (b0 == b1) {
+        const int tied = integer_tie_choice(pal, cand, o0, o1, o2, b0, i0);
+        if (tied >= 0) return tied;
+    }
+    return nearest_f64<CAP>(pal, o0, o1, o2);
+}
+
+// nearest_color restricted to the cell's list (same validation, same fallbacks).
+// `coarse` (wavefront kernel, palettes of 9..16 colours; else nullptr): an LDS copy of the lists of the 16x16x16 cells,
+// count and up to 7 indices as nibbles of one word (count 15: longer than that) -- 99.8 % of the cells of a 16-colour
+// palette; a step then needs no load from global memory at all (the 8x8x8 lists live in L2: ~600 cycles of latency that
+// every step of the dependency chain would pay).
+template <int CAP>
+__device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const float4 *__restrict__ cand,
+                                                   const uint32_t *__restrict__ coarse, const float o0, const float o1,
+                                                   const float o2)
+{
+    float b0 = __int_as_float(0x7f800000), b1 = b0;
+    int i0 = 0;
+    auto visit = [&](const float4 c, const int j, const bool ok) {
+        const float a = c.x - o0, b = c.y - o1, cc = c.z - o2;
+        float d = __fmaf_rn(a, a, __fmaf_rn(b, b, cc * cc));
+        d = ok ? d : __int_as_float(0x7f800000);
+        const bool lt0 = d < b0;
+        b1 = lt0 ? b0 : (d < b1 ? d : b1);
+        i0 = lt0 ? j : i0;
+        b0 = lt0 ? d : b0;
+    };
+    bool listed = false;
+    if (coarse) {
+        const uint32_t e = coarse[((uint32_t)o0 >> 4) | (((uint32_t)o1 >> 4) << 4) | (((uint32_t)o2 >> 4) << 8)];
+        const int n = (int)(e & 15u);
+        if (n <= 7) {
+            const int j1 = (e >> 4) & 15, j2 = (e >> 8) & 15, j3 = (e >> 12) & 15, j4 = (e >> 16) & 15;
+            const float4 c1 = cand[j1], c2 = cand[j2], c3 = cand[j3], c4 = cand[j4];
+            visit(c1, j1, n >= 1);
+            visit(c2, j2, n >= 2);
+            visit(c3, j3, n >= 3);
+            visit(c4, j4, n >= 4);
+            if (n > 4) {
+                const int j5 = (e >> 20) & 15, j6 = (e >> 24) & 15, j7 = (e >> 28) & 15;
+                const float4 c5 = cand[j5], c6 = cand[j6], c7 = cand[j7];
+                visit(c5, j5, true);
+                visit(c6, j6, n >= 6);
+                visit(c7, j7, n >= 7);
+            }
+            listed = true;
+        }
+    }
+    if (!listed) {
+        const uint32_t ci = ((uint32_t)o0 >> 3) | (((uint32_t)o1 >> 3) << 5) | (((uint32_t)o2 >> 3) << 10);
+        uint4 blk = pal.ed_cells[ci];
+        int n = (int)(blk.x & 255u);
+        if (n == 254) {  // a crowded cell (clustered palettes): refined into 4^3, 2^3, 1^3 sub-cells
+            const uint32_t i0 = (uint32_t)o0, i1 = (uint32_t)o1, i2 = (uint32_t)o2;
+            for (int bit = 2; n == 254; --bit) {
+                const uint32_t sub = ((i0 >> bit) & 1u) | (((i1 >> bit) & 1u) << 1) | (((i2 >> bit) & 1u) << 2);
+                blk = pal.ed_nodes[(size_t)(blk.x >> 8) * 8 + sub];
+                n = (int)(blk.x & 255u);
+            }
+        }
+        if (n > 15) return nearest_color<CAP>(pal, cand, o0, o1, o2);
+        // four entries per round, their reads in flight together (unused slots hold index 0: a valid, ignored read)
+        blk.x = __funnelshift_r(blk.x, blk.y, 8);  // drop the count byte
+        blk.y = __funnelshift_r(blk.y, blk.z, 8);
+        blk.z = __funnelshift_r(blk.z, blk.w, 8);
+        blk.w >>= 8;
+        for (; n > 0; n -= 4) {
+            const int j1 = (int)(blk.x & 255u), j2 = (int)((blk.x >> 8) & 255u), j3 = (int)((blk.x >> 16) & 255u), j4 = (int)(blk.x >> 24);
+            const float4 c1 = cand[j1], c2 = cand[j2], c3 = cand[j3], c4 = cand[j4];
+            visit(c1, j1, true);
+            visit(c2, j2, n >= 2);
+            visit(c3, j3, n >= 3);
+            visit(c4, j4, n >= 4);
+            blk.x = blk.y;
+            blk.y = blk.z;
+            blk.z = blk.w;
+            blk.w = 0u;
+        }
+    }
+    if (b1 > b0 * 1.000002f) return i0;
+    if (b0 == b1) {
+        const int tied = integer_tie_choice(pal, cand, o0, o1, o2, b0, i0);
+        if (tied >= 0) return tied;
+    }
+    return nearest_f64<CAP>(pal, o0, o1, o2);
+}
+
+}  // namespace
+}  // namespace dp

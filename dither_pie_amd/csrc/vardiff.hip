@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "dp_internal.h"
+#include "ed_nearest.cuh"
 #include "tree_query.cuh"
 #include "wave_util.cuh"
 
@@ -78,6 +79,10 @@ __device__ __forceinline__ int nearest_any(const PalDev &pal, const float4 *__re
     }
     for (; jj < K; ++jj) visit(cand[jj], jj);
     if (b1 > b0 * 1.000002f) return i0;
+    if (b0 == b1) {
+        const int tied = integer_tie_choice(pal, cand, o0, o1, o2, b0, i0);
+        if (tied >= 0) return tied;
+    }
     return nearest_any_f64<CAP>(pal, o0, o1, o2);
 }
 
@@ -347,6 +352,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     __shared__ uint8_t s_lut[256];
     __shared__ volatile uint32_t s_prog[kVWaves];
     __shared__ float4 s_pal[DP_MAX_COLORS];  // {x, y, z, out_rgb bits}
+    __shared__ uint32_t s_coarse[4096];      // candidate lists of the 16^3 cells (palettes of 9..16 colours, ediff.hip)
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -356,6 +362,9 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     uint32_t *gprog = gprog_all + f * (size_t)kVProgWords;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
     for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
+    if (pal.ed_coarse)
+        for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_coarse[i] = pal.ed_coarse[i];
+    const uint32_t *coarse = pal.ed_coarse ? s_coarse : nullptr;
     if (threadIdx.x < kVWaves) s_prog[threadIdx.x] = 0;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
@@ -563,7 +572,11 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                         o1 = clamp255f(o1);
                         o2 = clamp255f(o2);
                     }
-                    const int j = nearest_any<CAP>(pal, s_pal, o0, o1, o2);
+                    // points inside the colour cube (always, once clamped: Ostromoukhov) search only the candidate list of
+                    // their cell, as error diffusion does; a wave with a point outside scans the palette
+                    const bool inside = model == 4 || (o0 >= 0.0f && o0 <= 255.0f && o1 >= 0.0f && o1 <= 255.0f && o2 >= 0.0f && o2 <= 255.0f);
+                    const int j = (pal.ed_cells && __ballot(!inside) == 0ull) ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2)
+                                                                               : nearest_any<CAP>(pal, s_pal, o0, o1, o2);
                     const float4 pj = s_pal[j];
                     e0 = __fsub_rn(o0, pj.x);
                     e1 = __fsub_rn(o1, pj.y);

@@ -583,3 +583,27 @@ def test_variable_diffusers_frame_spread_over_workgroups(be, orc, monkeypatch, m
         _assert_same(_run_case(be, orc, arr, pal, mode, params, gamma), ref, f"spread {mode} gamma={gamma}")
     monkeypatch.setenv("DP_ED_ONE_WG", "1")
     _assert_same(_run_case(be, orc, arr, pal, mode, params, False), orc.apply_dithering(arr, pal, mode, params, False), f"one workgroup {mode}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,seed", [(16, 0), (27, 0), (64, 5), (256, 7)])
+def test_diffusers_exact_ties_at_integer_points(be, orc, K, seed):
+    """Under the adaptive-variance gate flat regions receive no error: the palette is queried with the pixels themselves,
+    and lattice / duplicated palettes tie exactly on many of them.  The kernels answer those from the accelerator's k=1
+    tie codes (exact float32 distances, entries in index order) instead of replaying the tree traversal; the result has
+    to be scipy's choice.  Content: palette colours, midpoints of palette pairs, lattice midpoints, noise."""
+    pal = orc.generate_uniform_palette(K) if seed == 0 else orc.palr(K, seed)
+    if K == 64:
+        pal = pal[:32] + pal[:32]  # duplicates
+    pa = np.asarray(pal, dtype=np.int64)
+    rs = np.random.RandomState(K)
+    h, w = 96, 150
+    i, j = rs.randint(0, len(pal), (2, h, w))
+    mid = ((pa[i] + pa[j]) // 2).astype(np.uint8)
+    arr = np.where(rs.randint(0, 4, (h, w, 1)) == 0, orc.rnd(h, w, K), mid)
+    arr[:8] = pa[i[:8]].astype(np.uint8)
+    for mode, params in (("adaptive_variance", {"var_threshold": 1e9, "window_radius": 1}),
+                         ("adaptive_variance", {"var_threshold": 900.0, "window_radius": 2}),
+                         ("ostromoukhov", {"serpentine": "false"}), ("error_diffusion", {"variant": "floyd_steinberg", "serpentine": "false"})):
+        out = _run_case(be, orc, arr, pal, mode, params, False)
+        _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False), f"K={K} {mode} {params}")
