@@ -575,7 +575,8 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     // points inside the colour cube (always, once clamped: Ostromoukhov) search only the candidate list of
                     // their cell, as error diffusion does; a wave with a point outside scans the palette
                     const bool inside = model == 4 || (o0 >= 0.0f && o0 <= 255.0f && o1 >= 0.0f && o1 <= 255.0f && o2 >= 0.0f && o2 <= 255.0f);
-                    const int j = (pal.ed_cells && __ballot(!inside) == 0ull) ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2)
+                    // (perceptual: its waves nearly always hold a point outside the cube -- measured, the lists only cost there)
+                    const int j = (model != 1 && pal.ed_cells && __ballot(!inside) == 0ull) ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2)
                                                                                : nearest_any<CAP>(pal, s_pal, o0, o1, o2);
                     const float4 pj = s_pal[j];
                     e0 = __fsub_rn(o0, pj.x);
