@@ -12,6 +12,7 @@
 // variance_gate: scipy.ndimage.uniform_filter(size, mode='nearest') restated (float32 passes along axis 0 then
 // axis 1, each a double running sum `tmp += entering - leaving`, out = tmp/size) on gray and gray^2, then
 // max(0, mean_sq - sq_mean^2) >= threshold  (dithering_lib.py:988-992, 1019-1025).
+#include <algorithm>
 #include <cstdlib>
 
 #include "dp_internal.h"
@@ -704,21 +705,41 @@ __global__ void var_axis1_kernel(const float *__restrict__ t_sq, const float *__
 
 }  // namespace
 
-size_t variance_gate_ws_bytes(int64_t n_frames, int h, int w) { return (size_t)n_frames * h * w * sizeof(float) * 2 + 256; }
+// The two float planes between the passes are kept for a chunk of frames only (about a gigabyte), whatever the batch
+static int64_t variance_gate_chunk(int64_t n_frames, int h, int w)
+{
+    const int64_t per_frame = (int64_t)h * w * (int64_t)sizeof(float) * 2;
+    int64_t budget = (int64_t)1 << 30;
+    if (const char *e = getenv("DP_GATE_CHUNK_BYTES")) budget = std::max<int64_t>(1, atoll(e));  // tests: force several chunks
+    int64_t c = per_frame > 0 ? budget / per_frame : n_frames;
+    c = c < 1 ? 1 : c;
+    return c < n_frames ? c : (n_frames < 1 ? 1 : n_frames);
+}
+
+size_t variance_gate_ws_bytes(int64_t n_frames, int h, int w)
+{
+    return (size_t)variance_gate_chunk(n_frames, h, w) * h * w * sizeof(float) * 2 + 256;
+}
 
 int launch_variance_gate(const uint8_t *in, uint8_t *gate, int64_t n_frames, int h, int w, const PalDev &pal, float thr,
                          int radius, void *ws, hipStream_t s)
 {
     const int size = 2 * radius + 1;
-    float *t_sq = reinterpret_cast<float *>(ws);
-    float *t_g = t_sq + (size_t)n_frames * h * w;
-    if (h > 65535 || n_frames > 65535) {
-        set_error("dp_variance_gate_u8: h or n_frames > 65535 not supported");
+    if (h > 65535) {
+        set_error("dp_variance_gate_u8: h > 65535 not supported");
         return DP_EUNSUPPORTED;
     }
-    const dim3 grid((w + 255) / 256, h, (unsigned)n_frames);
-    hipLaunchKernelGGL(var_axis0_kernel, grid, dim3(256), 0, s, in, pal.lut_in, t_sq, t_g, n_frames, h, w, size);
-    hipLaunchKernelGGL(var_axis1_kernel, grid, dim3(256), 0, s, t_sq, t_g, gate, n_frames, h, w, size, thr);
+    const int64_t chunk = std::min<int64_t>(variance_gate_chunk(n_frames, h, w), 65535);
+    float *t_sq = reinterpret_cast<float *>(ws);
+    float *t_g = t_sq + (size_t)chunk * h * w;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {  // chunks run back to back on the stream and reuse the planes
+        const int64_t nf = std::min<int64_t>(chunk, n_frames - f0);
+        const uint8_t *in_c = in + (size_t)f0 * h * w * 3;
+        uint8_t *gate_c = gate + (size_t)f0 * h * w;
+        const dim3 grid((w + 255) / 256, h, (unsigned)nf);
+        hipLaunchKernelGGL(var_axis0_kernel, grid, dim3(256), 0, s, in_c, pal.lut_in, t_sq, t_g, nf, h, w, size);
+        hipLaunchKernelGGL(var_axis1_kernel, grid, dim3(256), 0, s, t_sq, t_g, gate_c, nf, h, w, size, thr);
+    }
     DP_HIP(hipGetLastError());
     return DP_OK;
 }

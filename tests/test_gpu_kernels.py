@@ -607,3 +607,18 @@ def test_diffusers_exact_ties_at_integer_points(be, orc, K, seed):
                          ("ostromoukhov", {"serpentine": "false"}), ("error_diffusion", {"variant": "floyd_steinberg", "serpentine": "false"})):
         out = _run_case(be, orc, arr, pal, mode, params, False)
         _assert_same(out, orc.apply_dithering(arr, pal, mode, params, False), f"K={K} {mode} {params}")
+
+
+@pytest.mark.gpu
+def test_variance_gate_in_chunks_of_frames(be, orc, monkeypatch):
+    """The gate pass keeps its two float planes for a chunk of frames only (a gigabyte at most); with a tiny budget a small
+    batch already needs several chunks.  Every frame's gate has to equal the scipy restatement's."""
+    import torch
+    monkeypatch.setenv("DP_GATE_CHUNK_BYTES", str(3 * 33 * 47 * 8 + 100))  # three frames per chunk
+    frames = np.stack([orc.rnd(33, 47, 50 + i) for i in range(8)])
+    pal_f32, oc, lut = orc.prepare_palette(orc.palr(16), False)
+    P = be.Palette(pal_f32, oc, lut)
+    gates = be.variance_gate(torch.from_numpy(frames).cuda(), P, 250.0, 2).cpu().numpy()
+    for i in range(len(frames)):
+        ref, _ = orc.variance_gate(frames[i], 250.0, 2)
+        assert np.array_equal(gates[i], ref), i
