@@ -45,11 +45,14 @@ constexpr int kExcCap = 1 << 16;  // colours with an outcome outside the codes (
 
 template <int MW, int CAP>  // MW: mask words (32 palette entries each); CAP: traversal queue of the tie queries
 __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint32_t *__restrict__ masks,
-                                                         uint32_t *__restrict__ code1, uint32_t *__restrict__ code2,
-                                                         uint4 *__restrict__ exc, uint32_t *__restrict__ exc_count)
+                                                         uint32_t *__restrict__ nmasks, uint32_t *__restrict__ code1,
+                                                         uint32_t *__restrict__ code2, uint4 *__restrict__ exc,
+                                                         uint32_t *__restrict__ exc_count)
 {
     __shared__ uint32_t s_mask[9][MW];  // [0] the whole cell, [1+s] its 8x8x8 sub-cell s
+    __shared__ uint32_t s_nmask[MW];    // N(cell): the entries that are NEAREST (ties included) to some colour of the cell
     for (int i = threadIdx.x; i < 9 * MW; i += 256) (&s_mask[0][0])[i] = 0;
+    if (threadIdx.x < MW) s_nmask[threadIdx.x] = 0;
     __syncthreads();
     const int cell = blockIdx.x;
     const int rc = cell >> 8, gc = (cell >> 4) & 15, bc = cell & 15;
@@ -88,6 +91,17 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
                 const int dot = (int)__builtin_amdgcn_udot4(x4, pal.p4[j], 0u, false);
                 const int dj = (pal.nkey[j] - (dot << (kIdxBits + 1))) >> kIdxBits;
                 if (dj <= d1) mark(j);
+            }
+        }
+        // the nearest set: everything at the smallest distance
+        atomicOr(&s_nmask[c0 >> 5], 1u << (c0 & 31));
+        if (K > 1 && d1 == d0) atomicOr(&s_nmask[c1 >> 5], 1u << (c1 & 31));
+        if (K > 2 && d2 == d0) atomicOr(&s_nmask[c2 >> 5], 1u << (c2 & 31));
+        if (K > 3 && d3 == d0) {
+            for (int j = 0; j < K; ++j) {
+                const int dot = (int)__builtin_amdgcn_udot4(x4, pal.p4[j], 0u, false);
+                const int dj = (pal.nkey[j] - (dot << (kIdxBits + 1))) >> kIdxBits;
+                if (dj <= d0) atomicOr(&s_nmask[j >> 5], 1u << (j & 31));
             }
         }
         if (K < 2) continue;
@@ -130,6 +144,7 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 9 * MW; i += 256) masks[(size_t)cell * 9 * MW + i] = (&s_mask[0][0])[i];
+    if (threadIdx.x < MW) nmasks[(size_t)cell * MW + threadIdx.x] = s_nmask[threadIdx.x];
 }
 
 
@@ -366,13 +381,16 @@ __global__ __launch_bounds__(64) void accel_box_float_kernel(const PalDev pal, c
 namespace {
 
 constexpr int kCells = 4096;
+constexpr int kWideCap = 512;   // such lists per table at most
+constexpr int kNearSlots = 6;  // entries of an 8-entry block that the nearest-only path of ordered_fast_kernel reads
 constexpr int kTabCapWords = (160 * 1024 - 2048) / 4;  // LDS budget of the dither kernels
 constexpr int kTabMaxWords = 1 << 20;                 // largest table built (4 MB); what exceeds LDS stays in global memory
 // words the lean kernels stage when the table is larger than LDS: the 4096 cell blocks + the first split nodes
 constexpr int kTabStageWords = 4096 * 8 + 88 * 64;
 
 struct TableStats {
-    int n_split = 0, n_slow = 0, max_cnt = 0;
+    int n_split = 0, n_slow = 0, max_cnt = 0, max_near = 0;
+    bool wide_overflow = false;
     std::vector<Box> node_box;  // the box each split node covers, by node index
     int n_split_cells = 0;  // 16^3 cells that are split (the pixels of these cells leave the main path of the kernels)
     bool too_big = false;
@@ -381,10 +399,19 @@ struct TableStats {
 // Turns the per-cell membership masks into the LDS table: [4096 cells][8 words], then [n_split][8 sub-cells][8].
 // coord4[j]: integer coordinates r | g<<8 | b<<16 of entry j (used to choose padding entries); word[j]: what a
 // block stores for entry j.  box_masks(boxes, out) computes the membership masks (8 words each) of further boxes.
+// nmasks (optional): the nearest sets N(cell) of the 4096 cells.  With them a cell whose N has more than `ns` members is
+// split like an overflowing one, and perm[slot] receives, for every unsplit cell block, the order in which the fast
+// ordered kernel stages the block's entries into LDS -- the members of N first (field k, 3 bits for bw = 8, 2 bits
+// for bw = 4: which entry of the index-ordered block goes to LDS slot k; bits 28..31: |N|); 0xffffffff = split cell.
+// The table itself stays in palette-index order (the tie codes are defined on that order).
+// wide (with perm): for every SPLIT cell the whole list T(cell) in index order, padded to kWideList entries -- the fast
+// kernel resolves the pixels of split cells on it (one block read instead of a descent through the octree);
+// perm[slot] = 0xff000000 | list number.  A cell with a longer list sets st.wide_overflow (no fast kernel then).
 template <class BoxMasks>
 int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int bw, const int cap_words, const int K,
                    const std::vector<uint32_t> &coord4, const std::vector<uint32_t> &word, BoxMasks box_masks,
-                   std::vector<uint32_t> &tab, TableStats &st)
+                   std::vector<uint32_t> &tab, TableStats &st, const uint32_t *nmasks = nullptr, const int ns = 0,
+                   std::vector<uint32_t> *perm = nullptr, std::vector<uint32_t> *wide = nullptr)
 {
     // bw: entries per block (8, or 4 for small palettes); a split node is 8 child blocks
     tab.assign((size_t)kCells * bw, 0u);
@@ -446,14 +473,61 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int b
             }
         }
     };
+    if (perm) perm->assign(kCells, 0xffffffffu);
     for (int cell = 0; cell < kCells && !st.too_big; ++cell) {
         const uint32_t *m = &masks[(size_t)cell * 9 * mw];
         const int r0 = (cell >> 8) * 16, g0 = ((cell >> 4) & 15) * 16, b0 = (cell & 15) * 16;
         uint32_t blk[8];
         const size_t slot = (size_t)cell_slot(cell >> 8, (cell >> 4) & 15, cell & 15);
-        if (make_block(m, r0 + 8, g0 + 8, b0 + 8, blk)) {
+        bool fits = make_block(m, r0 + 8, g0 + 8, b0 + 8, blk);
+        if (fits && nmasks) {
+            // `list` holds the block's entries in index order: the nearest set first
+            const uint32_t *nm = nmasks + (size_t)cell * mw;
+            const int fb = bw == 8 ? 3 : 2;
+            uint32_t pw = 0;
+            int k = 0, n_near = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int i = 0; i < bw; ++i) {
+                    const int j = list[i];
+                    const bool near = (nm[j >> 5] >> (j & 31)) & 1u;
+                    if (near == (pass == 0)) {
+                        pw |= (uint32_t)i << (fb * k++);
+                        n_near += near;
+                    }
+                }
+            if (n_near > ns) fits = false;  // the nearest-only path of the kernel reads `ns` entries
+            else if (perm) (*perm)[slot] = pw | ((uint32_t)n_near << 28);
+            st.max_near = std::max(st.max_near, n_near);
+        }
+        if (fits) {
             std::copy(blk, blk + bw, tab.begin() + slot * bw);
         } else {
+            if (perm && wide) {
+                // the cell's whole list, index order, padded with the unused entries nearest to the centre
+                list.clear();
+                extra.clear();
+                for (int j = 0; j < K; ++j) ((m[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
+                if (K <= kWideList) {
+                    // the whole palette (the kernel reads min(K, kWideList) entries)
+                    (*perm)[slot] = 0xff000000u | (uint32_t)(wide->size() / kWideList);
+                    for (int i = 0; i < kWideList; ++i) wide->push_back(i < K ? word[i] : 0u);
+                } else if ((int)list.size() > kWideList) {
+                    st.wide_overflow = true;
+                } else {
+                    const size_t need = (size_t)kWideList - list.size();
+                    dkey.resize(extra.size());
+                    for (size_t q = 0; q < extra.size(); ++q) {
+                        const uint32_t c = coord4[extra[q]];
+                        const int r = c & 255, g = (c >> 8) & 255, b = (c >> 16) & 255;
+                        dkey[q] = ((uint64_t)((r - r0 - 8) * (r - r0 - 8) + (g - g0 - 8) * (g - g0 - 8) + (b - b0 - 8) * (b - b0 - 8)) << 16) | (uint64_t)extra[q];
+                    }
+                    std::partial_sort(dkey.begin(), dkey.begin() + need, dkey.end());
+                    for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
+                    std::sort(list.begin(), list.end());
+                    (*perm)[slot] = 0xff000000u | (uint32_t)(wide->size() / kWideList);
+                    for (int i = 0; i < kWideList; ++i) wide->push_back(word[list[i]]);
+                }
+            }
             split(slot * bw, Box{r0, g0, b0, 16}, m + mw);
             ++st.n_split_cells;
         }
@@ -633,8 +707,11 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     const int mw = K <= 256 ? 8 : 32;               // mask words per (sub-)cell
     const bool big_q = dev.n_inner > kQueueSmall;   // traversal queue of the tie queries
     // layout: code1 | code2 | table[max] | exceptions | exception count | table of 4-entry blocks [cap] |
-    //         table over warped cells [max] | the three warp maps [768 bytes]
-    const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + 2 * kTabMaxWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16 + 768;
+    //         table over warped cells [max] | the three warp maps [768 bytes] | staging orders of the 8- and the
+    //         4-entry table [2 x 4096 words]
+    //         | the flat lists of their split cells [2 x kWideCap x kWideList words]
+    const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + 2 * kTabMaxWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16 + 768 +
+                         sizeof(uint32_t) * (2 * kCells + 2 * kWideCap * kWideList);
     DP_HIP(hipMalloc((void **)&blob, bytes));
     struct DevFree {  // frees the scan masks on every way out
         void *p = nullptr;
@@ -643,8 +720,9 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
             if (p) (void)hipFree(p);
         }
     } masks_guard;
-    hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 9 * mw);
+    hipError_t e = hipMalloc((void **)&d_masks, sizeof(uint32_t) * kCells * 10 * mw);  // T masks [9] + N mask [1] per cell
     masks_guard.p = d_masks;
+    uint32_t *d_nmasks = d_masks + (size_t)kCells * 9 * mw;
     if (e == hipSuccess) e = hipMemset(blob, 0, sizeof(uint32_t) * 3 * kCodeWords);
     if (e != hipSuccess) {
         (void)hipFree(blob);
@@ -660,16 +738,17 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         (void)hipFree(blob);
         return hip_fail(e, "accelerator allocation");
     }
-#define DP_SCAN(MW, C) hipLaunchKernelGGL((accel_scan_kernel<MW, C>), dim3(kCells), dim3(256), 0, 0, dev, d_masks, code1, code2, d_exc, d_exc_count)
+#define DP_SCAN(MW, C) hipLaunchKernelGGL((accel_scan_kernel<MW, C>), dim3(kCells), dim3(256), 0, 0, dev, d_masks, d_nmasks, code1, code2, d_exc, d_exc_count)
     if (mw == 8) {
         if (big_q) DP_SCAN(8, kQueueLarge); else DP_SCAN(8, kQueueSmall);
     } else {
         if (big_q) DP_SCAN(32, kQueueLarge); else DP_SCAN(32, kQueueSmall);
     }
 #undef DP_SCAN
-    std::vector<uint32_t> masks((size_t)kCells * 9 * mw);
+    std::vector<uint32_t> masks((size_t)kCells * 9 * mw), nmasks((size_t)kCells * mw);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(masks.data(), d_masks, sizeof(uint32_t) * masks.size(), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(nmasks.data(), d_nmasks, sizeof(uint32_t) * nmasks.size(), hipMemcpyDeviceToHost);
     if (e != hipSuccess) {
         (void)hipFree(blob);
         return hip_fail(e, "accelerator scan");
@@ -685,11 +764,12 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     };
     // small palettes: most cells hold at most 4 candidates; a table of 4-entry blocks halves the work of the dither
     // kernel as long as few cells overflow into splits (their pixels take the deferred path)
-    std::vector<uint32_t> tab4;
+    std::vector<uint32_t> tab4, perm4, perm8, wide4, wide8;
     TableStats st4;
     bool use4 = false;
     if (K <= 64) {
-        const int rc4 = assemble_table(masks, mw, 4, kTabCapWords, K, p4_host, p4_host, box_masks, tab4, st4);
+        // (staging order with the nearest set first; four slots hold any nearest set that fits the block)
+        const int rc4 = assemble_table(masks, mw, 4, kTabCapWords, K, p4_host, p4_host, box_masks, tab4, st4, nmasks.data(), 4, &perm4, &wide4);
         if (rc4 != DP_OK) {
             (void)hipFree(blob);
             return rc4;
@@ -845,6 +925,59 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         dev.warp_total = (int)wtab.size();
         dev.warp_words = w_spilled ? std::min((int)wtab.size(), kTabStageWords - 3 * 64) : (int)wtab.size();
         dev.warp_adapt = (wbw == 8 && (w_spilled || wst.n_split_cells > kCells * 3 / 100 || w_mass * 4 >= n_mass)) ? 1 : 0;
+    }
+    // The fast ordered kernel (ordered.hip: ordered_fast_kernel) runs the pixels that can only take their nearest entry on
+    // the first kNearSlots entries of the cell's block, staged nearest set first.  When the plain 8-entry table is the one
+    // in use and uncrowded, build it again with the cells whose nearest set is larger split as well, and keep that
+    // version while the table stays uncrowded and within LDS (the pixels of split cells take the deferred path).
+    dev.cell_perm = dev.cell_perm4 = nullptr;
+    dev.near_slots = 0;
+    if (have8 && !st.too_big && !use4 && wbw == 0 && !dev.adapt && tab.size() <= (size_t)kTabCapWords && !getenv("DP_NO_FAST")) {
+        std::vector<uint32_t> tabn;
+        TableStats stn;
+        const int rcn = assemble_table(masks, mw, 8, kTabMaxWords, K, p4_host, p4_host, box_masks, tabn, stn, nmasks.data(), kNearSlots, &perm8, &wide8);
+        if (rcn != DP_OK) {
+            (void)hipFree(blob);
+            return rcn;
+        }
+        const bool keep = !stn.too_big && !stn.wide_overflow && tabn.size() <= (size_t)kTabCapWords && stn.n_split_cells <= kCells * 4 / 100 &&
+                          wide8.size() <= (size_t)kWideCap * kWideList;
+        if (getenv("DP_DEBUG_ACCEL"))
+            fprintf(stderr, "accel K=%d: nearest-first table (%d slots): %d split cells (were %d), %d nodes, %zu words, largest nearest set kept %d -> %s\n",
+                    K, kNearSlots, stn.n_split_cells, st.n_split_cells, stn.n_split, tabn.size(), stn.max_near, keep ? "in use" : "dropped");
+        if (keep) {
+            tab.swap(tabn);
+            st = stn;
+        } else {
+            perm8.clear();
+        }
+    }
+    uint32_t *d_perm8 = reinterpret_cast<uint32_t *>(d_lut + 768), *d_perm4 = d_perm8 + kCells;
+    uint32_t *d_wide8 = d_perm4 + kCells, *d_wide4 = d_wide8 + kWideCap * kWideList;
+    dev.cell_wide = dev.cell_wide4 = nullptr;
+    dev.n_wide = dev.n_wide4 = 0;
+    if (!perm8.empty()) {
+        e = hipMemcpy(d_perm8, perm8.data(), sizeof(uint32_t) * kCells, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !wide8.empty()) e = hipMemcpy(d_wide8, wide8.data(), sizeof(uint32_t) * wide8.size(), hipMemcpyHostToDevice);
+        dev.cell_wide = d_wide8;
+        dev.n_wide = (int)(wide8.size() / kWideList);
+        if (e != hipSuccess) {
+            (void)hipFree(blob);
+            return hip_fail(e, "accelerator upload (staging order)");
+        }
+        dev.cell_perm = d_perm8;
+        dev.near_slots = kNearSlots;
+    }
+    if (use4 && wbw == 0 && !perm4.empty() && !st4.wide_overflow && wide4.size() <= (size_t)kWideCap * kWideList && !getenv("DP_NO_FAST")) {
+        e = hipMemcpy(d_perm4, perm4.data(), sizeof(uint32_t) * kCells, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !wide4.empty()) e = hipMemcpy(d_wide4, wide4.data(), sizeof(uint32_t) * wide4.size(), hipMemcpyHostToDevice);
+        dev.cell_wide4 = d_wide4;
+        dev.n_wide4 = (int)(wide4.size() / kWideList);
+        if (e != hipSuccess) {
+            (void)hipFree(blob);
+            return hip_fail(e, "accelerator upload (staging order)");
+        }
+        dev.cell_perm4 = d_perm4;
     }
     dev.cell_tab = nullptr;
     dev.tab_words = 0;

@@ -17,6 +17,7 @@ constexpr int kQueueLarge = 256;  // ... larger palettes (K <= 1024) and degener
 constexpr int kQueueTiles = 65536;  // wave tiles (256 px) with a flagged pixel that the fix-up pass visits directly (queue in the workspace)
 constexpr int kIdxBits = 10;      // palette index bits packed under the distance key (brute-force kernels)
 constexpr int kLocalBits = 8;     // byte offset of a candidate inside its block (cell-table kernel)
+constexpr int kWideList = 16;     // entries of the flat candidate list of a split cell (ordered_fast_kernel, accel.hip)
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
@@ -67,6 +68,15 @@ struct PalDev {
     // the lean kernel prefers it (half the candidate work)
     const uint32_t *cell_tab4;
     int tab4_words;
+    // staging orders for ordered_fast_kernel (accel.hip, assemble_table): per cell block (by cell_slot) which entry of
+    // the index-ordered block goes to which LDS slot, nearest set first; nullptr = the fast kernel is not used.
+    const uint32_t *cell_perm;  // for cell_tab (3-bit fields); every unsplit cell's nearest set fits near_slots entries
+    const uint32_t *cell_perm4; // for cell_tab4 (2-bit fields)
+    int near_slots;
+    // ... and, for the cells that are split, the whole candidate list of the cell as a flat block of 16 entries in
+    // index order (perm word 0xff000000 | list number): n_wide lists of 16 words
+    const uint32_t *cell_wide, *cell_wide4;
+    int n_wide, n_wide4;
     int adapt;                  // the palette crowds a few cells of cell_tab: use the kernel instantiation that adapts per wave
     // crowded palettes (extracted from an image): a table over WARPED cells -- cell coordinates are
     // (warp_lut[r], warp_lut[256 + g], warp_lut[512 + b]) instead of (r, g, b) -- or nullptr.  Lean kernels only.
@@ -106,6 +116,9 @@ struct ThrDev {
     // (positions by masking; otherwise by an exact float64 reciprocal, inv_h / inv_w).
     const float *fpad;
     const uint32_t *mpad;
+    // cls[row * th_w + col] (present with fpad): bit q set = when lane 0 of a wave sits at (row, col) of the table and its
+    // 64 lanes x 4 pixels lie in one image row, no lane's pixel q has a threshold below 1/2 (ordered_fast_kernel)
+    const uint32_t *cls;
     int tw_pad;
     int pow2;
     double inv_h, inv_w;

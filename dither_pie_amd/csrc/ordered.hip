@@ -1098,6 +1098,493 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// ordered_fast_kernel: the lean kernel's successor for uncrowded integer palettes (plain cells).
+//
+// What bounds these kernels is the number of vector instructions per pixel: profiles/microbench/valu_rate*.txt
+// -- every integer operation used here (v_dot4, v_mad_i32_i24, v_med3, v_perm, compares ...) issues once per ~4.3
+// cycles per SIMD whatever the occupancy; only f32 add/mul/fma and v_mov reach ~2.4.  So the work is cut, not
+// rescheduled:
+//  * a pixel whose threshold is >= 1/2 always takes its NEAREST entry: f = s0/(s0+s1) <= 1/2 because s0 <= s1 and
+//    every rounding of the reference's float64 chain is monotone (dithering_lib.py:361-376).  Such a pixel needs the
+//    nearest entry and the knowledge that it is unique, nothing else.  Which entries can be nearest somewhere in a
+//    cell, N(cell), is known at build time (accel.hip): the kernel stages every cell block into LDS with the members
+//    of N first (at most kNearSlots8 = 6 of 8; the builder splits the ~1 % of cells with more) and runs those pixels on
+//    six candidates with a top-2 network and no decision arithmetic: 35 instead of 64 vector instructions.
+//  * whether a pixel slot q (pixel q of every lane's group of four) is of that kind is a property of the wave: with a
+//    Bayer matrix (any size) the lanes of a wave see at most two thresholds per slot, both on the same side of 1/2,
+//    so exactly half of the slots qualify; the test is one compare per slot and wave tile, the branch is scalar.
+//    Blue noise and IGN mix both kinds within a slot and keep the general path (same code as the lean kernel).
+//  * the table in global memory stays in palette-index order (the tie codes are defined on it); only the LDS copy is
+//    permuted, so the deferred path reads blocks (and split nodes, which are no longer staged) from global memory.
+// MODE as in ordered_lean_kernel.  BW = 8 or 4 (tables of small palettes: every slot is read either way).
+// ---------------------------------------------------------------------------------------------
+constexpr int kNearSlots8 = 6;
+
+// Keys of the first six entries of a block and the two smallest (see cand8)
+__device__ __forceinline__ void cand6n(const uint32_t x, const uint4 ca, const uint32_t c4, const uint32_t c5, const int neg2,
+                                       int &m0, int &m1)
+{
+    int n0, n1, n2, n3, n4, n5, p0, p1, p2, p3, p4, p5;
+    asm volatile(
+        "v_dot4_u32_u8 %[n0], %[c0], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[p0], %[x], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[n1], %[c1], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[p1], %[x], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[n2], %[c2], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[p2], %[x], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[n3], %[c3], %[c3], 0\n\t"
+        "v_dot4_u32_u8 %[p3], %[x], %[c3], 0\n\t"
+        "v_dot4_u32_u8 %[n4], %[c4], %[c4], 0\n\t"
+        "v_dot4_u32_u8 %[p4], %[x], %[c4], 0\n\t"
+        "v_dot4_u32_u8 %[n5], %[c5], %[c5], 0\n\t"
+        "v_dot4_u32_u8 %[p5], %[x], %[c5], 0\n\t"
+        "v_lshl_add_u32 %[n0], %[n0], 8, 0\n\t"
+        "v_lshl_add_u32 %[n1], %[n1], 8, 4\n\t"
+        "v_lshl_add_u32 %[n2], %[n2], 8, 8\n\t"
+        "v_lshl_add_u32 %[n3], %[n3], 8, 12\n\t"
+        "v_lshl_add_u32 %[n4], %[n4], 8, 16\n\t"
+        "v_lshl_add_u32 %[n5], %[n5], 8, 20\n\t"
+        "v_mad_i32_i24 %[n0], %[p0], %[ng], %[n0]\n\t"
+        "v_mad_i32_i24 %[n1], %[p1], %[ng], %[n1]\n\t"
+        "v_mad_i32_i24 %[n2], %[p2], %[ng], %[n2]\n\t"
+        "v_mad_i32_i24 %[n3], %[p3], %[ng], %[n3]\n\t"
+        "v_mad_i32_i24 %[n4], %[p4], %[ng], %[n4]\n\t"
+        "v_mad_i32_i24 %[n5], %[p5], %[ng], %[n5]\n\t"
+        // the two smallest (m0 <= m1)
+        "v_min3_i32 %[m0], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n3]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n3]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n4]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n4]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n5]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n5]\n\t"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [n4] "=&v"(n4), [n5] "=&v"(n5), [p0] "=&v"(p0),
+          [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [p4] "=&v"(p4), [p5] "=&v"(p5), [m0] "=&v"(m0), [m1] "=&v"(m1)
+        : [x] "v"(x), [c0] "v"(ca.x), [c1] "v"(ca.y), [c2] "v"(ca.z), [c3] "v"(ca.w), [c4] "v"(c4), [c5] "v"(c5),
+          [ng] "s"(neg2));
+}
+
+// The same for the four entries of a small block
+__device__ __forceinline__ void cand4n(const uint32_t x, const uint4 ca, const int neg2, int &m0, int &m1)
+{
+    int n0, n1, n2, n3, p0, p1, p2, p3;
+    asm volatile(
+        "v_dot4_u32_u8 %[n0], %[c0], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[p0], %[x], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[n1], %[c1], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[p1], %[x], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[n2], %[c2], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[p2], %[x], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[n3], %[c3], %[c3], 0\n\t"
+        "v_dot4_u32_u8 %[p3], %[x], %[c3], 0\n\t"
+        "v_lshl_add_u32 %[n0], %[n0], 8, 0\n\t"
+        "v_lshl_add_u32 %[n1], %[n1], 8, 4\n\t"
+        "v_lshl_add_u32 %[n2], %[n2], 8, 8\n\t"
+        "v_lshl_add_u32 %[n3], %[n3], 8, 12\n\t"
+        "v_mad_i32_i24 %[n0], %[p0], %[ng], %[n0]\n\t"
+        "v_mad_i32_i24 %[n1], %[p1], %[ng], %[n1]\n\t"
+        "v_mad_i32_i24 %[n2], %[p2], %[ng], %[n2]\n\t"
+        "v_mad_i32_i24 %[n3], %[p3], %[ng], %[n3]\n\t"
+        "v_min3_i32 %[m0], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n3]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n3]\n\t"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2),
+          [p3] "=&v"(p3), [m0] "=&v"(m0), [m1] "=&v"(m1)
+        : [x] "v"(x), [c0] "v"(ca.x), [c1] "v"(ca.y), [c2] "v"(ca.z), [c3] "v"(ca.w), [ng] "s"(neg2));
+}
+
+// the leaf of a colour, every block read from the (index-ordered) table in global memory
+template <int BW>
+__device__ __forceinline__ void leaf_find_global(const uint32_t x, const PalDev &pal, Leaf &lf)
+{
+    lf.blk = BW == 8 ? cell_offset(x) : cell_offset4(x);
+    lf.in_lds = false;
+    lf.stuck = false;
+    lf.ca = leaf_read4(lf, pal, nullptr, lf.blk);
+    lf.split = (lf.ca.x >> 31) != 0;
+    for (int bit = 3; leaf_pending(lf); --bit) {
+        if ((lf.ca.x & 0x40000000u) || bit < 0) {
+            lf.stuck = true;
+            break;
+        }
+        const uint32_t sub = (((x >> bit) & 1u) << 2) | (((x >> (8 + bit)) & 1u) << 1) | ((x >> (16 + bit)) & 1u);
+        lf.blk = (4096u * BW + ((lf.ca.x & 0xffffffu) * 8u + sub) * BW) * 4u;
+        lf.ca = leaf_read4(lf, pal, nullptr, lf.blk);
+    }
+}
+
+// threshold of pixel p (MODE 1: from the integer table in LDS; MODE 2: the padded float table; MODE 3: computed)
+template <int MODE>
+__device__ __forceinline__ void pixel_threshold(const uint32_t p, const Geo &g, const ThrDev &thr, const uint32_t *s_thr,
+                                                const float sx, const float sy, const float sc, LeanThr &th)
+{
+    th.mt = 0;
+    th.t = 0.0f;
+    if (MODE == 0) return;
+    uint32_t fy, fx;
+    locate(g, p, fy, fx);
+    if (MODE == 3) {
+        th.t = ign_threshold(g.x0 + (int)fx, g.y0 + (int)fy, sx, sy, sc);
+    } else {
+        uint32_t row, col;
+        thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
+        if (MODE == 1) th.mt = s_thr[row * thr.tw_pad + col];
+        else th.t = thr.fpad[row * thr.tw_pad + col];
+    }
+}
+
+// Queue B of the fast kernel: one pixel p resolved completely from global memory (index-ordered table with its octree,
+// tie codes, exception list, the float64 replay) -- what the few pixels need that the LDS copy cannot answer.
+template <int MODE, int BW>
+__device__ __forceinline__ void fast_pixel_global(const uint32_t p, const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                  unsigned long long *__restrict__ flags, const Geo &g, const PalDev &pal,
+                                                  const ThrDev &thr, const uint32_t *s_thr, const float sx, const float sy,
+                                                  const float sc)
+{
+    const uint8_t *b = in + (size_t)p * 3;
+    const uint32_t x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+    LeanThr th;
+    pixel_threshold<MODE>(p, g, thr, s_thr, sx, sy, sc, th);
+    bool slow, hard;
+    Leaf lf;
+    leaf_find_global<BW>(x, pal, lf);
+    const uint32_t c = resolve_pixel<MODE, BW>(x, th, lf, g, pal, thr, nullptr, slow, hard);
+    uint8_t *o = out + (size_t)p * 3;
+    o[0] = (uint8_t)c;
+    o[1] = (uint8_t)(c >> 8);
+    o[2] = (uint8_t)(c >> 16);
+    if (slow) flag_slow_pixel(p, flags, g);
+}
+
+// Queue A of the fast kernel: a pixel of a SPLIT cell on the cell's flat list in LDS (kWideList entries in index order,
+// n_valid of them real).  Returns false -- nothing written -- when the answer needs more than that: a tie among the three
+// nearest (tie codes) or exact equality in the decision (float64 replay); the caller passes the pixel on to queue B.
+template <int MODE>
+__device__ __forceinline__ bool resolve_wide(const uint32_t x, const LeanThr &th, const int sh, const uint32_t *s_list,
+                                             const int n_valid, uint32_t &c)
+{
+    constexpr int kBig = 0x7fffffff;
+    int m0 = kBig, m1 = kBig, m2 = kBig;
+    uint32_t cj[kWideList];
+#pragma unroll
+    for (int j4 = 0; j4 < kWideList; j4 += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(s_list + j4);
+        cj[j4] = v.x;
+        cj[j4 + 1] = v.y;
+        cj[j4 + 2] = v.z;
+        cj[j4 + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < kWideList; ++j) {
+        const int n = (int)__builtin_amdgcn_udot4(cj[j], cj[j], 0u, false);
+        const int p = (int)__builtin_amdgcn_udot4(x, cj[j], 0u, false);
+        int key = (n - 2 * p) * (1 << kLocalBits) + 4 * j;
+        if (j >= n_valid) key = kBig;
+        const int n2 = med3i(m1, m2, key);
+        const int n1 = med3i(m0, m1, key);
+        m0 = min(m0, key);
+        m1 = n1;
+        m2 = n2;
+    }
+    const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits, a2 = m2 >> kLocalBits;
+    int sel = m0;
+    if (MODE == 0) {
+        if (a0 == a1) return false;
+    } else {
+        if (a0 == a1 || a1 == a2) return false;
+        const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
+        const uint32_t d0 = (uint32_t)(a0 + xx);
+        const uint32_t S = d0 + (uint32_t)a1 + (uint32_t)xx;
+        bool eq;
+        const bool nearest = lean_decide<MODE == 0 ? 1 : MODE>(d0, S, th, sh, eq);
+        if (eq) return false;
+        sel = nearest ? m0 : m1;
+    }
+    c = s_list[((uint32_t)sel & 0xfcu) >> 2];
+    return true;
+}
+
+constexpr int kFastQueue = 128;  // entries per wave and queue (A and B)
+
+template <int MODE, int BW, int DBG = 0>  // DBG (measurements only, wrong pixels): 1 = nothing deferred is resolved
+__global__ __launch_bounds__(kCellBlock) void ordered_fast_kernel(const uint8_t *__restrict__ in,
+                                                                  uint8_t *__restrict__ out,
+                                                                  unsigned long long *__restrict__ flags,
+                                                                  const Geo g, const PalDev pal, const ThrDev thr,
+                                                                  const float sx, const float sy, const float sc,
+                                                                  const uint32_t n_tiles)
+{
+    // LDS: cell blocks (nearest set first) | flat lists of the split cells | integer thresholds | queue A | queue B
+    __shared__ __align__(16) uint32_t smem[kLeanLdsWords];
+    constexpr int kTop = 4096 * BW;
+    constexpr int kFieldBits = BW == 8 ? 3 : 2;
+    constexpr int kQueueAt = kLeanLdsWords - 2 * (kCellBlock / 64) * kFastQueue;
+    const int n_wide = BW == 8 ? pal.n_wide : pal.n_wide4;
+    const int thr_at = kTop + n_wide * kWideList;
+    {
+        const uint32_t *perm = BW == 8 ? pal.cell_perm : pal.cell_perm4;
+        for (int cell = threadIdx.x; cell < 4096; cell += kCellBlock) {
+            const uint32_t pw = perm[cell];
+            const bool split = (pw >> 24) == 0xffu;
+            uint32_t w[BW];
+#pragma unroll
+            for (int k = 0; k < BW; ++k)
+                w[k] = split ? 0u : pal.cell_tab[cell * BW + (int)((pw >> (kFieldBits * k)) & (uint32_t)(BW - 1))];
+            // a split cell: equal entries (their keys tie: deferred), the last one carrying the number of its flat list
+            if (split) w[BW - 1] = 0x80000000u | (pw & 0xffffffu);
+            *reinterpret_cast<uint4 *>(&smem[cell * BW]) = make_uint4(w[0], w[1], w[2], w[3]);
+            if (BW == 8) *reinterpret_cast<uint4 *>(&smem[cell * BW + 4]) = make_uint4(w[4 % BW], w[5 % BW], w[6 % BW], w[7 % BW]);
+        }
+        const uint32_t *wide = BW == 8 ? pal.cell_wide : pal.cell_wide4;
+        for (int i = threadIdx.x; i < n_wide * kWideList; i += kCellBlock) smem[kTop + i] = wide[i];
+    }
+    if (MODE == 1) {
+        const int n = thr.th_h * thr.tw_pad;
+        for (int i = threadIdx.x; i < n; i += kCellBlock) smem[thr_at + i] = thr.mpad[i];
+    }
+    __syncthreads();
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(smem);
+    const uint32_t *s_thr = smem + thr_at;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *s_qa = smem + kQueueAt + (threadIdx.x >> 6) * 2 * kFastQueue;
+    uint32_t *s_qb = s_qa + kFastQueue;
+    uint32_t qa = 0, qb = 0;      // wave-uniform fill of the queues
+    uint32_t pend_e = 0;          // queue-A entry (group << 4 | deferred pixels) whose bytes this lane has in flight (0: none)
+    uint3 pend_w = make_uint3(0u, 0u, 0u);  // ... the group's twelve bytes
+    bool pending = false;         // wave-uniform
+    const int n_valid = pal.K < kWideList ? pal.K : kWideList;
+    const uint3 *in3 = reinterpret_cast<const uint3 *>(in);
+    uint3 *out3 = reinterpret_cast<uint3 *>(out);
+    const uint32_t n_full = g.n_px >> 2;  // groups of four whole pixels; a partial last group goes through queue B
+
+    // queue B: pixels that need global memory (ties, exact equality, pixels of unsplit cells in straddling groups, ...)
+    auto drain_b = [&](const uint32_t n) {
+        qb -= n;
+        if (lane < n) fast_pixel_global<MODE, BW>(s_qb[qb + lane], in, out, flags, g, pal, thr, s_thr, sx, sy, sc);
+    };
+    auto push_b = [&](const bool want, const uint32_t p) {
+        const unsigned long long mb = __ballot(want);
+        if (mb != 0ull) {
+            if (want) s_qb[__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, qb))] = p;
+            qb += (uint32_t)__popcll(mb);
+            if (qb >= 64u) {
+                __threadfence_block();  // the stores of the main loop that the drain overwrites
+                drain_b(64u);
+            }
+        }
+    };
+    // queue A, second half: the bytes asked for one tile ago have arrived.  Pixels of split cells are resolved on the
+    // cell's flat list in LDS; whatever needs more (a tie, exact equality, an unsplit cell) goes on to queue B.
+    auto finish_a = [&]() {
+        pending = false;
+        uint32_t mask = pend_e & 15u;
+        const uint32_t group = pend_e >> 4;
+        uint32_t xq[4];
+        xq[0] = pend_w.x & 0xffffffu;
+        xq[1] = __builtin_amdgcn_perm(pend_w.y, pend_w.x, 0x0c050403u);
+        xq[2] = __builtin_amdgcn_perm(pend_w.z, pend_w.y, 0x0c040302u);
+        xq[3] = pend_w.z >> 8;
+        while (__ballot(mask != 0u) != 0ull) {  // wave-uniform: nearly always one round (one deferred pixel per group)
+            const bool have = mask != 0u;
+            const uint32_t k = (uint32_t)__builtin_ctz(mask | 16u) & 3u;
+            const uint32_t p = group * 4u + k;
+            bool to_b = have;
+            if (have) {
+                const uint32_t x = k == 0u ? xq[0] : (k == 1u ? xq[1] : (k == 2u ? xq[2] : xq[3]));
+                const uint32_t blk = BW == 8 ? cell_offset(x) : cell_offset4(x);
+                const uint32_t mk = *reinterpret_cast<const uint32_t *>(s_bytes + blk + (BW - 1) * 4);
+                if (mk >> 31) {
+                    LeanThr th;
+                    pixel_threshold<MODE>(p, g, thr, s_thr, sx, sy, sc, th);
+                    uint32_t c;
+                    if (resolve_wide<MODE>(x, th, thr.sh, smem + kTop + (mk & 0xffffffu) * kWideList, n_valid, c)) {
+                        uint8_t *o = out + (size_t)p * 3;
+                        o[0] = (uint8_t)c;
+                        o[1] = (uint8_t)(c >> 8);
+                        o[2] = (uint8_t)(c >> 16);
+                        to_b = false;
+                    }
+                }
+            }
+            push_b(to_b, p);
+            mask &= mask - 1u;
+        }
+        pend_e = 0u;
+    };
+    // queue A, first half: take up to 64 entries and ask for the bytes of their groups
+    auto start_a = [&]() {
+        const uint32_t n = qa < 64u ? qa : 64u;
+        qa -= n;
+        __threadfence_block();  // the group stores that are about to be overwritten
+        pend_e = 0u;
+        if (lane < n) {
+            pend_e = s_qa[qa + lane];
+            pend_w = in3[pend_e >> 4];
+        }
+        pending = true;
+    };
+
+    uint32_t tile = blockIdx.x;
+    uint32_t fy = 0, fx = 0;
+    uint3 wn = make_uint3(0u, 0u, 0u);
+    if (tile < n_tiles) {
+        const uint32_t gidx0 = tile * kCellBlock + threadIdx.x;
+        if (gidx0 < n_full) wn = in3[gidx0];
+        if (gidx0 * 4u < g.n_px) locate(g, gidx0 * 4u, fy, fx);
+    }
+    // Which pixel slots of this wave tile can only take their nearest entry (thr.cls, host.cpp): a property of the position
+    // of the wave's first pixel in the threshold table, valid when the 256 pixels of the wave lie in one image row.
+    const bool use_cls = (MODE == 1 || MODE == 2) && thr.cls != nullptr && thr.pow2 != 0 && !(DBG & 2);
+    auto tile_class = [&](const uint32_t ty, const uint32_t tx, const uint32_t gi) -> uint32_t {
+        if (MODE == 0) return 15u;
+        if (!use_cls) return 0u;
+        // (every lane looks at lane 0's position: uniform address, scalar load)
+        const uint32_t y0l = (uint32_t)__builtin_amdgcn_readfirstlane((int)ty), x0l = (uint32_t)__builtin_amdgcn_readfirstlane((int)tx);
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gi);
+        if (x0l + 256u > g.w || g0 + 64u > n_full) return 0u;
+        const uint32_t row = ((uint32_t)g.y0 + y0l) & (uint32_t)(thr.th_h - 1), col = ((uint32_t)g.x0 + x0l) & (uint32_t)(thr.th_w - 1);
+        return thr.cls[row * (uint32_t)thr.th_w + col];
+    };
+    uint32_t cls_next = tile < n_tiles ? tile_class(fy, fx, tile * kCellBlock + threadIdx.x) : 0u;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t gidx = tile * kCellBlock + threadIdx.x;
+        const uint3 wc = wn;
+        const uint32_t cls = cls_next;  // wave-uniform
+        const uint32_t cy = fy, cx = fx;
+        {
+            const uint32_t next = tile + gridDim.x;
+            const uint32_t gn = next * kCellBlock + threadIdx.x;
+            if (next < n_tiles && gn < n_full) wn = in3[gn];  // prefetch the next tile
+            // ... and its position and class
+            fx += g.adv_x;
+            fy += g.adv_y;
+            if (fx >= g.w) {
+                fx -= g.w;
+                ++fy;
+            }
+            if (fy >= g.h) fy -= g.h;
+            cls_next = next < n_tiles ? tile_class(fy, fx, gn) : 0u;
+        }
+        // all clear; the deferred paths OR in the bits of the pixels they leave to the fix-up pass later
+        if (lane < 4u) flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
+        bool rare[4] = {false, false, false, false};
+        if (gidx < n_full) {
+            uint32_t xq[4];
+            xq[0] = wc.x & 0xffffffu;
+            xq[1] = __builtin_amdgcn_perm(wc.y, wc.x, 0x0c050403u);
+            xq[2] = __builtin_amdgcn_perm(wc.z, wc.y, 0x0c040302u);
+            xq[3] = wc.z >> 8;
+            uint32_t blk[4];
+            uint4 ca[4], cb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                blk[q] = BW == 8 ? cell_offset(xq[q]) : cell_offset4(xq[q]);
+                ca[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q]);
+                if (BW == 8) {
+                    if (cls & (1u << q)) {  // scalar branch: the nearest-only path reads six entries
+                        const uint2 v = *reinterpret_cast<const uint2 *>(s_bytes + blk[q] + 16);
+                        cb[q] = make_uint4(v.x, v.y, 0u, 0u);
+                    } else {
+                        cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
+                    }
+                }
+            }
+            LeanThr th[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                th[q].mt = 0;
+                th[q].t = 0.0f;
+            }
+            if (cls != 15u) {
+                if (MODE == 1 || MODE == 2) {
+                    uint32_t row, col;
+                    thr_pos(thr, (uint32_t)g.y0 + cy, (uint32_t)g.x0 + cx, row, col);
+                    const uint32_t at = row * (uint32_t)thr.tw_pad + col;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (MODE == 1) th[q].mt = s_thr[at + q];
+                        else th[q].t = thr.fpad[at + q];
+                    }
+                } else if (MODE == 3) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) th[q].t = ign_threshold(g.x0 + (int)cx + q, g.y0 + (int)cy, sx, sy, sc);
+                }
+            }
+            // the group runs over the end of its row: all four through the queue (their positions differ)
+            const bool straddle = (MODE != 0) && (cx + 3u >= g.w);
+            uint32_t col[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = xq[q];
+                int sel;
+                if (cls & (1u << q)) {
+                    int m0, m1;
+                    if (BW == 8) {
+                        cand6n(x, ca[q], cb[q].x, cb[q].y, g.neg2, m0, m1);
+                    } else {
+                        int m2;
+                        cand4(x, ca[q], g.neg2, m0, m1, m2);  // (all four entries: a split cell's marker must meet two equal keys)
+                        m1 = ((uint32_t)(m1 ^ m2) < (1u << kLocalBits)) ? m0 : m1;
+                    }
+                    rare[q] = ((uint32_t)(m0 ^ m1) < (1u << kLocalBits)) | straddle;  // also: any split cell
+                    sel = m0;
+                } else {
+                    int m0, m1, m2;
+                    if (BW == 8) cand8(x, ca[q], cb[q], g.neg2, m0, m1, m2);
+                    else cand4(x, ca[q], g.neg2, m0, m1, m2);
+                    const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits;
+                    const bool tie = (a0 == a1) | ((uint32_t)(m1 ^ m2) < (1u << kLocalBits));  // also: any split cell
+                    const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
+                    const uint32_t d0 = (uint32_t)(a0 + xx);
+                    const uint32_t S = d0 + (uint32_t)a1 + (uint32_t)xx;
+                    bool eq;
+                    const bool nearest = lean_decide<MODE == 0 ? 1 : MODE>(d0, S, th[q], thr.sh, eq);
+                    rare[q] = tie | eq | straddle;
+                    sel = nearest ? m0 : m1;
+                }
+                col[q] = *reinterpret_cast<const uint32_t *>(s_bytes + (blk[q] | ((uint32_t)sel & 0xfcu)));
+            }
+            uint3 wo;
+            wo.x = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);
+            wo.y = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);
+            wo.z = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);
+            out3[gidx] = wo;
+        }
+        // one queue entry per group with deferred pixels: group << 4 | which of its four
+        const uint32_t rmask = (rare[0] ? 1u : 0u) | (rare[1] ? 2u : 0u) | (rare[2] ? 4u : 0u) | (rare[3] ? 8u : 0u);
+        const unsigned long long rb = __ballot(rmask != 0u);
+        if (rb != 0ull) {  // wave-uniform
+            if (rmask != 0u)
+                s_qa[__builtin_amdgcn_mbcnt_hi((uint32_t)(rb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rb, qa))] = (gidx << 4) | rmask;
+            qa += (uint32_t)__popcll(rb);
+        }
+        // the partial last group (its twelve bytes may not all exist): pixel by pixel through queue B
+        if ((tile + 1u) * kCellBlock > n_full && !(DBG & 1)) {  // scalar: the last tile of the launch only
+#pragma unroll
+            for (int q = 0; q < 4; ++q) push_b(gidx == n_full && gidx * 4u + (uint32_t)q < g.n_px, gidx * 4u + (uint32_t)q);
+        }
+        if (DBG & 1) {
+            qa = 0u;
+        } else {
+            if (pending) finish_a();
+            if (qa >= 64u) start_a();
+        }
+    }
+    if (!(DBG & 1)) {
+        while (pending || qa != 0u) {
+            if (pending) finish_a();
+            if (qa != 0u) start_a();
+        }
+        while (qb != 0u) {
+            __threadfence_block();
+            drain_b(qb < 64u ? qb : 64u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Float (gamma) palettes with a cell table (accel.hip, build_accel_float): blocks of 8 byte offsets into
 // the candidate table {x, y, z, out_rgb} held in LDS next to the cell table and lut_in.  Candidates are
 // ranked in float32 (key = distance bits with the block position in the low 3 bits); the ranking is
@@ -1614,6 +2101,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
     thr.sh = 0;
     thr.fpad = nullptr;
     thr.mpad = nullptr;
+    thr.cls = nullptr;
     thr.tw_pad = 0;
     thr.pow2 = 1;
     thr.inv_h = thr.inv_w = 1.0;
@@ -1663,8 +2151,8 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         const bool warp = pal.warp_tab != nullptr;
         const bool small = warp ? pal.warp_bw == 4 : pal.cell_tab4 != nullptr;
         const size_t lean_tab_bytes = warp ? 4 * (size_t)pal.warp_words + kWarpLutBytes : 4 * (size_t)(small ? pal.tab4_words : pal.tab_words);
-        const bool lean_geo = integer && (warp || small || pal.cell_tab != nullptr) && g.aligned && y0 >= 0 && x0 >= 0 &&
-                              lean_tab_bytes <= (size_t)kLeanTabBytes && g.n_px <= (1u << 30);
+        const bool geo_ok = integer && (warp || small || pal.cell_tab != nullptr) && g.aligned && y0 >= 0 && x0 >= 0 && g.n_px <= (1u << 30);
+        const bool lean_geo = geo_ok && lean_tab_bytes <= (size_t)kLeanTabBytes;
         const bool int_lean = thr.mpad != nullptr && lean_tab_bytes + (size_t)thr.th_h * thr.tw_pad * 4 <= (size_t)kLeanTabBytes;
         const bool lean_ok = lean_geo && (mode == DP_MODE_NEAREST || mode == DP_MODE_IGN ||
                                           (mode == DP_MODE_MATRIX && (int_lean || thr.fpad != nullptr)));
@@ -1705,7 +2193,48 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         else if (adapt) DP_LEAN_K(M, 8, true, false);                                                                    \
         else DP_LEAN_K(M, 8, false, false);                                                                              \
     } while (0)
-            if (lean_geo && mode == DP_MODE_NEAREST) {
+            // uncrowded palettes on plain cells: the fast kernel (nearest set staged first; see ordered_fast_kernel)
+            const uint32_t *perm = small ? pal.cell_perm4 : pal.cell_perm;
+            const size_t fast_tab_bytes = 4096u * (small ? 4u : 8u) * 4u;
+            // (the fast kernel stages the 4096 cell blocks, the flat lists of the split cells, integer thresholds, two queues)
+            const size_t fast_fixed = fast_tab_bytes + (size_t)(small ? pal.n_wide4 : pal.n_wide) * kWideList * 4 +
+                                      2 * (kCellBlock / 64) * kFastQueue * 4;
+            const bool int_fast = thr.mpad != nullptr && fast_fixed + (size_t)thr.th_h * thr.tw_pad * 4 <= sizeof(uint32_t) * kLeanLdsWords;
+            // Measured on MI355X (tools/bench_scripts/fast_vs_lean.py, 24 4K frames, 256 colours): nearest-only mode
+            // 0.45 ms against 0.50 ms of the lean kernel; with a matrix the per-slot class branches cost more than the
+            // shorter candidate network saves (0.66 against 0.55 ms), so the matrix / IGN modes stay on the lean kernel
+            // unless DP_FAST_ALL is set (experiments).
+            const bool fast_mode = mode == DP_MODE_NEAREST || getenv("DP_FAST_ALL") != nullptr;
+            const bool fast_ok = fast_mode && geo_ok && !warp && !adapt && perm != nullptr && fast_fixed <= sizeof(uint32_t) * kLeanLdsWords &&
+                                 (mode == DP_MODE_NEAREST || mode == DP_MODE_IGN ||
+                                  (mode == DP_MODE_MATRIX && (int_fast || thr.fpad != nullptr)));
+            const int dbg = getenv("DP_FAST_DBG") ? atoi(getenv("DP_FAST_DBG")) : 0;  // (measurement switch)
+#define DP_FAST(M)                                                                                                        \
+    do {                                                                                                                 \
+        if (dbg == 1 && !small) hipLaunchKernelGGL((ordered_fast_kernel<M, 8, 1>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, sx, sy, ign_scale, n_tiles); \
+        else if (dbg == 2 && !small) hipLaunchKernelGGL((ordered_fast_kernel<M, 8, 2>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, sx, sy, ign_scale, n_tiles); \
+        else if (dbg == 3 && !small) hipLaunchKernelGGL((ordered_fast_kernel<M, 8, 3>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, sx, sy, ign_scale, n_tiles); \
+        else if (small) hipLaunchKernelGGL((ordered_fast_kernel<M, 4>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, sx, sy, ign_scale, n_tiles); \
+        else hipLaunchKernelGGL((ordered_fast_kernel<M, 8>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, sx, sy, ign_scale, n_tiles); \
+    } while (0)
+            if (fast_ok && mode == DP_MODE_NEAREST) {
+                DP_FAST(0);
+                rc = DP_OK;
+                fix_mode = 0;
+            } else if (fast_ok && mode == DP_MODE_IGN) {
+                DP_FAST(3);
+                rc = DP_OK;
+                fix_mode = 3;
+            } else if (fast_ok && mode == DP_MODE_MATRIX && int_fast) {
+                DP_FAST(1);
+                rc = DP_OK;
+                fix_mode = 2;
+            } else if (fast_ok && mode == DP_MODE_MATRIX && thr.fpad != nullptr) {
+                DP_FAST(2);
+                rc = DP_OK;
+                fix_mode = 2;
+#undef DP_FAST
+            } else if (lean_geo && mode == DP_MODE_NEAREST) {
                 DP_LEAN(0);
                 rc = DP_OK;
                 fix_mode = 0;
