@@ -4,6 +4,9 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Without a launcher (no WORLD_SIZE in the environment) and N > 1, this process starts the N ranks itself through
+torch.distributed.run BEFORE it touches the GPU, relays rank 0's JSON line and exits with the launcher's code.
+
 Workload (config.workload = "C2"): Bayer 8x8 + 256-colour nearest-palette on 3840x2160 RGB frames
 (BASELINE.json configs[1]); one step = one pass of ImageDitherer.apply_dithering_frames over a batch of
 24 distinct synthetic 4K frames (597 MB in, 597 MB out: larger than the 256 MiB Infinity Cache) that are
@@ -35,15 +38,30 @@ def palr(K, seed=7):
     return [tuple(int(v) for v in c) for c in np.random.RandomState(seed).randint(0, 256, (K, 3))]
 
 
-def make_frames(torch, n, h, w, dev, first_seed=None):
-    """n synthetic uint8 frames in HBM: i.i.d. uniform bytes (frame 0 optionally the numpy-seeded KAT frame)."""
+def make_frames(torch, n, h, w, dev, first_seed=None, numpy_frames=0):
+    """n synthetic uint8 frames in HBM: i.i.d. uniform bytes.  The first `numpy_frames` of them are SURVEY 8(d)'s
+    rnd(h, w, first_seed + i) (numpy legacy RNG, generated on the host); the others come from torch's device generator
+    (same distribution, no host time)."""
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
     frames = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device=dev, generator=g)
     if first_seed is not None:
-        kat = np.random.RandomState(first_seed).randint(0, 256, (h, w, 3), dtype=np.uint8)
-        frames[0].copy_(torch.from_numpy(kat))
+        for i in range(min(n, max(1, numpy_frames))):
+            kat = np.random.RandomState(first_seed + i).randint(0, 256, (h, w, 3), dtype=np.uint8)
+            frames[i].copy_(torch.from_numpy(kat))
     return frames
+
+
+def kernel_sources_sha16():
+    """Identity of the kernels a PMC file was taken with: sha256 over the ordered-path sources."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for name in ("ordered.hip", "accel.hip", "dp_internal.h", "tree_query.hip.h"):
+        path = os.path.join(ROOT, "dither_pie_amd", "csrc", name)
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                hsh.update(f.read())
+    return hsh.hexdigest()[:16]
 
 
 def cpu_baseline(n_frames=16):
@@ -62,8 +80,34 @@ def cpu_baseline(n_frames=16):
         dt += time.perf_counter() - t0
         px += arr.shape[0] * arr.shape[1]
     res = {"value": round(px / dt / 1e6, 3), "unit": "Mpixel/s", "cores": threads, "kind": "port",
+           "os_cpu_count": os.cpu_count(), "cpus_available": avail,
            "sample": f"{n_frames} full 3840x2160 frames rnd(2160,3840,1234+i), Bayer 8x8, 256 colours; C oracle "
                      f"(scipy-order KD-tree query per pixel), OpenMP over rows on {threads} threads, {dt:.2f} s"}
+    # the same port on ONE thread (SURVEY 8d leg a), two frames
+    orc.set_threads(1)
+    t0 = time.perf_counter()
+    for i in range(2):
+        orc.apply_dithering(orc.rnd(H4K, W4K, 1234 + i), pal, "bayer", {"size": "8x8"})
+    dt1 = time.perf_counter() - t0
+    orc.set_threads(threads)
+    res["single_thread"] = {"value": round(2 * H4K * W4K / dt1 / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+                            "sample": f"2 full 4K frames, the same C oracle on one thread, {dt1:.2f} s"}
+    # the reference's video parallelism (video_processor.py:43-45, 321-322): multiprocessing.Pool(min(4, cores-1)) over
+    # frames, here 1080p Bayer 4x4 / 16 uniform colours (C5), each worker running the single-threaded port on its frames
+    try:
+        import multiprocessing as mp
+        workers = min(4, max(1, (os.cpu_count() or 2) - 1))
+        nfr = 4 * workers
+        with mp.get_context("fork").Pool(processes=workers) as pool:
+            pool.map(_c5_frame_worker, range(workers))  # warm-up: library load in every worker
+            t0 = time.perf_counter()
+            pool.map(_c5_frame_worker, range(nfr))
+            dtp = time.perf_counter() - t0
+        res["video_pool"] = {"value": round(nfr / dtp, 2), "unit": "1080p frames/s", "cores": workers, "kind": "port",
+                             "sample": f"{nfr} frames rnd(1080,1920,i), Bayer 4x4, 16 uniform colours, Pool({workers}) of "
+                                       f"single-threaded C-oracle workers (no PNG/ffmpeg I/O), {dtp:.2f} s"}
+    except Exception as e:  # noqa: BLE001
+        res["video_pool"] = {"error": str(e)}
     try:  # the same math stated with the reference's own third-party calls (scipy KDTree.query(k=2) + numpy)
         arr = orc.rnd(H4K, W4K, 1234)
         t0 = time.perf_counter()
@@ -79,6 +123,28 @@ def cpu_baseline(n_frames=16):
     return res
 
 
+def _c5_frame_worker(i):
+    from oracle import oracle as orc
+    orc.set_threads(1)
+    out = orc.apply_dithering(orc.rnd(1080, 1920, i), orc.generate_uniform_palette(16), "bayer", {"size": "4x4"})
+    return int(out[0, 0, 0])
+
+
+def spawn_ranks(n, argv):
+    """Parent of a self-launched multi-GPU run: never touches the GPU; starts n ranks through torch.distributed.run
+    (127.0.0.1 rendezvous on a free port), passes everything through and relays the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,7 +153,14 @@ def main():
     ap.add_argument("--frames", type=int, default=24, help="4K frames per batch (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary 1080p / error-diffusion lines")
+    ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        raise SystemExit(spawn_ranks(args.gpus, [a for a in sys.argv[1:] if a != "--spawn"]))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={os.environ['WORLD_SIZE']}")
 
     import torch
     import torch.distributed as dist
@@ -124,15 +197,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, warmup):
+    step_ms = []  # per-step durations of the last timed() call with per_step=True (events on the launch stream)
+
+    def timed(fn, steps, warmup, per_step=False):
         for _ in range(warmup):
             fn()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step else None
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        if per_step:
+            evs[0].record()
+        for i in range(steps):
             fn()
+            if per_step:
+                evs[i + 1].record()
         barrier()
         dt = time.perf_counter() - t0
+        if per_step:
+            step_ms[:] = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
         if distributed:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -142,15 +224,19 @@ def main():
     # ---------------- headline: C2 --------------------------------------------------------------
     pal256 = palr(256)
     dith = ImageDitherer(256, DitherMode.BAYER, pal256, False, {"size": "8x8"})
-    frames = make_frames(torch, args.frames, H4K, W4K, dev, first_seed=1234)
+    frames = make_frames(torch, args.frames, H4K, W4K, dev, first_seed=1234, numpy_frames=args.frames)
     out = torch.empty_like(frames)
     px_per_step = args.frames * H4K * W4K
 
     def step():
         dith.apply_dithering_frames(frames, out=out)
 
+    # one-off per palette, outside the timed region (a video reuses it for every frame): KD-tree + cell table + tie codes
+    torch.cuda.synchronize()
+    t_acc = time.perf_counter()
     step()
     torch.cuda.synchronize()
+    first_call_ms = (time.perf_counter() - t_acc) * 1e3
     import hashlib
     kat_ok = hashlib.sha256(out[0].cpu().numpy().tobytes()).hexdigest()[:16] == "7041bd52fdea90b5"
 
@@ -160,24 +246,30 @@ def main():
         step()
     torch.cuda.synchronize()
     backend.profile_enable(True)
-    dt = timed(step, args.steps, args.warmup)
+    dt = timed(step, args.steps, args.warmup, per_step=True)
     main_ms, fix_ms, launches = backend.profile_read()
     backend.profile_enable(False)
+    per_step = sorted(step_ms)
     # warm-up launches are in the record too: average per launch is what matters
     k_ms = main_ms / max(launches, 1)
     value = world * px_per_step * args.steps / dt / 1e6
     achieved = BYTES_PER_PX * px_per_step / (k_ms * 1e-3) / 1e9
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
     # comes from the committed rocprofv3 --pmc pass of this same command (profiles/pmc_pass.sh)
+    # (profiles/pmc_pass.sh); the file names the kernel sources it was taken with and is ignored when they have changed
     traffic, traffic_src, valu_per_launch = None, None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_final_pmc_ordered_lean.json")
+    pmc_name = "r02_pmc_ordered.json"
+    pmc_file = os.path.join(ROOT, "profiles", pmc_name)
     if args.frames == 24 and os.path.exists(pmc_file):
         try:
             with open(pmc_file) as f:
                 pmc = json.load(f)
-            traffic = int(pmc["derived"]["hbm_traffic_bytes_per_launch"])
-            traffic_src = "profiles/r01_final_pmc_ordered_lean.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-            valu_per_launch = [v["SQ_INSTS_VALU"] for k, v in pmc["counters_mean_per_launch"].items() if "ordered_lean" in k][0]
+            if pmc.get("kernel_sources_sha16") == kernel_sources_sha16():
+                traffic = int(pmc["derived"]["hbm_traffic_bytes_per_launch"])
+                traffic_src = f"profiles/{pmc_name} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, same kernel sources)"
+                valu_per_launch = pmc["derived"].get("valu_wave_instructions_per_launch")
+            else:
+                traffic_src = f"profiles/{pmc_name} was taken with other kernel sources: not reported"
         except Exception:  # noqa: BLE001
             traffic = None
     result = {
@@ -185,26 +277,65 @@ def main():
         "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "C2: Bayer 8x8 + 256-colour nearest palette, 3840x2160 RGB, "
-                               f"{args.frames} distinct frames per GPU resident in HBM, frames sharded per rank",
+        "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
+        "rccl_world_size": dist.get_world_size() if distributed else 1,
+        "config": {"workload": "C2: Bayer 8x8 + 256-colour nearest palette palr(256,7), 3840x2160 RGB, "
+                               f"{args.frames} distinct frames rnd(2160,3840,1234+i) per GPU resident in HBM, frames sharded per rank",
                    "frames_per_gpu": args.frames, "h": H4K, "w": W4K, "colors": 256, "matrix": "8x8",
                    "parallelism": f"frames x{world}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "ordered_lean_kernel<1>", "kernel_ms": round(k_ms, 4),
+                     "kernel": "ordered_lean_kernel<1,8> (main pass of dp_ordered_u8)", "kernel_ms": round(k_ms, 4),
                      "fixup_ms": round(fix_ms / max(launches, 1), 4), "launches": launches,
                      "algorithmic_bytes_per_launch": BYTES_PER_PX * px_per_step},
         "parity_kat_4k": bool(kat_ok),
+        "first_call_ms": round(first_call_ms, 2),
     }
     if valu_per_launch:
         # what actually bounds the kernel: wave64 VALU instructions of one launch (same PMC file) against
         # the issue rate of 1024 SIMDs, one instruction per 4 cycles, at the 2.4 GHz peak clock
-        result["roofline"]["valu_issue_frac"] = round(valu_per_launch * 4 / (1024 * 2.4e9 * k_ms * 1e-3), 4)
+        # profiles/microbench/valu_rate_results.txt: these integer operations issue once per ~4.3 cycles per SIMD
+        result["roofline"]["valu_issue_frac"] = round(valu_per_launch * 4.3 / (1024 * 2.4e9 * k_ms * 1e-3), 4)
         result["roofline"]["valu_wave_instructions_per_launch"] = int(valu_per_launch)
+
+    # ---------------- C5 (the metric's second half): 1000 x 1080p frames, Bayer 4x4, 16 uniform colours -------------
+    # STRONG scaling: the 1000 frames are split into contiguous blocks over the ranks, frames resident in
+    # HBM, compute only; frames/s = 1000 / max-over-ranks time of one pass.
+    from dither_pie_amd.dithering_lib import ColorReducer
+    total = 1000
+    lo, hi = rank * total // world, (rank + 1) * total // world
+    d5 = ImageDitherer(16, DitherMode.BAYER, ColorReducer.generate_uniform_palette(16), False, {"size": "4x4"})
+    chunk = 100
+    f5 = make_frames(torch, min(chunk, max(1, hi - lo)), 1080, 1920, dev)
+    o5 = torch.empty_like(f5)
+
+    def video_pass():
+        done = 0
+        while done < hi - lo:
+            n = min(chunk, hi - lo - done)
+            d5.apply_dithering_frames(f5[:n], out=o5[:n])
+            done += n
+
+    t5 = timed(video_pass, 3, 1)
+    result["c5_video"] = {"metric": "1080p frames/s, Bayer 4x4 + 16 uniform colours, 1000 frames", "scaling": "strong",
+                          "frames_total": total, "n_gpus": world, "frames_per_s": round(total * 3 / t5, 1),
+                          "frames_this_rank": hi - lo,
+                          "note": "contiguous blocks of 1000/N frames per rank, frames resident in HBM, no collective"}
+    del f5, o5
 
     # ---------------- secondary lines (same process, after the headline) -------------------------
     if not args.no_extra:
         extra = {}
+        # what the first call on a new palette pays once: KD-tree + 16^3 cell table + tie codes of all 2^24 colours
+        from dither_pie_amd.dithering_lib import prepare_palette
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        pal_obj = backend.Palette(*prepare_palette(palr(256, 11), False), accel=True)
+        torch.cuda.synchronize()
+        extra["accel_build_ms"] = round((time.perf_counter() - t_b) * 1e3, 2)
+        extra["accel_build_note"] = ("dp_palette_create + dp_palette_build_accel for a fresh 256-colour palette; outside the timed "
+                                     "region (a video keeps its palette), but it is what ONE 4K image pays on top of the kernel")
+        del pal_obj
         # on-box streaming copy of the same 597 MB batch (3 B read + 3 B written per pixel, like the kernel)
         tc = timed(lambda: out.copy_(frames), 10, 2) / 10
         copy_gbs = BYTES_PER_PX * px_per_step / tc / 1e9
@@ -249,26 +380,7 @@ def main():
         tgm = timed(lambda: dgam.apply_dithering_frames(frames, out=out), 3, 1) / 3
         extra["c2_use_gamma_mpixel_per_s"] = round(world * px_per_step / tgm / 1e6, 1)
         del out
-        # C5: 1000 synthetic 1080p frames, Bayer 4x4, 16 uniform colours, frames sharded over the ranks
         from dither_pie_amd.dithering_lib import ColorReducer
-        total = 1000
-        lo, hi = rank * total // world, (rank + 1) * total // world
-        d5 = ImageDitherer(16, DitherMode.BAYER, ColorReducer.generate_uniform_palette(16), False, {"size": "4x4"})
-        chunk = 100
-        f5 = make_frames(torch, min(chunk, hi - lo), 1080, 1920, dev)
-        o5 = torch.empty_like(f5)
-
-        def video_pass():
-            done = 0
-            while done < hi - lo:
-                n = min(chunk, hi - lo - done)
-                d5.apply_dithering_frames(f5[:n], out=o5[:n])
-                done += n
-
-        t5 = timed(video_pass, 3, 1)
-        extra["c5_1080p_bayer4_k16_frames_per_s"] = round(total * 3 / t5, 1)
-        extra["c5_note"] = "1000 frames total split into contiguous blocks per rank (strong scaling), compute only"
-        del f5, o5
         # C3: Floyd-Steinberg, 16 colours, 4K, a batch of frames (one wave per frame)
         nf3 = 256
         d3 = ImageDitherer(16, DitherMode.ERROR_DIFFUSION, ColorReducer.generate_uniform_palette(16), False,

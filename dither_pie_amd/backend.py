@@ -4,6 +4,8 @@ libditherpie_hip.so.  Nothing here computes pixels on the host."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -53,20 +55,27 @@ class Palette:
         self.is_integer = bool(integer.value)
         self.n_nodes = nodes.value
         self.accel_entries = self.accel_max_list = 0
-        self._accel_tried = False
+        self._accel_done = False
+        self._accel_lock = threading.Lock()
+        self.device = torch.device("cuda", torch.cuda.current_device())
         if accel:
             self.build_accel()
 
     def build_accel(self):
         """Build the LDS cell table + tie codes (synchronous, idempotent; a no-op for palettes that do
-        not qualify)."""
-        if self._accel_tried:
+        not qualify).  Thread-safe: concurrent callers wait until the one build has finished, so nobody launches
+        with a half-built accelerator."""
+        if self._accel_done:
             return
-        self._accel_tried = True
-        check(_lib.load().dp_palette_build_accel(self._h))
-        pe, mc = C.c_int(), C.c_int()
-        check(_lib.load().dp_palette_accel_info(self._h, C.byref(pe), C.byref(mc)))
-        self.accel_entries, self.accel_max_list = pe.value, mc.value
+        with self._accel_lock:
+            if self._accel_done:
+                return
+            with torch.cuda.device(self.device):
+                check(_lib.load().dp_palette_build_accel(self._h))
+            pe, mc = C.c_int(), C.c_int()
+            check(_lib.load().dp_palette_accel_info(self._h, C.byref(pe), C.byref(mc)))
+            self.accel_entries, self.accel_max_list = pe.value, mc.value
+            self._accel_done = True
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -115,6 +124,11 @@ class Thresholds:
             self._h = None
 
 
+def _check_palette_device(pal, f):
+    if getattr(pal, "device", f.device) != f.device:
+        raise ValueError(f"palette lives on {pal.device}, frames on {f.device}")
+
+
 def _frames(t):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8):
         raise TypeError("frames must be a CUDA uint8 tensor")
@@ -125,17 +139,64 @@ def _frames(t):
     return t.contiguous()
 
 
-_ws_cache = {}
+def _check_out(out, f):
+    """A caller-supplied output buffer must be exactly what the kernel writes: uint8, contiguous, same device,
+    as many elements as the frames.  Returns it viewed in the frames' [N,H,W,3] shape."""
+    if out is None:
+        return torch.empty_like(f)
+    if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.uint8):
+        raise TypeError("out must be a CUDA uint8 tensor")
+    if out.device != f.device:
+        raise ValueError(f"out is on {out.device}, frames on {f.device}")
+    if out.numel() != f.numel() or not out.is_contiguous():
+        raise ValueError("out must be contiguous and hold exactly as many bytes as the frames")
+    return out.view(f.shape)
 
 
-def _workspace(nbytes, device):
-    """grow-only per-device scratch tensor (flags bitmap, error rows)"""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    t = _ws_cache.get(key)
-    if t is None or t.numel() < nbytes:
-        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[key] = t
-    return t
+# Scratch per (device, stream): the launch sequences of one call (memset, pass 1, fix-up; progress words, wavefront
+# kernel) use it in stream order, so two host threads on the SAME stream must not interleave their sequences (ctypes
+# drops the GIL): workspace acquisition + launches run under the lock of that (device, stream).  Different streams
+# have different workspaces and run concurrently.
+_WS_KEEP = 8                 # (device, stream) scratch buffers kept; the least recently used one is dropped beyond that
+_WS_SHRINK = 8               # a buffer more than this many times larger than a request is replaced by a smaller one
+_ws_cache = OrderedDict()    # key -> [tensor, lock]
+_ws_guard = threading.Lock()
+
+
+class _Launch:
+    """with _Launch(device, nbytes) as ws: ... -- the (device, stream) lock held, ws a scratch tensor of >= nbytes."""
+
+    def __init__(self, device, nbytes):
+        self.key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        self.device, self.nbytes = device, max(int(nbytes), 1)
+
+    def __enter__(self):
+        with _ws_guard:
+            ent = _ws_cache.get(self.key)
+            if ent is None:
+                ent = _ws_cache[self.key] = [None, threading.RLock()]
+            _ws_cache.move_to_end(self.key)
+            while len(_ws_cache) > _WS_KEEP:
+                k = next(iter(_ws_cache))
+                if k == self.key:
+                    break
+                del _ws_cache[k]  # (a thread still inside that entry keeps its own references)
+        self.ent = ent
+        ent[1].acquire()
+        t = ent[0]
+        if t is None or t.numel() < self.nbytes or t.numel() > _WS_SHRINK * max(self.nbytes, 1 << 20):
+            t = ent[0] = torch.empty(max(self.nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return t
+
+    def __exit__(self, *exc):
+        self.ent[1].release()
+        return False
+
+
+def release_workspaces():
+    """Drop every cached scratch buffer (they are re-created on demand)."""
+    with _ws_guard:
+        _ws_cache.clear()
 
 
 def ordered(frames, pal: Palette, mode, thr: Thresholds | None = None, ign_scale=1.0, ign_seed=0, y0=0, x0=0,
@@ -143,37 +204,36 @@ def ordered(frames, pal: Palette, mode, thr: Thresholds | None = None, ign_scale
     """nearest / threshold-matrix / IGN dithering of uint8 frames already in HBM -> uint8 frames."""
     f = _frames(frames)
     n, h, w, _ = f.shape
-    if out is None:
-        out = torch.empty_like(f)
+    out = _check_out(out, f)
+    _check_palette_device(pal, f)
     L = _lib.load()
     ws_bytes = L.dp_ordered_workspace_bytes(n, h, w)
-    ws = _workspace(ws_bytes, f.device)
     with torch.cuda.device(f.device):
         if n * h * w >= Palette.ACCEL_MIN_PIXELS:
             pal.build_accel()
-        check(L.dp_ordered_u8(f.data_ptr(), out.data_ptr(), n, h, w, int(y0), int(x0), pal._h, int(mode),
-                              thr._h if thr is not None else None, float(ign_scale), int(ign_seed),
-                              ws.data_ptr(), ws.numel(), _stream()))
-    return out if frames.dim() == 4 else out[0]
+        with _Launch(f.device, ws_bytes) as ws:
+            check(L.dp_ordered_u8(f.data_ptr(), out.data_ptr(), n, h, w, int(y0), int(x0), pal._h, int(mode),
+                                  thr._h if thr is not None else None, float(ign_scale), int(ign_seed),
+                                  ws.data_ptr(), ws.numel(), _stream()))
+    return out.view(frames.shape)
 
 
 def error_diffusion(frames, pal: Palette, taps, divisor, serpentine=False, out=None):
     """taps: [(dx, dy, weight)] in the reference's list order."""
     f = _frames(frames)
     n, h, w, _ = f.shape
-    if out is None:
-        out = torch.empty_like(f)
+    out = _check_out(out, f)
+    _check_palette_device(pal, f)
     dx = np.array([t[0] for t in taps], np.int32)
     dy = np.array([t[1] for t in taps], np.int32)
     wq = np.array([t[2] / divisor for t in taps], np.float64).astype(np.float32)
     L = _lib.load()
     ws_bytes = L.dp_error_diffusion_workspace_bytes(n, h, w)
-    ws = _workspace(ws_bytes, f.device)
-    with torch.cuda.device(f.device):
+    with torch.cuda.device(f.device), _Launch(f.device, ws_bytes) as ws:
         check(L.dp_error_diffusion_u8(f.data_ptr(), out.data_ptr(), n, h, w, pal._h, _np_ptr(dx), _np_ptr(dy),
                                       _np_ptr(wq), len(taps), 1 if serpentine else 0, ws.data_ptr(), ws.numel(),
                                       _stream()))
-    return out if frames.dim() == 4 else out[0]
+    return out.view(frames.shape)
 
 
 DIFFUSER_PERCEPTUAL, DIFFUSER_HYBRID, DIFFUSER_ADAPTIVE_VARIANCE, DIFFUSER_OSTROMOUKHOV = 1, 2, 3, 4
@@ -184,10 +244,10 @@ def variance_gate(frames, pal: Palette, var_threshold=300.0, window_radius=1):
     f = _frames(frames)
     n, h, w, _ = f.shape
     gate = torch.empty((n, h, w), dtype=torch.uint8, device=f.device)
+    _check_palette_device(pal, f)
     L = _lib.load()
     ws_bytes = L.dp_variance_gate_workspace_bytes(n, h, w)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f.device)
-    with torch.cuda.device(f.device):
+    with torch.cuda.device(f.device), _Launch(f.device, ws_bytes) as ws:
         check(L.dp_variance_gate_u8(f.data_ptr(), gate.data_ptr(), n, h, w, pal._h, float(var_threshold),
                                     int(window_radius), ws.data_ptr(), ws.numel(), _stream()))
     return gate
@@ -197,21 +257,20 @@ def variable_diffusion(frames, pal: Palette, model, p0=0.0, p1=0.0, serpentine=F
     """Perceptual / hybrid / adaptive-variance / Ostromoukhov diffusion of uint8 frames in HBM."""
     f = _frames(frames)
     n, h, w, _ = f.shape
-    if out is None:
-        out = torch.empty_like(f)
+    out = _check_out(out, f)
+    _check_palette_device(pal, f)
     L = _lib.load()
     ws_bytes = L.dp_error_diffusion_workspace_bytes(n, h, w)
-    ws = _workspace(ws_bytes, f.device)
     if gate is not None and n * h * w >= Palette.ACCEL_MIN_PIXELS:
         # adaptive variance: gated-off (flat) regions query the palette with the pixels themselves; exact ties at integer
         # points are then resolved from the accelerator's tie codes instead of a traversal replay per pixel
         pal.build_accel()
-    with torch.cuda.device(f.device):
+    with torch.cuda.device(f.device), _Launch(f.device, ws_bytes) as ws:
         check(L.dp_variable_diffusion_u8(f.data_ptr(), out.data_ptr(), n, h, w, pal._h, int(model), float(p0), float(p1),
                                          1 if serpentine else 0, gate.data_ptr() if gate is not None else None,
                                          coef.data_ptr() if coef is not None else None, ws.data_ptr(), ws.numel(),
                                          _stream()))
-    return out if frames.dim() == 4 else out[0]
+    return out.view(frames.shape)
 
 
 def ign_thresholds(h, w, scale=1.0, seed=0, y0=0, x0=0, device="cuda"):
@@ -236,6 +295,23 @@ def kmeans_step(px, centers):
         check(_lib.load().dp_kmeans_step_u8(px.data_ptr(), px.numel() // 3, centers.data_ptr(), K, sums.data_ptr(),
                                             counts.data_ptr(), sumsq.data_ptr(), _stream()))
     return sums, counts, sumsq
+
+
+def kmeans_step_into(px, centers, totals, want_sq=True):
+    """One Lloyd pass written into the planar totals buffer `totals` (int64 [5K]: sums [K,3] | counts [K] | squared
+    norms [K]); with want_sq=False the last part is left alone.  No allocation, nothing read back."""
+    K = centers.shape[0]
+    base = totals.data_ptr()
+    with torch.cuda.device(px.device):
+        check(_lib.load().dp_kmeans_step_u8(px.data_ptr(), px.numel() // 3, centers.data_ptr(), K, base, base + 8 * 3 * K,
+                                            (base + 8 * 4 * K) if want_sq else None, _stream()))
+
+
+def kmeans_update(totals, centers, prev, status, tol, max_iter):
+    """The centre update of one Lloyd iteration on the device (dp_kmeans_update); everything stays in HBM."""
+    with torch.cuda.device(centers.device):
+        check(_lib.load().dp_kmeans_update(totals.data_ptr(), centers.data_ptr(), prev.data_ptr(), status.data_ptr(),
+                                           centers.shape[0], float(tol), int(max_iter), _stream()))
 
 
 def resize_nearest(frames, oh, ow):

@@ -31,7 +31,7 @@
 #include <vector>
 
 #include "dp_internal.h"
-#include "tree_query.cuh"
+#include "tree_query.hip.h"
 
 namespace dp {
 namespace {

@@ -7,6 +7,7 @@
 // with "first maximum of min_dist in list order" (max value, then smallest list position), reduced
 // across the wave with DPP shuffles and across waves through LDS.
 #include "dp_internal.h"
+#include "wave_util.hip.h"
 
 namespace dp {
 namespace {
@@ -107,8 +108,8 @@ __global__ __launch_bounds__(kThreads) void blue_noise_kernel(const int size, co
         }
         for (int off = 32; off >= 1; off >>= 1) {
             Best o;
-            o.v = __shfl_xor(mine.v, off);
-            o.pos = __shfl_xor(mine.pos, off);
+            o.v = lane_xor_f32(mine.v, off);
+            o.pos = lane_xor_u32(mine.pos, off);
             mine = better(mine, o);
         }
         if ((tid & 63) == 0) s_part[tid >> 6] = mine;
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(kThreads) void blue_noise_kernel(const int size, co
             if (tid < kThreads / 64) b = s_part[tid];
             for (int off = 8; off >= 1; off >>= 1) {
                 Best o;
-                o.v = __shfl_xor(b.v, off);
-                o.pos = __shfl_xor(b.pos, off);
+                o.v = lane_xor_f32(b.v, off);
+                o.pos = lane_xor_u32(b.pos, off);
                 b = better(b, o);
             }
             if (tid == 0) s_best = b;

@@ -4,7 +4,7 @@
 // (vardiff.hip).
 #pragma once
 #include "dp_internal.h"
-#include "tree_query.cuh"
+#include "tree_query.hip.h"
 
 namespace dp {
 namespace {

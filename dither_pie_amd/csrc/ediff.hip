@@ -38,9 +38,9 @@
 #include <vector>
 
 #include "dp_internal.h"
-#include "tree_query.cuh"
-#include "wave_util.cuh"
-#include "ed_nearest.cuh"
+#include "tree_query.hip.h"
+#include "wave_util.hip.h"
+#include "ed_nearest.hip.h"
 
 namespace dp {
 namespace {
@@ -117,8 +117,18 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
                                                                       float *__restrict__ bnd_all, const int G,
-                                                                      uint32_t *__restrict__ gprog_all)
+                                                                      uint32_t *__restrict__ gprog_all, const int test_giveup)
 {
+    // G == 1 with progress words given: the REPAIR launch that follows a G > 1 launch on the stream -- only the frames
+    // whose give-up flag is set are done again, one workgroup per frame (the others return at once).
+    if (G == 1 && gprog_all != nullptr &&
+        __hip_atomic_load(&gprog_all[(size_t)blockIdx.x * kEdProgWords + kEdProgWords - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        return;
+    if (G != 1 && test_giveup) {  // tests: every workgroup gives up before it has written a pixel
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&gprog_all[(size_t)(blockIdx.x / (unsigned)G) * kEdProgWords + kEdProgWords - 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     // G > 1: a frame's bands are spread over G workgroups (few frames in flight: more CUs per frame, fewer waves per
     // CU).  Waves of different workgroups then meet through progress words in global memory instead of s_prog, and the
     // boundary rows are written with agent-scope stores (the workgroups may sit on different XCDs, i.e. L2s).
@@ -833,7 +843,20 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
                 }
             }
         }
-#define DP_EDW(C, N) hipLaunchKernelGGL((ed_wavefront_kernel<C, N>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws), G, gprog)
+        // A wave of a G > 1 launch that waits too long for another workgroup (a preempted or CU-masked GPU) sets its
+        // frame's give-up flag and ends.  The repair launch right behind it (same stream, one workgroup per frame,
+        // G = 1, frames without the flag return immediately) does those frames again, so the call never reports success
+        // over partly written frames.
+        const int test_giveup = getenv("DP_ED_TEST_GIVEUP") ? 1 : 0;
+        const int nw1 = n_bands < kMaxWaves ? n_bands : kMaxWaves;
+#define DP_EDW(C, N)                                                                                                      \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL((ed_wavefront_kernel<C, N>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, t, \
+                           reinterpret_cast<float *>(ws), G, gprog, test_giveup);                                        \
+        if (G > 1)                                                                                                       \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out, h, w, pal, t, \
+                               reinterpret_cast<float *>(ws), 1, gprog, 0);                                              \
+    } while (0)
         const bool big = pal.n_inner > kQueueSmall;
         if (ntaps <= 4) {
             if (big) DP_EDW(kQueueLarge, 4); else DP_EDW(kQueueSmall, 4);

@@ -741,11 +741,21 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
 int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
                       int64_t *counts_dev, int64_t *sumsq_dev, void *stream)
 {
-    if ((!px_dev && n > 0) || n < 0 || !centers_dev || K < 1 || K > 1024 || !sums_dev || !counts_dev || !sumsq_dev) {
+    if ((!px_dev && n > 0) || n < 0 || !centers_dev || K < 1 || K > 1024 || !sums_dev || !counts_dev) {
         set_error("dp_kmeans_step_u8: bad argument");
         return DP_EINVAL;
     }
     return launch_kmeans_step(px_dev, n, centers_dev, K, sums_dev, counts_dev, sumsq_dev, (hipStream_t)stream);
+}
+
+int dp_kmeans_update(const int64_t *totals_dev, double *centers_dev, int64_t *prev_dev, double *status_dev, int K,
+                     double tol, int max_iter, void *stream)
+{
+    if (!totals_dev || !centers_dev || !prev_dev || !status_dev || K < 1 || K > 1024 || max_iter < 1 || !(tol >= 0.0)) {
+        set_error("dp_kmeans_update: bad argument");
+        return DP_EINVAL;
+    }
+    return launch_kmeans_update(totals_dev, centers_dev, prev_dev, status_dev, K, tol, max_iter, (hipStream_t)stream);
 }
 
 int dp_resize_nearest_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int oh,

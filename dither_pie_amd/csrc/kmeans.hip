@@ -1,22 +1,30 @@
-// One Lloyd pass of the k-means palette extractor (ColorReducer.generate_kmeans_palette,
+// Lloyd passes of the k-means palette extractor (ColorReducer.generate_kmeans_palette,
 // dithering_lib.py:1845-1857 -> sklearn KMeans) over packed uint8 RGB pixels.
 //
-// HBM-read bound by construction: 3 B/pixel in, nothing out but K*(3+1+1) int64 totals.  Each lane
-// owns 4 consecutive pixels (12 B, three coalesced dword loads); centres sit in LDS (float64 and a
-// float32 copy) and are read as wave-wide broadcasts.  The label is found with a float32 scan that
-// keeps the two smallest distances; when they are closer than the float32 error bound the float64 scan
-// decides (lowest index on exact ties).  Per-cluster totals accumulate in LDS as three packed 64-bit
-// words (r | g<<24, b | count<<24, sum of squares; a workgroup sees 2^16 pixels, so every field fits)
-// and leave the workgroup as one int64 atomic per non-empty entry.  All totals are integers, so any rank count / reduction order gives
-// identical results; the float64 inertia is derived from them on the host.
+// kmeans_step_kernel: 3 B/pixel in, nothing out but K*(3+1[+1]) int64 totals.  Each lane owns 4 consecutive pixels
+// (one dwordx3 load); the centres sit in LDS as float32 {-2c_r, -2c_g, -2c_b, |c|^2} and are read as wave-wide
+// broadcasts.  The label comes from a float32 scan of  score_j = |c_j|^2 - 2 c_j.x  (three v_fma_f32 per pixel and
+// centre: the f32 add/mul/fma instructions are the ones that issue at 2-3 cycles on gfx950, see
+// profiles/microbench) that keeps the two smallest scores (v_cmp, v_cndmask, v_med3_f32, v_min_f32); when they are
+// closer than the float32 error bound, the float64 scan over (x-c)^2 decides (lowest index on exact ties), so labels
+// are the float64 labels of the reference.  Per-cluster totals accumulate in LDS as packed 64-bit words
+// (r | g<<28, b | count<<28[, sum of squares]; one set per wave, a workgroup sees < 2^16 pixels between flushes, so
+// every field fits) and leave the workgroup as int64 atomics.  All totals are integers: any rank count and any
+// reduction order give identical results.
+//
+// kmeans_update_kernel: the centre update of one Lloyd iteration on the device (means, squared shift, sklearn's
+// tolerance test, "assignments unchanged" test, inertia), so that the host loop launches iterations back to back and
+// reads the status back only every few iterations.
 #include "dp_internal.h"
 
 namespace dp {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kPxPerBlock = 1 << 16;  // pixels per workgroup (<< 2^20 keeps uint32 sums exact)
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kGroupsPerFlush = 1 << 14;  // groups of 4 pixels a workgroup accumulates before it flushes (2^16 pixels)
 
+template <bool SQ>
 __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__restrict__ px, const int64_t n,
                                                              const double *__restrict__ centers, const int K,
                                                              unsigned long long *__restrict__ sums,
@@ -24,39 +32,65 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
                                                              unsigned long long *__restrict__ sumsq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    double *s_c = reinterpret_cast<double *>(smem);                                   // K*3
-    unsigned long long *s_rg = reinterpret_cast<unsigned long long *>(s_c + 3 * K);   // K: sum r | sum g << 24
-    unsigned long long *s_bn = s_rg + K;                                              // K: sum b | count << 24
-    unsigned long long *s_sq = s_bn + K;                                              // K: sum of r^2+g^2+b^2
-    float *s_cf = reinterpret_cast<float *>(s_sq + K);                                // K*3
-
-    for (int i = threadIdx.x; i < 3 * K; i += kBlock) {
-        s_c[i] = centers[i];
-        s_cf[i] = (float)centers[i];
+    float4 *s_c4 = reinterpret_cast<float4 *>(smem);                                    // K: {-2c, |c|^2} float32
+    double *s_c = reinterpret_cast<double *>(s_c4 + K);                                  // K*3 float64 (near ties)
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 3 * K);     // [waves][K][2 or 3]
+    constexpr int kW = SQ ? 3 : 2;
+    for (int i = threadIdx.x; i < K; i += kBlock) {
+        const double c0 = centers[3 * i], c1 = centers[3 * i + 1], c2 = centers[3 * i + 2];
+        s_c[3 * i] = c0;
+        s_c[3 * i + 1] = c1;
+        s_c[3 * i + 2] = c2;
+        s_c4[i] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2), (float)(c0 * c0 + c1 * c1 + c2 * c2));
     }
-    for (int i = threadIdx.x; i < K; i += kBlock) s_rg[i] = s_bn[i] = s_sq[i] = 0;
+    for (int i = threadIdx.x; i < kWavesPerBlock * K * kW; i += kBlock) s_acc[i] = 0;
     __syncthreads();
+    unsigned long long *acc = s_acc + (size_t)(threadIdx.x >> 6) * K * kW;  // this wave's totals
 
-    const int64_t base = (int64_t)blockIdx.x * kPxPerBlock;
-    const int64_t lim = min(n, base + kPxPerBlock);
+    const int64_t n_groups = (n + 3) / 4;
     const bool aligned = ((uintptr_t)px & 3) == 0;
-    for (int64_t p0 = base + (int64_t)threadIdx.x * 4; p0 < lim; p0 += kBlock * 4) {
-        uint32_t v[4];
-        int cnt = (int)min<int64_t>(4, lim - p0);
-        if (aligned && cnt == 4) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(px + p0 * 3);
-            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
-            v[0] = w0 & 0xffffffu;
-            v[1] = (w0 >> 24) | ((w1 & 0xffffu) << 8);
-            v[2] = (w1 >> 16) | ((w2 & 0xffu) << 16);
-            v[3] = w2 >> 8;
-        } else {
-            for (int q = 0; q < 4; ++q) {
-                v[q] = 0;
-                if (q < cnt) {
-                    const uint8_t *b = px + (p0 + q) * 3;
-                    v[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+    uint32_t since_flush = 0;
+    auto flush = [&]() {
+        __syncthreads();
+        for (int i = threadIdx.x; i < K; i += kBlock) {
+            unsigned long long rg = 0, bn = 0, sq = 0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) {
+                unsigned long long *a = s_acc + ((size_t)w * K + i) * kW;
+                rg += a[0];
+                bn += a[1];
+                a[0] = a[1] = 0;
+                if (SQ) {
+                    sq += a[2];
+                    a[2] = 0;
                 }
+            }
+            // (the per-wave fields hold < 2^16 pixels each: summed over 4 waves r and g stay below 2^26 -- unpack first)
+            if (bn >> 28) {
+                atomicAdd(&sums[3 * i], rg & 0xfffffffull);
+                atomicAdd(&sums[3 * i + 1], rg >> 28);
+                atomicAdd(&sums[3 * i + 2], bn & 0xfffffffull);
+                atomicAdd(&counts[i], bn >> 28);
+                if (SQ) atomicAdd(&sumsq[i], sq);
+            }
+        }
+        __syncthreads();
+    };
+    for (int64_t g0 = (int64_t)blockIdx.x * kBlock; g0 < n_groups; g0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t gi = g0 + threadIdx.x;
+        const int64_t p0 = gi * 4;
+        const int cnt = gi < n_groups ? (int)min<int64_t>(4, n - p0) : 0;
+        uint32_t v[4] = {0u, 0u, 0u, 0u};
+        if (aligned && cnt == 4) {
+            const uint3 w = reinterpret_cast<const uint3 *>(px)[gi];
+            v[0] = w.x & 0xffffffu;
+            v[1] = __builtin_amdgcn_perm(w.y, w.x, 0x0c050403u);
+            v[2] = __builtin_amdgcn_perm(w.z, w.y, 0x0c040302u);
+            v[3] = w.z >> 8;
+        } else {
+            for (int q = 0; q < cnt; ++q) {
+                const uint8_t *b = px + (p0 + q) * 3;
+                v[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
             }
         }
         // centre loop outermost: each centre is read from LDS once for the lane's four pixels
@@ -70,51 +104,147 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
             b0[q] = b1[q] = __int_as_float(0x7f800000);
             best[q] = 0;
         }
+#pragma unroll 4
         for (int j = 0; j < K; ++j) {
-            const float c0 = s_cf[3 * j], c1 = s_cf[3 * j + 1], c2 = s_cf[3 * j + 2];
+            const float4 c = s_c4[j];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float a = fr[q] - c0, c = fg[q] - c1, e = fb[q] - c2;
-                const float d = a * a + c * c + e * e;
-                const bool lt0 = d < b0[q];
-                b1[q] = lt0 ? b0[q] : (d < b1[q] ? d : b1[q]);
-                best[q] = lt0 ? j : best[q];
-                b0[q] = lt0 ? d : b0[q];
+                const float t = __fmaf_rn(fb[q], c.z, __fmaf_rn(fg[q], c.y, __fmaf_rn(fr[q], c.x, c.w)));
+                best[q] = t < b0[q] ? j : best[q];
+                b1[q] = __builtin_amdgcn_fmed3f(b0[q], b1[q], t);  // second smallest of {b0 <= b1, t}
+                b0[q] = fminf(b0[q], t);
             }
         }
-        for (int q = 0; q < cnt; ++q) {
-            const uint32_t r = v[q] & 255u, g = (v[q] >> 8) & 255u, b = v[q] >> 16;
-            int lab = best[q];
-            // float32 centres are off by <= 255*2^-24, distances by <= ~5e-5*sqrt(d) + 4e-7*d <= 0.05 + 1e-6 d
-            if (!(b1[q] - b0[q] > 0.05f + 1e-6f * b1[q])) {
-                const double x0 = (double)r, x1 = (double)g, x2 = (double)b;
-                double bd = __longlong_as_double(0x7ff0000000000000LL);
-                for (int j = 0; j < K; ++j) {
-                    const double a = __dsub_rn(x0, s_c[3 * j]), c = __dsub_rn(x1, s_c[3 * j + 1]),
-                                 e = __dsub_rn(x2, s_c[3 * j + 2]);
-                    const double d = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(c, c)), __dmul_rn(e, e));
-                    if (d < bd) {
-                        bd = d;
-                        lab = j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < cnt) {
+                const uint32_t r = v[q] & 255u, g = (v[q] >> 8) & 255u, b = v[q] >> 16;
+                int lab = best[q];
+                // float32 evaluation of |c|^2 - 2 c.x: the rounded coefficients are off by <= 2^-24 relative (|2c| <= 510,
+                // x <= 255: 0.008 per term), three fma roundings of values below 2^19.6 (<= 0.024 each), |c|^2 by 0.012:
+                // each score is within 0.11 of its exact value, so a gap of more than 0.25 (+ 1e-6 relative) settles the
+                // order; anything closer -- and K == 1 leaves b1 infinite -- is decided in float64 as the reference does
+                if (!(b1[q] - b0[q] > 0.25f + 1e-6f * fabsf(b1[q]))) {
+                    const double x0 = (double)r, x1 = (double)g, x2 = (double)b;
+                    double bd = __longlong_as_double(0x7ff0000000000000LL);
+                    for (int j = 0; j < K; ++j) {
+                        const double a = __dsub_rn(x0, s_c[3 * j]), c = __dsub_rn(x1, s_c[3 * j + 1]),
+                                     e = __dsub_rn(x2, s_c[3 * j + 2]);
+                        const double d = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(c, c)), __dmul_rn(e, e));
+                        if (d < bd) {
+                            bd = d;
+                            lab = j;
+                        }
                     }
                 }
+                atomicAdd(&acc[lab * kW], (unsigned long long)r | ((unsigned long long)g << 28));
+                atomicAdd(&acc[lab * kW + 1], (unsigned long long)b | (1ull << 28));
+                if (SQ) atomicAdd(&acc[lab * kW + 2], (unsigned long long)(r * r + g * g + b * b));
             }
-            atomicAdd(&s_rg[lab], (unsigned long long)r | ((unsigned long long)g << 24));
-            atomicAdd(&s_bn[lab], (unsigned long long)b | (1ull << 24));
-            atomicAdd(&s_sq[lab], (unsigned long long)(r * r + g * g + b * b));
+        }
+        since_flush += kBlock;
+        if (since_flush >= (uint32_t)kGroupsPerFlush) {  // block-uniform
+            flush();
+            since_flush = 0;
+        }
+    }
+    flush();
+}
+
+// status words (float64) of the device-side Lloyd loop
+enum { kStDone = 0, kStIter = 1, kStInertia = 2, kStShift = 3, kStTolAbs = 4, kStQTotal = 5, kStWords = 8 };
+
+// One workgroup.  totals: 5K int64, planar as dp_kmeans_step_u8 writes them into one buffer: sums [K][3] | counts [K] |
+// squared norms [K] (the last part only has to be valid in the first iteration: its total is a constant of the data).  centers: K*3 float64, updated in place.  prev: [K][4]
+// int64 scratch (the previous iteration's sums and counts).  status: kStWords float64.
+//   done = 0 running; 1 assignments unchanged (centres kept: converged strictly); 2 shift <= tol or max_iter reached
+//   (centres updated; the inertia of these final centres needs one more pass, flagged by done = 2 -> 3 below)
+// An iteration that finds done != 0 on entry only refreshes the inertia once (done 2 -> 3) and changes nothing else.
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const long long *__restrict__ totals, double *__restrict__ centers,
+                                                            long long *__restrict__ prev, double *__restrict__ status,
+                                                            const int K, const double tol, const int max_iter)
+{
+    __shared__ double s_red[256];
+    const int t = threadIdx.x;
+    const int done = (int)status[kStDone];
+    auto block_sum = [&](double v) -> double {
+        s_red[t] = v;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (t < off) s_red[t] = __dadd_rn(s_red[t], s_red[t + off]);
+            __syncthreads();
+        }
+        const double r = s_red[0];
+        __syncthreads();
+        return r;
+    };
+    // inertia of the CURRENT centres with these totals: sum_k (q_k - 2 c_k.s_k + n_k |c_k|^2), q summed separately
+    double part = 0.0, qpart = 0.0, npart = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int k = t; k < K; k += 256) {
+        const double a = (double)totals[3 * k], b = (double)totals[3 * k + 1], c = (double)totals[3 * k + 2],
+                     nn = (double)totals[3 * K + k];
+        const double c0 = centers[3 * k], c1 = centers[3 * k + 1], c2 = centers[3 * k + 2];
+        part += -2.0 * (c0 * a + c1 * b + c2 * c) + nn * (c0 * c0 + c1 * c1 + c2 * c2);
+        qpart += (double)totals[4 * K + k];
+        npart += nn;
+        s0 += a;
+        s1 += b;
+        s2 += c;
+    }
+    const double cross = block_sum(part);
+    if (done == 3 || done == 1) return;  // nothing left to do
+    const int iter = (int)status[kStIter] + (done == 0 ? 1 : 0);
+    double qtot = status[kStQTotal];
+    if (iter == 1 && done == 0) {
+        qtot = block_sum(qpart);
+        const double N = block_sum(npart), m0 = block_sum(s0) / N, m1 = block_sum(s1) / N, m2 = block_sum(s2) / N;
+        if (t == 0) {
+            status[kStQTotal] = qtot;
+            // sklearn: tol * mean of the per-channel variances
+            status[kStTolAbs] = tol * ((qtot / N - (m0 * m0 + m1 * m1 + m2 * m2)) / 3.0);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < K; i += kBlock) {
-        const unsigned long long rg = s_rg[i], bn = s_bn[i];
-        const unsigned long long c = bn >> 24;
-        if (c) {
-            atomicAdd(&sums[3 * i], rg & 0xffffffull);
-            atomicAdd(&sums[3 * i + 1], rg >> 24);
-            atomicAdd(&sums[3 * i + 2], bn & 0xffffffull);
-            atomicAdd(&counts[i], c);
-            atomicAdd(&sumsq[i], s_sq[i]);
+    if (done == 2) {  // the extra pass after the last update: the inertia of the final centres
+        if (t == 0) {
+            status[kStInertia] = qtot + cross;
+            status[kStDone] = 3.0;
         }
+        return;
+    }
+    // same assignments as in the previous iteration?  (sums and counts all equal)
+    double diff = 0.0, shift = 0.0;
+    for (int k = t; k < K; k += 256) {
+        for (int c = 0; c < 4; ++c) {
+            const long long cur = c < 3 ? totals[3 * k + c] : totals[3 * K + k];
+            if (iter > 1 && prev[4 * k + c] != cur) diff += 1.0;
+            if (iter == 1) diff += 1.0;
+        }
+        const double nn = (double)totals[3 * K + k];
+        if (nn > 0.0) {
+            for (int c = 0; c < 3; ++c) {
+                const double nw = (double)totals[3 * k + c] / nn, d = nw - centers[3 * k + c];
+                shift += d * d;
+            }
+        }
+    }
+    const double ndiff = block_sum(diff);
+    const double tshift = block_sum(shift);
+    const bool same = ndiff == 0.0;
+    const double tol_abs = status[kStTolAbs];
+    __syncthreads();
+    for (int k = t; k < K; k += 256) {
+        for (int c = 0; c < 4; ++c) prev[4 * k + c] = c < 3 ? totals[3 * k + c] : totals[3 * K + k];
+        const double nn = (double)totals[3 * K + k];
+        if (!same && nn > 0.0)
+            for (int c = 0; c < 3; ++c) centers[3 * k + c] = (double)totals[3 * k + c] / nn;
+    }
+    if (t == 0) {
+        status[kStIter] = (double)iter;
+        status[kStInertia] = qtot + cross;  // of the centres this pass was run with
+        status[kStShift] = tshift;
+        if (same) status[kStDone] = 1.0;
+        else if (tshift <= tol_abs || iter >= max_iter) status[kStDone] = 2.0;
     }
 }
 
@@ -125,19 +255,37 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
 {
     DP_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * 3 * (size_t)K, s));
     DP_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)K, s));
-    DP_HIP(hipMemsetAsync(sumsq, 0, sizeof(int64_t) * (size_t)K, s));
+    if (sumsq) DP_HIP(hipMemsetAsync(sumsq, 0, sizeof(int64_t) * (size_t)K, s));
     if (n == 0) return DP_OK;
-    const int64_t blocks = (n + kPxPerBlock - 1) / kPxPerBlock;
-    if (blocks > 0x7fffffff) {
-        set_error("dp_kmeans_step_u8: too many pixels for one launch");
-        return DP_EINVAL;
-    }
+    const int64_t groups = (n + 3) / 4;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int64_t want = (groups + kBlock - 1) / kBlock;
+    const unsigned blocks = (unsigned)std::min<int64_t>(want, (int64_t)cus * 8);  // persistent: 8 workgroups of 4 waves per CU
     ProfMark *pm = prof_begin(s);
-    const size_t smem = sizeof(double) * 3 * K + sizeof(unsigned long long) * 3 * K + sizeof(float) * 3 * K;
-    hipLaunchKernelGGL(kmeans_step_kernel, dim3((unsigned)blocks), dim3(kBlock), smem, s, px, n, centers, K,
-                       reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
-                       reinterpret_cast<unsigned long long *>(sumsq));
+    const size_t kw = sumsq ? 3 : 2;
+    const size_t smem = sizeof(float4) * K + sizeof(double) * 3 * K + sizeof(unsigned long long) * kWavesPerBlock * K * kw;
+    if (smem > 64 * 1024) {
+        set_error("dp_kmeans_step_u8: too many clusters for the LDS accumulators");
+        return DP_EUNSUPPORTED;
+    }
+    if (sumsq)
+        hipLaunchKernelGGL(kmeans_step_kernel<true>, dim3(blocks), dim3(kBlock), smem, s, px, n, centers, K,
+                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
+                           reinterpret_cast<unsigned long long *>(sumsq));
+    else
+        hipLaunchKernelGGL(kmeans_step_kernel<false>, dim3(blocks), dim3(kBlock), smem, s, px, n, centers, K,
+                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr);
     prof_end(pm, s);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
+int launch_kmeans_update(const int64_t *totals, double *centers, int64_t *prev, double *status, int K, double tol, int max_iter,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const long long *>(totals), centers,
+                       reinterpret_cast<long long *>(prev), status, K, tol, max_iter);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }

@@ -21,7 +21,7 @@
 // float path, only set a flag bit; fixup_kernel compacts the flagged pixels per workgroup into LDS and
 // resolves them through the scipy-order KD-tree emulation (tree_query) and the literal float64 chain.
 #include "dp_internal.h"
-#include "tree_query.cuh"
+#include "tree_query.hip.h"
 
 namespace dp {
 

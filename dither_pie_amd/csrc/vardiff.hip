@@ -16,9 +16,9 @@
 #include <cstdlib>
 
 #include "dp_internal.h"
-#include "ed_nearest.cuh"
-#include "tree_query.cuh"
-#include "wave_util.cuh"
+#include "ed_nearest.hip.h"
+#include "tree_query.hip.h"
+#include "wave_util.hip.h"
 
 namespace dp {
 namespace {
@@ -344,8 +344,18 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                                                                      uint8_t *__restrict__ out, const int h, const int w,
                                                                      const PalDev pal, const VarParams vp,
                                                                      float *__restrict__ bnd_all, const int G,
-                                                                     uint32_t *__restrict__ gprog_all)
+                                                                     uint32_t *__restrict__ gprog_all, const int test_giveup)
 {
+    // G == 1 with progress words given: the repair launch behind a G > 1 launch (see ed_wavefront_kernel) -- only frames
+    // whose give-up flag is set are done again
+    if (G == 1 && gprog_all != nullptr &&
+        __hip_atomic_load(&gprog_all[(size_t)blockIdx.x * kVProgWords + kVProgWords - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        return;
+    if (G != 1 && test_giveup) {
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&gprog_all[(size_t)(blockIdx.x / (unsigned)G) * kVProgWords + kVProgWords - 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     // G > 1: the bands of a frame are spread over G workgroups (few frames in flight), see ed_wavefront_kernel
     __shared__ float s_ring[kVWaves][64][kVRing][4];
     __shared__ float s_vring[kVWaves][2][64][4];
@@ -774,7 +784,17 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
                 DP_HIP(hipMemsetAsync(gprog, 0, (size_t)n_frames * kVProgWords * sizeof(uint32_t), s));
             }
         }
-#define DP_VARW(C, M) hipLaunchKernelGGL((var_wavefront_kernel<C, M>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, vp, reinterpret_cast<float *>(ws), G, gprog)
+        const int test_giveup = getenv("DP_ED_TEST_GIVEUP") ? 1 : 0;
+        const int nw1 = n_bands < kVWaves ? n_bands : kVWaves;
+        // (behind a G > 1 launch: the repair launch for frames whose workgroups gave up waiting for each other)
+#define DP_VARW(C, M)                                                                                                     \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL((var_wavefront_kernel<C, M>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, vp, \
+                           reinterpret_cast<float *>(ws), G, gprog, test_giveup);                                        \
+        if (G > 1)                                                                                                       \
+            hipLaunchKernelGGL((var_wavefront_kernel<C, M>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out, h, w, pal, vp, \
+                               reinterpret_cast<float *>(ws), 1, gprog, 0);                                              \
+    } while (0)
 #define DP_VARW_M(C)                   \
     do {                               \
         if (model == 1) DP_VARW(C, 1); \

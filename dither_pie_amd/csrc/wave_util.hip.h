@@ -30,4 +30,16 @@ __device__ __forceinline__ float wave_min_to_all(const float vf)
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, 63));
 }
 
+// Value of lane (lane ^ mask) -- the butterfly exchange of wave-wide reductions over pairs (value, position), for which
+// no fused DPP minimum exists; one ds_bpermute_b32 (LDS crossbar, no memory).
+__device__ __forceinline__ uint32_t lane_xor_u32(const uint32_t v, const int mask)
+{
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, (int)v);
+}
+__device__ __forceinline__ float lane_xor_f32(const float v, const int mask)
+{
+    return __uint_as_float(lane_xor_u32(__float_as_uint(v), mask));
+}
+
 }  // namespace dp

@@ -213,19 +213,24 @@ class DitherUtils:
 
 # ------------------------------------------------------------------------------------- device-object caches
 class _LRU(OrderedDict):
+    """Small LRU of device objects; get_or_make is atomic (the GUI calls the ditherer from several threads)."""
+
     def __init__(self, cap):
         super().__init__()
         self.cap = cap
+        import threading
+        self._lock = threading.RLock()
 
     def get_or_make(self, key, make):
-        if key in self:
-            self.move_to_end(key)
-            return self[key]
-        val = make()
-        self[key] = val
-        while len(self) > self.cap:
-            self.popitem(last=False)
-        return val
+        with self._lock:
+            if key in self:
+                self.move_to_end(key)
+                return self[key]
+            val = make()
+            self[key] = val
+            while len(self) > self.cap:
+                self.popitem(last=False)
+            return val
 
 
 # device handles are process-local and never stored on the (picklable) ditherer objects
@@ -819,8 +824,10 @@ class ImageDitherer:
             first = frames if frames.dim() == 3 else frames[0]
             self._ensure_palette(first.cpu().numpy())
         strategy = self._get_dither_strategy(self.dither_mode)
-        pal = _device_palette(*prepare_palette(self.palette, self.use_gamma))
-        return strategy._run(frames, pal, y0=y0, x0=x0, out=out)
+        import torch
+        with torch.cuda.device(frames.device):  # palette, thresholds and launches on the device that holds the frames
+            pal = _device_palette(*prepare_palette(self.palette, self.use_gamma))
+            return strategy._run(frames, pal, y0=y0, x0=x0, out=out)
 
     def apply_dithering(self, image):
         """PIL image -> PIL 'RGB' image (dithering_lib.py:1952-1992).  Host <-> device copies go through

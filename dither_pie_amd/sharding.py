@@ -30,6 +30,77 @@ def dither_frames_sharded(ditherer, frames_local, out=None):
     return ditherer.apply_dithering_frames(frames_local, out=out)
 
 
+def my_frame_block(n_frames: int, group=None):
+    """[lo, hi) of this rank's contiguous block of an n_frames video (one process per GPU)."""
+    rank, world = world_info(group)
+    return shard_range(n_frames, rank, world)
+
+
+def gather_frames(local_out, n_frames: int, group=None):
+    """All-gather the per-rank blocks of equally shaped frames back into [n_frames, H, W, 3] on every rank
+    (only for callers that need the whole video in one place; the dither itself needs no exchange)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = world_info(group)
+    if world == 1:
+        return local_out
+    sizes = [hi - lo for lo, hi in (shard_range(n_frames, r, world) for r in range(world))]
+    pad = max(sizes)
+    buf = torch.zeros((pad,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=local_out.device)
+    buf[: local_out.shape[0]] = local_out
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def visible_devices():
+    import torch
+    return list(range(torch.cuda.device_count()))
+
+
+def process_on_devices(frames_host, fn, devices=None, chunk: int = 32):
+    """In-process data parallelism over the GPUs of the node -- what the reference's multiprocessing.Pool over frames
+    (video_processor.py:304-346) becomes here: the frames [N,H,W,3] (host uint8 tensor, ideally pinned) are cut into one
+    contiguous block per device; one worker thread per device copies its block up in chunks on a stream of its own,
+    runs `fn(frames_on_device) -> frames_on_device` and copies the result back.  Returns the host tensor
+    [N,H',W',3].  Frames are independent: no exchange between devices.  `devices` may name a device more than once
+    (two streams on one GPU)."""
+    import threading
+    import torch
+    devices = visible_devices() if devices is None else list(devices)
+    if not devices:
+        raise RuntimeError("no HIP device visible: the MI355X backend has no CPU fallback")
+    n = int(frames_host.shape[0])
+    blocks = [shard_range(n, i, len(devices)) for i in range(len(devices))]
+    outs, errors = [None] * len(devices), []
+
+    def work(i, dev_index, lo, hi):
+        try:
+            dev = torch.device("cuda", dev_index)
+            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
+                parts = []
+                for a in range(lo, hi, chunk):
+                    b = min(hi, a + chunk)
+                    y = fn(frames_host[a:b].to(dev, non_blocking=True))
+                    host = torch.empty(tuple(y.shape), dtype=y.dtype, pin_memory=True)
+                    host.copy_(y, non_blocking=True)
+                    parts.append(host)
+                torch.cuda.current_stream().synchronize()
+                outs[i] = parts
+        except Exception as e:  # noqa: BLE001 - reported to the caller below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i, d, lo, hi)) for i, (d, (lo, hi)) in enumerate(zip(devices, blocks)) if hi > lo]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    flat = [p for parts in outs if parts for p in parts]
+    return torch.cat(flat, dim=0) if flat else torch.empty((0,) + tuple(frames_host.shape[1:]), dtype=torch.uint8)
+
+
 def dither_band(ditherer, band, y_lo: int):
     """Dither a row band of a larger image; `y_lo` is the band's first row in the full image, so the
     threshold tile / IGN field are addressed with global coordinates (ordered modes only)."""

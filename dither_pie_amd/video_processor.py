@@ -119,11 +119,18 @@ class VideoProcessor:
     """video_processor.py:27-390"""
 
     def __init__(self, num_workers: Optional[int] = None,
-                 progress_callback: Optional[Callable[[float, str], None]] = None):
+                 progress_callback: Optional[Callable[[float, str], None]] = None, devices=None):
         if num_workers is None:
             num_workers = min(4, max(1, cpu_count() - 1))
         self.num_workers = num_workers  # kept for interface compatibility; frames batch on the GPU instead
         self.progress_callback = progress_callback
+        # an addition: the GPUs the frame batches are spread over (contiguous blocks, one worker thread and stream per
+        # device -- the reference's Pool over frames, video_processor.py:304-346).  None = every visible device.
+        self.devices = devices
+
+    def _devices(self):
+        from . import sharding
+        return sharding.visible_devices() if self.devices is None else list(self.devices)
 
     def _report_progress(self, fraction: float, message: str):
         if self.progress_callback:
@@ -180,9 +187,13 @@ class VideoProcessor:
                         duration = v
             if frame_count is None and duration is not None:
                 frame_count = int(duration * fps)
+            self._probe_ok = True
             return {"fps": fps, "width": width, "height": height, "duration": duration, "frame_count": frame_count}
         except Exception as e:  # noqa: BLE001
             print(f"Warning: Could not get video info: {e}", file=sys.stderr)
+            # the reference's defaults (video_processor.py:164-170); _probe_ok tells the pipe path that width and
+            # height are guesses it must not slice a byte stream with
+            self._probe_ok = False
             return {"fps": 30.0, "width": 1920, "height": 1080, "duration": None, "frame_count": None}
 
     def _process_batch(self, files, ditherer, pixelize_method, max_size, final_resize_multiplier):
@@ -215,8 +226,12 @@ class VideoProcessor:
         w, h, fps = int(info["width"]), int(info["height"]), info["fps"]
         frame_bytes = w * h * 3
         total_hint = info.get("frame_count") or 0
-        dec = subprocess.Popen(["ffmpeg", "-v", "error", "-i", input_path, "-f", "rawvideo", "-pix_fmt", "rgb24",
-                                "pipe:1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        # the byte stream is sliced into frames of exactly w x h: make the decoder's geometry explicit (no rotation
+        # from display-matrix metadata, output forced to the probed size)
+        devs = self._devices()
+        batch_size = batch_size * len(devs)  # one batch per device in flight
+        dec = subprocess.Popen(["ffmpeg", "-v", "error", "-noautorotate", "-i", input_path, "-f", "rawvideo", "-pix_fmt",
+                                "rgb24", "-s", f"{w}x{h}", "pipe:1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         enc = None
         done = 0
         stage = torch.empty(batch_size * frame_bytes, dtype=torch.uint8, pin_memory=True)
@@ -231,10 +246,20 @@ class VideoProcessor:
                         break
                     got += n
                 n_frames = got // frame_bytes
+                if got % frame_bytes:
+                    raise RuntimeError(f"decoder stream is not a whole number of {w}x{h} rgb24 frames "
+                                       f"({got % frame_bytes} bytes left over)")
                 if n_frames == 0:
                     break
-                frames = stage[:n_frames * frame_bytes].view(n_frames, h, w, 3).cuda(non_blocking=True)
-                out = process_frames(frames, ditherer, method, max_size, final_resize_multiplier)
+                host_frames = stage[:n_frames * frame_bytes].view(n_frames, h, w, 3)
+                if len(devs) > 1:
+                    from . import sharding
+                    out = sharding.process_on_devices(
+                        host_frames, lambda x: process_frames(x, ditherer, method, max_size, final_resize_multiplier), devs)
+                else:
+                    with torch.cuda.device(devs[0]):
+                        out = process_frames(host_frames.cuda(non_blocking=True), ditherer, method, max_size,
+                                             final_resize_multiplier)
                 if enc is None:
                     oh, ow = int(out.shape[1]), int(out.shape[2])
                     enc = subprocess.Popen(
@@ -245,7 +270,8 @@ class VideoProcessor:
                         stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                     out_host = torch.empty((batch_size,) + tuple(out.shape[1:]), dtype=torch.uint8, pin_memory=True)
                 out_host[:n_frames].copy_(out, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
+                if out.is_cuda:
+                    torch.cuda.current_stream(out.device).synchronize()
                 enc.stdin.write(memoryview(out_host[:n_frames].numpy()).cast("B"))
                 done += n_frames
                 frac = done / total_hint if total_hint else 0.5
@@ -272,8 +298,11 @@ class VideoProcessor:
         """video_processor.py:172-390; pixelize_func is the reference's tuple (method_str, max_size) or None.
         use_pipes (an addition): rawvideo pipes instead of the reference's PNG files on disk."""
         if use_pipes:
+            info = self.get_video_info(input_path)
+            if not getattr(self, "_probe_ok", True):
+                use_pipes = False  # frame size unknown: the PNG-file exchange below does not depend on it
+        if use_pipes:
             try:
-                info = self.get_video_info(input_path)
                 self._report_progress(0.0, "Initializing video processing...")
                 self._report_progress(0.05, "Extracting frames...")
                 method, max_size = (None, 64) if pixelize_func is None else pixelize_func

@@ -155,6 +155,27 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
  *   sum_k ( sumsq_k - 2 c_k . sums_k + counts_k |c_k|^2 ). */
 int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
                       int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
+/* (sumsq_dev may be NULL: the squared norms are then not accumulated -- their total is a constant of the data, only
+ * the first pass of a fit needs it.)
+ *
+ * The centre update of one Lloyd iteration ON THE DEVICE, so that a host loop can launch iterations back to back
+ * (pass, all-reduce of the totals across ranks, update) and look at the status only every few iterations -- sklearn's
+ * _kmeans_single_lloyd as dithering_lib.py:1854-1856 runs it: empty clusters keep their centre, stop when the
+ * assignments (sums and counts) did not change or the squared centre shift is <= tol * mean(var(X)) or after
+ * max_iter iterations.
+ *   totals_dev   5K int64 (already summed over all ranks), planar: sums [K][3] | counts [K] | squared norms [K] --
+ *                dp_kmeans_step_u8 called with sums_dev = totals_dev, counts_dev = totals_dev + 3K, sumsq_dev =
+ *                totals_dev + 4K writes exactly this (the last part has to be valid in the first iteration only)
+ *   centers_dev  K*3 float64, updated in place
+ *   prev_dev     [K][4] int64 scratch, owned by the fit
+ *   status_dev   8 float64, zeroed by the caller before the first iteration:
+ *                [0] done: 0 running, 1 assignments unchanged (centres kept), 2 tolerance / max_iter reached (centres
+ *                    updated; run ONE more pass + update to get their inertia: done becomes 3), 3 finished
+ *                [1] iterations so far   [2] inertia of the centres the last pass used   [3] squared centre shift
+ *                [4] tol * mean(var)     [5] total of the squared norms
+ * A call that finds done = 1 or 3 changes nothing. */
+int dp_kmeans_update(const int64_t *totals_dev, double *centers_dev, int64_t *prev_dev, double *status_dev, int K,
+                     double tol, int max_iter, void *stream);
 
 /* NEAREST resize of packed RGB frames (pixelize_regular / final upscale,
  * video_processor.py:563-577, 393-420), bit-identical to Pillow's Image.resize(..., NEAREST): source indices

@@ -135,6 +135,16 @@ CASES += [
     ("ed_fs_mc16_smooth", "error_diffusion", {"variant": "floyd_steinberg"}, ("mc", 16), ("imgl", 96, 128, 11, "smooth"), False, True),
     ("ed_jjn_mc256_dark", "error_diffusion", {"variant": "jjn"}, ("mc", 256), ("imgl", 64, 96, 12, "dark"), False, True),
 ]
+# BASELINE.json's configurations at their FULL sizes (hashes only): C1 exactly as examples/image_basic.json runs it (Bayer
+# default 4x4, 16 colours by median cut of the image itself), one C5 frame, the whole C4 image (the GPU tests dither it
+# in 8 row bands), and the C3 frame (pure-Python error diffusion: ~7 minutes in the reference).
+CASES += [
+    ("c1_bayer4_mc16_rnd512", "bayer", {"size": "4x4"}, ("mc", 16), ("rnd", 512, 512, 1234), False, False),
+    ("c5_bayer4_U16_rnd1080", "bayer", {"size": "4x4"}, ("U", 16), ("rnd", 1080, 1920, 0), False, False),
+    ("c4_blue64_p32_rnd8k", "blue_noise", {"size": 64, "seed": 42}, ("palr", 32), ("rnd", 4320, 7680, 99), False, False),
+    ("c3_ed_fs_U16_rnd4k", "error_diffusion", {"variant": "floyd_steinberg", "serpentine": "false"}, ("U", 16),
+     ("rnd", 2160, 3840, 1234), False, False),
+]
 for v in ED_VARIANTS:
     for s in ("false", "true"):
         CASES.append((f"ed_{v}_{s}_U16_grad", "error_diffusion", {"variant": v, "serpentine": s},

@@ -94,3 +94,69 @@ def test_lloyd_matches_sklearn_fixture_from_same_init(gold, kat):
     centers, inertia, n_iter = kmeans.lloyd(torch.from_numpy(px), init, step_fn=_oracle_step)
     assert np.abs(centers - gold["km16_centers"]).max() < 1e-6
     assert abs(inertia - m["inertia"]) <= 1e-6 * m["inertia"]
+
+
+class _OracleDitherer:
+    """Stand-in for ImageDitherer on CPU tensors (tests only): the oracle does the pixels, so that the partition logic
+    of dither_pie_amd.sharding -- who takes which frames / rows, with which global offsets -- is what is under test."""
+
+    def __init__(self, pal, mode, params):
+        self.pal, self.mode, self.params = pal, mode, params
+
+    def apply_dithering_frames(self, frames, y0=0, x0=0, out=None):
+        import torch
+        from oracle import oracle as orc
+        a = frames.numpy()
+        if a.ndim == 3:
+            return torch.from_numpy(orc.apply_dithering(a, self.pal, self.mode, self.params, False, y0=y0, x0=x0))
+        return torch.from_numpy(np.stack([orc.apply_dithering(f, self.pal, self.mode, self.params, False, y0=y0, x0=x0) for f in a]))
+
+
+def _shard_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dither_pie_amd import sharding
+        from oracle import oracle as orc
+        pal = orc.palr(16, 3)
+        # video: 7 frames in contiguous blocks (C5's partition), gathered back in frame order
+        frames = np.stack([orc.rnd(24, 40, 100 + i) for i in range(7)])
+        dv = _OracleDitherer(pal, "bayer", {"size": "4x4"})
+        lo, hi = sharding.my_frame_block(7)
+        mine = sharding.dither_frames_sharded(dv, torch.from_numpy(frames[lo:hi]))
+        video = sharding.gather_frames(mine, 7)
+        # one image in row bands with global coordinates (C4's partition), gathered back
+        img = orc.rnd(45, 52, 9)
+        db = _OracleDitherer(pal, "blue_noise", {"size": 32, "seed": 0})
+        blo, bhi = sharding.shard_range(45, rank, world)
+        band = sharding.dither_band(db, torch.from_numpy(np.ascontiguousarray(img[blo:bhi])), blo)
+        whole = sharding.gather_bands(band, 45)
+        q.put((rank, (lo, hi), video.numpy(), (blo, bhi), whole.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frames_and_row_bands_two_ranks_equal_one_rank():
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    pal = orc.palr(16, 3)
+    frames = np.stack([orc.rnd(24, 40, 100 + i) for i in range(7)])
+    ref_video = np.stack([orc.apply_dithering(f, pal, "bayer", {"size": "4x4"}) for f in frames])
+    ref_img = orc.apply_dithering(orc.rnd(45, 52, 9), pal, "blue_noise", {"size": 32, "seed": 0})
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [(0, 3), (3, 7)] and [r[3] for r in res] == [(0, 22), (22, 45)]
+    for rank, _, video, _, whole in res:
+        assert np.array_equal(video, ref_video), rank
+        assert np.array_equal(whole, ref_img), rank

@@ -1,0 +1,270 @@
+"""GPU tier: BASELINE.json's configurations at their FULL sizes, and the robustness paths around the kernels.
+
+Chain of custody of the expected values: `kat.json` holds hashes computed by the REFERENCE itself
+(tests/golden/make_golden.py) for C1 (512x512, median-cut 16), C2 (4K, 256 colours), C3 (4K Floyd-Steinberg, ~7 min in
+the reference), C4's dither half (7680x4320 blue noise) and one C5 frame; where a test compares with the C oracle
+instead (batches of other frames, k-means totals), the oracle is the one tests/test_oracle_golden.py pins against those
+same reference hashes at the same sizes."""
+import hashlib
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, case_input, case_palette
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, "kat.json")) as _f:
+    _KAT = json.load(_f)
+_BY_NAME = {c["name"]: c for c in _KAT["cases"]}
+
+
+def H(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.fixture(scope="module")
+def d():
+    import torch
+    assert torch.cuda.is_available()
+    from dither_pie_amd import dithering_lib
+    return dithering_lib
+
+
+@pytest.fixture(scope="module")
+def be():
+    from dither_pie_amd import backend
+    return backend
+
+
+def _need(name):
+    if name not in _BY_NAME:
+        pytest.skip(f"{name} not in kat.json (regenerate with tests/golden/make_golden.py --append)")
+    return _BY_NAME[name]
+
+
+# ------------------------------------------------------------------------------------------------ C3
+def test_c3_floyd_steinberg_4k_both_schedules(d, orc, monkeypatch):
+    """rnd(2160,3840,1234), U16, Floyd-Steinberg: one frame (bands spread over workgroups), the same frame with one
+    workgroup per frame, and a 24-frame batch, all against the reference's own hash of that frame."""
+    import torch
+    case = _need("c3_ed_fs_U16_rnd4k")
+    arr = case_input(orc, case["input"])
+    assert H(arr) == case["h_in"]
+    pal = case_palette(orc, case["palette"])
+    it = d.ImageDitherer(len(pal), d.DitherMode.ERROR_DIFFUSION, pal, False, dict(case["params"]))
+    x = torch.from_numpy(arr).cuda()
+    assert H(it.apply_dithering_frames(x).cpu().numpy()) == case["h_out"]          # G > 1 schedule
+    monkeypatch.setenv("DP_ED_ONE_WG", "1")
+    assert H(it.apply_dithering_frames(x).cpu().numpy()) == case["h_out"]          # one workgroup per frame
+    monkeypatch.delenv("DP_ED_ONE_WG")
+    # a batch of 24: frames 0, 7, 23 are the KAT frame, the others rnd(.., 1235 + i) against the oracle for two of them
+    others = {3: orc.rnd(2160, 3840, 1238), 16: orc.rnd(2160, 3840, 1251)}
+    batch = torch.empty((24, 2160, 3840, 3), dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    batch.copy_(torch.randint(0, 256, batch.shape, dtype=torch.uint8, device="cuda", generator=g))
+    for i in (0, 7, 23):
+        batch[i].copy_(x)
+    for i, a in others.items():
+        batch[i].copy_(torch.from_numpy(a))
+    out = it.apply_dithering_frames(batch)
+    for i in (0, 7, 23):
+        assert H(out[i].cpu().numpy()) == case["h_out"], i
+    for i, a in others.items():
+        ref = orc.apply_dithering(a, pal, "error_diffusion", case["params"])
+        assert np.array_equal(out[i].cpu().numpy(), ref), i
+
+
+def test_error_diffusion_gives_up_and_repairs(d, be, orc, monkeypatch):
+    """A workgroup of a multi-workgroup launch that gives up waiting sets a flag; the repair launch behind it redoes the
+    frame.  DP_ED_TEST_GIVEUP makes every workgroup of the first launch give up before it writes anything."""
+    import torch
+    pal = orc.generate_uniform_palette(16)
+    frames = np.stack([orc.rnd(300, 200, 40 + i) for i in range(3)])  # 5 bands each: spread over workgroups
+    x = torch.from_numpy(frames).cuda()
+    monkeypatch.setenv("DP_ED_TEST_GIVEUP", "1")
+    for mode, params in [("error_diffusion", {"variant": "floyd_steinberg", "serpentine": "false"}),
+                         ("error_diffusion", {"variant": "jjn", "serpentine": "false"}),
+                         ("perceptual", {}), ("hybrid", {}), ("ostromoukhov", {"serpentine": "false"})]:
+        it = d.ImageDitherer(16, d.DitherMode(mode), pal, False, params)
+        out = torch.full_like(x, 0x55)
+        it.apply_dithering_frames(x, out=out)
+        got = out.cpu().numpy()
+        for i in range(3):
+            assert np.array_equal(got[i], orc.apply_dithering(frames[i], pal, mode, params)), (mode, i)
+
+
+# ------------------------------------------------------------------------------------------------ C4
+def test_c4_8k_in_eight_row_bands(d, be, orc):
+    """7680x4320 rnd(.., 99), blue noise (64, 42), 32 colours: dithered as 8 bands of 540 rows with global coordinates,
+    the concatenation has the hash the reference computed for the whole image; Bayer and IGN bands against the oracle."""
+    import torch
+    case = _need("c4_blue64_p32_rnd8k")
+    arr = case_input(orc, case["input"])
+    assert H(arr) == case["h_in"]
+    pal = case_palette(orc, case["palette"])
+    from dither_pie_amd import sharding
+    it = d.ImageDitherer(len(pal), d.DitherMode.BLUE_NOISE, pal, False, dict(case["params"]))
+    outs = []
+    for lo, hi in sharding.row_bands(4320, 8):
+        outs.append(sharding.dither_band(it, torch.from_numpy(arr[lo:hi]).cuda(), lo).cpu().numpy())
+    assert H(np.concatenate(outs)) == case["h_out"]
+    for mode, params in [("bayer", {"size": "8x8"}), ("IGN", {"scale": 1.0, "seed": 3})]:
+        it = d.ImageDitherer(len(pal), d.DitherMode(mode), pal, False, params)
+        ref = orc.apply_dithering(arr, pal, mode, params)
+        for lo, hi in sharding.row_bands(4320, 8)[2:5]:
+            got = sharding.dither_band(it, torch.from_numpy(arr[lo:hi]).cuda(), lo).cpu().numpy()
+            assert np.array_equal(got, ref[lo:hi]), (mode, lo)
+
+
+def test_c4_kmeans_totals_over_all_8k_pixels(be, orc):
+    """One Lloyd pass over all 33 M pixels of the C4 image: exact integer totals equal the oracle's, whole image and
+    summed over 8 bands; then the full fit under a 1-rank NCCL (RCCL) group with the real kernel."""
+    import torch
+    arr = orc.rnd(4320, 7680, 99)
+    px = torch.from_numpy(arr).cuda().reshape(-1, 3)
+    rs = np.random.RandomState(1)
+    centers = rs.rand(32, 3) * 255.0
+    s_ref, n_ref, _ = orc.kmeans_step(arr.reshape(-1, 3), centers)
+    s, n, q = be.kmeans_step(px, torch.from_numpy(centers))
+    assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(n.cpu().numpy(), n_ref)
+    x64 = arr.reshape(-1, 3).astype(np.int64)
+    assert int(q.sum().item()) == int((x64 * x64).sum())
+    from dither_pie_amd import sharding
+    acc_s, acc_n = torch.zeros_like(s), torch.zeros_like(n)
+    for lo, hi in sharding.row_bands(4320, 8):
+        bs, bn, _ = be.kmeans_step(px[lo * 7680:hi * 7680], torch.from_numpy(centers))
+        acc_s += bs
+        acc_n += bn
+    assert torch.equal(acc_s, s) and torch.equal(acc_n, n)
+
+
+def test_fit_palette_under_one_rank_nccl_group(be, orc):
+    """kmeans.fit_palette with torch.distributed initialised on the RCCL backend (world size 1): the all-reduce of the
+    integer totals runs through RCCL on device tensors produced by the real kernel, and changes nothing."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from dither_pie_amd import kmeans
+    arr = orc.rnd(300, 400, 21)
+    px = torch.from_numpy(arr).cuda().reshape(-1, 3)
+    pal0, c0, i0, n0 = kmeans.fit_palette(px, 16, 42)
+    if dist.is_initialized():
+        pytest.skip("a process group is already active")
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        pal1, c1, i1, n1 = kmeans.fit_palette(px, 16, 42, group=dist.group.WORLD)
+    finally:
+        dist.destroy_process_group()
+    assert pal1 == pal0 and np.array_equal(c1, c0) and i1 == i0 and n1 == n0
+    c_or, i_or, _ = orc.kmeans_lloyd(arr.reshape(-1, 3), kmeans.kmeans_plusplus(
+        kmeans.seed_sample(px, px.shape[0], 0, 42), 16, np.random.RandomState(42)))
+    assert np.abs(c_or - c1).max() < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------ C5 / C1 / C2
+def test_c5_1080p_frames_in_a_batch(d, orc):
+    import torch
+    case = _need("c5_bayer4_U16_rnd1080")
+    pal = case_palette(orc, case["palette"])
+    it = d.ImageDitherer(len(pal), d.DitherMode.BAYER, pal, False, dict(case["params"]))
+    frames = np.stack([orc.rnd(1080, 1920, i) for i in range(4)])
+    out = it.apply_dithering_frames(torch.from_numpy(frames).cuda()).cpu().numpy()
+    assert H(frames[0]) == case["h_in"] and H(out[0]) == case["h_out"]
+    for i in (1, 3):
+        assert np.array_equal(out[i], orc.apply_dithering(frames[i], pal, "bayer", case["params"])), i
+
+
+def test_c1_image_basic_exact(d, orc):
+    """examples/image_basic.json as the reference runs it: palette=None => median cut of the image to 16 colours, Bayer
+    default 4x4; the palette the object keeps and the output equal the reference's."""
+    from PIL import Image
+    case = _need("c1_bayer4_mc16_rnd512")
+    arr = case_input(orc, case["input"])
+    it = d.ImageDitherer(16, d.DitherMode.BAYER, None, False, dict(case["params"]))
+    out = np.array(it.apply_dithering(Image.fromarray(arr)))
+    assert [list(map(int, c)) for c in it.palette] == case["palette"][1]
+    assert H(out) == case["h_out"]
+
+
+# ------------------------------------------------------------------------------------------------ robustness
+def test_out_buffer_is_validated(d, be, orc):
+    import torch
+    P = be.Palette(*orc.prepare_palette(orc.palr(16), False))
+    thr = be.Thresholds.from_matrix(orc.bayer_matrix("4x4"))
+    x = torch.from_numpy(orc.rnd(20, 30, 1)).cuda()
+    ref = be.ordered(x, P, be.MODE_MATRIX, thr=thr)
+    assert ref.shape == x.shape
+    out3 = torch.empty_like(x)
+    got = be.ordered(x, P, be.MODE_MATRIX, thr=thr, out=out3)           # 3-D out for a 3-D frame: the image, not a row
+    assert got.shape == x.shape and torch.equal(got, ref) and got.data_ptr() == out3.data_ptr()
+    with pytest.raises(ValueError):
+        be.ordered(x, P, be.MODE_MATRIX, thr=thr, out=torch.empty((20, 31, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        be.ordered(x, P, be.MODE_MATRIX, thr=thr, out=torch.empty((40, 30, 3), dtype=torch.uint8, device="cuda")[::2])
+    with pytest.raises(TypeError):
+        be.ordered(x, P, be.MODE_MATRIX, thr=thr, out=torch.empty((20, 30, 3), dtype=torch.float32, device="cuda"))
+    with pytest.raises(TypeError):
+        be.ordered(x, P, be.MODE_MATRIX, thr=thr, out=torch.empty((20, 30, 3), dtype=torch.uint8))
+    taps, div = orc.ed_kernel("floyd_steinberg")
+    with pytest.raises(ValueError):
+        be.error_diffusion(x, P, taps, div, False, out=torch.empty((10, 30, 3), dtype=torch.uint8, device="cuda"))
+
+
+def test_two_threads_share_a_stream(d, orc):
+    """The GUI calls apply_dithering from worker threads on the default stream: two threads hammering different modes,
+    palettes and sizes get exactly the single-threaded results (workspace + launch sequences are serialised per stream,
+    accelerator builds and the device-object caches are locked)."""
+    import torch
+    jobs = []
+    for k, (mode, params, K, shape, seed) in enumerate([
+            ("bayer", {"size": "8x8"}, 256, (700, 1600), 1), ("error_diffusion", {"variant": "floyd_steinberg"}, 16, (300, 260), 2),
+            ("none", {}, 64, (512, 2048), 3), ("blue_noise", {"size": 32, "seed": 1}, 32, (900, 1300), 4),
+            ("IGN", {}, 256, (640, 1800), 5), ("hybrid", {}, 16, (280, 300), 6)]):
+        arr = orc.rnd(shape[0], shape[1], seed)
+        pal = orc.palr(K, 20 + k)   # fresh palettes: both threads trigger accelerator builds
+        jobs.append((mode, params, pal, arr, orc.apply_dithering(arr, pal, mode, params)))
+    errors = []
+
+    def worker(order):
+        try:
+            for rep in range(3):
+                for j in order:
+                    mode, params, pal, arr, ref = jobs[j]
+                    it = d.ImageDitherer(len(pal), d.DitherMode(mode), pal, False, params)
+                    out = it.apply_dithering_frames(torch.from_numpy(arr).cuda()).cpu().numpy()
+                    if not np.array_equal(out, ref):
+                        errors.append((mode, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(o,)) for o in ([0, 1, 2, 3, 4, 5], [5, 4, 3, 2, 1, 0])]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
+def test_frames_over_devices_in_process(d, orc):
+    """sharding.process_on_devices: contiguous frame blocks, one worker thread and stream per device entry (the one GPU
+    of the test box named twice), result equal to the single-call result and in frame order."""
+    import torch
+    from dither_pie_amd import sharding, video_processor as v
+    pal = orc.palr(16, 3)
+    it = d.ImageDitherer(16, d.DitherMode.BAYER, pal, False, {"size": "4x4"})
+    frames = torch.from_numpy(np.stack([orc.rnd(90, 120, i) for i in range(11)]))
+    ref = v.process_frames(frames.cuda(), it, "regular", 32, 2).cpu()
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        got = sharding.process_on_devices(frames, lambda x: v.process_frames(x, it, "regular", 32, 2), devs, chunk=3)
+        assert got.shape == ref.shape and torch.equal(got, ref), devs

@@ -421,7 +421,7 @@ def test_randomised_cases_against_oracle(be, orc, seed):
     """150 random (mode, parameters, palette size, gamma, shape, tile origin, tie-rich content) cases per seed."""
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_scripts", "fuzz_ordered.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_ordered.py")
     spec = importlib.util.spec_from_file_location("fuzz_ordered", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -10,7 +10,7 @@ from conftest import GOLDEN, case_input, case_palette
 with open(os.path.join(GOLDEN, "kat.json")) as _f:
     _KAT = json.load(_f)
 _CASES = _KAT["cases"]
-_BIG = {"bayer8_p256_rnd4k"}
+_BIG = {"bayer8_p256_rnd4k", "c4_blue64_p32_rnd8k", "c3_ed_fs_U16_rnd4k"}
 
 
 def test_threshold_tables(orc, gold, kat):
@@ -124,6 +124,19 @@ def test_dither_config2_4k(orc):
     arr = case_input(orc, case["input"])
     out = orc.apply_dithering(arr, case_palette(orc, case["palette"]), "bayer", case["params"], False)
     assert orc.H(arr) == case["h_in"] and orc.H(out) == case["h_out"]
+
+
+def test_full_size_configs_c3_c4(orc):
+    """The oracle at BASELINE.json's full sizes against the reference's own hashes: C3 (4K Floyd-Steinberg, 16 uniform
+    colours; the reference needs ~7 minutes for it) and C4's dither half (7680x4320, blue noise 64/42, 32 colours)."""
+    for name in ("c3_ed_fs_U16_rnd4k", "c4_blue64_p32_rnd8k"):
+        case = next((c for c in _CASES if c["name"] == name), None)
+        if case is None:
+            pytest.skip(f"{name} not in kat.json")
+        arr = case_input(orc, case["input"])
+        assert orc.H(arr) == case["h_in"]
+        out = orc.apply_dithering(arr, case_palette(orc, case["palette"]), case["mode"], case["params"], False)
+        assert orc.H(out) == case["h_out"], name
 
 
 def test_tile_offsets_match_full_frame(orc):
