@@ -389,7 +389,7 @@ constexpr int kTabMaxWords = 1 << 20;                 // largest table built (4 
 constexpr int kTabStageWords = 4096 * 8 + 88 * 64;
 
 struct TableStats {
-    int n_split = 0, n_slow = 0, max_cnt = 0, max_near = 0;
+    int n_split = 0, n_slow = 0, max_cnt = 0, max_near = 0, n_near_overflow = 0;
     bool wide_overflow = false;
     std::vector<Box> node_box;  // the box each split node covers, by node index
     int n_split_cells = 0;  // 16^3 cells that are split (the pixels of these cells leave the main path of the kernels)
@@ -480,6 +480,7 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int b
         uint32_t blk[8];
         const size_t slot = (size_t)cell_slot(cell >> 8, (cell >> 4) & 15, cell & 15);
         bool fits = make_block(m, r0 + 8, g0 + 8, b0 + 8, blk);
+        bool near_overflow = false;
         if (fits && nmasks) {
             // `list` holds the block's entries in index order: the nearest set first
             const uint32_t *nm = nmasks + (size_t)cell * mw;
@@ -495,13 +496,15 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int b
                         n_near += near;
                     }
                 }
-            if (n_near > ns) fits = false;  // the nearest-only path of the kernel reads `ns` entries
-            else if (perm) (*perm)[slot] = pw | ((uint32_t)n_near << 28);
+            // a nearest set larger than the nearest-only path of the fast kernel reads: the cell keeps its block in the table,
+            // but the fast kernel treats it as split (staging order = flat list below)
+            near_overflow = n_near > ns;
+            if (!near_overflow && perm) (*perm)[slot] = pw | ((uint32_t)n_near << 28);
             st.max_near = std::max(st.max_near, n_near);
+            st.n_near_overflow += near_overflow;
         }
-        if (fits) {
-            std::copy(blk, blk + bw, tab.begin() + slot * bw);
-        } else {
+        if (fits) std::copy(blk, blk + bw, tab.begin() + slot * bw);
+        if (!fits || near_overflow) {
             if (perm && wide) {
                 // the cell's whole list, index order, padded with the unused entries nearest to the centre
                 list.clear();
@@ -528,6 +531,8 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int b
                     for (int i = 0; i < kWideList; ++i) wide->push_back(word[list[i]]);
                 }
             }
+        }
+        if (!fits) {
             split(slot * bw, Box{r0, g0, b0, 16}, m + mw);
             ++st.n_split_cells;
         }
@@ -785,7 +790,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     // the table of 8-entry blocks (palettes of fewer than 8 colours cannot fill a block: 4-entry blocks only)
     const bool have8 = K >= 8;
     if (have8) {
-        const int rc = assemble_table(masks, mw, 8, kTabMaxWords, K, p4_host, p4_host, box_masks, tab, st);
+        const int rc = assemble_table(masks, mw, 8, kTabMaxWords, K, p4_host, p4_host, box_masks, tab, st, nmasks.data(), kNearSlots, &perm8, &wide8);
         if (rc != DP_OK) {
             (void)hipFree(blob);
             return rc;
@@ -927,31 +932,16 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         dev.warp_adapt = (wbw == 8 && (w_spilled || wst.n_split_cells > kCells * 3 / 100 || w_mass * 4 >= n_mass)) ? 1 : 0;
     }
     // The fast ordered kernel (ordered.hip: ordered_fast_kernel) runs the pixels that can only take their nearest entry on
-    // the first kNearSlots entries of the cell's block, staged nearest set first.  When the plain 8-entry table is the one
-    // in use and uncrowded, build it again with the cells whose nearest set is larger split as well, and keep that
-    // version while the table stays uncrowded and within LDS (the pixels of split cells take the deferred path).
+    // the first kNearSlots entries of the cell's block, staged nearest set first (perm8 / perm4 from assemble_table); it is
+    // used with the plain tables of uncrowded palettes only.
     dev.cell_perm = dev.cell_perm4 = nullptr;
     dev.near_slots = 0;
-    if (have8 && !st.too_big && !use4 && wbw == 0 && !dev.adapt && tab.size() <= (size_t)kTabCapWords && !getenv("DP_NO_FAST")) {
-        std::vector<uint32_t> tabn;
-        TableStats stn;
-        const int rcn = assemble_table(masks, mw, 8, kTabMaxWords, K, p4_host, p4_host, box_masks, tabn, stn, nmasks.data(), kNearSlots, &perm8, &wide8);
-        if (rcn != DP_OK) {
-            (void)hipFree(blob);
-            return rcn;
-        }
-        const bool keep = !stn.too_big && !stn.wide_overflow && tabn.size() <= (size_t)kTabCapWords && stn.n_split_cells <= kCells * 4 / 100 &&
-                          wide8.size() <= (size_t)kWideCap * kWideList;
-        if (getenv("DP_DEBUG_ACCEL"))
-            fprintf(stderr, "accel K=%d: nearest-first table (%d slots): %d split cells (were %d), %d nodes, %zu words, largest nearest set kept %d -> %s\n",
-                    K, kNearSlots, stn.n_split_cells, st.n_split_cells, stn.n_split, tabn.size(), stn.max_near, keep ? "in use" : "dropped");
-        if (keep) {
-            tab.swap(tabn);
-            st = stn;
-        } else {
-            perm8.clear();
-        }
-    }
+    const bool fast8 = have8 && !st.too_big && !st.wide_overflow && !use4 && wbw == 0 && !dev.adapt && tab.size() <= (size_t)kTabCapWords &&
+                       wide8.size() <= (size_t)kWideCap * kWideList && !getenv("DP_NO_FAST");
+    if (getenv("DP_DEBUG_ACCEL") && have8)
+        fprintf(stderr, "accel K=%d: fast kernel on the 8-entry table: %s (%d cells with a nearest set above %d entries, %zu flat lists)\n", K,
+                fast8 ? "yes" : "no", st.n_near_overflow, kNearSlots, wide8.size() / kWideList);
+    if (!fast8) perm8.clear();
     uint32_t *d_perm8 = reinterpret_cast<uint32_t *>(d_lut + 768), *d_perm4 = d_perm8 + kCells;
     uint32_t *d_wide8 = d_perm4 + kCells, *d_wide4 = d_wide8 + kWideCap * kWideList;
     dev.cell_wide = dev.cell_wide4 = nullptr;
