@@ -116,9 +116,12 @@ struct ThrDev {
     // (positions by masking; otherwise by an exact float64 reciprocal, inv_h / inv_w).
     const float *fpad;
     const uint32_t *mpad;
-    // cls[row * th_w + col] (present with fpad): bit q set = when lane 0 of a wave sits at (row, col) of the table and its
-    // 64 lanes x 4 pixels lie in one image row, no lane's pixel q has a threshold below 1/2 (ordered_fast_kernel)
-    const uint32_t *cls;
+    // Classes of the wave tiles (ordered kernels): nibble row * th_w + col of cls_nib, bit q set = when lane 0 of a wave
+    // sits at (row, col) of the table and its 64 lanes x 4 pixels lie in one image row, no lane's pixel q has a threshold
+    // below 1/2.  Held BY VALUE (kernel arguments: scalar loads, no memory dependence) for tables of up to 256 entries
+    // that have such slots at all (has_cls); larger tables (blue noise) have none worth testing for.
+    uint32_t cls_nib[32];
+    int has_cls;
     int tw_pad;
     int pow2;
     double inv_h, inv_w;

@@ -465,7 +465,8 @@ static int thresholds_from_device_f32(float *dev_f32, int th_h, int th_w, const 
     t->dev.sh = 0;
     t->dev.fpad = nullptr;
     t->dev.mpad = nullptr;
-    t->dev.cls = nullptr;
+    for (uint32_t &wd : t->dev.cls_nib) wd = 0;
+    t->dev.has_cls = 0;
     t->dev.tw_pad = 0;
     t->blob_pad = nullptr;
     if (sh >= 0) {
@@ -487,26 +488,32 @@ static int thresholds_from_device_f32(float *dev_f32, int th_h, int th_w, const 
     if ((int64_t)th_h * (th_w + 3) <= (1 << 18)) {
         const int twp = th_w + 3;
         const size_t np = (size_t)th_h * twp;
-        std::vector<uint32_t> pad(2 * np + (size_t)n);  // float32 bit patterns, then the integer form, then the classes
+        std::vector<uint32_t> pad(2 * np);  // float32 bit patterns, then the integer form
         for (int y = 0; y < th_h; ++y)
             for (int x = 0; x < twp; ++x) {
                 const size_t src = (size_t)y * th_w + (x % th_w);
                 std::memcpy(&pad[(size_t)y * twp + x], &host_copy[src], sizeof(float));
                 pad[np + (size_t)y * twp + x] = sh >= 0 ? m[src] : 0u;
             }
-        // classes (ordered_fast_kernel): a wave covers 256 consecutive pixels of a row, lane l the pixels 4l .. 4l+3.
-        // cls[r][p] bit q: with lane 0 at column p of threshold row r, no lane's pixel q has a threshold below 1/2 --
+        // classes (ordered kernels): a wave covers 256 consecutive pixels of a row, lane l the pixels 4l .. 4l+3.
+        // nibble (r, p) bit q: with lane 0 at column p of threshold row r, no lane's pixel q has a threshold below 1/2 --
         // such pixels always take the nearest entry (dithering_lib.py:361-376: factor <= 1/2).
-        for (int r = 0; r < th_h; ++r)
-            for (int p0 = 0; p0 < th_w; ++p0) {
-                uint32_t bits = 0;
-                for (int q = 0; q < 4; ++q) {
-                    bool all = true;
-                    for (int l = 0; l < 64 && all; ++l) all = host_copy[(size_t)r * th_w + (size_t)((p0 + 4 * l + q) % th_w)] >= 0.5f;
-                    bits |= all ? (1u << q) : 0u;
+        if (n <= 256 && t->dev.pow2) {
+            bool any = false;
+            for (int r = 0; r < th_h; ++r)
+                for (int p0 = 0; p0 < th_w; ++p0) {
+                    uint32_t bits = 0;
+                    for (int q = 0; q < 4; ++q) {
+                        bool all = true;
+                        for (int l = 0; l < 64 && all; ++l) all = host_copy[(size_t)r * th_w + (size_t)((p0 + 4 * l + q) % th_w)] >= 0.5f;
+                        bits |= all ? (1u << q) : 0u;
+                    }
+                    const int idx = r * th_w + p0;
+                    t->dev.cls_nib[idx >> 3] |= bits << ((idx & 7) * 4);
+                    any |= bits != 0;
                 }
-                pad[2 * np + (size_t)r * th_w + p0] = bits;
-            }
+            t->dev.has_cls = any ? 1 : 0;
+        }
         void *dp = nullptr;
         hipError_t e = hipMalloc(&dp, sizeof(uint32_t) * pad.size());
         if (e == hipSuccess) e = hipMemcpy(dp, pad.data(), sizeof(uint32_t) * pad.size(), hipMemcpyHostToDevice);
@@ -518,7 +525,6 @@ static int thresholds_from_device_f32(float *dev_f32, int th_h, int th_w, const 
         t->blob_pad = dp;
         t->dev.fpad = (const float *)dp;
         t->dev.mpad = sh >= 0 ? (const uint32_t *)dp + np : nullptr;
-        t->dev.cls = (const uint32_t *)dp + 2 * np;
         t->dev.tw_pad = twp;
     }
     *out = t;

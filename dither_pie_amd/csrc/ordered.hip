@@ -20,6 +20,8 @@
 // Pixels whose result depends on scipy's visiting order in a way no table expresses, and near ties of the
 // float path, only set a flag bit; fixup_kernel compacts the flagged pixels per workgroup into LDS and
 // resolves them through the scipy-order KD-tree emulation (tree_query) and the literal float64 chain.
+#include <type_traits>
+
 #include "dp_internal.h"
 #include "tree_query.hip.h"
 
@@ -327,6 +329,62 @@ __device__ __forceinline__ void cand8(const uint32_t x, const uint4 ca, const ui
           [n6] "=&v"(n6), [n7] "=&v"(n7), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3),
           [p4] "=&v"(p4), [p5] "=&v"(p5), [p6] "=&v"(p6), [p7] "=&v"(p7), [m0] "=&v"(m0), [m1] "=&v"(m1),
           [m2] "=&v"(m2)
+        : [x] "v"(x), [c0] "v"(ca.x), [c1] "v"(ca.y), [c2] "v"(ca.z), [c3] "v"(ca.w), [c4] "v"(cb.x),
+          [c5] "v"(cb.y), [c6] "v"(cb.z), [c7] "v"(cb.w), [ng] "s"(neg2));
+}
+
+// The same keys, the TWO smallest only (pixels that take their nearest entry whatever the second one is): 44 operations
+__device__ __forceinline__ void cand8n(const uint32_t x, const uint4 ca, const uint4 cb, const int neg2, int &m0, int &m1)
+{
+    int n0, n1, n2, n3, n4, n5, n6, n7, p0, p1, p2, p3, p4, p5, p6, p7;
+    asm volatile(
+        "v_dot4_u32_u8 %[n0], %[c0], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[p0], %[x], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[n1], %[c1], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[p1], %[x], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[n2], %[c2], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[p2], %[x], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[n3], %[c3], %[c3], 0\n\t"
+        "v_dot4_u32_u8 %[p3], %[x], %[c3], 0\n\t"
+        "v_dot4_u32_u8 %[n4], %[c4], %[c4], 0\n\t"
+        "v_dot4_u32_u8 %[p4], %[x], %[c4], 0\n\t"
+        "v_dot4_u32_u8 %[n5], %[c5], %[c5], 0\n\t"
+        "v_dot4_u32_u8 %[p5], %[x], %[c5], 0\n\t"
+        "v_dot4_u32_u8 %[n6], %[c6], %[c6], 0\n\t"
+        "v_dot4_u32_u8 %[p6], %[x], %[c6], 0\n\t"
+        "v_dot4_u32_u8 %[n7], %[c7], %[c7], 0\n\t"
+        "v_dot4_u32_u8 %[p7], %[x], %[c7], 0\n\t"
+        "v_lshl_add_u32 %[n0], %[n0], 8, 0\n\t"
+        "v_lshl_add_u32 %[n1], %[n1], 8, 4\n\t"
+        "v_lshl_add_u32 %[n2], %[n2], 8, 8\n\t"
+        "v_lshl_add_u32 %[n3], %[n3], 8, 12\n\t"
+        "v_lshl_add_u32 %[n4], %[n4], 8, 16\n\t"
+        "v_lshl_add_u32 %[n5], %[n5], 8, 20\n\t"
+        "v_lshl_add_u32 %[n6], %[n6], 8, 24\n\t"
+        "v_lshl_add_u32 %[n7], %[n7], 8, 28\n\t"
+        "v_mad_i32_i24 %[n0], %[p0], %[ng], %[n0]\n\t"
+        "v_mad_i32_i24 %[n1], %[p1], %[ng], %[n1]\n\t"
+        "v_mad_i32_i24 %[n2], %[p2], %[ng], %[n2]\n\t"
+        "v_mad_i32_i24 %[n3], %[p3], %[ng], %[n3]\n\t"
+        "v_mad_i32_i24 %[n4], %[p4], %[ng], %[n4]\n\t"
+        "v_mad_i32_i24 %[n5], %[p5], %[ng], %[n5]\n\t"
+        "v_mad_i32_i24 %[n6], %[p6], %[ng], %[n6]\n\t"
+        "v_mad_i32_i24 %[n7], %[p7], %[ng], %[n7]\n\t"
+        "v_min3_i32 %[m0], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n3]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n3]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n4]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n4]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n5]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n5]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n6]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n6]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n7]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n7]\n\t"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [n4] "=&v"(n4), [n5] "=&v"(n5),
+          [n6] "=&v"(n6), [n7] "=&v"(n7), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3),
+          [p4] "=&v"(p4), [p5] "=&v"(p5), [p6] "=&v"(p6), [p7] "=&v"(p7), [m0] "=&v"(m0), [m1] "=&v"(m1)
         : [x] "v"(x), [c0] "v"(ca.x), [c1] "v"(ca.y), [c2] "v"(ca.z), [c3] "v"(ca.w), [c4] "v"(cb.x),
           [c5] "v"(cb.y), [c6] "v"(cb.z), [c7] "v"(cb.w), [ng] "s"(neg2));
 }
@@ -899,13 +957,47 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
         if (gidx0 < n_full) wn = in3[gidx0];
         if (gidx0 * 4u < g.n_px) locate(g, gidx0 * 4u, fy, fx);
     }
+    // Which pixel slots of a wave tile can only take their nearest entry (thr.cls, host.cpp: every lane's threshold of that
+    // slot is >= 1/2, and then f = s0/(s0+s1) <= 1/2 <= t whatever the second entry is -- every rounding of the
+    // reference's float64 chain is monotone, dithering_lib.py:361-376): a property of the position of the wave's first
+    // pixel in the threshold table, valid when the wave's 256 pixels lie in one image row.  With a Bayer matrix that is
+    // every other slot.  Such slots run a top-2 network and no decision arithmetic (47 instead of 64 vector instructions).
+    const bool use_cls = (MODE == 1 || MODE == 2) && thr.has_cls != 0 && !ADAPT;
+    // (the table word is fetched one tile ahead and only shifted / masked when the tile starts, so that the scalar load
+    // has a whole tile to arrive)
+    uint32_t cls_word = 0, cls_shift = 0;  // wave-uniform
+    auto tile_class = [&](const uint32_t ty, const uint32_t tx, const uint32_t gi) {
+        cls_word = 0;
+        cls_shift = 0;
+        if (MODE == 0 || !use_cls) return;
+        // (every lane looks at lane 0's position: uniform address, scalar load from the kernel arguments)
+        const uint32_t y0l = (uint32_t)__builtin_amdgcn_readfirstlane((int)ty), x0l = (uint32_t)__builtin_amdgcn_readfirstlane((int)tx);
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gi);
+        if (x0l + 256u > g.w || g0 + 64u > n_full) return;
+        const uint32_t row = ((uint32_t)g.y0 + y0l) & (uint32_t)(thr.th_h - 1), col = ((uint32_t)g.x0 + x0l) & (uint32_t)(thr.th_w - 1);
+        const uint32_t idx = row * (uint32_t)thr.th_w + col;  // < 256
+        cls_word = thr.cls_nib[idx >> 3];
+        cls_shift = (idx & 7u) * 4u;
+    };
+    if (tile < n_tiles) tile_class(fy, fx, tile * kCellBlock + threadIdx.x);
     for (; tile < n_tiles; tile += gridDim.x) {
         const uint32_t gidx = tile * kCellBlock + threadIdx.x;
         const uint3 wc = wn;
+        const uint32_t cls = MODE == 0 ? 15u : ((cls_word >> cls_shift) & 15u);  // wave-uniform
+        const uint32_t cy = fy, cx = fx;  // this tile's position; fy / fx move on to the next tile's
         {
             const uint32_t next = tile + gridDim.x;
             const uint32_t gn = next * kCellBlock + threadIdx.x;
             if (next < n_tiles && gn < n_full) wn = in3[gn];  // prefetch the next tile
+            fx += g.adv_x;
+            fy += g.adv_y;
+            if (fx >= g.w) {
+                fx -= g.w;
+                ++fy;
+            }
+            if (fy >= g.h) fy -= g.h;
+            cls_word = 0;
+            if (next < n_tiles) tile_class(fy, fx, gn);
         }
         // all clear; lean_pixel_full ORs in the bits of the pixels it leaves to the fix-up pass later
         if (lane < 4u) flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
@@ -928,7 +1020,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
             }
             if (MODE == 1 || MODE == 2) {
                 uint32_t row, col;
-                thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
+                thr_pos(thr, (uint32_t)g.y0 + cy, (uint32_t)g.x0 + cx, row, col);
                 const uint32_t at = row * (uint32_t)thr.tw_pad + col;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -937,9 +1029,9 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                 }
             } else if (MODE == 3) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) th[q].t = ign_threshold(g.x0 + (int)fx + q, g.y0 + (int)fy, sx, sy, sc);
+                for (int q = 0; q < 4; ++q) th[q].t = ign_threshold(g.x0 + (int)cx + q, g.y0 + (int)cy, sx, sy, sc);
             }
-            if ((MODE != 0) && (fx + 3u >= g.w)) {
+            if ((MODE != 0) && (cx + 3u >= g.w)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) rare[q] = true;  // the group straddles a row end: through the queue
             } else {
@@ -987,56 +1079,84 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                 ca[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q]);
                 if (BW == 8) cb[q] = *reinterpret_cast<const uint4 *>(s_bytes + blk[q] + 16);
             }
-            LeanThr th[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                th[q].mt = 0;
-                th[q].t = 0.0f;
-            }
-            if (MODE == 1 || MODE == 2) {
-                uint32_t row, col;
-                thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
-                const uint32_t at = row * (uint32_t)thr.tw_pad + col;
+            // one straight-line body per class pattern (bit q: slot q takes its nearest entry whatever the second one is)
+            auto body = [&](auto cls_c) {
+                constexpr uint32_t CLS = (uint32_t)decltype(cls_c)::value;
+                LeanThr th[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (MODE == 1) th[q].mt = smem[pal.tab_words + at + q];
-                    else th[q].t = thr.fpad[at + q];
+                    th[q].mt = 0;
+                    th[q].t = 0.0f;
                 }
-            } else if (MODE == 3) {
+                if (CLS != 15u) {
+                    if (MODE == 1 || MODE == 2) {
+                        uint32_t row, col;
+                        thr_pos(thr, (uint32_t)g.y0 + cy, (uint32_t)g.x0 + cx, row, col);
+                        const uint32_t at = row * (uint32_t)thr.tw_pad + col;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) th[q].t = ign_threshold(g.x0 + (int)fx + q, g.y0 + (int)fy, sx, sy, sc);
-            }
-            // the group runs over the end of its row: all four through the queue (their positions differ)
-            const bool straddle = (MODE != 0) && (fx + 3u >= g.w);
-            uint32_t col[4];
+                        for (int q = 0; q < 4; ++q) {
+                            if ((CLS >> q) & 1u) continue;
+                            if (MODE == 1) th[q].mt = smem[pal.tab_words + at + q];
+                            else th[q].t = thr.fpad[at + q];
+                        }
+                    } else if (MODE == 3) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t x = xq[q];
-                int m0, m1, m2;
-                if (BW == 8) cand8(x, ca[q], cb[q], g.neg2, m0, m1, m2);
-                else cand4(x, ca[q], g.neg2, m0, m1, m2);
-                const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits;
-                const bool tie = (a0 == a1) | ((uint32_t)(m1 ^ m2) < (1u << kLocalBits));  // also: any split cell
-                int sel;
-                if (MODE == 0) {
-                    sel = m0;
-                    rare[q] = tie;
-                } else {
-                    const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
-                    const uint32_t d0 = (uint32_t)(a0 + xx);
-                    const uint32_t S = d0 + (uint32_t)a1 + (uint32_t)xx;
-                    bool eq;
-                    const bool nearest = lean_decide<MODE>(d0, S, th[q], thr.sh, eq);
-                    rare[q] = tie | eq | straddle;
-                    sel = nearest ? m0 : m1;
+                        for (int q = 0; q < 4; ++q) th[q].t = ign_threshold(g.x0 + (int)cx + q, g.y0 + (int)cy, sx, sy, sc);
+                    }
                 }
-                col[q] = *reinterpret_cast<const uint32_t *>(s_bytes + (blk[q] | ((uint32_t)sel & 0xfcu)));
-            }
-            uint3 wo;
-            wo.x = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);
-            wo.y = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);
-            wo.z = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);
-            out3[gidx] = wo;
+                // the group runs over the end of its row: all four through the queue (their positions differ)
+                const bool straddle = (MODE != 0) && (cx + 3u >= g.w);
+                uint32_t col[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t x = xq[q];
+                    int sel;
+                    if ((CLS >> q) & 1u) {
+                        int m0, m1;
+                        if (BW == 8) {
+                            cand8n(x, ca[q], cb[q], g.neg2, m0, m1);
+                        } else {
+                            int m2;
+                            cand4(x, ca[q], g.neg2, m0, m1, m2);  // (a split cell's marker block: three equal entries behind the marker)
+                            m1 = ((uint32_t)(m1 ^ m2) < (1u << kLocalBits)) ? m0 : m1;
+                        }
+                        // a tie for the nearest entry, or a split cell (its marker word may well have the smallest key: with only
+                        // two keys kept the equal entries behind it do not show as a tie -- test the marker itself)
+                        rare[q] = ((uint32_t)(m0 ^ m1) < (1u << kLocalBits)) | ((int)ca[q].x < 0) | straddle;
+                        sel = m0;
+                    } else {
+                        int m0, m1, m2;
+                        if (BW == 8) cand8(x, ca[q], cb[q], g.neg2, m0, m1, m2);
+                        else cand4(x, ca[q], g.neg2, m0, m1, m2);
+                        const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits;
+                        const bool tie = (a0 == a1) | ((uint32_t)(m1 ^ m2) < (1u << kLocalBits));  // also: any split cell
+                        if (MODE == 0) {
+                            sel = m0;
+                            rare[q] = tie;
+                        } else {
+                            const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
+                            const uint32_t d0 = (uint32_t)(a0 + xx);
+                            const uint32_t S = d0 + (uint32_t)a1 + (uint32_t)xx;
+                            bool eq;
+                            const bool nearest = lean_decide<MODE>(d0, S, th[q], thr.sh, eq);
+                            rare[q] = tie | eq | straddle;
+                            sel = nearest ? m0 : m1;
+                        }
+                    }
+                    col[q] = *reinterpret_cast<const uint32_t *>(s_bytes + (blk[q] | ((uint32_t)sel & 0xfcu)));
+                }
+                uint3 wo;
+                wo.x = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);
+                wo.y = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);
+                wo.z = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);
+                out3[gidx] = wo;
+            };
+            if (MODE == 0) body(std::integral_constant<int, 15>{});
+            else if (MODE == 3 || ADAPT) body(std::integral_constant<int, 0>{});
+            else if (cls == 5u) body(std::integral_constant<int, 5>{});
+            else if (cls == 10u) body(std::integral_constant<int, 10>{});
+            else if (cls == 15u) body(std::integral_constant<int, 15>{});
+            else body(std::integral_constant<int, 0>{});
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) rare[q] = gidx * 4u + (uint32_t)q < g.n_px;  // the partial last group
@@ -1074,13 +1194,6 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
         } else if (rare_px > 96u) {
             deep = true;
         }
-        fx += g.adv_x;
-        fy += g.adv_y;
-        if (fx >= g.w) {
-            fx -= g.w;
-            ++fy;
-        }
-        if (fy >= g.h) fy -= g.h;
     }
     while (qcount != 0u) {
         const uint32_t n = qcount < 64u ? qcount : 64u;
@@ -1436,7 +1549,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_fast_kernel(const uint8_t 
     }
     // Which pixel slots of this wave tile can only take their nearest entry (thr.cls, host.cpp): a property of the position
     // of the wave's first pixel in the threshold table, valid when the 256 pixels of the wave lie in one image row.
-    const bool use_cls = (MODE == 1 || MODE == 2) && thr.cls != nullptr && thr.pow2 != 0 && !(DBG & 2);
+    const bool use_cls = (MODE == 1 || MODE == 2) && thr.has_cls != 0 && !(DBG & 2);
     auto tile_class = [&](const uint32_t ty, const uint32_t tx, const uint32_t gi) -> uint32_t {
         if (MODE == 0) return 15u;
         if (!use_cls) return 0u;
@@ -1445,7 +1558,8 @@ __global__ __launch_bounds__(kCellBlock) void ordered_fast_kernel(const uint8_t 
         const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gi);
         if (x0l + 256u > g.w || g0 + 64u > n_full) return 0u;
         const uint32_t row = ((uint32_t)g.y0 + y0l) & (uint32_t)(thr.th_h - 1), col = ((uint32_t)g.x0 + x0l) & (uint32_t)(thr.th_w - 1);
-        return thr.cls[row * (uint32_t)thr.th_w + col];
+        const uint32_t idx = row * (uint32_t)thr.th_w + col;  // < 256
+        return (thr.cls_nib[idx >> 3] >> ((idx & 7u) * 4u)) & 15u;
     };
     uint32_t cls_next = tile < n_tiles ? tile_class(fy, fx, tile * kCellBlock + threadIdx.x) : 0u;
     for (; tile < n_tiles; tile += gridDim.x) {
@@ -2101,7 +2215,8 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
     thr.sh = 0;
     thr.fpad = nullptr;
     thr.mpad = nullptr;
-    thr.cls = nullptr;
+    for (uint32_t &wd : thr.cls_nib) wd = 0;
+    thr.has_cls = 0;
     thr.tw_pad = 0;
     thr.pow2 = 1;
     thr.inv_h = thr.inv_w = 1.0;
