@@ -33,8 +33,25 @@ class Palette:
     pal_f32 [K,3] float32 as the KD-tree sees it; out_colors [K,3] uint8 written for each entry;
     lut_in optional 256-entry uint8 map applied to the input bytes."""
 
-    # pixels in one call from which building the search accelerator (tens of ms, once) pays off
-    ACCEL_MIN_PIXELS = 1 << 20
+    # Building the search accelerator (KD-tree aside: a scan of all 2^24 colours, cell table, tie codes) takes ~12 ms,
+    # once per palette; the brute-force kernels need ~9 K vector instructions per pixel against ~70 with it.  A palette
+    # therefore runs on the brute-force kernels until the pixels it has served would have paid for the build
+    # (break-even ~ 4.9e10 / K pixels: 190 Mpixel at 256 colours, 3 Gpixel at 16) and builds it then -- never more
+    # than twice the cost of the better choice, whatever follows.  One image or a GUI preview never builds it; a
+    # video does within its first frames.  build_accel() forces it (long-running jobs that know what is coming).
+    ACCEL_BUILD_SECONDS = 0.012
+    BRUTE_SECONDS_PER_PIXEL_PER_COLOUR = 2.46e-13
+
+    def accel_break_even_pixels(self):
+        return self.ACCEL_BUILD_SECONDS / (self.BRUTE_SECONDS_PER_PIXEL_PER_COLOUR * max(self.K, 1))
+
+    def note_pixels(self, n_px):
+        """Account n_px pixels about to be processed; builds the accelerator once they have paid for it."""
+        if self._accel_done:
+            return
+        self._px_served += int(n_px)
+        if self._px_served >= self.accel_break_even_pixels():
+            self.build_accel()
 
     def __init__(self, pal_f32, out_colors, lut_in=None, accel=False):
         require_gpu()
@@ -56,6 +73,7 @@ class Palette:
         self.n_nodes = nodes.value
         self.accel_entries = self.accel_max_list = 0
         self._accel_done = False
+        self._px_served = 0
         self._accel_lock = threading.Lock()
         self.device = torch.device("cuda", torch.cuda.current_device())
         if accel:
@@ -209,8 +227,7 @@ def ordered(frames, pal: Palette, mode, thr: Thresholds | None = None, ign_scale
     L = _lib.load()
     ws_bytes = L.dp_ordered_workspace_bytes(n, h, w)
     with torch.cuda.device(f.device):
-        if n * h * w >= Palette.ACCEL_MIN_PIXELS:
-            pal.build_accel()
+        pal.note_pixels(n * h * w)
         with _Launch(f.device, ws_bytes) as ws:
             check(L.dp_ordered_u8(f.data_ptr(), out.data_ptr(), n, h, w, int(y0), int(x0), pal._h, int(mode),
                                   thr._h if thr is not None else None, float(ign_scale), int(ign_seed),
@@ -261,7 +278,7 @@ def variable_diffusion(frames, pal: Palette, model, p0=0.0, p1=0.0, serpentine=F
     _check_palette_device(pal, f)
     L = _lib.load()
     ws_bytes = L.dp_error_diffusion_workspace_bytes(n, h, w)
-    if gate is not None and n * h * w >= Palette.ACCEL_MIN_PIXELS:
+    if gate is not None and n * h * w >= (1 << 20):
         # adaptive variance: gated-off (flat) regions query the palette with the pixels themselves; exact ties at integer
         # points are then resolved from the accelerator's tie codes instead of a traversal replay per pixel
         pal.build_accel()

@@ -931,8 +931,14 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                                                                   const uint32_t n_tiles)
 {
     __shared__ __align__(16) uint32_t smem[kLeanLdsWords];  // static: LDS addresses need no base register
-    for (int i = threadIdx.x * 4; i < pal.tab_words; i += kCellBlock * 4)
-        *reinterpret_cast<uint4 *>(&smem[i]) = *reinterpret_cast<const uint4 *>(&pal.cell_tab[i]);
+    for (int i = threadIdx.x * 4; i < pal.tab_words; i += kCellBlock * 4) {
+        uint4 v = *reinterpret_cast<const uint4 *>(&pal.cell_tab[i]);
+        // The LDS copy of a marker block (marker word + equal entries) carries the marker TWICE: should the marker's key
+        // be the smallest of the block, it ties with its copy, so that the top-2 network of the nearest-only slots
+        // sees a split cell as a tie just as the top-3 network does.  (Blocks start at multiples of BW words.)
+        if ((i % BW) == 0 && (v.x >> 31)) v.y = v.x;
+        *reinterpret_cast<uint4 *>(&smem[i]) = v;
+    }
     if (MODE == 1) {
         const int n = thr.th_h * thr.tw_pad;
         for (int i = threadIdx.x; i < n; i += kCellBlock) smem[pal.tab_words + i] = thr.mpad[i];
@@ -1120,9 +1126,8 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                             cand4(x, ca[q], g.neg2, m0, m1, m2);  // (a split cell's marker block: three equal entries behind the marker)
                             m1 = ((uint32_t)(m1 ^ m2) < (1u << kLocalBits)) ? m0 : m1;
                         }
-                        // a tie for the nearest entry, or a split cell (its marker word may well have the smallest key: with only
-                        // two keys kept the equal entries behind it do not show as a tie -- test the marker itself)
-                        rare[q] = ((uint32_t)(m0 ^ m1) < (1u << kLocalBits)) | ((int)ca[q].x < 0) | straddle;
+                        // a tie for the nearest entry; also: any split cell (the marker word is staged twice, see above)
+                        rare[q] = ((uint32_t)(m0 ^ m1) < (1u << kLocalBits)) | straddle;
                         sel = m0;
                     } else {
                         int m0, m1, m2;

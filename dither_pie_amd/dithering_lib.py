@@ -829,6 +829,20 @@ class ImageDitherer:
             pal = _device_palette(*prepare_palette(self.palette, self.use_gamma))
             return strategy._run(frames, pal, y0=y0, x0=x0, out=out)
 
+    def prepare(self, device=None, accel=True):
+        """Create the device-side palette now (and, with accel=True, its search accelerator: ~12 ms once) instead of on
+        first use / once enough pixels have been served -- for long-running jobs (a video) that know what is coming.
+        An addition to the reference's interface; nothing is stored on the (picklable) object."""
+        import torch
+        if self.palette is None:
+            raise ValueError("prepare() needs an explicit palette")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(dev):
+            pal = _device_palette(*prepare_palette(self.palette, self.use_gamma))
+            if accel:
+                pal.build_accel()
+        return self
+
     def apply_dithering(self, image):
         """PIL image -> PIL 'RGB' image (dithering_lib.py:1952-1992).  Host <-> device copies go through
         per-thread pinned staging buffers that are reused from call to call (the GUI calls this from worker

@@ -47,6 +47,32 @@ def kmeans_plusplus(sample_u8, K, rs):
     return centers
 
 
+def kmeans_plusplus_device(sample, K, rs):
+    """The same seeding on the device that holds `sample` (uint8 tensor [n,3]): identical draws from `rs` (they do not
+    depend on the data), float64 arithmetic in torch, nothing read back inside the loop (a few hundred small launches,
+    ~3 ms, instead of ~25 ms of numpy on the host).  The prefix sum runs as a device scan, so a pick that falls within
+    rounding of a boundary may differ from the host version's; every rank runs the same code on the same sample.
+    -> float64 tensor [K,3] on that device"""
+    import torch
+    X = sample.reshape(-1, 3).to(torch.float64)
+    n = X.shape[0]
+    n_trials = 2 + int(np.log(K))
+    centers = torch.empty((K, 3), dtype=torch.float64, device=X.device)
+    centers[0] = X[int(rs.choice(n))]
+    closest = ((X - centers[0]) ** 2).sum(dim=1)
+    pot = closest.sum()
+    for c in range(1, K):
+        r = torch.from_numpy(rs.uniform(size=n_trials)).to(X.device) * pot
+        picks = torch.searchsorted(torch.cumsum(closest, 0), r).clamp_(max=n - 1)
+        d = ((X[picks][:, None, :] - X[None, :, :]) ** 2).sum(dim=2)
+        d = torch.minimum(d, closest)
+        pots = d.sum(dim=1)
+        best = torch.argmin(pots)
+        pot, closest = pots[best], d[best]
+        centers[c] = X[picks[best]]
+    return centers
+
+
 def _all_reduce_totals(totals, group):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -74,7 +100,10 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None):
     if not flat.is_contiguous():
         flat = flat.contiguous()
     dev = flat.device
-    centers = torch.as_tensor(np.array(init_centers, dtype=np.float64).reshape(-1, 3)).to(dev).contiguous()
+    if isinstance(init_centers, torch.Tensor):
+        centers = init_centers.to(device=dev, dtype=torch.float64).reshape(-1, 3).contiguous().clone()
+    else:
+        centers = torch.as_tensor(np.array(init_centers, dtype=np.float64).reshape(-1, 3)).to(dev).contiguous()
     K = centers.shape[0]
     totals = torch.zeros(5 * K, dtype=torch.int64, device=dev)
     prev = torch.zeros(4 * K, dtype=torch.int64, device=dev)
@@ -141,9 +170,10 @@ def _lloyd_host(px, init_centers, max_iter, tol, group, step_fn):
     return centers.cpu().numpy(), inertia, n_iter
 
 
-def seed_sample(px, n_total, offset, random_state, group=None):
+def seed_sample(px, n_total, offset, random_state, group=None, as_tensor=False):
     """The pixels at the global indices RandomState(random_state).randint(0, n_total, SAMPLE) (all of them
-    when n_total <= SAMPLE), gathered from the local band [offset, offset+len(px)) and summed across ranks."""
+    when n_total <= SAMPLE), gathered from the local band [offset, offset+len(px)) and summed across ranks.
+    -> uint8 numpy array [n,3] (as_tensor: uint8 tensor on px's device)"""
     import torch
     flat = px.reshape(-1, 3)
     if n_total <= SAMPLE:
@@ -156,6 +186,8 @@ def seed_sample(px, n_total, offset, random_state, group=None):
         sel = torch.from_numpy(idx[local] - offset).to(flat.device)
         buf[torch.from_numpy(np.nonzero(local)[0]).to(flat.device)] = flat[sel].to(torch.int64)
     buf = _all_reduce_totals(buf, group)
+    if as_tensor:
+        return buf.to(torch.uint8)
     return buf.cpu().numpy().astype(np.uint8)
 
 
@@ -163,8 +195,12 @@ def fit_palette(px, K, random_state=42, n_total=None, offset=0, group=None, max_
     """px: uint8 CUDA tensor [...,3] holding this rank's band of the image.  -> (palette list, centers, inertia, n_iter)"""
     n_local = px.numel() // 3
     n_total = n_local if n_total is None else int(n_total)
-    sample = seed_sample(px, n_total, offset, random_state, group)
-    init = kmeans_plusplus(sample, K, np.random.RandomState(random_state))
+    if px.is_cuda:
+        sample = seed_sample(px, n_total, offset, random_state, group, as_tensor=True)
+        init = kmeans_plusplus_device(sample, K, np.random.RandomState(random_state))
+    else:
+        sample = seed_sample(px, n_total, offset, random_state, group)
+        init = kmeans_plusplus(sample, K, np.random.RandomState(random_state))
     centers, inertia, n_iter = lloyd(px, init, max_iter=max_iter, tol=tol, group=group)
     palette = [tuple(int(v) for v in c) for c in centers.astype(int)]
     return palette, centers, inertia, n_iter

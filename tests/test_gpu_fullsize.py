@@ -167,9 +167,12 @@ def test_fit_palette_under_one_rank_nccl_group(be, orc):
     finally:
         dist.destroy_process_group()
     assert pal1 == pal0 and np.array_equal(c1, c0) and i1 == i0 and n1 == n0
-    c_or, i_or, _ = orc.kmeans_lloyd(arr.reshape(-1, 3), kmeans.kmeans_plusplus(
-        kmeans.seed_sample(px, px.shape[0], 0, 42), 16, np.random.RandomState(42)))
+    init = kmeans.kmeans_plusplus_device(kmeans.seed_sample(px, px.shape[0], 0, 42, as_tensor=True), 16, np.random.RandomState(42))
+    c_or, i_or, _ = orc.kmeans_lloyd(arr.reshape(-1, 3), init.cpu().numpy())
     assert np.abs(c_or - c1).max() < 1e-9
+    # the device seeding is the host seeding (same draws, same arithmetic up to the order of the prefix sum)
+    init_h = kmeans.kmeans_plusplus(kmeans.seed_sample(px, px.shape[0], 0, 42), 16, np.random.RandomState(42))
+    assert np.abs(init.cpu().numpy() - init_h).max() == 0.0
 
 
 # ------------------------------------------------------------------------------------------------ C5 / C1 / C2
@@ -268,3 +271,40 @@ def test_frames_over_devices_in_process(d, orc):
     for devs in ([0], [0, 0], [0, 0, 0]):
         got = sharding.process_on_devices(frames, lambda x: v.process_frames(x, it, "regular", 32, 2), devs, chunk=3)
         assert got.shape == ref.shape and torch.equal(got, ref), devs
+
+
+def test_c2_4k_with_and_without_accelerator(d, orc):
+    """BASELINE config 2 through the drop-in API, both ways a palette can serve it: the first frames of a new palette run
+    on the brute-force kernels + fix-up pass (one image never pays for the accelerator), prepare() / enough pixels switch
+    to the LDS cell-table kernels; both give the reference's bytes.  Likewise nearest-only and IGN."""
+    import torch
+    case = _need("bayer8_p256_rnd4k")
+    arr = case_input(orc, case["input"])
+    pal = [tuple(c) for c in orc.palr(256, 7)]
+    x = torch.from_numpy(arr).cuda()
+    pal_b = list(pal)
+    it = d.ImageDitherer(256, d.DitherMode.BAYER, pal_b, False, dict(case["params"]))
+    from dither_pie_amd.dithering_lib import _device_palette, prepare_palette
+    P = _device_palette(*prepare_palette(pal_b, False))
+    if not P._accel_done:
+        assert H(it.apply_dithering_frames(x).cpu().numpy()) == case["h_out"]      # brute force + fix-up
+    it.prepare()
+    assert P._accel_done
+    assert H(it.apply_dithering_frames(x).cpu().numpy()) == case["h_out"]          # cell-table kernel
+    for mode, params in [("none", {}), ("IGN", {"scale": 1.0, "seed": 3}), ("bayer", {"size": "4x4"})]:
+        it2 = d.ImageDitherer(256, d.DitherMode(mode), pal_b, False, params)
+        assert np.array_equal(it2.apply_dithering_frames(x[:700]).cpu().numpy(), orc.apply_dithering(arr[:700], pal, mode, params)), mode
+
+
+def test_accelerator_is_built_once_the_pixels_paid_for_it(d, be, orc):
+    import torch
+    pal = orc.palr(256, 31)
+    P = be.Palette(*orc.prepare_palette(pal, False))
+    thr = be.Thresholds.from_matrix(orc.bayer_matrix("8x8"))
+    assert 1.5e8 < P.accel_break_even_pixels() < 2.5e8 and not P._accel_done
+    x = torch.from_numpy(orc.rnd(2160, 3840, 5)).cuda().unsqueeze(0).repeat(8, 1, 1, 1)   # 66 Mpixel per call
+    ref = orc.apply_dithering(orc.rnd(2160, 3840, 5), pal, "bayer", {"size": "8x8"})
+    for call in range(4):
+        out = be.ordered(x, P, be.MODE_MATRIX, thr=thr)
+        assert P._accel_done == (call >= 2), call      # 66, 133 Mpixel served by brute force; the third call builds it
+        assert np.array_equal(out[call % 8].cpu().numpy(), ref)
