@@ -16,7 +16,14 @@
  *   - images are packed uint8 RGB, HWC, row pitch = 3*w bytes, frames back to back
  *     (frame stride = 3*h*w bytes).  Output has the same layout.
  *   - the library uses the calling thread's current HIP device.
- *   - re-entrant and thread-safe: no mutable global state besides the thread-local error text.
+ *   - no mutable global state besides the thread-local error text and profiling marks.  One call is a SEQUENCE of
+ *     launches that use the caller's workspace in stream order (flag bitmap, progress words): concurrent calls are fine
+ *     on different streams with different workspaces; calls that share a workspace and stream must not be issued from
+ *     two host threads at once (the Python layer serialises them per (device, stream)).  dp_palette_build_accel
+ *     mutates the palette: finish it before another thread launches with that palette.
+ *   - environment variables read by the library are experiment / test switches only (DP_DEBUG_ACCEL, DP_FORCE_TABLE,
+ *     DP_NO_WARP, DP_NO_FAST, DP_FAST_ALL, DP_FAST_DBG, DP_ED_ONE_WG, DP_ED_TEST_GIVEUP, DP_GATE_CHUNK_BYTES;
+ *     INTEGRATION.md lists what each does); production callers set none of them.
  */
 #ifndef DITHERPIE_HIP_H
 #define DITHERPIE_HIP_H
@@ -69,8 +76,9 @@ int dp_palette_info(const dp_palette *p, int *K, int *is_integer, int *n_nodes);
  * palettes (4..1024 colours whose output colours are the palette colours) also per-colour tie codes and an
  * exception list, so that scipy's tie order needs no tree traversal; float palettes (use_gamma, 8..256
  * colours) get the same table over the lut_in-mapped pixel values.  Building it scans all 2^24 colours once
- * (a few milliseconds to tens of milliseconds, synchronous), which pays off from a few megapixels on; without
- * it dp_ordered_u8 runs the brute-force kernels.  dp_palette_build_accel is idempotent and returns DP_OK
+ * (~8-12 ms all told, synchronous), which pays off only after ~4.9e10 / K pixels (190 Mpixel at 256 colours: the
+ * brute-force kernels need ~9 K vector instructions per pixel, the table kernels ~70); without it dp_ordered_u8 runs
+ * the brute-force kernels.  dp_palette_build_accel is idempotent and returns DP_OK
  * without building when the palette does not qualify or the table would not fit LDS.
  * dp_palette_accel_info: size of the LDS table in 32-bit words and the longest exact candidate list; both 0
  * when there is no accelerator. */
