@@ -318,9 +318,10 @@ def main():
             d5.apply_dithering_frames(f5[:n], out=o5[:n])
             done += n
 
-    t5 = timed(video_pass, 3, 1)
+    n5 = 10  # passes between the two barriers: at 8 ranks a pass is ~0.5 ms, the same order as an RCCL barrier
+    t5 = timed(video_pass, n5, 2)
     result["c5_video"] = {"metric": "1080p frames/s, Bayer 4x4 + 16 uniform colours, 1000 frames", "scaling": "strong",
-                          "frames_total": total, "n_gpus": world, "frames_per_s": round(total * 3 / t5, 1),
+                          "frames_total": total, "n_gpus": world, "frames_per_s": round(total * n5 / t5, 1), "passes": n5,
                           "frames_this_rank": hi - lo,
                           "note": "contiguous blocks of 1000/N frames per rank, frames resident in HBM, no collective"}
     del f5, o5
