@@ -48,6 +48,7 @@ namespace {
 constexpr int kMaxTaps = 16;
 constexpr int kRing = 8;    // per-row error ring depth (positions): skew*dy+dx <= 8 for every supported tap set
 constexpr int kMaxWaves = 16;
+constexpr int kRingStride = kRing * 3 + 3;  // words per row of the LDS error ring (see ed_wavefront_kernel)
 
 struct Taps {
     int n;
@@ -132,13 +133,19 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     // G > 1: a frame's bands are spread over G workgroups (few frames in flight: more CUs per frame, fewer waves per
     // CU).  Waves of different workgroups then meet through progress words in global memory instead of s_prog, and the
     // boundary rows are written with agent-scope stores (the workgroups may sit on different XCDs, i.e. L2s).
-    __shared__ float s_ring[kMaxWaves][64][kRing][3];    // errors of the band's own rows (last 8 columns)
+    // errors of the band's own rows (last 8 columns).  A row's ring is padded to 27 words: at step t lane L reads (and
+    // writes) slot (t - skew*L - dx) & 7 of a row, so with the natural stride of 24 words the lanes L, L+8, L+16, ... --
+    // eight of them -- meet in one LDS bank on every ring access (SQ_LDS_BANK_CONFLICT: 72 % of the LDS cycles, the LDS
+    // pipe 80 % busy with 16 waves per CU); 27 makes the accesses conflict-free at skew 2 and two-way at skew 3.
+    __shared__ float s_ring[kMaxWaves][64][kRingStride];
     __shared__ float s_vring[kMaxWaves][2][64][3];       // errors of the two rows above the band (64-column ring)
     __shared__ float s_bout[kMaxWaves][2][kPeriod][3];   // this period's errors of rows 62/63, flushed to global
     __shared__ uint8_t s_lut[256];
     __shared__ volatile uint32_t s_prog[kMaxWaves];      // (band << 16) | (acknowledged column of row 63 + 1024)
-    __shared__ float4 s_pal[DP_MAX_COLORS];              // {x, y, z, out_rgb bits}
-    __shared__ uint32_t s_coarse[4096];                  // candidate lists of the 16^3 cells (palettes of 9..16 colours)
+    // {x, y, z, out_rgb bits} of the palette; palettes of 9..16 colours keep the candidate lists of the 16^3 cells
+    // (4096 words) behind their 16 entries
+    __shared__ float4 s_pal[DP_MAX_COLORS + 16];
+    uint32_t *s_coarse = reinterpret_cast<uint32_t *>(s_pal + 16);
     __shared__ float s_zero[4];                          // the "error" of pixels that do not exist
     typedef const __attribute__((address_space(3))) float lds_float_t;
     const int L = threadIdx.x & 63;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
         for (int k = 0; k < NT; ++k) {
             const int rel = L - taps.dy[k];
             const bool exists = k < taps.n && r - taps.dy[k] >= 0;
-            const float *row = rel >= 0 ? &s_ring[wv][rel & 63][0][0] : &s_vring[wv][(rel + 2) & 1][0][0];
+            const float *row = rel >= 0 ? &s_ring[wv][rel & 63][0] : &s_vring[wv][(rel + 2) & 1][0][0];
             tbase[k] = exists ? (lds_float_t *)row : (lds_float_t *)s_zero;
             tmask[k] = exists ? (rel >= 0 ? (uint32_t)(kRing - 1) : 63u) : 0u;
         }
@@ -330,8 +337,16 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                     // this step's pixel: bytes 3q..3q+2 of the round's twelve
                     const uint32_t pxv = q == 0 ? cur[0] : (q == 1 ? __funnelshift_r(cur[0], cur[1], 24)
                                                                : (q == 2 ? __funnelshift_r(cur[1], cur[2], 16) : (cur[2] >> 8)));
-                    float a0 = (float)s_lut[pxv & 255u], a1 = (float)s_lut[(pxv >> 8) & 255u],
-                          a2 = (float)s_lut[(pxv >> 16) & 255u];
+                    float a0, a1, a2;
+                    if (pal.lut_in) {
+                        a0 = (float)s_lut[pxv & 255u];
+                        a1 = (float)s_lut[(pxv >> 8) & 255u];
+                        a2 = (float)s_lut[(pxv >> 16) & 255u];
+                    } else {  // no gamma table: v_cvt_f32_ubyte0/1/2 straight from the packed pixel
+                        a0 = (float)(pxv & 255u);
+                        a1 = (float)((pxv >> 8) & 255u);
+                        a2 = (float)((pxv >> 16) & 255u);
+                    }
                     // fully unrolled with constant indices: the tap parameters stay in scalar registers instead of
                     // being re-read from the kernel arguments at every step
 #pragma unroll
@@ -360,9 +375,10 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (act) {
-                    s_ring[wv][L][x & (kRing - 1)][0] = e0;
-                    s_ring[wv][L][x & (kRing - 1)][1] = e1;
-                    s_ring[wv][L][x & (kRing - 1)][2] = e2;
+                    float *slot = &s_ring[wv][L][(x & (kRing - 1)) * 3];
+                    slot[0] = e0;
+                    slot[1] = e1;
+                    slot[2] = e2;
                     if (L >= 62) {
                         s_bout[wv][L - 62][i][0] = e0;
                         s_bout[wv][L - 62][i][1] = e1;
@@ -763,6 +779,26 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
             if (list.size() <= 7) {
                 word = (uint32_t)list.size();
                 for (size_t n = 0; n < list.size(); ++n) word |= (uint32_t)list[n] << (4 * (n + 1));
+                // The unused positions name the entry farthest from the cell that is not on the list (K > 8 > list size:
+                // there is one).  The key scan of nearest_color_cells evaluates every position of a group of 4 (or 7)
+                // without a per-position validity test; an entry that is not listed can never be the nearest one, and
+                // if it comes within the margin of the nearest the exact scan (which honours the count) decides.
+                int filler = -1;
+                double far_d = -1.0;
+                for (int j = 0; j < K; ++j) {
+                    if (std::find(list.begin(), list.end(), j) != list.end()) continue;
+                    double near2 = 0.0;
+                    for (int k = 0; k < 3; ++k) {
+                        const double c = pts[3 * j + k];
+                        const double m = std::max(std::max(lo[k] - c, c - (lo[k] + 16.0)), 0.0);
+                        near2 += m * m;
+                    }
+                    if (near2 > far_d) {
+                        far_d = near2;
+                        filler = j;
+                    }
+                }
+                for (size_t n = list.size(); n < 7 && filler >= 0; ++n) word |= (uint32_t)filler << (4 * (n + 1));
             }
             coarse[cell] = word;
         }

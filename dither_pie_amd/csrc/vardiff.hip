@@ -336,6 +336,7 @@ __global__ __launch_bounds__(64) void os_rowserial_kernel(const uint8_t *__restr
 // that the wider rings fit LDS.  All four models have skew 2 (their only upward-left tap is dx=-1, dy=1).
 constexpr int kVWaves = 12;
 constexpr int kVRing = 8;
+constexpr int kVRingStride = kVRing * 4 + 4;
 constexpr int kVPeriod = 16;
 constexpr int kVProgWords = 64;  // progress words per frame when a frame's bands are spread over workgroups (ediff.hip)
 
@@ -357,13 +358,16 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
         return;
     }
     // G > 1: the bands of a frame are spread over G workgroups (few frames in flight), see ed_wavefront_kernel
-    __shared__ float s_ring[kVWaves][64][kVRing][4];
+    // a row's ring padded from 32 to 36 words: with 32, sixteen lanes meet in one LDS bank on every ring access (the
+    // slot a lane touches depends on the lane: (t - 2L - dx) & 7); 36 keeps the 16-byte alignment and is conflict-free
+    __shared__ __align__(16) float s_ring[kVWaves][64][kVRingStride];
     __shared__ float s_vring[kVWaves][2][64][4];
     __shared__ float s_bout[kVWaves][2][kVPeriod][4];
     __shared__ uint8_t s_lut[256];
     __shared__ volatile uint32_t s_prog[kVWaves];
-    __shared__ float4 s_pal[DP_MAX_COLORS];  // {x, y, z, out_rgb bits}
-    __shared__ uint32_t s_coarse[4096];      // candidate lists of the 16^3 cells (palettes of 9..16 colours, ediff.hip)
+    // {x, y, z, out_rgb bits}; palettes of 9..16 colours keep the candidate lists of the 16^3 cells behind their 16 entries (ediff.hip)
+    __shared__ float4 s_pal[DP_MAX_COLORS + 16];
+    uint32_t *s_coarse = reinterpret_cast<uint32_t *>(s_pal + 16);
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                         const int sr = r - dy;
                         if (sxp < 0 || sxp >= w || sr < 0) continue;
                         const int rel = L - dy;
-                        const float *src = rel >= 0 ? &s_ring[wv][rel][sxp & (kVRing - 1)][0]
+                        const float *src = rel >= 0 ? &s_ring[wv][rel][(sxp & (kVRing - 1)) * 4]
                                                     : &s_vring[wv][rel + 2][sxp & 63][0];
                         const float sa = src[3];
                         float wk;
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (act) {
-                    float *dst = &s_ring[wv][L][x & (kVRing - 1)][0];
+                    float *dst = &s_ring[wv][L][(x & (kVRing - 1)) * 4];
                     dst[0] = e0;
                     dst[1] = e1;
                     dst[2] = e2;
