@@ -113,7 +113,9 @@ constexpr int kPeriod = 16;
 // progress words per frame when a frame's bands are spread over several workgroups (the last one: give-up flag)
 constexpr int kEdProgWords = 64;
 
-template <int CAP, int NT>  // NT: tap slots compiled in (taps.n <= NT)
+// NT: tap slots compiled in (taps.n <= NT); EXACT: taps.n == NT, the slots carry no test (the reference's eight tap sets
+// have 3, 4, 6, 7, 10 or 12 taps), so all LDS reads of a step's taps are in flight together
+template <int CAP, int NT, bool EXACT>
 __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
@@ -188,14 +190,15 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int rel = L - taps.dy[k];
-            const bool exists = k < taps.n && r - taps.dy[k] >= 0;
+            const bool exists = (EXACT || k < taps.n) && r - taps.dy[k] >= 0;
             const float *row = rel >= 0 ? &s_ring[wv][rel & 63][0] : &s_vring[wv][(rel + 2) & 1][0][0];
             tbase[k] = exists ? (lds_float_t *)row : (lds_float_t *)s_zero;
             tmask[k] = exists ? (rel >= 0 ? (uint32_t)(kRing - 1) : 63u) : 0u;
         }
         uint32_t pix[12], cur[13], outb[13];  // 16 pixels in flight / being consumed / being produced (raw bytes)
         float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;  // boundary errors in flight (one column per lane)
-        int pb_col = -1;
+        int pb_col = 0;
+        bool pb_valid = false;
 #pragma unroll
         for (int k = 0; k < 12; ++k) pix[k] = 0;
 #pragma unroll
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                 else __hip_atomic_store(&gprog[gw], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // park the boundary errors fetched during the previous period
-            if (pb_col >= 0) {
+            if (pb_valid) {
                 float *dst = &s_vring[wv][L >> 5][pb_col & 63][0];
                 dst[0] = pb0;
                 dst[1] = pb1;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                 }
             }
             // ---- boundary rows of the band above: columns [x0n-14, x0n+18) around lane 0's next period
-            pb_col = -1;
+            pb_valid = false;
             if (band > 0) {
                 const int x0n = t0 + kPeriod;      // lane 0's first column of the next period (wave-uniform)
                 int need = x0n + 18;               // one past the last column fetched
@@ -313,6 +316,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                         pb1 = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pb2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pb_col = col;
+                        pb_valid = true;
+                    } else if (col >= -2 && col < w + 2) {  // the two columns either side of the image: zero errors
+                        pb0 = pb1 = pb2 = 0.f;
+                        pb_col = col;
+                        pb_valid = true;
                     }
                 }
             }
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                 const int i = i4 + q;
                 const int t = t0 + i;
                 const int x = t - skew * L;
-                const bool act = row_ok && x >= 0 && x < w && t >= 0 && t < steps;
+                const bool act = row_ok && (uint32_t)x < (uint32_t)w;  // (0 <= t < steps follows for the rows of the band)
                 float e0 = 0.f, e1 = 0.f, e2 = 0.f;
                 uint32_t cbytes = 0;
                 if (act) {
@@ -349,11 +357,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                     }
                     // fully unrolled with constant indices: the tap parameters stay in scalar registers instead of
                     // being re-read from the kernel arguments at every step
+                    // no column test: the rings hold zero errors for the two columns either side of the image (below)
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
-                        if (k < taps.n) {
-                            const int sxp = x - taps.dx[k];
-                            lds_float_t *src = (uint32_t)sxp < (uint32_t)w ? tbase[k] + (sxp & (int)tmask[k]) * 3 : (lds_float_t *)s_zero;
+                        if (EXACT || k < taps.n) {
+                            lds_float_t *src = tbase[k] + ((x - taps.dx[k]) & (int)tmask[k]) * 3;
                             const float wq = taps.wq[k];
                             a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
                             a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
@@ -374,12 +382,14 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                 // the row two below reads in this very step for a dx=+2 tap)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (act) {
+                // columns -2, -1, w and w+1 are written too, with zero errors (e is 0 without a pixel): a tap that reaches
+                // past either end of a row reads them instead of testing its column
+                if (row_ok && x >= -2 && x < w + 2) {
                     float *slot = &s_ring[wv][L][(x & (kRing - 1)) * 3];
                     slot[0] = e0;
                     slot[1] = e1;
                     slot[2] = e2;
-                    if (L >= 62) {
+                    if (act && L >= 62) {
                         s_bout[wv][L - 62][i][0] = e0;
                         s_bout[wv][L - 62][i][1] = e1;
                         s_bout[wv][L - 62][i][2] = e2;
@@ -859,6 +869,10 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         }
         const int n_bands = (h + 63) / 64;
         int nw = n_bands < kMaxWaves ? n_bands : kMaxWaves;
+        if (const char *e = getenv("DP_ED_WAVES")) {  // experiments: waves per one-workgroup frame
+            const int v = atoi(e);
+            if (v >= 1 && v <= kMaxWaves && v <= n_bands) nw = v;
+        }
         // Few frames in flight: spread each frame's bands over G workgroups so that the batch covers the CUs (one
         // workgroup per frame leaves all but n_frames CUs idle and packs 16 waves onto one CU's four SIMDs) and up to
         // 32 bands of a frame advance together.  The workgroups of a frame meet through progress words in the workspace.
@@ -885,24 +899,28 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         // over partly written frames.
         const int test_giveup = getenv("DP_ED_TEST_GIVEUP") ? 1 : 0;
         const int nw1 = n_bands < kMaxWaves ? n_bands : kMaxWaves;
-#define DP_EDW(C, N)                                                                                                      \
+#define DP_EDW(C, N, X)                                                                                                   \
     do {                                                                                                                 \
-        hipLaunchKernelGGL((ed_wavefront_kernel<C, N>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, t, \
+        hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, t, \
                            reinterpret_cast<float *>(ws), G, gprog, test_giveup);                                        \
         if (G > 1)                                                                                                       \
-            hipLaunchKernelGGL((ed_wavefront_kernel<C, N>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out, h, w, pal, t, \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out, h, w, pal, t, \
                                reinterpret_cast<float *>(ws), 1, gprog, 0);                                              \
     } while (0)
-        const bool big = pal.n_inner > kQueueSmall;
-        if (ntaps <= 4) {
-            if (big) DP_EDW(kQueueLarge, 4); else DP_EDW(kQueueSmall, 4);
-        } else if (ntaps <= 8) {
-            if (big) DP_EDW(kQueueLarge, 8); else DP_EDW(kQueueSmall, 8);
-        } else if (ntaps <= 12) {
-            if (big) DP_EDW(kQueueLarge, 12); else DP_EDW(kQueueSmall, 12);
-        } else {
-            if (big) DP_EDW(kQueueLarge, kMaxTaps); else DP_EDW(kQueueSmall, kMaxTaps);
+#define DP_EDN(N, X)                                                                                                      \
+    do {                                                                                                                 \
+        if (pal.n_inner > kQueueSmall) DP_EDW(kQueueLarge, N, X); else DP_EDW(kQueueSmall, N, X);                         \
+    } while (0)
+        switch (ntaps) {  // the tap counts of the reference's kernels get a test-free instance
+        case 3: DP_EDN(3, true); break;
+        case 4: DP_EDN(4, true); break;
+        case 6: DP_EDN(6, true); break;
+        case 7: DP_EDN(7, true); break;
+        case 10: DP_EDN(10, true); break;
+        case 12: DP_EDN(12, true); break;
+        default: DP_EDN(kMaxTaps, false); break;
         }
+#undef DP_EDN
 #undef DP_EDW
     } else if (n_frames <= 0x7fffffff &&
                ((size_t)9 * w + 4) * sizeof(float) + (pal.K > 64 ? (size_t)pal.K * 16 : 0) + 512 <= (size_t)158 * 1024) {
