@@ -15,6 +15,8 @@
 // kmeans_update_kernel: the centre update of one Lloyd iteration on the device (means, squared shift, sklearn's
 // tolerance test, "assignments unchanged" test, inertia), so that the host loop launches iterations back to back and
 // reads the status back only every few iterations.
+#include <cstdlib>
+
 #include "dp_internal.h"
 
 namespace dp {
@@ -151,6 +153,192 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
     flush();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// kmeans_mfma_kernel (K <= 256): the scores on the matrix cores.  NOT the default: measured slower than the VALU kernel
+// at every K (table below); kept selectable (DP_KMEANS_MFMA=1) with its own parity test as the evidence for that choice.
+//   score[centre i][pixel j] = (|c_i|^2 + BIAS) - 2 c_i . x_j  as two chained v_mfma_f32_32x32x2_f32 per 32 centres x 32
+//   pixels (A = {-2c_r | -2c_g} then {-2c_b | 0}, B = {r | g} then {b | .}, C = |c|^2 + BIAS), so the VALU is left with
+//   the reduction only: 3 instructions per pixel and centre instead of 7.  BIAS = 2^19 + 195076 puts every score into
+//   [2^19, 2^20): one exponent, so the float bits shifted left by 8 still order like the scores and leave room for a
+//   tag -- key = bits << 8 | (block of 32 centres << 4 | register number) (v_lshl_or_b32), the two smallest keys so far
+//   kept by v_med3_i32 + v_min_i32, the two halves of a pixel's scores (lanes j and j + 32) merged at the end through
+//   v_permlane32_swap_b32.  A wave takes 4 tiles of 32 pixels per round so that a block's A and C registers are
+//   loaded once per 128 pixels.
+//   Exactness: a score is within 0.3 of its exact value (coefficients rounded to float32: 0.03 + 0.023; three products
+//   and three accumulations at < 2^20, whatever the matrix core's internal rounding: 6 x 0.0625 / 2 = 0.19, 0.29 if it
+//   truncates); a gap of more than 12 ulp (0.75) between the two smallest proves the float64 order, anything closer is
+//   decided by the float64 scan of kmeans_step_kernel.  The int64 totals are therefore the reference's, bit for bit.
+//   D layout (CDNA3/4 ISA, V_MFMA_F32_32X32X2_F32): lane l, register r holds row (r & 3) + 4 (l >> 5) + 8 (r >> 2) of
+//   column l & 31.
+//   Measured per 8K pass (33 M pixels, MI355X, profiles/experiments/r02_kmeans_mfma_scores.md), VALU / MFMA kernel:
+//   K = 32: 0.233 / 0.307 ms, 64: 0.397 / 0.499, 128: 0.770 / 0.940, 256: 1.557 / 1.974.  The reduction alone is
+//   3 instructions per score, but with the accumulator traffic of the matrix instruction in the same register file the
+//   VALU issues one instruction per ~7 cycles instead of 4.3 (SQ_WAIT_INST_ANY 58 % of the wave cycles), and the
+//   kernel has a larger fixed part (one dword load per pixel and lane pair, LDS atomics from half-filled waves).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr float kScoreBias = 524288.0f + 195076.0f;
+constexpr int kNearKeys = (12 << 8) | 255;
+constexpr int kMfmaMaxK = 256;
+constexpr int kTiles = 4;  // tiles of 32 pixels a wave takes per round
+
+__device__ __forceinline__ int med3_s32(const int a, const int b, const int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <bool SQ>
+__global__ __launch_bounds__(kBlock) void kmeans_mfma_kernel(const uint8_t *__restrict__ px, const int64_t n,
+                                                             const double *__restrict__ centers, const int K,
+                                                             unsigned long long *__restrict__ sums,
+                                                             unsigned long long *__restrict__ counts,
+                                                             unsigned long long *__restrict__ sumsq)
+{
+    constexpr int kW = SQ ? 3 : 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int KB = (K + 31) >> 5, KP = KB * 32;  // blocks of 32 centre rows (rows >= K: a score no pixel reaches)
+    float4 *s_c4 = reinterpret_cast<float4 *>(smem);                                  // KP: {-2c, |c|^2 + BIAS}
+    double *s_c = reinterpret_cast<double *>(s_c4 + KP);                               // 3 KP float64 (near ties)
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 3 * KP);  // [waves][KP][2 or 3]
+    for (int i = threadIdx.x; i < KP; i += kBlock) {
+        if (i < K) {
+            const double c0 = centers[3 * i], c1 = centers[3 * i + 1], c2 = centers[3 * i + 2];
+            s_c[3 * i] = c0;
+            s_c[3 * i + 1] = c1;
+            s_c[3 * i + 2] = c2;
+            s_c4[i] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2),
+                                  (float)(c0 * c0 + c1 * c1 + c2 * c2 + (double)kScoreBias));
+        } else {
+            s_c4[i] = make_float4(0.f, 0.f, 0.f, 1048000.0f);  // above every real score (< 2^19 + 390152), below 2^20
+        }
+    }
+    for (int i = threadIdx.x; i < kWavesPerBlock * KP * kW; i += kBlock) s_acc[i] = 0;
+    __syncthreads();
+    unsigned long long *acc = s_acc + (size_t)(threadIdx.x >> 6) * KP * kW;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+
+    auto flush = [&]() {
+        __syncthreads();
+        for (int i = threadIdx.x; i < K; i += kBlock) {
+            unsigned long long rg = 0, bn = 0, sq = 0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) {
+                unsigned long long *a = s_acc + ((size_t)w * KP + i) * kW;
+                rg += a[0];
+                bn += a[1];
+                a[0] = a[1] = 0;
+                if (SQ) {
+                    sq += a[2];
+                    a[2] = 0;
+                }
+            }
+            if (bn >> 28) {
+                atomicAdd(&sums[3 * i], rg & 0xfffffffull);
+                atomicAdd(&sums[3 * i + 1], rg >> 28);
+                atomicAdd(&sums[3 * i + 2], bn & 0xfffffffull);
+                atomicAdd(&counts[i], bn >> 28);
+                if (SQ) atomicAdd(&sumsq[i], sq);
+            }
+        }
+        __syncthreads();
+    };
+    // one pixel per lane pair: lanes j and j + 32 load the same (unaligned) dword {r, g, b, next r}
+    auto load_px = [&](const int64_t p) -> uint32_t {
+        if (p + 1 < n) {
+            uint32_t v;
+            __builtin_memcpy(&v, px + p * 3, 4);
+            return v;
+        }
+        if (p < n) return (uint32_t)px[p * 3] | ((uint32_t)px[p * 3 + 1] << 8) | ((uint32_t)px[p * 3 + 2] << 16);
+        return 0u;
+    };
+    constexpr int kRoundPx = kWavesPerBlock * kTiles * 32;  // pixels a workgroup takes per round
+    uint32_t since_flush = 0;
+    const int64_t bstride = (int64_t)gridDim.x * kRoundPx;
+    const int64_t lane_px = (threadIdx.x >> 6) * (kTiles * 32) + j;
+    uint32_t wn[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) wn[t] = load_px((int64_t)blockIdx.x * kRoundPx + lane_px + 32 * t);
+    // (block-uniform bounds: every wave of a workgroup runs the same number of rounds, for the flush barriers)
+    for (int64_t b0 = (int64_t)blockIdx.x * kRoundPx; b0 < n; b0 += bstride) {
+        const int64_t p0 = b0 + lane_px;
+        uint32_t w[kTiles];
+        float x1[kTiles], x2[kTiles];
+        int m0[kTiles], m1[kTiles];
+        const uint32_t sh = 8u * (uint32_t)h;
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            w[t] = wn[t];
+            wn[t] = load_px(p0 + bstride + 32 * t);  // the next round's pixels, in flight during this round
+            x1[t] = (float)((w[t] >> sh) & 255u);
+            x2[t] = (float)((w[t] >> 16) & 255u);
+            m0[t] = m1[t] = 0x7fffffff;
+        }
+        for (int blk = 0; blk < KB; ++blk) {
+            const float4 cj = s_c4[32 * blk + j];
+            const float a1 = h ? cj.y : cj.x, a2 = h ? 0.0f : cj.z;
+            floatx16 cbias;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cbias[r] = s_c4[32 * blk + (r & 3) + 4 * h + 8 * (r >> 2)].w;
+            const uint32_t tag0 = (uint32_t)blk << 4;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) {
+                floatx16 d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x1[t], cbias, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, x2[t], d, 0, 0, 0);
+                int a = m0[t], b = m1[t];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = (int)((__float_as_uint(d[r]) << 8) | (tag0 + (uint32_t)r));
+                    b = med3_s32(a, b, key);
+                    a = min(a, key);
+                }
+                m0[t] = a;
+                m1[t] = b;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            // lanes 0..31 hold the rows with h = 0, lanes 32..63 those with h = 1: after the swap x[0] is the lower half's
+            // value in every lane and x[1] the upper half's
+            const auto sa = __builtin_amdgcn_permlane32_swap((unsigned)m0[t], (unsigned)m0[t], false, false);
+            const auto sb = __builtin_amdgcn_permlane32_swap((unsigned)m1[t], (unsigned)m1[t], false, false);
+            const int a_lo = (int)sa[0], a_hi = (int)sa[1], b_lo = (int)sb[0], b_hi = (int)sb[1];
+            const int k0 = min(a_lo, a_hi), k1 = min(min(max(a_lo, a_hi), b_lo), b_hi);
+            const int hh = a_hi < a_lo ? 1 : 0;  // which half owns the smallest (equal keys: the margin test below)
+            const int r = k0 & 15, blk = (k0 >> 4) & 15;
+            int lab = (r & 3) + 4 * hh + 8 * (r >> 2) + 32 * blk;
+            const int64_t p = p0 + 32 * t;
+            const uint32_t cr = w[t] & 255u, cg = (w[t] >> 8) & 255u, cbl = (w[t] >> 16) & 255u;
+            if (p < n) {
+                if (k1 - k0 <= kNearKeys || lab >= K) {  // a near tie (or K == 1): float64, lowest index on exact ties
+                    const double x0 = (double)cr, x1d = (double)cg, x2d = (double)cbl;
+                    double bd = __longlong_as_double(0x7ff0000000000000LL);
+                    for (int q = 0; q < K; ++q) {
+                        const double a = __dsub_rn(x0, s_c[3 * q]), c = __dsub_rn(x1d, s_c[3 * q + 1]), e = __dsub_rn(x2d, s_c[3 * q + 2]);
+                        const double d = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(c, c)), __dmul_rn(e, e));
+                        if (d < bd) {
+                            bd = d;
+                            lab = q;
+                        }
+                    }
+                }
+                // lanes j add r | g << 28, lanes j + 32 add b | count << 28 (and nobody else touches this pixel)
+                const unsigned long long v = h ? ((unsigned long long)cbl | (1ull << 28)) : ((unsigned long long)cr | ((unsigned long long)cg << 28));
+                atomicAdd(&acc[lab * kW + h], v);
+                if (SQ && h == 0) atomicAdd(&acc[lab * kW + 2], (unsigned long long)(cr * cr + cg * cg + cbl * cbl));
+            }
+        }
+        since_flush += kRoundPx;
+        if (since_flush >= (uint32_t)(kGroupsPerFlush * 4)) {  // block-uniform
+            flush();
+            since_flush = 0;
+        }
+    }
+    flush();
+}
+
 // status words (float64) of the device-side Lloyd loop
 enum { kStDone = 0, kStIter = 1, kStInertia = 2, kStShift = 3, kStTolAbs = 4, kStQTotal = 5, kStWords = 8 };
 
@@ -268,6 +456,25 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
     if (smem > 64 * 1024) {
         set_error("dp_kmeans_step_u8: too many clusters for the LDS accumulators");
         return DP_EUNSUPPORTED;
+    }
+    const bool want_mfma = getenv("DP_KMEANS_MFMA") != nullptr;  // measured slower at every K: opt-in only
+    if (want_mfma && K <= kMfmaMaxK) {
+        // scores on the matrix cores: a wave takes 128 pixels per round, 4 workgroups of 4 waves per CU
+        constexpr int kRoundPx = kWavesPerBlock * kTiles * 32;
+        const int KP = ((K + 31) / 32) * 32;
+        const size_t msmem = sizeof(float4) * KP + sizeof(double) * 3 * KP + sizeof(unsigned long long) * kWavesPerBlock * KP * kw;
+        const int64_t rounds = (n + kRoundPx - 1) / kRoundPx;
+        const unsigned mblocks = (unsigned)std::min<int64_t>(rounds, (int64_t)cus * 4);
+        if (sumsq)
+            hipLaunchKernelGGL(kmeans_mfma_kernel<true>, dim3(mblocks), dim3(kBlock), msmem, s, px, n, centers, K,
+                               reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
+                               reinterpret_cast<unsigned long long *>(sumsq));
+        else
+            hipLaunchKernelGGL(kmeans_mfma_kernel<false>, dim3(mblocks), dim3(kBlock), msmem, s, px, n, centers, K,
+                               reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr);
+        prof_end(pm, s);
+        DP_HIP(hipGetLastError());
+        return DP_OK;
     }
     if (sumsq)
         hipLaunchKernelGGL(kmeans_step_kernel<true>, dim3(blocks), dim3(kBlock), smem, s, px, n, centers, K,

@@ -143,6 +143,26 @@ def test_c4_kmeans_totals_over_all_8k_pixels(be, orc):
     assert torch.equal(acc_s, s) and torch.equal(acc_n, n)
 
 
+@pytest.mark.parametrize("K", [1, 5, 32, 33, 100, 256])
+def test_kmeans_matrix_core_kernel_totals(be, orc, monkeypatch, K):
+    """The opt-in matrix-core Lloyd pass (kmeans_mfma_kernel, DP_KMEANS_MFMA=1; measured slower, kept as evidence):
+    same integer totals as the oracle and as the product kernel, ragged pixel count, centres on and off the lattice."""
+    import torch
+    arr = orc.rnd(517, 1031, 7 + K)
+    flat = arr.reshape(-1, 3)[:517 * 1031 - 3]
+    px = torch.from_numpy(np.ascontiguousarray(flat)).cuda()
+    rs = np.random.RandomState(K)
+    centers = rs.rand(K, 3) * 255.0
+    centers[: K // 2] = np.round(centers[: K // 2])  # integer centres: exact ties between clusters do occur
+    s_ref, n_ref, _ = orc.kmeans_step(flat, centers)
+    monkeypatch.setenv("DP_KMEANS_MFMA", "1")
+    s, n, q = be.kmeans_step(px, torch.from_numpy(centers))
+    monkeypatch.delenv("DP_KMEANS_MFMA")
+    s2, n2, q2 = be.kmeans_step(px, torch.from_numpy(centers))
+    assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(n.cpu().numpy(), n_ref)
+    assert torch.equal(s, s2) and torch.equal(n, n2) and torch.equal(q, q2)
+
+
 def test_fit_palette_under_one_rank_nccl_group(be, orc):
     """kmeans.fit_palette with torch.distributed initialised on the RCCL backend (world size 1): the all-reduce of the
     integer totals runs through RCCL on device tensors produced by the real kernel, and changes nothing."""
