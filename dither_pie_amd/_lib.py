@@ -56,6 +56,7 @@ _SIGS = {
     "dp_variance_gate_u8": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _i, _vp, _sz, _vp]),
     "dp_kmeans_step_u8": (_i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _vp]),
     "dp_kmeans_update": (_i, [_vp, _vp, _vp, _vp, _i, C.c_double, _i, _vp]),
+    "dp_kmeans_plusplus_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "dp_resize_nearest_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "dp_profile_enable": (_i, [_i]),
     "dp_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),

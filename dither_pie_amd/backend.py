@@ -331,6 +331,29 @@ def kmeans_update(totals, centers, prev, status, tol, max_iter):
                                            centers.shape[0], float(tol), int(max_iter), _stream()))
 
 
+KMEANS_PP_MAX_SAMPLE = 16384  # points dp_kmeans_plusplus_u8 holds in LDS
+
+
+def kmeans_plusplus(sample, K, first, uniforms):
+    """sklearn's k-means++ seeding on the device (dp_kmeans_plusplus_u8): `sample` uint8 [n,3] on the GPU, `first` the
+    first centre's index, `uniforms` float64 numpy [(K-1), n_trials] drawn by the caller.  -> (ids int32 [K], centers
+    float64 [K,3]) on the device, nothing read back."""
+    s = sample.reshape(-1, 3)
+    if not s.is_contiguous():
+        s = s.contiguous()
+    n = s.shape[0]
+    u = torch.as_tensor(np.ascontiguousarray(uniforms, dtype=np.float64)).reshape(-1).to(s.device)
+    n_trials = int(uniforms.shape[1]) if K > 1 else 1
+    if K == 1:
+        u = torch.zeros(1, dtype=torch.float64, device=s.device)
+    ids = torch.empty(K, dtype=torch.int32, device=s.device)
+    centers = torch.empty((K, 3), dtype=torch.float64, device=s.device)
+    with torch.cuda.device(s.device):
+        check(_lib.load().dp_kmeans_plusplus_u8(s.data_ptr(), n, int(K), int(first), u.data_ptr(), n_trials, ids.data_ptr(),
+                                                centers.data_ptr(), _stream()))
+    return ids, centers
+
+
 def resize_nearest(frames, oh, ow):
     f = _frames(frames)
     n, h, w, _ = f.shape

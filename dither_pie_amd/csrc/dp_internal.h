@@ -185,6 +185,8 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
 size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w);
 int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int K, int64_t *sums, int64_t *counts,
                        int64_t *sumsq, hipStream_t s);
+int launch_kmeans_pp(const uint8_t *sample, int n, int K, int first, const double *uniforms, int n_trials, int *out_ids,
+                     double *out_centers, hipStream_t s);
 int launch_kmeans_update(const int64_t *totals, double *centers, int64_t *prev, double *status, int K, double tol, int max_iter,
                          hipStream_t s);
 int launch_variance_gate(const uint8_t *in, uint8_t *gate, int64_t n_frames, int h, int w, const PalDev &pal, float thr,

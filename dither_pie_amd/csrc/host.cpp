@@ -764,6 +764,17 @@ int dp_kmeans_update(const int64_t *totals_dev, double *centers_dev, int64_t *pr
     return launch_kmeans_update(totals_dev, centers_dev, prev_dev, status_dev, K, tol, max_iter, (hipStream_t)stream);
 }
 
+int dp_kmeans_plusplus_u8(const uint8_t *sample_dev, int n, int K, int first, const double *uniforms_dev, int n_trials,
+                          int32_t *ids_dev, double *centers_dev, void *stream)
+{
+    if (!sample_dev || !uniforms_dev || !ids_dev || !centers_dev || n < 1 || K < 1 || K > n || first < 0 || first >= n ||
+        n_trials < 1) {
+        set_error("dp_kmeans_plusplus_u8: bad argument");
+        return DP_EINVAL;
+    }
+    return launch_kmeans_pp(sample_dev, n, K, first, uniforms_dev, n_trials, ids_dev, centers_dev, (hipStream_t)stream);
+}
+
 int dp_resize_nearest_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int oh,
                          int ow, void *stream)
 {

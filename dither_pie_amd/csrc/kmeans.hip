@@ -26,7 +26,19 @@ constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kGroupsPerFlush = 1 << 14;  // groups of 4 pixels a workgroup accumulates before it flushes (2^16 pixels)
 
-template <bool SQ>
+__device__ __forceinline__ int med3_s32(const int a, const int b, const int c)
+{
+    return max(min(a, b), min(max(a, b), c));  // selected as one v_med3_i32
+}
+
+// KEYS (K <= 256): the scores carry a bias of 2^19 + 195076, which puts every one of them into [2^19, 2^20) -- one
+// exponent, so the float bits shifted left by 8 order like the scores and leave room for the centre's index:
+// key = bits << 8 | j (v_lshl_or_b32), the two smallest keys by v_med3_i32 + v_min_i32 -- 6 instructions per pixel and
+// centre instead of 7 (no compare + select for the label).  The bias costs precision (scores within 0.15 of their exact
+// value instead of 0.11): the float64 scan decides below a gap of 6 ulp (0.375).
+constexpr float kScoreBias = 524288.0f + 195076.0f;
+
+template <bool SQ, bool KEYS>
 __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__restrict__ px, const int64_t n,
                                                              const double *__restrict__ centers, const int K,
                                                              unsigned long long *__restrict__ sums,
@@ -43,7 +55,8 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
         s_c[3 * i] = c0;
         s_c[3 * i + 1] = c1;
         s_c[3 * i + 2] = c2;
-        s_c4[i] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2), (float)(c0 * c0 + c1 * c1 + c2 * c2));
+        s_c4[i] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2),
+                              (float)(c0 * c0 + c1 * c1 + c2 * c2 + (KEYS ? (double)kScoreBias : 0.0)));
     }
     for (int i = threadIdx.x; i < kWavesPerBlock * K * kW; i += kBlock) s_acc[i] = 0;
     __syncthreads();
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
         }
         // centre loop outermost: each centre is read from LDS once for the lane's four pixels
         float fr[4], fg[4], fb[4], b0[4], b1[4];
-        int best[4];
+        int best[4], k0[4], k1[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             fr[q] = (float)(v[q] & 255u);
@@ -105,6 +118,7 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
             fb[q] = (float)(v[q] >> 16);
             b0[q] = b1[q] = __int_as_float(0x7f800000);
             best[q] = 0;
+            k0[q] = k1[q] = 0x7fffffff;
         }
 #pragma unroll 4
         for (int j = 0; j < K; ++j) {
@@ -112,21 +126,31 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float t = __fmaf_rn(fb[q], c.z, __fmaf_rn(fg[q], c.y, __fmaf_rn(fr[q], c.x, c.w)));
-                best[q] = t < b0[q] ? j : best[q];
-                b1[q] = __builtin_amdgcn_fmed3f(b0[q], b1[q], t);  // second smallest of {b0 <= b1, t}
-                b0[q] = fminf(b0[q], t);
+                if (KEYS) {
+                    const int key = (int)((__float_as_uint(t) << 8) + (uint32_t)j);  // one v_lshl_add_u32
+                    k1[q] = med3_s32(k0[q], k1[q], key);  // second smallest of {k0 <= k1, key}
+                    k0[q] = min(k0[q], key);
+                } else {
+                    best[q] = t < b0[q] ? j : best[q];
+                    b1[q] = __builtin_amdgcn_fmed3f(b0[q], b1[q], t);  // second smallest of {b0 <= b1, t}
+                    b0[q] = fminf(b0[q], t);
+                }
             }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q < cnt) {
                 const uint32_t r = v[q] & 255u, g = (v[q] >> 8) & 255u, b = v[q] >> 16;
-                int lab = best[q];
+                int lab = KEYS ? (k0[q] & 255) : best[q];
                 // float32 evaluation of |c|^2 - 2 c.x: the rounded coefficients are off by <= 2^-24 relative (|2c| <= 510,
                 // x <= 255: 0.008 per term), three fma roundings of values below 2^19.6 (<= 0.024 each), |c|^2 by 0.012:
                 // each score is within 0.11 of its exact value, so a gap of more than 0.25 (+ 1e-6 relative) settles the
                 // order; anything closer -- and K == 1 leaves b1 infinite -- is decided in float64 as the reference does
-                if (!(b1[q] - b0[q] > 0.25f + 1e-6f * fabsf(b1[q]))) {
+                // KEYS: values below 2^20 (three roundings <= 0.031 each, the biased |c|^2 by 0.031, coefficients 0.024:
+                // within 0.15), keys 256 apart per ulp of 0.0625: a gap of more than 6 ulp settles the order (K == 1
+                // leaves k1 at its initial value, far away, and the label is 0 either way)
+                const bool near_tie = KEYS ? (k1[q] - k0[q] <= (6 << 8) + 255) : !(b1[q] - b0[q] > 0.25f + 1e-6f * fabsf(b1[q]));
+                if (near_tie) {
                     const double x0 = (double)r, x1 = (double)g, x2 = (double)b;
                     double bd = __longlong_as_double(0x7ff0000000000000LL);
                     for (int j = 0; j < K; ++j) {
@@ -177,17 +201,9 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
 //   kernel has a larger fixed part (one dword load per pixel and lane pair, LDS atomics from half-filled waves).
 // ---------------------------------------------------------------------------------------------------------------
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-constexpr float kScoreBias = 524288.0f + 195076.0f;
 constexpr int kNearKeys = (12 << 8) | 255;
 constexpr int kMfmaMaxK = 256;
 constexpr int kTiles = 4;  // tiles of 32 pixels a wave takes per round
-
-__device__ __forceinline__ int med3_s32(const int a, const int b, const int c)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 
 template <bool SQ>
 __global__ __launch_bounds__(kBlock) void kmeans_mfma_kernel(const uint8_t *__restrict__ px, const int64_t n,
@@ -436,14 +452,152 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const long long *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// kmeans_pp_kernel: sklearn's _kmeans_plusplus (greedy k-means++ with 2 + int(ln K) local trials) on the seeding sample,
+// one workgroup.  The sample points are uint8 triples and every centre is one of them, so all squared distances, their
+// prefix sums and the candidates' potentials are integers below 2^53: the float64 arithmetic of the reference
+// (euclidean_distances, stable_cumsum, the dot with the sample weights) is exact and independent of summation order,
+// and only `uniform * potential` rounds -- once, in float64, here as there.  The uniforms do not depend on the data:
+// the host draws them from numpy's RandomState in the order sklearn would.
+// Per centre: block prefix sum of the closest distances, the trials' picks (first index whose prefix sum >= value:
+// np.searchsorted, clipped to n - 1), the potentials of the candidates, the first smallest one (np.argmin).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kPpThreads = 1024;
+constexpr int kPpMaxN = 16384;   // points held in LDS (the reference's sample is 10 000)
+constexpr int kPpPer = kPpMaxN / kPpThreads;
+constexpr int kPpMaxTrials = 8;  // 2 + int(ln 1024) = 8
+
+__global__ __launch_bounds__(kPpThreads) void kmeans_pp_kernel(const uint8_t *__restrict__ sample, const int n, const int K,
+                                                                const int first, const double *__restrict__ uniforms,
+                                                                const int n_trials, int *__restrict__ out_ids,
+                                                                double *__restrict__ out_centers)
+{
+    __shared__ uint32_t s_pt[kPpMaxN];
+    __shared__ unsigned long long s_scan[kPpThreads];
+    __shared__ unsigned long long s_red[kPpMaxTrials][kPpThreads / 64];
+    __shared__ int s_pick[kPpMaxTrials];
+    __shared__ int s_best;
+    const int t = threadIdx.x;
+    for (int i = t; i < n; i += kPpThreads) s_pt[i] = (uint32_t)sample[3 * i] | ((uint32_t)sample[3 * i + 1] << 8) | ((uint32_t)sample[3 * i + 2] << 16);
+    __syncthreads();
+    auto dist2 = [](const uint32_t a, const uint32_t b) -> uint32_t {
+        const int d0 = (int)(a & 255u) - (int)(b & 255u), d1 = (int)((a >> 8) & 255u) - (int)((b >> 8) & 255u),
+                  d2 = (int)(a >> 16) - (int)(b >> 16);
+        return (uint32_t)(d0 * d0 + d1 * d1 + d2 * d2);
+    };
+    // thread t owns the points [lo, hi): contiguous, so that a prefix sum over threads is the prefix sum over points
+    const int per = (n + kPpThreads - 1) / kPpThreads;
+    const int lo = min(n, t * per), hi = min(n, lo + per);
+    uint32_t closest[kPpPer];
+    const uint32_t c0 = s_pt[first];
+#pragma unroll
+    for (int e = 0; e < kPpPer; ++e) closest[e] = lo + e < hi ? dist2(s_pt[lo + e], c0) : 0u;
+    if (t == 0) {
+        out_ids[0] = first;
+        out_centers[0] = (double)(c0 & 255u);
+        out_centers[1] = (double)((c0 >> 8) & 255u);
+        out_centers[2] = (double)(c0 >> 16);
+    }
+    for (int c = 1; c < K; ++c) {
+        // inclusive prefix sums over the threads' own totals (Hillis-Steele in LDS)
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int e = 0; e < kPpPer; ++e) mine += closest[e];
+        s_scan[t] = mine;
+        if (t < kPpMaxTrials) s_pick[t] = n - 1;  // np.clip(picks, None, n - 1): a value above the total
+        __syncthreads();
+        for (int off = 1; off < kPpThreads; off <<= 1) {
+            const unsigned long long add = t >= off ? s_scan[t - off] : 0ull;
+            __syncthreads();
+            s_scan[t] += add;
+            __syncthreads();
+        }
+        const unsigned long long incl = s_scan[t], excl = incl - mine;
+        const double pot = (double)s_scan[kPpThreads - 1];
+        // the trials' picks: the first point whose inclusive prefix sum is >= value lies in exactly one thread's range
+        for (int q = 0; q < n_trials; ++q) {
+            const double rv = __dmul_rn(uniforms[(size_t)(c - 1) * n_trials + q], pot);
+            if (lo < hi && !((double)excl >= rv && t > 0) && (double)incl >= rv) {
+                unsigned long long run = excl;
+#pragma unroll
+                for (int e = 0; e < kPpPer; ++e) {
+                    if (lo + e < hi) {
+                        run += closest[e];
+                        if ((double)run >= rv) {
+                            atomicMin(&s_pick[q], lo + e);
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // potentials of the candidates: sum over all points of min(closest, distance to the candidate)
+        uint32_t cand[kPpMaxTrials];
+        unsigned long long part[kPpMaxTrials];
+#pragma unroll
+        for (int q = 0; q < kPpMaxTrials; ++q) {
+            cand[q] = q < n_trials ? s_pt[s_pick[q]] : 0u;
+            part[q] = 0;
+        }
+#pragma unroll
+        for (int e = 0; e < kPpPer; ++e) {
+            if (lo + e < hi) {
+                const uint32_t x = s_pt[lo + e];
+#pragma unroll
+                for (int q = 0; q < kPpMaxTrials; ++q)
+                    if (q < n_trials) part[q] += min(closest[e], dist2(x, cand[q]));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kPpMaxTrials; ++q) {
+            if (q < n_trials) {
+                unsigned long long v = part[q];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+                if ((t & 63) == 0) s_red[q][t >> 6] = v;
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            int best = 0;
+            unsigned long long best_pot = ~0ull;
+            for (int q = 0; q < n_trials; ++q) {
+                unsigned long long v = 0;
+                for (int w = 0; w < kPpThreads / 64; ++w) v += s_red[q][w];
+                if (v < best_pot) {  // np.argmin: the first smallest
+                    best_pot = v;
+                    best = q;
+                }
+            }
+            s_best = s_pick[best];
+            out_ids[c] = s_pick[best];
+            const uint32_t b = s_pt[s_pick[best]];
+            out_centers[3 * c] = (double)(b & 255u);
+            out_centers[3 * c + 1] = (double)((b >> 8) & 255u);
+            out_centers[3 * c + 2] = (double)(b >> 16);
+        }
+        __syncthreads();
+        const uint32_t nb = s_pt[s_best];
+#pragma unroll
+        for (int e = 0; e < kPpPer; ++e)
+            if (lo + e < hi) closest[e] = min(closest[e], dist2(s_pt[lo + e], nb));
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int K, int64_t *sums, int64_t *counts,
                        int64_t *sumsq, hipStream_t s)
 {
-    DP_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * 3 * (size_t)K, s));
-    DP_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)K, s));
-    if (sumsq) DP_HIP(hipMemsetAsync(sumsq, 0, sizeof(int64_t) * (size_t)K, s));
+    if (counts == sums + 3 * (size_t)K && (sumsq == nullptr || sumsq == counts + K)) {
+        // one planar totals buffer (the device-side Lloyd loop, dp_kmeans_update): one memset instead of three launches
+        DP_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * (size_t)K * (sumsq ? 5 : 4), s));
+    } else {
+        DP_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * 3 * (size_t)K, s));
+        DP_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)K, s));
+        if (sumsq) DP_HIP(hipMemsetAsync(sumsq, 0, sizeof(int64_t) * (size_t)K, s));
+    }
     if (n == 0) return DP_OK;
     const int64_t groups = (n + 3) / 4;
     int cus = 0, dev = 0;
@@ -476,13 +630,17 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
         DP_HIP(hipGetLastError());
         return DP_OK;
     }
-    if (sumsq)
-        hipLaunchKernelGGL(kmeans_step_kernel<true>, dim3(blocks), dim3(kBlock), smem, s, px, n, centers, K,
-                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
-                           reinterpret_cast<unsigned long long *>(sumsq));
-    else
-        hipLaunchKernelGGL(kmeans_step_kernel<false>, dim3(blocks), dim3(kBlock), smem, s, px, n, centers, K,
-                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr);
+    const bool keys = K <= 256 && !getenv("DP_KMEANS_NO_KEYS");
+#define DP_KM(SQF, KF)                                                                                                    \
+    hipLaunchKernelGGL((kmeans_step_kernel<SQF, KF>), dim3(blocks), dim3(kBlock), smem, s, px, n, centers, K,            \
+                       reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),   \
+                       reinterpret_cast<unsigned long long *>(sumsq))
+    if (sumsq) {
+        if (keys) DP_KM(true, true); else DP_KM(true, false);
+    } else {
+        if (keys) DP_KM(false, true); else DP_KM(false, false);
+    }
+#undef DP_KM
     prof_end(pm, s);
     DP_HIP(hipGetLastError());
     return DP_OK;
@@ -497,4 +655,19 @@ int launch_kmeans_update(const int64_t *totals, double *centers, int64_t *prev, 
     return DP_OK;
 }
 
+}  // namespace dp
+
+namespace dp {
+int launch_kmeans_pp(const uint8_t *sample, int n, int K, int first, const double *uniforms, int n_trials, int *out_ids,
+                     double *out_centers, hipStream_t s)
+{
+    if (n > kPpMaxN || n_trials > kPpMaxTrials) {
+        set_error("dp_kmeans_plusplus_u8: sample larger than 16384 points (or more than 8 local trials)");
+        return DP_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(kmeans_pp_kernel, dim3(1), dim3(kPpThreads), 0, s, sample, n, K, first, uniforms, n_trials, out_ids,
+                       out_centers);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
 }  // namespace dp

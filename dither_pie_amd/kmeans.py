@@ -49,14 +49,19 @@ def kmeans_plusplus(sample_u8, K, rs):
 
 def kmeans_plusplus_device(sample, K, rs):
     """The same seeding on the device that holds `sample` (uint8 tensor [n,3]): identical draws from `rs` (they do not
-    depend on the data), float64 arithmetic in torch, nothing read back inside the loop (a few hundred small launches,
-    ~3 ms, instead of ~25 ms of numpy on the host).  The prefix sum runs as a device scan, so a pick that falls within
-    rounding of a boundary may differ from the host version's; every rank runs the same code on the same sample.
+    depend on the data), one launch of dp_kmeans_plusplus_u8 (one workgroup, the sample in LDS, ~0.2 ms instead of
+    ~25 ms of numpy on the host), nothing read back.  All distances, prefix sums and potentials are integers below 2^53,
+    so the picks are the host version's.  Samples above the kernel's LDS capacity run the same steps as torch ops.
     -> float64 tensor [K,3] on that device"""
     import torch
-    X = sample.reshape(-1, 3).to(torch.float64)
-    n = X.shape[0]
+    from . import backend
+    n = sample.reshape(-1, 3).shape[0]
     n_trials = 2 + int(np.log(K))
+    if n <= backend.KMEANS_PP_MAX_SAMPLE and n_trials <= 8 and K <= n:
+        first = int(rs.choice(n))
+        uniforms = np.stack([rs.uniform(size=n_trials) for _ in range(1, K)]) if K > 1 else np.zeros((0, n_trials))
+        return backend.kmeans_plusplus(sample, K, first, uniforms)[1]
+    X = sample.reshape(-1, 3).to(torch.float64)
     centers = torch.empty((K, 3), dtype=torch.float64, device=X.device)
     centers[0] = X[int(rs.choice(n))]
     closest = ((X - centers[0]) ** 2).sum(dim=1)

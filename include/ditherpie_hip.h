@@ -185,6 +185,18 @@ int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_de
 int dp_kmeans_update(const int64_t *totals_dev, double *centers_dev, int64_t *prev_dev, double *status_dev, int K,
                      double tol, int max_iter, void *stream);
 
+/* k-means++ seeding (sklearn.cluster._kmeans._kmeans_plusplus, reached from KMeans.fit as
+ * dithering_lib.py:1854-1856 calls it: greedy, n_trials = 2 + int(ln K) local trials per centre) on a SAMPLE of the
+ * pixels held on the device, one workgroup, nothing read back inside the loop.
+ *   sample_dev    n packed uint8 RGB points, n <= 16384 (DP_EUNSUPPORTED above: seed on the host)
+ *   first         index of the first centre (the host's RandomState.choice(n))
+ *   uniforms_dev  (K-1) * n_trials float64 in [0,1): RandomState.uniform(size=n_trials) per centre, in order (they do
+ *                 not depend on the data)
+ *   ids_dev       out: K int32 sample indices of the centres;  centers_dev  out: K*3 float64 (the points themselves)
+ * All distances and potentials are integers below 2^53, so the reference's float64 arithmetic is reproduced exactly. */
+int dp_kmeans_plusplus_u8(const uint8_t *sample_dev, int n, int K, int first, const double *uniforms_dev, int n_trials,
+                          int32_t *ids_dev, double *centers_dev, void *stream);
+
 /* NEAREST resize of packed RGB frames (pixelize_regular / final upscale,
  * video_processor.py:563-577, 393-420), bit-identical to Pillow's Image.resize(..., NEAREST): source indices
  * come from Pillow's double-accumulated coordinate tables. */

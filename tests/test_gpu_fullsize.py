@@ -163,6 +163,22 @@ def test_kmeans_matrix_core_kernel_totals(be, orc, monkeypatch, K):
     assert torch.equal(s, s2) and torch.equal(n, n2) and torch.equal(q, q2)
 
 
+@pytest.mark.parametrize("n,K,seed", [(10000, 32, 42), (10000, 256, 1), (9999, 16, 7), (517, 8, 3), (64, 64, 5), (40, 5, 11), (16384, 2, 2), (3, 1, 0)])
+def test_kmeans_plusplus_kernel_equals_host_seeding(be, n, K, seed):
+    """dp_kmeans_plusplus_u8 (one workgroup, integer arithmetic) picks the centres sklearn's float64 code picks: compared
+    with the numpy statement of _kmeans_plusplus that the sklearn fixtures pin (tests/test_oracle_golden.py), on random
+    samples, on samples full of duplicates (zero distances, equal potentials) and at the LDS capacity."""
+    import torch
+    from dither_pie_amd import kmeans
+    rs = np.random.RandomState(seed)
+    sample = rs.randint(0, 256, (n, 3)).astype(np.uint8)
+    if n in (64, 40):
+        sample = sample[rs.randint(0, max(K, 6), n)]  # few distinct colours: candidates at distance 0, tied potentials
+    host = kmeans.kmeans_plusplus(sample, K, np.random.RandomState(seed))
+    dev = kmeans.kmeans_plusplus_device(torch.from_numpy(sample).cuda(), K, np.random.RandomState(seed))
+    assert np.array_equal(dev.cpu().numpy(), host)
+
+
 def test_fit_palette_under_one_rank_nccl_group(be, orc):
     """kmeans.fit_palette with torch.distributed initialised on the RCCL backend (world size 1): the all-reduce of the
     integer totals runs through RCCL on device tensors produced by the real kernel, and changes nothing."""
