@@ -122,10 +122,12 @@ __device__ __forceinline__ int nearest_color(const PalDev &pal, const float4 *__
 // count and up to 7 indices as nibbles of one word (count 15: longer than that) -- 99.8 % of the cells of a 16-colour
 // palette; a step then needs no load from global memory at all (the 8x8x8 lists live in L2: ~600 cycles of latency that
 // every step of the dependency chain would pay).
+// `lists16` (wavefront kernel on the few-frames schedule, palettes of 17..256 colours; else nullptr): an LDS copy of the
+// lists of the 16x16x16 cells in the format of the 8x8x8 table (count byte 255: more than 15 entries, use that table).
 template <int CAP>
 __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const float4 *__restrict__ cand,
                                                    const uint32_t *__restrict__ coarse, const float o0, const float o1,
-                                                   const float o2)
+                                                   const float o2, const uint4 *__restrict__ lists16 = nullptr)
 {
     float b0 = __int_as_float(0x7f800000), b1 = b0;
     int i0 = 0;
@@ -185,9 +187,14 @@ __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const floa
         }
     }
     if (!listed) {
-        const uint32_t ci = ((uint32_t)o0 >> 3) | (((uint32_t)o1 >> 3) << 5) | (((uint32_t)o2 >> 3) << 10);
-        uint4 blk = pal.ed_cells[ci];
+        uint4 blk = make_uint4(255u, 0u, 0u, 0u);
+        if (lists16) blk = lists16[((uint32_t)o0 >> 4) | (((uint32_t)o1 >> 4) << 4) | (((uint32_t)o2 >> 4) << 8)];
         int n = (int)(blk.x & 255u);
+        if (n == 255) {  // (no LDS lists, or a cell with more than 15 entries)
+            const uint32_t ci = ((uint32_t)o0 >> 3) | (((uint32_t)o1 >> 3) << 5) | (((uint32_t)o2 >> 3) << 10);
+            blk = pal.ed_cells[ci];
+            n = (int)(blk.x & 255u);
+        }
         if (n == 254) {  // a crowded cell (clustered palettes): refined into 4^3, 2^3, 1^3 sub-cells
             const uint32_t i0 = (uint32_t)o0, i1 = (uint32_t)o1, i2 = (uint32_t)o2;
             for (int bit = 2; n == 254; --bit) {

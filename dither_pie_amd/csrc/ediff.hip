@@ -115,8 +115,11 @@ constexpr int kEdProgWords = 64;
 
 // NT: tap slots compiled in (taps.n <= NT); EXACT: taps.n == NT, the slots carry no test (the reference's eight tap sets
 // have 3, 4, 6, 7, 10 or 12 taps), so all LDS reads of a step's taps are in flight together
-template <int CAP, int NT, bool EXACT>
-__global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
+// MAXW: waves per workgroup this instance is built for -- 16 (one workgroup per frame) or 4 (the few-frames schedule: a
+// frame's bands over up to 16 workgroups of <= 4 waves, one wave per SIMD).  The small one has the registers of a
+// 256-thread workgroup (no spills) and LDS to spare, which it uses for the 16^3-cell lists of palettes above 16 colours.
+template <int CAP, int NT, bool EXACT, int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
                                                                       float *__restrict__ bnd_all, const int G,
@@ -139,11 +142,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     // writes) slot (t - skew*L - dx) & 7 of a row, so with the natural stride of 24 words the lanes L, L+8, L+16, ... --
     // eight of them -- meet in one LDS bank on every ring access (SQ_LDS_BANK_CONFLICT: 72 % of the LDS cycles, the LDS
     // pipe 80 % busy with 16 waves per CU); 27 makes the accesses conflict-free at skew 2 and two-way at skew 3.
-    __shared__ float s_ring[kMaxWaves][64][kRingStride];
-    __shared__ float s_vring[kMaxWaves][2][64][3];       // errors of the two rows above the band (64-column ring)
-    __shared__ float s_bout[kMaxWaves][2][kPeriod][3];   // this period's errors of rows 62/63, flushed to global
+    __shared__ float s_ring[MAXW][64][kRingStride];
+    __shared__ float s_vring[MAXW][2][64][3];            // errors of the two rows above the band (64-column ring)
+    __shared__ float s_bout[MAXW][2][kPeriod][3];        // this period's errors of rows 62/63, flushed to global
     __shared__ uint8_t s_lut[256];
-    __shared__ volatile uint32_t s_prog[kMaxWaves];      // (band << 16) | (acknowledged column of row 63 + 1024)
+    __shared__ volatile uint32_t s_prog[MAXW];           // (band << 16) | (acknowledged column of row 63 + 1024)
     // {x, y, z, out_rgb bits} of the palette; palettes of 9..16 colours keep the candidate lists of the 16^3 cells
     // (4096 words) behind their 16 entries
     __shared__ float4 s_pal[DP_MAX_COLORS + 16];
@@ -162,7 +165,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
     if (pal.ed_coarse)
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_coarse[i] = pal.ed_coarse[i];
     const uint32_t *coarse = pal.ed_coarse ? s_coarse : nullptr;
-    if (threadIdx.x < kMaxWaves) s_prog[threadIdx.x] = 0;
+    __shared__ uint4 s_lists16[MAXW <= 4 ? 4096 : 1];
+    const uint4 *lists16 = nullptr;
+    if (MAXW <= 4 && pal.ed_lists16) {
+        for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_lists16[i] = pal.ed_lists16[i];
+        lists16 = s_lists16;
+    }
+    if (threadIdx.x < MAXW) s_prog[threadIdx.x] = 0;
     if (threadIdx.x < 4) s_zero[threadIdx.x] = 0.0f;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void ed_wavefront_kernel(const uint
                         }
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-                    const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2)
+                    const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2, lists16)
                                                : nearest_color<CAP>(pal, s_pal, o0, o1, o2);
                     const float4 pj = s_pal[j];
                     e0 = __fsub_rn(o0, pj.x);
@@ -665,7 +674,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     *blob_out = nullptr;
     const int K = dev.K;
     uint4 *cells = nullptr;
-    constexpr size_t kCoarseQuads = 4096 / 4;  // room for the 16^3-cell table behind the lists (and the nodes)
+    constexpr size_t kCoarseQuads = 4096;  // room for a 16^3-cell table behind the lists (and the nodes): 4096 words or 4096 quads
     DP_HIP(hipMalloc((void **)&cells, sizeof(uint4) * (kEdCells + kCoarseQuads)));
     hipLaunchKernelGGL(ed_cells_kernel, dim3(kEdCells / 256), dim3(256), 0, 0, dev, cells);
     hipError_t e = hipGetLastError();
@@ -701,6 +710,31 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
             if (near2 <= bound) list.push_back(j);
         }
     };
+    // A sharper (still conservative) list for a box: entry j is dropped if some other listed entry k is closer to EVERY
+    // point of the box, i.e. the box lies strictly on k's side of the bisector of j and k:
+    //   max over the box of |x - c_k|^2 - |x - c_j|^2 = max of 2 x.(c_j - c_k) + |c_k|^2 - |c_j|^2 < 0   (linear in x).
+    // The true nearest entry of a point of the box is dominated by nobody, so it stays listed, with everything tied with it.
+    auto prune_list = [&](const double lo[3], const double size, std::vector<int> &list) {
+        std::vector<int> keep;
+        for (int j : list) {
+            bool dominated = false;
+            for (int k : list) {
+                if (k == j) continue;
+                double mx = 0.0;
+                for (int d = 0; d < 3; ++d) {
+                    const double a = 2.0 * (pts[3 * j + d] - pts[3 * k + d]);
+                    mx += std::max(a * lo[d], a * (lo[d] + size));
+                    mx += pts[3 * k + d] * pts[3 * k + d] - pts[3 * j + d] * pts[3 * j + d];
+                }
+                if (mx < -1e-9 * (1.0 + std::fabs(mx))) {
+                    dominated = true;
+                    break;
+                }
+            }
+            if (!dominated) keep.push_back(j);
+        }
+        list.swap(keep);
+    };
     auto pack = [](const std::vector<int> &list) {
         uint32_t w[4] = {(uint32_t)list.size(), 0u, 0u, 0u};
         for (size_t n = 1; n <= list.size(); ++n) w[n >> 2] |= (uint32_t)list[n - 1] << (8 * (n & 3));
@@ -716,6 +750,21 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     std::vector<Work> stack;
     std::vector<int> all(K), list;
     for (int j = 0; j < K; ++j) all[j] = j;
+    // the kernel's lists (the geometric criterion), sharpened by the pairwise test
+    bool pruned_any = false;
+    for (int cell = 0; cell < kEdCells; ++cell) {
+        const uint32_t w4[4] = {host[cell].x, host[cell].y, host[cell].z, host[cell].w};
+        const int n = (int)(w4[0] & 255u);
+        if (n < 2 || n > 15) continue;
+        list.clear();
+        for (int i = 1; i <= n; ++i) list.push_back((int)((w4[i >> 2] >> (8 * (i & 3))) & 255u));
+        const double lo[3] = {(double)((cell & 31) * 8), (double)(((cell >> 5) & 31) * 8), (double)((cell >> 10) * 8)};
+        prune_list(lo, 8.0, list);
+        if ((int)list.size() < n) {
+            host[cell] = pack(list);
+            pruned_any = true;
+        }
+    }
     for (int cell = 0; cell < kEdCells; ++cell)
         if ((host[cell].x & 255u) == 255u) {
             Work wk;
@@ -726,6 +775,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
             wk.lo[2] = (double)((cell >> 10) * 8);
             wk.size = 8.0;
             box_list(all, wk.lo, 8.0, wk.from);  // the cell's full list
+            prune_list(wk.lo, 8.0, wk.from);
             stack.push_back(std::move(wk));
         }
     bool give_up = false;
@@ -755,6 +805,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
                 ch.lo[2] = wk.lo[2] + ((sub & 4) ? hs : 0.0);
                 ch.size = hs;
                 box_list(wk.from, ch.lo, hs, ch.from);
+                prune_list(ch.lo, hs, ch.from);
                 stack.push_back(std::move(ch));
             }
         }
@@ -775,16 +826,44 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
         }
         cells = both;
         d_nodes = both + kEdCells;
+    } else if (!give_up && pruned_any) {
+        e = hipMemcpy(cells, host.data(), sizeof(uint4) * kEdCells, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(cells);
+            return hip_fail(e, "error-diffusion candidate lists");
+        }
     }
     dev.ed_cells = cells;
     dev.ed_nodes = d_nodes;
     dev.ed_coarse = nullptr;
+    dev.ed_lists16 = nullptr;
+    if (K > 16) {
+        // lists of the 16x16x16 cells in the format of the 8x8x8 table, for the LDS of the wavefront kernel's few-frames
+        // variant (one wave per SIMD: the read of the 8x8x8 table from L2 is half of a step's latency there)
+        std::vector<uint4> l16(4096);
+        for (int cell = 0; cell < 4096; ++cell) {
+            const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
+            box_list(all, lo, 16.0, list);
+            prune_list(lo, 16.0, list);
+            l16[cell] = list.size() <= 15 ? pack(list) : make_uint4(255u, 0u, 0u, 0u);
+        }
+        uint4 *d_l16 = cells + kEdCells + nodes.size() * (d_nodes ? 1 : 0);
+        e = hipMemcpy(d_l16, l16.data(), sizeof(uint4) * 4096, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(cells);
+            dev.ed_cells = nullptr;
+            dev.ed_nodes = nullptr;
+            return hip_fail(e, "error-diffusion candidate lists");
+        }
+        dev.ed_lists16 = d_l16;
+    }
     if (K <= 16) {
         // lists of the 16x16x16 cells for the wavefront kernel's LDS: count | up to 7 indices, one nibble each
         std::vector<uint32_t> coarse(4096);
         for (int cell = 0; cell < 4096; ++cell) {
             const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
             box_list(all, lo, 16.0, list);
+            prune_list(lo, 16.0, list);
             uint32_t word = 15u;
             if (list.size() <= 7) {
                 word = (uint32_t)list.size();
@@ -901,11 +980,15 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         const int nw1 = n_bands < kMaxWaves ? n_bands : kMaxWaves;
 #define DP_EDW(C, N, X)                                                                                                   \
     do {                                                                                                                 \
-        hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, t, \
-                           reinterpret_cast<float *>(ws), G, gprog, test_giveup);                                        \
+        if (nw <= 4)                                                                                                     \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, 4>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, \
+                               pal, t, reinterpret_cast<float *>(ws), G, gprog, test_giveup);                            \
+        else                                                                                                             \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in,  \
+                               out, h, w, pal, t, reinterpret_cast<float *>(ws), G, gprog, test_giveup);                 \
         if (G > 1)                                                                                                       \
-            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out, h, w, pal, t, \
-                               reinterpret_cast<float *>(ws), 1, gprog, 0);                                              \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out,  \
+                               h, w, pal, t, reinterpret_cast<float *>(ws), 1, gprog, 0);                                \
     } while (0)
 #define DP_EDN(N, X)                                                                                                      \
     do {                                                                                                                 \
