@@ -402,6 +402,12 @@ def main():
         extra["c3_fs_k16_4k_one_frame_ms"] = round(t1f * 1e3, 2)
         extra["c3_note"] = (f"{nf3} frames in flight per GPU (one workgroup of 16 waves per frame), "
                             "bit-exact float32 error accumulation")
+        # the same frame with 256 (random) colours: candidate lists instead of a 16-entry table
+        pal3b = [tuple(int(v) for v in c) for c in np.random.RandomState(7).randint(0, 256, (256, 3))]
+        d3b = ImageDitherer(256, DitherMode.ERROR_DIFFUSION, pal3b, False, {"variant": "floyd_steinberg", "serpentine": "false"})
+        d3b.apply_dithering_frames(frames[:1], out=o24[:1])
+        t1b = timed(lambda: d3b.apply_dithering_frames(frames[:1], out=o24[:1]), 2, 1) / 2
+        extra["c3_fs_k256_4k_one_frame_ms"] = round(t1b * 1e3, 2)
         # C4: k-means 32-colour palette from a 7680x4320 image + blue-noise dither, the image split into row
         # bands over the ranks; the per-iteration exchange is one RCCL all-reduce of [32,5] int64
         from dither_pie_amd import kmeans, sharding
@@ -422,6 +428,15 @@ def main():
         iters4 = c4()
         t4 = timed(c4, 1, 0)
         extra["c4_8k_kmeans32_plus_blue_noise_seconds"] = round(t4, 4)
+        # one Lloyd pass over this rank's band on its own (dp_kmeans_step_u8 with its memset)
+        from dither_pie_amd import backend as _be
+        c4c = torch.from_numpy(np.random.RandomState(1).rand(32, 3) * 255.0).to(dev)
+        tot4 = torch.zeros(160, dtype=torch.int64, device=dev)
+        bpx = band.reshape(-1, 3)
+        _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False)
+        tp4 = timed(lambda: _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False), 10, 2) / 10
+        extra["c4_kmeans_pass_ms"] = round(tp4 * 1e3, 4)
+        extra["c4_kmeans_pass_hbm_gbs"] = round(bpx.numel() / tp4 / 1e9, 1)
         extra["c4_note"] = (f"7680x4320 in {world} row band(s), Lloyd over all pixels ({iters4} iterations, one int64 "
                             "all-reduce each), blue-noise(64,42) dither of the band with global coordinates")
         result["extra"] = extra
