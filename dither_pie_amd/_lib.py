@@ -11,7 +11,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libditherpie_hip.so")
+# DP_LIB_PATH: another build of the same library (A/B measurements of kernel variants: tools/bench_scripts/ab_kernel.py)
+LIB_PATH = os.environ.get("DP_LIB_PATH") or os.path.join(_HERE, "libditherpie_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_OK, DP_EINVAL, DP_EUNSUPPORTED, DP_EHIP, DP_ENOMEM, DP_EWORKSPACE = range(6)
