@@ -22,8 +22,9 @@
  *     two host threads at once (the Python layer serialises them per (device, stream)).  dp_palette_build_accel
  *     mutates the palette: finish it before another thread launches with that palette.
  *   - environment variables read by the library are experiment / test switches only (DP_DEBUG_ACCEL, DP_FORCE_TABLE,
- *     DP_NO_WARP, DP_NO_FAST, DP_FAST_ALL, DP_FAST_DBG, DP_ED_ONE_WG, DP_ED_TEST_GIVEUP, DP_GATE_CHUNK_BYTES;
- *     INTEGRATION.md lists what each does); production callers set none of them.
+ *     DP_NO_WARP, DP_NO_FAST, DP_FAST_ALL, DP_FAST_DBG, DP_ED_ONE_WG, DP_ED_WAVES, DP_ED_TEST_GIVEUP,
+ *     DP_GATE_CHUNK_BYTES, DP_KMEANS_MFMA, DP_KMEANS_NO_KEYS; INTEGRATION.md lists what each does); production
+ *     callers set none of them.
  */
 #ifndef DITHERPIE_HIP_H
 #define DITHERPIE_HIP_H

@@ -9,8 +9,8 @@ for K in ([int(a) for a in sys.argv[1:]] or [8, 16, 32, 64, 128, 256]):
     c = torch.from_numpy(np.random.RandomState(1).rand(K, 3) * 255.0).cuda()
     res = {}
     for which in ("VALU", "MFMA"):
-        os.environ.pop("DP_KMEANS_VALU", None); os.environ.pop("DP_KMEANS_MFMA", None)
-        os.environ["DP_KMEANS_" + which] = "1"
+        os.environ.pop("DP_KMEANS_MFMA", None)
+        if which == "MFMA": os.environ["DP_KMEANS_MFMA"] = "1"
         tot = torch.zeros(5 * K, dtype=torch.int64, device='cuda')
         for _ in range(2): be.kmeans_step_into(px, c, tot, want_sq=True)
         ts = []
