@@ -101,6 +101,7 @@ struct PalDev {
     const uint4 *ed_cells;
     const uint4 *ed_nodes;      // refinement of overflowing cells: 8 entries per node (count byte 254 = refined further)
     const uint32_t *ed_coarse;  // palettes of 9..16 colours: lists of the 16^3 cells, count | 7 index nibbles (count 15: too long)
+    const uint32_t *ed_coarse_ext;  // the same for the diffusers that do not clamp (vardiff.hip): the outermost cells stand for the half-spaces beyond the cube
     const uint4 *ed_lists16;    // palettes of 17..256 colours: lists of the 16^3 cells, count byte | up to 15 index bytes (255: too long)
     const uint4 *exc;           // colours whose outcome no code expresses, sorted by colour:
     int n_exc;                  //   {colour, k=2 indices i0 | i1<<16, k=1 index, 0}; n_exc < 0: list overflowed

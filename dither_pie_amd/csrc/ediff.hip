@@ -837,6 +837,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     dev.ed_nodes = d_nodes;
     dev.ed_coarse = nullptr;
     dev.ed_lists16 = nullptr;
+    dev.ed_coarse_ext = nullptr;
     if (K > 16) {
         // lists of the 16x16x16 cells in the format of the 8x8x8 table, for the LDS of the wavefront kernel's few-frames
         // variant (one wave per SIMD: the read of the 8x8x8 table from L2 is half of a step's latency there)
@@ -900,6 +901,67 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
             return hip_fail(e, "error-diffusion candidate lists");
         }
         dev.ed_coarse = d_coarse;
+        // The same table for query points that are NOT clamped to the cube (the perceptual / hybrid / adaptive-variance
+        // diffusers of vardiff.hip): a point is looked up in the cell of its clamped coordinates, so the outermost cells
+        // stand for everything beyond them -- their boxes are unbounded on that side.  With an unbounded box the geometric
+        // criterion lists everybody; the pairwise test alone decides (K <= 16: 256 pairs per cell): over a box that is
+        // unbounded in a direction in which |x - c_k|^2 - |x - c_j|^2 grows, k cannot dominate j.
+        std::vector<uint32_t> ext(4096);
+        const double kInf = std::numeric_limits<double>::infinity();
+        for (int cell = 0; cell < 4096; ++cell) {
+            const int ci[3] = {cell & 15, (cell >> 4) & 15, cell >> 8};
+            double blo[3], bhi[3];
+            for (int d = 0; d < 3; ++d) {
+                blo[d] = ci[d] == 0 ? -kInf : (double)(ci[d] * 16);
+                bhi[d] = ci[d] == 15 ? kInf : (double)(ci[d] * 16 + 16);
+            }
+            list.clear();
+            for (int j = 0; j < K; ++j) {
+                bool dominated = false;
+                for (int k = 0; k < K && !dominated; ++k) {
+                    if (k == j) continue;
+                    double mx = 0.0;
+                    for (int d = 0; d < 3; ++d) {
+                        const double a = 2.0 * (pts[3 * j + d] - pts[3 * k + d]);
+                        if (a > 0.0) mx += bhi[d] == kInf ? kInf : a * bhi[d];
+                        else if (a < 0.0) mx += blo[d] == -kInf ? kInf : a * blo[d];
+                        mx += pts[3 * k + d] * pts[3 * k + d] - pts[3 * j + d] * pts[3 * j + d];
+                    }
+                    if (mx < -1e-9 * (1.0 + std::fabs(mx))) dominated = true;
+                }
+                if (!dominated) list.push_back(j);
+            }
+            uint32_t word = 15u;
+            if (list.size() <= 7) {
+                word = (uint32_t)list.size();
+                for (size_t n = 0; n < list.size(); ++n) word |= (uint32_t)list[n] << (4 * (n + 1));
+                int filler = -1;
+                double far_d = -1.0;
+                for (int j = 0; j < K; ++j) {  // unused positions: the unlisted entry farthest from the cell's inner corner
+                    if (std::find(list.begin(), list.end(), j) != list.end()) continue;
+                    double d2 = 0.0;
+                    for (int d = 0; d < 3; ++d) {
+                        const double m = pts[3 * j + d] - (double)(ci[d] * 16 + 8);
+                        d2 += m * m;
+                    }
+                    if (d2 > far_d) {
+                        far_d = d2;
+                        filler = j;
+                    }
+                }
+                for (size_t n = list.size(); n < 7 && filler >= 0; ++n) word |= (uint32_t)filler << (4 * (n + 1));
+            }
+            ext[cell] = word;
+        }
+        e = hipMemcpy(d_coarse + 4096, ext.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(cells);
+            dev.ed_cells = nullptr;
+            dev.ed_nodes = nullptr;
+            dev.ed_coarse = nullptr;
+            return hip_fail(e, "error-diffusion candidate lists");
+        }
+        dev.ed_coarse_ext = d_coarse + 4096;
     }
     *blob_out = cells;
     return DP_OK;

@@ -87,6 +87,42 @@ __device__ __forceinline__ int nearest_any(const PalDev &pal, const float4 *__re
     return nearest_any_f64<CAP>(pal, o0, o1, o2);
 }
 
+// Palettes of up to 16 colours, any query point: the key scan of nearest_color_cells (ed_nearest.hip.h) over the list of
+// the point's cell in the EXTENDED 16^3 table (ediff.hip, build_ed_cells: the outermost cells stand for the half-spaces
+// beyond the cube, a point is looked up by its clamped coordinates).  These diffusers do not clamp their values, and a
+// wave nearly always holds a point outside the cube: without this every step scanned the whole palette.
+template <int CAP>
+__device__ __forceinline__ int nearest_ext(const PalDev &pal, const float4 *__restrict__ cand, const uint32_t *__restrict__ ext,
+                                           const float o0, const float o1, const float o2)
+{
+    const int c0 = min(max((int)o0 >> 4, 0), 15), c1 = min(max((int)o1 >> 4, 0), 15), c2 = min(max((int)o2 >> 4, 0), 15);
+    const uint32_t e = ext[c0 | (c1 << 4) | (c2 << 8)];
+    const int n = (int)(e & 15u);
+    if (n <= 7) {
+        const int j1 = (e >> 4) & 15, j2 = (e >> 8) & 15, j3 = (e >> 12) & 15, j4 = (e >> 16) & 15;
+        const float4 q1 = cand[j1], q2 = cand[j2], q3 = cand[j3], q4 = cand[j4];
+        int k1 = ed_key(q1, o0, o1, o2, 1u), k2 = ed_key(q2, o0, o1, o2, 2u), k3 = ed_key(q3, o0, o1, o2, 3u),
+            k4 = ed_key(q4, o0, o1, o2, 4u);
+        int m0 = min(min(k1, k2), k3), m1 = ed_med3(k1, k2, k3);
+        m1 = ed_med3(m0, m1, k4);
+        m0 = min(m0, k4);
+        if (n > 4) {
+            const int j5 = (e >> 20) & 15, j6 = (e >> 24) & 15, j7 = (e >> 28) & 15;
+            const float4 q5 = cand[j5], q6 = cand[j6], q7 = cand[j7];
+            const int k5 = ed_key(q5, o0, o1, o2, 5u), k6 = ed_key(q6, o0, o1, o2, 6u), k7 = ed_key(q7, o0, o1, o2, 7u);
+            m1 = ed_med3(m0, m1, k5);
+            m0 = min(m0, k5);
+            m1 = ed_med3(m0, m1, k6);
+            m0 = min(m0, k6);
+            m1 = ed_med3(m0, m1, k7);
+            m0 = min(m0, k7);
+        }
+        const float f0 = __int_as_float(m0 & ~7), f1 = __int_as_float(m1 & ~7);
+        if (f1 > f0 * 1.000003f) return (int)((e >> (4 * (m0 & 7))) & 15u);
+    }
+    return nearest_any<CAP>(pal, cand, o0, o1, o2);  // long lists, near ties, exact ties: the full scan and its validation
+}
+
 struct VarParams {
     int model;
     int serpentine;
@@ -377,9 +413,11 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     uint32_t *gprog = gprog_all + f * (size_t)kVProgWords;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
     for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
-    if (pal.ed_coarse)
-        for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_coarse[i] = pal.ed_coarse[i];
-    const uint32_t *coarse = pal.ed_coarse ? s_coarse : nullptr;
+    // (model 4 clamps its values: the plain table; the others look their unclamped values up in the extended one)
+    const uint32_t *coarse_src = MODEL == 4 ? pal.ed_coarse : pal.ed_coarse_ext;
+    if (coarse_src)
+        for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_coarse[i] = coarse_src[i];
+    const uint32_t *coarse = coarse_src ? s_coarse : nullptr;
     if (threadIdx.x < kVWaves) s_prog[threadIdx.x] = 0;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
@@ -591,8 +629,10 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     // their cell, as error diffusion does; a wave with a point outside scans the palette
                     const bool inside = model == 4 || (o0 >= 0.0f && o0 <= 255.0f && o1 >= 0.0f && o1 <= 255.0f && o2 >= 0.0f && o2 <= 255.0f);
                     // (perceptual: its waves nearly always hold a point outside the cube -- measured, the lists only cost there)
-                    const int j = (model != 1 && pal.ed_cells && __ballot(!inside) == 0ull) ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2)
-                                                                               : nearest_any<CAP>(pal, s_pal, o0, o1, o2);
+                    int j;
+                    if (model != 4 && coarse) j = nearest_ext<CAP>(pal, s_pal, coarse, o0, o1, o2);
+                    else if (model != 1 && pal.ed_cells && __ballot(!inside) == 0ull) j = nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2);
+                    else j = nearest_any<CAP>(pal, s_pal, o0, o1, o2);
                     const float4 pj = s_pal[j];
                     e0 = __fsub_rn(o0, pj.x);
                     e1 = __fsub_rn(o1, pj.y);
