@@ -711,6 +711,73 @@ __device__ __forceinline__ float gray_of(const uint8_t *p, const uint8_t *lut)
 // [0, 65025] whose bits span less than 53 binary places together with the partial sums (gray = f32 sums of
 // 0.299*r etc.: >= 2^-27 granularity, <= 2^8; gray^2: >= 2^-30, <= 2^16; windows of <= 129 terms), so every partial
 // sum is exact and the running sum equals the plain window sum in any order: one thread per pixel reproduces it.
+// (float)(t / size) as scipy computes it -- the double quotient correctly rounded, then rounded to float32 -- without the
+// ~40 instructions of a float64 division: q = t * (1/size) is within 2 ulp of the rounded quotient, and both round to the
+// same float32 unless a float32 rounding boundary (low 29 mantissa bits = 0x10000000) lies that close; then divide.
+__device__ __forceinline__ float mean_f32(const double t, const double size, const double rcp)
+{
+    double q = __dmul_rn(t, rcp);
+    const uint32_t lo = (uint32_t)__double2loint(q) & 0x1fffffffu;
+    if (lo - 0x0ffffffcu <= 8u) q = __ddiv_rn(t, size);
+    return (float)q;
+}
+
+// Both axes in one kernel for windows up to 9 x 9: a workgroup takes a tile of 64 x 16 pixels, stages gray and gray^2 of
+// the tile and its halo in LDS (edge pixels repeated: mode='nearest'), runs axis 0 into a second LDS plane (the
+// float32 values scipy stores between the axes) and axis 1 from there.  3 B read and 1 B written per pixel instead of
+// 3 + 8 written + 8 read + 1, and four multiplications instead of four float64 divisions.
+constexpr int kGateTW = 64, kGateTH = 16, kGateMaxR = 4;
+
+__global__ __launch_bounds__(256) void var_gate_fused_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ lut,
+                                                              uint8_t *__restrict__ gate, const int h, const int w,
+                                                              const int radius, const float thr)
+{
+    constexpr int kMaxW = kGateTW + 2 * kGateMaxR, kMaxH = kGateTH + 2 * kGateMaxR;
+    __shared__ float s_g[kMaxH][kMaxW], s_q[kMaxH][kMaxW];        // gray, gray^2 of the tile + halo
+    __shared__ float s_tg[kGateTH][kMaxW], s_tq[kGateTH][kMaxW];  // after axis 0
+    const int64_t f = blockIdx.z;
+    const uint8_t *fin = in + (size_t)f * h * w * 3;
+    uint8_t *fgate = gate + (size_t)f * h * w;
+    const int x0 = blockIdx.x * kGateTW, y0 = blockIdx.y * kGateTH;
+    const int size = 2 * radius + 1, tw = kGateTW + 2 * radius, th = kGateTH + 2 * radius;
+    const double dsize = (double)size, rcp = 1.0 / dsize;
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        int y = y0 + ty - radius, x = x0 + tx - radius;
+        y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+        x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+        const float g = gray_of(fin + ((size_t)y * w + x) * 3, lut);
+        s_g[ty][tx] = g;
+        s_q[ty][tx] = __fmul_rn(g, g);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tw * kGateTH; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        double tg = 0.0, ts = 0.0;
+        for (int k = 0; k < size; ++k) {
+            tg = __dadd_rn(tg, (double)s_g[ty + k][tx]);
+            ts = __dadd_rn(ts, (double)s_q[ty + k][tx]);
+        }
+        s_tg[ty][tx] = mean_f32(tg, dsize, rcp);
+        s_tq[ty][tx] = mean_f32(ts, dsize, rcp);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kGateTW * kGateTH; i += 256) {
+        const int ty = i / kGateTW, tx = i - ty * kGateTW;
+        const int y = y0 + ty, x = x0 + tx;
+        if (y >= h || x >= w) continue;
+        double tg = 0.0, ts = 0.0;
+        for (int k = 0; k < size; ++k) {
+            tg = __dadd_rn(tg, (double)s_tg[ty][tx + k]);
+            ts = __dadd_rn(ts, (double)s_tq[ty][tx + k]);
+        }
+        const float mean_sq = mean_f32(ts, dsize, rcp), mean = mean_f32(tg, dsize, rcp);
+        float var = __fsub_rn(mean_sq, __fmul_rn(mean, mean));
+        var = var > 0.0f ? var : 0.0f;
+        fgate[(size_t)y * w + x] = var >= thr ? 1 : 0;
+    }
+}
+
 // pass 1: along axis 0 on gray^2 (t_sq) and gray (t_g), float32 results as scipy stores them between the axes
 __global__ void var_axis0_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ lut, float *__restrict__ t_sq,
                                  float *__restrict__ t_g, const int64_t n_frames, const int h, const int w, const int size)
@@ -782,6 +849,16 @@ int launch_variance_gate(const uint8_t *in, uint8_t *gate, int64_t n_frames, int
     if (h > 65535) {
         set_error("dp_variance_gate_u8: h > 65535 not supported");
         return DP_EUNSUPPORTED;
+    }
+    if (radius <= kGateMaxR && !getenv("DP_GATE_TWO_PASS")) {
+        for (int64_t f0 = 0; f0 < n_frames; f0 += 65535) {
+            const int64_t nf = std::min<int64_t>(65535, n_frames - f0);
+            const dim3 grid((w + kGateTW - 1) / kGateTW, (h + kGateTH - 1) / kGateTH, (unsigned)nf);
+            hipLaunchKernelGGL(var_gate_fused_kernel, grid, dim3(256), 0, s, in + (size_t)f0 * h * w * 3, pal.lut_in,
+                               gate + (size_t)f0 * h * w, h, w, radius, thr);
+        }
+        DP_HIP(hipGetLastError());
+        return DP_OK;
     }
     const int64_t chunk = std::min<int64_t>(variance_gate_chunk(n_frames, h, w), 65535);
     float *t_sq = reinterpret_cast<float *>(ws);
