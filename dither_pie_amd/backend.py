@@ -235,21 +235,31 @@ def ordered(frames, pal: Palette, mode, thr: Thresholds | None = None, ign_scale
     return out.view(frames.shape)
 
 
-def error_diffusion(frames, pal: Palette, taps, divisor, serpentine=False, out=None):
-    """taps: [(dx, dy, weight)] in the reference's list order."""
+def error_diffusion(frames, pal: Palette, taps, divisor, serpentine=False, out=None, arithmetic="python"):
+    """taps: [(dx, dy, weight)] in the reference's list order.  arithmetic: "python" -- the reference's pure-Python
+    branch (dithering_lib.py:655-690: KD-tree nearest, float32 products and sums) -- or "numba" -- its
+    _error_diffusion_numba branch (:213-308: float32 linear-scan nearest, float64 products and sums rounded on the store)."""
     f = _frames(frames)
     n, h, w, _ = f.shape
     out = _check_out(out, f)
     _check_palette_device(pal, f)
     dx = np.array([t[0] for t in taps], np.int32)
     dy = np.array([t[1] for t in taps], np.int32)
-    wq = np.array([t[2] / divisor for t in taps], np.float64).astype(np.float32)
     L = _lib.load()
     ws_bytes = L.dp_error_diffusion_workspace_bytes(n, h, w)
+    if arithmetic not in ("python", "numba"):
+        raise ValueError("arithmetic must be 'python' or 'numba'")
     with torch.cuda.device(f.device), _Launch(f.device, ws_bytes) as ws:
-        check(L.dp_error_diffusion_u8(f.data_ptr(), out.data_ptr(), n, h, w, pal._h, _np_ptr(dx), _np_ptr(dy),
-                                      _np_ptr(wq), len(taps), 1 if serpentine else 0, ws.data_ptr(), ws.numel(),
-                                      _stream()))
+        if arithmetic == "numba":
+            wts = np.array([t[2] for t in taps], np.float32)  # the reference: np.array([...], dtype=np.float32)
+            check(L.dp_error_diffusion_numba_u8(f.data_ptr(), out.data_ptr(), n, h, w, pal._h, _np_ptr(dx), _np_ptr(dy),
+                                                _np_ptr(wts), float(divisor), len(taps), 1 if serpentine else 0,
+                                                ws.data_ptr(), ws.numel(), _stream()))
+        else:
+            wq = np.array([t[2] / divisor for t in taps], np.float64).astype(np.float32)
+            check(L.dp_error_diffusion_u8(f.data_ptr(), out.data_ptr(), n, h, w, pal._h, _np_ptr(dx), _np_ptr(dy),
+                                          _np_ptr(wq), len(taps), 1 if serpentine else 0, ws.data_ptr(), ws.numel(),
+                                          _stream()))
     return out.view(frames.shape)
 
 

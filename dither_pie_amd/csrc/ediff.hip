@@ -55,7 +55,38 @@ struct Taps {
     int skew;
     int dx[kMaxTaps], dy[kMaxTaps];
     float wq[kMaxTaps];
+    double wq64[kMaxTaps];  // numba arithmetic: (double)float32(weight) / divisor
 };
+
+// ---- the reference's OTHER error-diffusion arithmetic: _error_diffusion_numba (dithering_lib.py:213-308), which the
+// reference takes instead of the pure-Python loop when numba is installed (dispatch at :638-653).  Same scan, same taps,
+// different numbers: (1) the nearest entry is the FIRST minimum of a float32 linear scan
+//   dist = ((dr*dr + dg*dg) + db*db), every operation rounded to float32   (not the float64 KD-tree query), and
+// (2) an error is pushed as  work[ny, nx] = float32( float64(work[ny, nx]) + float64(err) * (float64(w_f32) / divisor) )
+//   -- the product and the sum in float64, one rounding on the store (not float32 product + float32 sum).
+// No fixtures pin this branch: numba is not installable in the build image (no network), so the restatement in
+// the CPU restatement (orc_error_diffusion_numba_u8) is checked against an independent numpy transcription only.
+__device__ __forceinline__ int nearest_numba_f32(const float4 *__restrict__ cand, const int K, const float o0, const float o1,
+                                                 const float o2)
+{
+    float best = __int_as_float(0x7f800000);
+    int j0 = 0;
+    for (int j = 0; j < K; ++j) {
+        const float4 c = cand[j];
+        const float dr = __fsub_rn(o0, c.x), dg = __fsub_rn(o1, c.y), db = __fsub_rn(o2, c.z);
+        const float dist = __fadd_rn(__fadd_rn(__fmul_rn(dr, dr), __fmul_rn(dg, dg)), __fmul_rn(db, db));
+        if (dist < best) {
+            best = dist;
+            j0 = j;
+        }
+    }
+    return j0;
+}
+
+__device__ __forceinline__ float push_numba(const float acc, const float err, const double w)
+{
+    return (float)__dadd_rn((double)acc, __dmul_rn((double)err, w));
+}
 
 // min(max(v, 0), 255) for every non-NaN v, in one instruction
 __device__ __forceinline__ float clamp255(const float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f); }
@@ -118,7 +149,8 @@ constexpr int kEdProgWords = 64;
 // MAXW: waves per workgroup this instance is built for -- 16 (one workgroup per frame) or 4 (the few-frames schedule: a
 // frame's bands over up to 16 workgroups of <= 4 waves, one wave per SIMD).  The small one has the registers of a
 // 256-thread workgroup (no spills) and LDS to spare, which it uses for the 16^3-cell lists of palettes above 16 colours.
-template <int CAP, int NT, bool EXACT, int MAXW>
+// NB: the numba arithmetic (above)
+template <int CAP, int NT, bool EXACT, int MAXW, bool NB = false>
 __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
@@ -371,15 +403,23 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     for (int k = 0; k < NT; ++k) {
                         if (EXACT || k < taps.n) {
                             lds_float_t *src = tbase[k] + ((x - taps.dx[k]) & (int)tmask[k]) * 3;
-                            const float wq = taps.wq[k];
-                            a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
-                            a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
-                            a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
+                            if (NB) {
+                                const double w64 = taps.wq64[k];
+                                a0 = push_numba(a0, src[0], w64);
+                                a1 = push_numba(a1, src[1], w64);
+                                a2 = push_numba(a2, src[2], w64);
+                            } else {
+                                const float wq = taps.wq[k];
+                                a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
+                                a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
+                                a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
+                            }
                         }
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-                    const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2, lists16)
-                                               : nearest_color<CAP>(pal, s_pal, o0, o1, o2);
+                    const int j = NB ? nearest_numba_f32(s_pal, pal.K, o0, o1, o2)
+                                     : (pal.ed_cells ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2, lists16)
+                                                     : nearest_color<CAP>(pal, s_pal, o0, o1, o2));
                     const float4 pj = s_pal[j];
                     e0 = __fsub_rn(o0, pj.x);
                     e1 = __fsub_rn(o1, pj.y);
@@ -430,7 +470,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
 }
 
 // lane = frame; err rows: ring[3][w][3][n_frames] floats (frame index fastest => coalesced)
-template <int CAP>
+template <int CAP, bool NB = false>
 __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                        const int64_t n_frames, const int h, const int w,
                                                        const PalDev pal, const Taps taps, const int serpentine,
@@ -460,14 +500,22 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
                 const int sxp = x - taps.dx[k] * sdir;
                 if (sxp < 0 || sxp >= w) continue;
                 const float *e = ring + (((size_t)(sr % 3) * w + sxp) * 3) * nf + f;
-                const float wq = taps.wq[k];
-                a0 = __fadd_rn(a0, __fmul_rn(e[0], wq));
-                a1 = __fadd_rn(a1, __fmul_rn(e[nf], wq));
-                a2 = __fadd_rn(a2, __fmul_rn(e[2 * nf], wq));
+                if (NB) {
+                    const double w64 = taps.wq64[k];
+                    a0 = push_numba(a0, e[0], w64);
+                    a1 = push_numba(a1, e[nf], w64);
+                    a2 = push_numba(a2, e[2 * nf], w64);
+                } else {
+                    const float wq = taps.wq[k];
+                    a0 = __fadd_rn(a0, __fmul_rn(e[0], wq));
+                    a1 = __fadd_rn(a1, __fmul_rn(e[nf], wq));
+                    a2 = __fadd_rn(a2, __fmul_rn(e[2 * nf], wq));
+                }
             }
             const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-            const int j = pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, nullptr, o0, o1, o2)
-                                       : nearest_color<CAP>(pal, pal.fcand, o0, o1, o2);
+            const int j = NB ? nearest_numba_f32(pal.fcand, pal.K, o0, o1, o2)
+                             : (pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, nullptr, o0, o1, o2)
+                                             : nearest_color<CAP>(pal, pal.fcand, o0, o1, o2));
             float *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
             e[0] = __fsub_rn(o0, (float)pal.pts[3 * j]);
             e[nf] = __fsub_rn(o1, (float)pal.pts[3 * j + 1]);
@@ -969,8 +1017,10 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
 
 int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal,
                            const int32_t *dx, const int32_t *dy, const float *wq, int ntaps, int serpentine,
-                           void *ws, size_t ws_bytes, hipStream_t s)
+                           void *ws, size_t ws_bytes, hipStream_t s, const double *wq64)
 {
+    // wq64 != nullptr: the numba arithmetic (see nearest_numba_f32) with these float64 tap weights
+    const bool numba = wq64 != nullptr;
     Taps t;
     t.n = ntaps;
     // reference visiting order of the source pixels: earlier rows first (dy descending), and inside a
@@ -991,6 +1041,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         t.dx[i] = dx[order[i]];
         t.dy[i] = dy[order[i]];
         t.wq[i] = wq[order[i]];
+        t.wq64[i] = numba ? wq64[order[i]] : 0.0;
         // a source on row y-dy at x-dx must be finished strictly before step t: skew*dy > -dx
         if (t.dy[i] > 0) {
             const int need = (-t.dx[i]) / t.dy[i] + 1;
@@ -1001,6 +1052,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
     for (int i = ntaps; i < kMaxTaps; ++i) {
         t.dx[i] = t.dy[i] = 0;
         t.wq[i] = 0.f;
+        t.wq64[i] = 0.0;
     }
     ProfMark *pm = prof_begin(s);
     if (!serpentine && skew * 2 + 2 <= kRing && w < 60000) {
@@ -1056,6 +1108,17 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
     do {                                                                                                                 \
         if (pal.n_inner > kQueueSmall) DP_EDW(kQueueLarge, N, X); else DP_EDW(kQueueSmall, N, X);                         \
     } while (0)
+        if (numba) {  // one general instance per workgroup size (a full float32 palette scan per pixel, no candidate lists)
+            if (nw <= 4)
+                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, 4, true>), dim3((unsigned)(n_frames * G)), dim3(64 * nw),
+                                   0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws), G, gprog, test_giveup);
+            else
+                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, kMaxWaves, true>), dim3((unsigned)(n_frames * G)),
+                                   dim3(64 * nw), 0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws), G, gprog, test_giveup);
+            if (G > 1)
+                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, kMaxWaves, true>), dim3((unsigned)n_frames),
+                                   dim3(64 * nw1), 0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws), 1, gprog, 0);
+        } else
         switch (ntaps) {  // the tap counts of the reference's kernels get a test-free instance
         case 3: DP_EDN(3, true); break;
         case 4: DP_EDN(4, true); break;
@@ -1067,7 +1130,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         }
 #undef DP_EDN
 #undef DP_EDW
-    } else if (n_frames <= 0x7fffffff &&
+    } else if (!numba && n_frames <= 0x7fffffff &&
                ((size_t)9 * w + 4) * sizeof(float) + (pal.K > 64 ? (size_t)pal.K * 16 : 0) + 512 <= (size_t)158 * 1024) {
         // any scan direction, one wave per frame (three error rows in LDS)
         const size_t lds = ((((size_t)9 * w + 3) & ~(size_t)3)) * sizeof(float) + (pal.K > 64 ? (size_t)pal.K * 16 : 0);
@@ -1089,7 +1152,10 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
 #undef DP_EDR
     } else {
         const int64_t blocks = (n_frames + 63) / 64;
-        if (pal.n_inner > kQueueSmall)
+        if (numba)  // serpentine scan with the numba arithmetic: the frame-parallel kernel (lane = frame)
+            hipLaunchKernelGGL((ed_serial_kernel<kQueueSmall, true>), dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h,
+                               w, pal, t, serpentine, reinterpret_cast<float *>(ws));
+        else if (pal.n_inner > kQueueSmall)
             hipLaunchKernelGGL(ed_serial_kernel<kQueueLarge>, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h,
                                w, pal, t, serpentine, reinterpret_cast<float *>(ws));
         else

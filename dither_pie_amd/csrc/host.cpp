@@ -674,10 +674,43 @@ size_t dp_error_diffusion_workspace_bytes(int64_t n_frames, int h, int w)
     return error_diffusion_ws_bytes(n_frames, h, w);
 }
 
+static int error_diffusion_common(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
+                                  const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *wq,
+                                  const double *wq64, int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
+                                  void *stream);
+
 int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
                           const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *wq,
                           int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
                           void *stream)
+{
+    return error_diffusion_common(in_dev, out_dev, n_frames, h, w, pal, dx, dy, wq, nullptr, ntaps, serpentine, workspace_dev,
+                                  workspace_bytes, stream);
+}
+
+int dp_error_diffusion_numba_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
+                                const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *weights,
+                                double divisor, int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
+                                void *stream)
+{
+    if (ntaps < 0 || ntaps > 16 || (ntaps && !weights) || !(divisor > 0.0)) {
+        set_error("dp_error_diffusion_numba_u8: bad argument");
+        return DP_EINVAL;
+    }
+    float wq[16];
+    double wq64[16];
+    for (int k = 0; k < ntaps; ++k) {
+        wq64[k] = (double)weights[k] / divisor;  // numba: float32 weight / float64 divisor
+        wq[k] = (float)wq64[k];
+    }
+    return error_diffusion_common(in_dev, out_dev, n_frames, h, w, pal, dx, dy, wq, wq64, ntaps, serpentine, workspace_dev,
+                                  workspace_bytes, stream);
+}
+
+static int error_diffusion_common(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
+                                  const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *wq,
+                                  const double *wq64, int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
+                                  void *stream)
 {
     if (n_frames == 0 && pal && h >= 1 && w >= 1) return DP_OK;  // nothing to do (pointers may be null)
     if (!in_dev || !out_dev || !pal || n_frames < 0 || h < 1 || w < 1 || ntaps < 0 || ntaps > 16 ||
@@ -700,7 +733,7 @@ int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_fra
         return DP_EWORKSPACE;
     }
     return launch_error_diffusion(in_dev, out_dev, n_frames, h, w, pal->dev, dx, dy, wq, ntaps, serpentine,
-                                  workspace_dev, workspace_bytes, (hipStream_t)stream);
+                                  workspace_dev, workspace_bytes, (hipStream_t)stream, wq64);
 }
 
 int dp_variable_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,

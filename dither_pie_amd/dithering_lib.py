@@ -16,6 +16,8 @@ batches of frames already resident in HBM, and tile offsets (y0, x0) for row-ban
 """
 from __future__ import annotations
 
+import os
+
 import math
 from collections import OrderedDict
 from enum import Enum
@@ -494,9 +496,16 @@ class InterleavedGradientNoiseDitherStrategy(BaseDitherStrategy):
         return {"scale": self.scale, "seed": self.seed}
 
 
+# Which of the reference's two error-diffusion arithmetics to reproduce (dithering_lib.py:638-653 picks by whether numba
+# imports): "python" -- the pure-Python loop (:655-690), what the reference runs in an environment without numba, pinned by
+# the golden fixtures -- or "numba" -- _error_diffusion_numba (:213-308: float32 linear-scan nearest with the lowest index
+# on ties, float64 products and sums with one rounding on the store), restated in the oracle but not pinned by fixtures.
+ERROR_DIFFUSION_ARITHMETIC = os.environ.get("DITHER_PIE_ED_ARITHMETIC", "python")
+
+
 class ErrorDiffusionDitherStrategy(BaseDitherStrategy):
-    """dithering_lib.py:576-690 (semantics of the pure-Python branch, which is what runs when numba is
-    not installed; parameters are the reference's strings)."""
+    """dithering_lib.py:576-690 (by default the semantics of the pure-Python branch, which is what runs when numba is
+    not installed -- see ERROR_DIFFUSION_ARITHMETIC; parameters are the reference's strings)."""
 
     @staticmethod
     def get_parameter_info() -> Dict[str, Any]:
@@ -524,7 +533,7 @@ class ErrorDiffusionDitherStrategy(BaseDitherStrategy):
         if y0 or x0:
             raise ValueError("error diffusion carries state across the whole raster and cannot be tiled")
         return backend.error_diffusion(frames, pal, self._kernel["weights"], self._kernel["divisor"],
-                                       self.serpentine, out=out)
+                                       self.serpentine, out=out, arithmetic=ERROR_DIFFUSION_ARITHMETIC)
 
     def dither(self, pixels, palette_arr, image_size):
         out = self._run(_pixels_to_frame(pixels, image_size), _index_palette(palette_arr))

@@ -133,6 +133,17 @@ int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_fra
                           int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
                           void *stream);
 
+/* The same with the arithmetic of the reference's numba branch (_error_diffusion_numba, dithering_lib.py:213-308, taken
+ * at :638-653 when numba is importable): nearest entry = first minimum of a float32 linear scan
+ * ((dr*dr + dg*dg) + db*db), errors pushed as float32(float64(v) + float64(err) * (float64(weights[k]) / divisor)).
+ *   weights  host array of ntaps float32 (the reference's np.float32 weight values), divisor as the reference passes it
+ * Parity status: restated in the CPU oracle (orc_error_diffusion_numba_u8); NOT pinned by fixtures (numba cannot be
+ * installed in the build image). */
+int dp_error_diffusion_numba_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
+                                const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *weights,
+                                double divisor, int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
+                                void *stream);
+
 /* variable-weight diffusers -------------------------------------------------------
  * Replaces the pure-Python branches of PerceptualDitherStrategy.dither (dithering_lib.py:1030-1066, model 1),
  * HybridDitherStrategy.dither (:1111-1155, model 2; p0 = lum_factor, p1 = col_factor),

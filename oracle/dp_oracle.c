@@ -25,6 +25,7 @@
  *   orc_ign_thresholds    _generate_thresholds             dithering_lib.py:539-549
  *   orc_blue_noise        generate_blue_noise              dithering_lib.py:381-399
  *                         (numpy legacy RandomState.shuffle = MT19937, restated)
+ *   orc_error_diffusion_numba_u8  the same strategy's numba branch (:213-308) -- parity unpinned, see the function
  *   orc_error_diffusion_u8 ErrorDiffusionDitherStrategy.dither, pure-Python
  *                         branch                           dithering_lib.py:655-690
  *   orc_kmeans_step       one Lloyd assignment + accumulation pass of
@@ -635,6 +636,85 @@ int orc_error_diffusion_u8(const uint8_t *in, uint8_t *out, int h, int w, const 
         out[i * 3 + 2] = out_colors[j * 3 + 2];
     }
     free(t);
+    free(W);
+    free(pick);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* error diffusion, the numba branch: _error_diffusion_numba,          */
+/* dithering_lib.py:213-308 (dispatch :638-653, arrays built :640-642) */
+/* work float32; palette float32; weights float32; divisor float64.    */
+/*  nearest: first minimum of  dist = (dr*dr + dg*dg) + db*db  with    */
+/*  every operation in float32 (numba keeps float32 x float32 in       */
+/*  float32; best_dist starts at 1e20);                                */
+/*  push: wgt = weights[k] / divisor is float64, err * wgt is float64, */
+/*  work[ny,nx] += ... adds in float64 and rounds to float32 on the    */
+/*  store.  PARITY UNPINNED: numba cannot be installed in the build    */
+/*  image, so no reference output exists for this function.            */
+/* ------------------------------------------------------------------ */
+int orc_error_diffusion_numba_u8(const uint8_t *in, uint8_t *out, int h, int w, const float *pal, int K,
+                                 const uint8_t *out_colors, const uint8_t *lut_in, const int *dx, const int *dy,
+                                 const float *weights, double divisor, int ntaps, int serpentine)
+{
+    float *W = (float *)malloc(sizeof(float) * 3 * (size_t)h * w);
+    int32_t *pick = (int32_t *)malloc(sizeof(int32_t) * (size_t)h * w);
+    if (!W || !pick || K < 1) {
+        free(W);
+        free(pick);
+        return -1;
+    }
+    for (size_t i = 0; i < (size_t)h * w * 3; i++)
+        W[i] = (float)(lut_in ? lut_in[in[i]] : in[i]);
+    for (int y = 0; y < h; y++) {
+        int rev = serpentine && (y & 1);
+        int dir = rev ? -1 : 1;
+        for (int step = 0; step < w; step++) {
+            int x = rev ? (w - 1 - step) : step;
+            float *p = W + ((size_t)y * w + x) * 3;
+            float v[3];
+            for (int c = 0; c < 3; c++) {
+                float t = p[c];
+                v[c] = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+            }
+            int best = 0;
+            double best_dist = 1e20;
+            for (int i = 0; i < K; i++) {
+                volatile float dr = v[0] - pal[i * 3 + 0], dg = v[1] - pal[i * 3 + 1], db = v[2] - pal[i * 3 + 2];
+                volatile float rr = dr * dr, gg = dg * dg, bb = db * db;  /* (volatile: no contraction into fma) */
+                volatile float s1 = rr + gg;
+                volatile float dist = s1 + bb;
+                if ((double)dist < best_dist) {
+                    best_dist = (double)dist;
+                    best = i;
+                }
+            }
+            pick[(size_t)y * w + x] = best;
+            float err[3];
+            for (int c = 0; c < 3; c++) {
+                p[c] = pal[best * 3 + c];
+                err[c] = v[c] - pal[best * 3 + c];
+            }
+            for (int k = 0; k < ntaps; k++) {
+                int nx = x + dx[k] * dir, ny = y + dy[k];
+                if (nx >= 0 && nx < w && ny >= 0 && ny < h) {
+                    volatile double wgt = (double)weights[k] / divisor;
+                    float *tp = W + ((size_t)ny * w + nx) * 3;
+                    for (int c = 0; c < 3; c++) {
+                        volatile double prod = (double)err[c] * wgt;
+                        volatile double sum = (double)tp[c] + prod;
+                        tp[c] = (float)sum;
+                    }
+                }
+            }
+        }
+    }
+    for (size_t i = 0; i < (size_t)h * w; i++) {
+        int j = pick[i];
+        out[i * 3 + 0] = out_colors[j * 3 + 0];
+        out[i * 3 + 1] = out_colors[j * 3 + 1];
+        out[i * 3 + 2] = out_colors[j * 3 + 2];
+    }
     free(W);
     free(pick);
     return 0;

@@ -55,6 +55,9 @@ def lib():
         L.orc_error_diffusion_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int]
+        L.orc_error_diffusion_numba_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_double, C.c_int, C.c_int]
         L.orc_blue_noise.argtypes = [C.c_int, C.c_uint32, C.c_void_p]
         L.orc_var_diffusion_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
@@ -294,6 +297,61 @@ def error_diffusion_u8(arr, pal_f32, out_colors, lut_in, variant="atkinson", ser
     if rc != 0:
         raise ValueError("oracle error_diffusion_u8 failed")
     return out
+
+
+def error_diffusion_numba_u8(arr, pal_f32, out_colors, lut_in, variant="atkinson", serpentine=False):
+    """The reference's numba branch (_error_diffusion_numba, dithering_lib.py:213-308) restated in C.  PARITY UNPINNED:
+    numba cannot be installed here, so nothing the reference produced pins it; tests/test_oracle_golden.py checks it
+    against an independent numpy transcription of the same lines."""
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    h, w, _ = arr.shape
+    out = np.empty_like(arr)
+    taps, div = ed_kernel(variant)
+    dx = np.array([t[0] for t in taps], np.int32)
+    dy = np.array([t[1] for t in taps], np.int32)
+    wts = np.array([t[2] for t in taps], np.float32)
+    rc = lib().orc_error_diffusion_numba_u8(_p(arr), _p(out), h, w, _p(pal_f32), pal_f32.shape[0], _p(out_colors),
+                                            _p(lut_in), _p(dx), _p(dy), _p(wts), float(div), len(taps), 1 if serpentine else 0)
+    if rc != 0:
+        raise ValueError("oracle error_diffusion_numba_u8 failed")
+    return out
+
+
+def error_diffusion_numba_numpy(arr, pal_f32, out_colors, lut_in, variant="atkinson", serpentine=False):
+    """A second, independent statement of the same lines with numpy scalar types doing the arithmetic (np.float32 /
+    np.float64 objects: every operation rounds as the dtype says).  Slow: small images only."""
+    arr = np.asarray(arr, np.uint8)
+    h, w, _ = arr.shape
+    taps, div = ed_kernel(variant)
+    work = (lut_in[arr] if lut_in is not None else arr).astype(np.float32)
+    pal = np.asarray(pal_f32, np.float32)
+    weights = np.array([t[2] for t in taps], np.float32)
+    divisor = float(div)
+    pick = np.zeros((h, w), np.int64)
+    f0, f255 = np.float32(0.0), np.float32(255.0)
+    for y in range(h):
+        rev = serpentine and (y % 2 == 1)
+        xs = range(w - 1, -1, -1) if rev else range(w)
+        xdir = -1 if rev else 1
+        for x in xs:
+            r, g, b = (min(max(work[y, x, c], f0), f255) for c in range(3))
+            best, best_dist = 0, 1e20
+            for i in range(pal.shape[0]):
+                dr, dg, db = r - pal[i, 0], g - pal[i, 1], b - pal[i, 2]
+                dist = dr * dr + dg * dg + db * db  # np.float32 scalars: each product and sum rounded to float32
+                if float(dist) < best_dist:
+                    best_dist, best = float(dist), i
+            pick[y, x] = best
+            c0, c1, c2 = pal[best]
+            work[y, x] = (c0, c1, c2)
+            err = (r - c0, g - c1, b - c2)
+            for k, (tdx, tdy, _) in enumerate(taps):
+                nx, ny = x + tdx * xdir, y + tdy
+                if 0 <= nx < w and 0 <= ny < h:
+                    wgt = np.float64(weights[k]) / np.float64(divisor)
+                    for c in range(3):
+                        work[ny, nx, c] = np.float32(np.float64(work[ny, nx, c]) + np.float64(err[c]) * wgt)
+    return np.asarray(out_colors, np.uint8)[pick]
 
 
 def uniform_filter_f32(a, size):

@@ -175,6 +175,61 @@ def test_error_diffusion_vs_oracle(be, orc, variant, serp):
         _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, False), f"{variant} {serp}")
 
 
+@pytest.mark.parametrize("variant", ["floyd_steinberg", "jjn", "atkinson", "sierra_lite", "burkes"])
+@pytest.mark.parametrize("serp", [False, True])
+def test_error_diffusion_numba_arithmetic_vs_oracle(be, orc, variant, serp):
+    """The reference's numba branch (dithering_lib.py:213-308: float32 linear-scan nearest, float64 pushes rounded on the
+    store) through dp_error_diffusion_numba_u8 against its C restatement -- several bands, several frames, a palette with
+    exact float32 ties (uniform) and one without, with and without the gamma table.  (That restatement is itself not
+    pinned by reference output: numba is not installable here.)"""
+    import torch
+    for arr, pal, gamma in [(orc.rnd(150, 97, 4), orc.palr(16, 3), False), (orc.grad(131, 200), orc.generate_uniform_palette(16), False),
+                            (orc.rnd(70, 40, 5), orc.palr(40, 9), True), (orc.rnd(9, 5, 6), orc.palr(2, 1), False)]:
+        pal_f32, out_colors, lut_in = orc.prepare_palette(pal, gamma)
+        P = be.Palette(pal_f32, out_colors, lut_in)
+        taps, div = orc.ed_kernel(variant)
+        frames = np.stack([arr, arr[::-1].copy()])
+        out = be.error_diffusion(torch.from_numpy(frames).cuda(), P, taps, div, serp, arithmetic="numba").cpu().numpy()
+        for f in range(2):
+            ref = orc.error_diffusion_numba_u8(frames[f], pal_f32, out_colors, lut_in, variant, serp)
+            _assert_same(out[f], ref, f"numba arithmetic {variant} serp={serp} frame {f}")
+
+
+def test_error_diffusion_numba_arithmetic_1080p_bands_over_workgroups(be, orc):
+    """One 1080p frame (17 bands spread over workgroups, the few-frames schedule) and the strategy-level switch."""
+    import torch
+    from dither_pie_amd import dithering_lib as dl
+    arr = orc.rnd(1080, 1920, 11)
+    pal = orc.generate_uniform_palette(16)
+    pal_f32, out_colors, lut_in = orc.prepare_palette(pal, False)
+    ref = orc.error_diffusion_numba_u8(arr, pal_f32, out_colors, lut_in, "floyd_steinberg", False)
+    old = dl.ERROR_DIFFUSION_ARITHMETIC
+    dl.ERROR_DIFFUSION_ARITHMETIC = "numba"
+    try:
+        d = dl.ImageDitherer(16, dl.DitherMode.ERROR_DIFFUSION, pal, False, {"variant": "floyd_steinberg", "serpentine": "false"})
+        out = d.apply_dithering_frames(torch.from_numpy(arr).cuda()).cpu().numpy()
+    finally:
+        dl.ERROR_DIFFUSION_ARITHMETIC = old
+    _assert_same(out, ref, "numba arithmetic, 1080p")
+    # inputs on which the two arithmetics disagree (exact ties: lowest index against scipy's traversal order; even values
+    # against a 4x4x4 lattice): the numba entry point follows the numba restatement, the default one the pure-Python branch
+    lv = [0, 64, 128, 192, 255]
+    for pal2, arr2 in [([(a, b, c) for a in lv for b in lv for c in lv], np.full((70, 16, 3), 32, np.uint8)),
+                       ([(a, b, c) for a in lv[:4] for b in lv[:4] for c in lv[:4]],
+                        (np.random.RandomState(0).randint(0, 128, (48, 48, 3)) * 2).astype(np.uint8))]:
+        pf, oc, lut = orc.prepare_palette(pal2, False)
+        P = be.Palette(pf, oc, lut)
+        taps, div = orc.ed_kernel("floyd_steinberg")
+        t = torch.from_numpy(arr2).cuda()
+        nb = be.error_diffusion(t, P, taps, div, False, arithmetic="numba").cpu().numpy()
+        py = be.error_diffusion(t, P, taps, div, False).cpu().numpy()
+        ref_nb = orc.error_diffusion_numba_u8(arr2, pf, oc, lut, "floyd_steinberg", False)
+        ref_py = orc.error_diffusion_u8(arr2, pf, oc, lut, "floyd_steinberg", False)
+        assert len(pal2) != 125 or not np.array_equal(ref_nb, ref_py)  # (the constant frame on the 5x5x5 lattice: every pixel)
+        _assert_same(nb, ref_nb, "numba arithmetic on a tie-rich input")
+        _assert_same(py, ref_py, "python arithmetic on a tie-rich input")
+
+
 def test_error_diffusion_batch_and_gamma(be, orc):
     pal = orc.palr(16, 3)
     frames = np.stack([orc.rnd(80, 60, s) for s in range(3)])

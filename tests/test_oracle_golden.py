@@ -190,3 +190,25 @@ def test_variance_map_restatement(orc, gold):
     g = np.random.RandomState(3).rand(41, 29).astype(np.float32) * 255
     for size in (3, 5, 11):
         assert np.array_equal(orc.uniform_filter_f32(g, size), nd.uniform_filter(g, size=size, mode="nearest"))
+
+
+@pytest.mark.parametrize("variant,serp", [("floyd_steinberg", False), ("atkinson", True), ("jjn", False), ("sierra_lite", True)])
+def test_numba_branch_restatement_agrees_with_a_numpy_transcription(variant, serp):
+    """The numba branch of the reference (dithering_lib.py:213-308) cannot be run here (numba is not installable), so its C
+    restatement is UNPINNED; what can be checked is that two independent statements of those lines agree -- the C one and
+    a numpy one in which np.float32 / np.float64 scalars do the rounding -- on images with clamping, ties and both scans."""
+    from oracle import oracle as orc
+    for arr, pal, gamma in [(orc.rnd(13, 17, 3), orc.generate_uniform_palette(16), False), (orc.grad(9, 21), orc.palr(9, 5), True)]:
+        pal_f32, out_colors, lut_in = orc.prepare_palette(pal, gamma)
+        a = orc.error_diffusion_numba_u8(arr, pal_f32, out_colors, lut_in, variant, serp)
+        b = orc.error_diffusion_numba_numpy(arr, pal_f32, out_colors, lut_in, variant, serp)
+        assert np.array_equal(a, b)
+    # and it is a different function from the pure-Python branch where ties are many: a constant frame half-way between
+    # two levels of a 5x5x5 lattice (the lowest index against scipy's traversal order)
+    lv = [0, 64, 128, 192, 255]
+    pal = [(a, b, c) for a in lv for b in lv for c in lv]
+    arr = np.full((16, 16, 3), 32, np.uint8)
+    pal_f32, out_colors, lut_in = orc.prepare_palette(pal, False)
+    a = orc.error_diffusion_numba_u8(arr, pal_f32, out_colors, lut_in, variant, serp)
+    assert np.array_equal(a, orc.error_diffusion_numba_numpy(arr, pal_f32, out_colors, lut_in, variant, serp))
+    assert not np.array_equal(a, orc.error_diffusion_u8(arr, pal_f32, out_colors, lut_in, variant, serp))
