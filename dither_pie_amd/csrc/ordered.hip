@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
 //    permuted, so the deferred path reads blocks (and split nodes, which are no longer staged) from global memory.
 // MODE as in ordered_lean_kernel.  BW = 8 or 4 (tables of small palettes: every slot is read either way).
 // ---------------------------------------------------------------------------------------------
-constexpr int kNearSlots8 = 6;
+[[maybe_unused]] constexpr int kNearSlots8 = 6;
 
 // Keys of the first six entries of a block and the two smallest (see cand8)
 __device__ __forceinline__ void cand6n(const uint32_t x, const uint4 ca, const uint32_t c4, const uint32_t c5, const int neg2,

@@ -8,7 +8,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 pal = ColorReducer.generate_uniform_palette(K) if K <= 64 else [tuple(int(v) for v in c) for c in np.random.RandomState(7).randint(0, 256, (K, 3))]
 g = torch.Generator(device='cuda'); g.manual_seed(1)
-nmax = 256 if K <= 16 else 64
+nmax = 256
 f = torch.randint(0, 256, (nmax, 2160, 3840, 3), dtype=torch.uint8, device='cuda', generator=g); o = torch.empty_like(f)
 d = ImageDitherer(K, DitherMode.ERROR_DIFFUSION, pal, False, {"variant": variant, "serpentine": "false"})
 for nf in (1, 24, nmax):
