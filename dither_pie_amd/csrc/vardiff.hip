@@ -401,6 +401,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     __shared__ float s_bout[kVWaves][2][kVPeriod][4];
     __shared__ uint8_t s_lut[256];
     __shared__ volatile uint32_t s_prog[kVWaves];
+    __shared__ __align__(16) float s_zero4[4];  // the "error" of rows that do not exist (weight read as 1.0, error 0)
     // {x, y, z, out_rgb bits}; palettes of 9..16 colours keep the candidate lists of the 16^3 cells behind their 16 entries (ediff.hip)
     __shared__ float4 s_pal[DP_MAX_COLORS + 16];
     uint32_t *s_coarse = reinterpret_cast<uint32_t *>(s_pal + 16);
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_coarse[i] = coarse_src[i];
     const uint32_t *coarse = coarse_src ? s_coarse : nullptr;
     if (threadIdx.x < kVWaves) s_prog[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_zero4[threadIdx.x] = threadIdx.x == 3 ? 1.0f : 0.0f;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
     const uint8_t *fgate = vp.gate ? vp.gate + f * (size_t)h * w : nullptr;
@@ -442,9 +444,29 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
         const long row_byte = (long)r * w * 3;
         const long row_gate = (long)r * w;
 
+        // the taps as immediates (Floyd-Steinberg's four, or Ostromoukhov's three), in the reference's visiting order
+        constexpr int kDx[4] = {MODEL == 4 ? 0 : 1, MODEL == 4 ? -1 : 0, MODEL == 4 ? 1 : -1, 1};
+        constexpr int kDy[4] = {1, 1, MODEL == 4 ? 0 : 1, 0};
+        constexpr float kW[4] = {1.0f / 16, 5.0f / 16, 3.0f / 16, 7.0f / 16};
+        constexpr int kCol[3] = {2, 1, 0};
+        // where each tap of this lane's row finds its source row: the ring of a row of the band, the ring of the two rows
+        // above the band, or -- the row does not exist -- the zero slot; the rings hold zero errors for the two columns
+        // either side of the image (below), so a tap needs neither a row nor a column test
+        typedef const __attribute__((address_space(3))) float lds_float_t;
+        lds_float_t *tb[4];
+        uint32_t tm[4];
+#pragma unroll
+        for (int k = 0; k < ntaps; ++k) {
+            const int rel = L - kDy[k];
+            const bool exists = r - kDy[k] >= 0;
+            const float *row = rel >= 0 ? &s_ring[wv][rel][0] : &s_vring[wv][rel + 2][0][0];
+            tb[k] = exists ? (lds_float_t *)row : (lds_float_t *)s_zero4;
+            tm[k] = exists ? (rel >= 0 ? (uint32_t)(kVRing - 1) : 63u) : 0u;
+        }
         uint32_t pix[12], cur[13], outb[13], gpx[4], gcur[5];
-        float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f, pb3 = 0.f;
-        int pb_col = -1;
+        float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f, pb3 = 1.0f;
+        int pb_col = 0;
+        bool pb_valid = false;
 #pragma unroll
         for (int k = 0; k < 12; ++k) pix[k] = 0;
 #pragma unroll
@@ -462,7 +484,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                 if (G == 1) s_prog[wv] = word;
                 else __hip_atomic_store(&gprog[gw], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (pb_col >= 0) {
+            if (pb_valid) {
                 float *dst = &s_vring[wv][L >> 5][pb_col & 63][0];
                 dst[0] = pb0;
                 dst[1] = pb1;
@@ -547,7 +569,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     }
                 }
             }
-            pb_col = -1;
+            pb_valid = false;
             if (band > 0) {
                 const int x0n = t0 + kVPeriod;
                 int need = x0n + 18;
@@ -573,6 +595,12 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                         pb2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pb3 = __hip_atomic_load(b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pb_col = col;
+                        pb_valid = true;
+                    } else if (col >= -2 && col < w + 2) {  // the two columns either side of the image: zero errors
+                        pb0 = pb1 = pb2 = 0.f;
+                        pb3 = 1.0f;
+                        pb_col = col;
+                        pb_valid = true;
                     }
                 }
             }
@@ -587,7 +615,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                 const int i = i4 + q;
                 const int t = t0 + i;
                 const int x = t - skew * L;
-                const bool act = row_ok && x >= 0 && x < w && t >= 0 && t < steps;
+                const bool act = row_ok && (uint32_t)x < (uint32_t)w;  // (0 <= t < steps follows for the rows of the band)
                 float e0 = 0.f, e1 = 0.f, e2 = 0.f, aux = 1.0f;
                 uint32_t cbytes = 0;
                 if (act) {
@@ -596,25 +624,19 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     const float g0 = (float)s_lut[pxv & 255u], g1 = (float)s_lut[(pxv >> 8) & 255u],
                                 g2 = (float)s_lut[(pxv >> 16) & 255u];
                     float a0 = g0, a1 = g1, a2 = g2;
+#pragma unroll
                     for (int k = 0; k < ntaps; ++k) {
-                        const int dx = model == 4 ? kOsDx[k] : kFsDx[k], dy = model == 4 ? kOsDy[k] : kFsDy[k];
-                        const int sxp = x - dx;
-                        const int sr = r - dy;
-                        if (sxp < 0 || sxp >= w || sr < 0) continue;
-                        const int rel = L - dy;
-                        const float *src = rel >= 0 ? &s_ring[wv][rel][(sxp & (kVRing - 1)) * 4]
-                                                    : &s_vring[wv][rel + 2][sxp & 63][0];
+                        lds_float_t *src = tb[k] + ((x - kDx[k]) & (int)tm[k]) * 4;
                         const float sa = src[3];
                         float wk;
                         if (model == 1)
-                            wk = __fmul_rn(kFsW[k], sa);
-                        else if (model == 3) {
-                            if (sa == 0.0f) continue;
-                            wk = kFsW[k];
-                        } else if (model == 4)
-                            wk = vp.coef[3 * (int)sa + kOsCol[k]];
+                            wk = __fmul_rn(kW[k], sa);
+                        else if (model == 3)
+                            wk = sa == 0.0f ? 0.0f : kW[k];  // a closed gate: the source adds +-0, which changes nothing (a is never -0)
+                        else if (model == 4)
+                            wk = vp.coef[3 * (int)sa + kCol[k]];
                         else
-                            wk = kFsW[k];
+                            wk = kW[k];
                         a0 = __fadd_rn(a0, __fmul_rn(src[0], wk));
                         a1 = __fadd_rn(a1, __fmul_rn(src[1], wk));
                         a2 = __fadd_rn(a2, __fmul_rn(src[2], wk));
@@ -657,13 +679,14 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                 cb[q] = cbytes;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (act) {
+                // columns -2, -1, w and w+1 are written too, with zero errors (e is 0, aux 1 without a pixel)
+                if (row_ok && x >= -2 && x < w + 2) {
                     float *dst = &s_ring[wv][L][(x & (kVRing - 1)) * 4];
                     dst[0] = e0;
                     dst[1] = e1;
                     dst[2] = e2;
                     dst[3] = aux;
-                    if (L >= 62) {
+                    if (act && L >= 62) {
                         float *bo = &s_bout[wv][L - 62][i][0];
                         bo[0] = e0;
                         bo[1] = e1;
