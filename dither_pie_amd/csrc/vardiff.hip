@@ -556,6 +556,10 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     }
                     if (model == 3) {  // the next 16 gate bytes of this row
                         const long G = row_gate + xn;
+                        if (G >= 0 && G + 16 <= gate_bytes) {  // four (unaligned) dword loads instead of sixteen byte loads
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) gpx[k] = *reinterpret_cast<const uint32_t *>(fgate + G + 4 * k);
+                        } else
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             uint32_t v = 0;
@@ -751,10 +755,12 @@ __device__ __forceinline__ float mean_f32(const double t, const double size, con
 // 3 + 8 written + 8 read + 1, and four multiplications instead of four float64 divisions.
 constexpr int kGateTW = 64, kGateTH = 16, kGateMaxR = 4;
 
+template <int RADIUS>  // compiled per window radius: the tile widths are constants (index arithmetic without divisions)
 __global__ __launch_bounds__(256) void var_gate_fused_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ lut,
                                                               uint8_t *__restrict__ gate, const int h, const int w,
-                                                              const int radius, const float thr)
+                                                              const float thr)
 {
+    constexpr int radius = RADIUS;
     constexpr int kMaxW = kGateTW + 2 * kGateMaxR, kMaxH = kGateTH + 2 * kGateMaxR;
     __shared__ float s_g[kMaxH][kMaxW], s_q[kMaxH][kMaxW];        // gray, gray^2 of the tile + halo
     __shared__ float s_tg[kGateTH][kMaxW], s_tq[kGateTH][kMaxW];  // after axis 0
@@ -762,14 +768,28 @@ __global__ __launch_bounds__(256) void var_gate_fused_kernel(const uint8_t *__re
     const uint8_t *fin = in + (size_t)f * h * w * 3;
     uint8_t *fgate = gate + (size_t)f * h * w;
     const int x0 = blockIdx.x * kGateTW, y0 = blockIdx.y * kGateTH;
-    const int size = 2 * radius + 1, tw = kGateTW + 2 * radius, th = kGateTH + 2 * radius;
+    constexpr int size = 2 * radius + 1, tw = kGateTW + 2 * radius, th = kGateTH + 2 * radius;
     const double dsize = (double)size, rcp = 1.0 / dsize;
     for (int i = threadIdx.x; i < tw * th; i += 256) {
         const int ty = i / tw, tx = i - ty * tw;
         int y = y0 + ty - radius, x = x0 + tx - radius;
         y = y < 0 ? 0 : (y >= h ? h - 1 : y);
         x = x < 0 ? 0 : (x >= w ? w - 1 : x);
-        const float g = gray_of(fin + ((size_t)y * w + x) * 3, lut);
+        // one (unaligned) dword per pixel instead of three byte loads; the frame's very last pixel has no fourth byte
+        const size_t at = ((size_t)y * w + x) * 3;
+        float g;
+        if (at + 4 <= (size_t)h * w * 3) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(fin + at);
+            uint32_t c0 = v & 255u, c1 = (v >> 8) & 255u, c2 = (v >> 16) & 255u;
+            if (lut) {
+                c0 = lut[c0];
+                c1 = lut[c1];
+                c2 = lut[c2];
+            }
+            g = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, (float)c0), __fmul_rn(0.587f, (float)c1)), __fmul_rn(0.114f, (float)c2));
+        } else {
+            g = gray_of(fin + at, lut);
+        }
         s_g[ty][tx] = g;
         s_q[ty][tx] = __fmul_rn(g, g);
     }
@@ -877,8 +897,17 @@ int launch_variance_gate(const uint8_t *in, uint8_t *gate, int64_t n_frames, int
         for (int64_t f0 = 0; f0 < n_frames; f0 += 65535) {
             const int64_t nf = std::min<int64_t>(65535, n_frames - f0);
             const dim3 grid((w + kGateTW - 1) / kGateTW, (h + kGateTH - 1) / kGateTH, (unsigned)nf);
-            hipLaunchKernelGGL(var_gate_fused_kernel, grid, dim3(256), 0, s, in + (size_t)f0 * h * w * 3, pal.lut_in,
-                               gate + (size_t)f0 * h * w, h, w, radius, thr);
+#define DP_GATE(R)                                                                                                       \
+    hipLaunchKernelGGL(var_gate_fused_kernel<R>, grid, dim3(256), 0, s, in + (size_t)f0 * h * w * 3, pal.lut_in,           \
+                       gate + (size_t)f0 * h * w, h, w, thr)
+            switch (radius) {
+            case 0: DP_GATE(0); break;
+            case 1: DP_GATE(1); break;
+            case 2: DP_GATE(2); break;
+            case 3: DP_GATE(3); break;
+            default: DP_GATE(4); break;
+            }
+#undef DP_GATE
         }
         DP_HIP(hipGetLastError());
         return DP_OK;
