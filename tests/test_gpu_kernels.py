@@ -484,6 +484,21 @@ def test_randomised_cases_against_oracle(be, orc, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22])
+def test_randomised_diffusion_cases_against_oracle(be, orc, seed):
+    """150 random diffusion cases per seed: the eight tap sets, both scans, both arithmetics, the four variable-coefficient
+    diffusers; palette sizes around every table boundary, uniform / random / clustered palettes, gamma, shapes from 1x1 to
+    a few bands, batches (tests/fuzz_diffusion.py)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_diffusion.py")
+    spec = importlib.util.spec_from_file_location("fuzz_diffusion", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(seed, 150) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K", [4, 5, 7, 8, 16, 27, 64])
 @pytest.mark.parametrize("mode,params", [("none", {}), ("bayer", {"size": "4x4"}), ("IGN", {})])
 def test_small_palettes_four_entry_blocks(be, orc, K, mode, params):
