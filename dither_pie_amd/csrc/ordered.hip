@@ -1856,21 +1856,11 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
                     m0 = min(m0, key[c]);
                 }
                 s |= (m1 - m0) <= kFloatKeyGap;
-                // the winners' record offsets: read back from the block by position (a select chain over the eight
-                // registers costs 31 instructions; blocks read from global memory -- deep nodes -- keep it)
-                uint32_t o0, o1;
-                if (!from_global) {
-                    o0 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + (((uint32_t)m0 & 7u) << 2));
-                    o1 = *reinterpret_cast<const uint32_t *>(s_bytes + blk + (((uint32_t)m1 & 7u) << 2));
-                    if (s && (ca.x == cand_base)) o0 = o1 = cand_base;
-                } else {
-                    o0 = off[0];
-                    o1 = off[0];
+                uint32_t o0 = off[0], o1 = off[0];
 #pragma unroll
-                    for (int c = 1; c < 8; ++c) {
-                        o0 = ((uint32_t)m0 & 7u) == (uint32_t)c ? off[c] : o0;
-                        o1 = ((uint32_t)m1 & 7u) == (uint32_t)c ? off[c] : o1;
-                    }
+                for (int c = 1; c < 8; ++c) {
+                    o0 = ((uint32_t)m0 & 7u) == (uint32_t)c ? off[c] : o0;
+                    o1 = ((uint32_t)m1 & 7u) == (uint32_t)c ? off[c] : o1;
                 }
                 const uint32_t a0 = s ? cand_base : o0;
                 uint32_t cpick = *reinterpret_cast<const uint32_t *>(s_bytes + a0 + 12);  // the winner's output colour
@@ -1885,10 +1875,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
                     const float s0f = __uint_as_float((uint32_t)m0 & ~7u), s1f = __uint_as_float((uint32_t)m1 & ~7u);
                     const float gap = __fdividef(s0f, s0f + s1f) - tq[q];
                     bool use_nearest = gap <= 0.0f;
-                    // (a wave-uniform test first: as a plain per-lane branch the compiler turns the float64 replay into
-                    // straight-line predicated code that every pixel pays for -- 24 float64 operations)
-                    const bool replay = fabsf(gap) <= 2e-5f && !s;
-                    if (__ballot(replay) != 0ull && replay) {
+                    if (fabsf(gap) <= 2e-5f && !s) {
                         const float4 c0 = *reinterpret_cast<const float4 *>(s_bytes + a0);
                         const float4 c1 = *reinterpret_cast<const float4 *>(s_bytes + a1);
                         const double p0[3] = {(double)c0.x, (double)c0.y, (double)c0.z};
