@@ -17,6 +17,13 @@ __device__ __forceinline__ int ed_key(const float4 c, const float o0, const floa
     return (int)((__float_as_uint(d) & ~7u) | tag);
 }
 
+__device__ __forceinline__ int ed_key16(const float4 c, const float o0, const float o1, const float o2, const uint32_t tag)
+{
+    const float a = c.x - o0, b = c.y - o1, cc = c.z - o2;
+    const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, cc * cc));
+    return (int)((__float_as_uint(d) & ~15u) | tag);
+}
+
 __device__ __forceinline__ int ed_med3(const int a, const int b, const int c)
 {
     int r;
@@ -204,6 +211,41 @@ __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const floa
             }
         }
         if (n > 15) return nearest_color<CAP>(pal, cand, o0, o1, o2);
+        // Lists of up to 12 entries (padded to a multiple of 4 positions by the builder, ediff.hip: pack): the key scan first --
+        // float32 distance bits with the position in the low 4 bits, the two smallest kept by v_med3 / v_min, groups of
+        // four without per-position tests; a second key within 4e-6 (relative: 2e-6 of the evaluation + 15 ulp of the tag)
+        // of the first leaves the decision to the exact scan below.
+        if (n >= 1 && n <= 12 && pal.K > 16) {
+            uint4 b = blk;
+            b.x = __funnelshift_r(b.x, b.y, 8);  // drop the count byte
+            b.y = __funnelshift_r(b.y, b.z, 8);
+            b.z = __funnelshift_r(b.z, b.w, 8);
+            int m0 = 0x7fffffff, m1 = 0x7fffffff;
+            uint32_t tag = 0u;
+            for (int left = n; left > 0; left -= 4, tag += 4u) {
+                const int j1 = (int)(b.x & 255u), j2 = (int)((b.x >> 8) & 255u), j3 = (int)((b.x >> 16) & 255u), j4 = (int)(b.x >> 24);
+                const float4 c1 = cand[j1], c2 = cand[j2], c3 = cand[j3], c4 = cand[j4];
+                const int k1 = ed_key16(c1, o0, o1, o2, tag), k2 = ed_key16(c2, o0, o1, o2, tag + 1u),
+                          k3 = ed_key16(c3, o0, o1, o2, tag + 2u), k4 = ed_key16(c4, o0, o1, o2, tag + 3u);
+                m1 = ed_med3(m0, m1, k1);
+                m0 = min(m0, k1);
+                m1 = ed_med3(m0, m1, k2);
+                m0 = min(m0, k2);
+                m1 = ed_med3(m0, m1, k3);
+                m0 = min(m0, k3);
+                m1 = ed_med3(m0, m1, k4);
+                m0 = min(m0, k4);
+                b.x = b.y;
+                b.y = b.z;
+                b.z = 0u;
+            }
+            const float f0 = __int_as_float(m0 & ~15), f1 = __int_as_float(m1 & ~15);
+            if (f1 > f0 * 1.000004f) {
+                const uint32_t pos = ((uint32_t)m0 & 15u) + 1u;  // byte 1..12 of the block
+                const uint32_t wsel = pos < 4u ? blk.x : (pos < 8u ? blk.y : (pos < 12u ? blk.z : blk.w));
+                return (int)((wsel >> ((pos & 3u) * 8u)) & 255u);
+            }
+        }
         // four entries per round, their reads in flight together (unused slots hold index 0: a valid, ignored read)
         blk.x = __funnelshift_r(blk.x, blk.y, 8);  // drop the count byte
         blk.y = __funnelshift_r(blk.y, blk.z, 8);

@@ -783,9 +783,31 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
         }
         list.swap(keep);
     };
-    auto pack = [](const std::vector<int> &list) {
+    // count byte + up to 15 index bytes.  Lists of up to 12 entries are padded to a multiple of 4 positions with an entry that is
+    // NOT on the list (the one farthest from the box): the key scan of nearest_color_cells evaluates whole groups of four
+    // without per-position tests; an unlisted entry is never the nearest of a point of the box, and should float32
+    // rounding bring it within the margin of the nearest, the exact scan -- which honours the count -- decides.
+    auto pack = [&](const std::vector<int> &list, const double *lo = nullptr, const double size = 0.0) {
         uint32_t w[4] = {(uint32_t)list.size(), 0u, 0u, 0u};
         for (size_t n = 1; n <= list.size(); ++n) w[n >> 2] |= (uint32_t)list[n - 1] << (8 * (n & 3));
+        if (lo && !list.empty() && list.size() <= 12 && (int)list.size() < K) {
+            int filler = -1;
+            double far_d = -1.0;
+            for (int j = 0; j < K; ++j) {
+                if (std::find(list.begin(), list.end(), j) != list.end()) continue;
+                double d2 = 0.0;
+                for (int d = 0; d < 3; ++d) {
+                    const double m = pts[3 * j + d] - (lo[d] + 0.5 * size);
+                    d2 += m * m;
+                }
+                if (d2 > far_d) {
+                    far_d = d2;
+                    filler = j;
+                }
+            }
+            const size_t upto = (list.size() + 3) / 4 * 4;
+            for (size_t n = list.size() + 1; n <= upto && filler >= 0; ++n) w[n >> 2] |= (uint32_t)filler << (8 * (n & 3));
+        }
         return make_uint4(w[0], w[1], w[2], w[3]);
     };
     struct Work {
@@ -803,15 +825,13 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     for (int cell = 0; cell < kEdCells; ++cell) {
         const uint32_t w4[4] = {host[cell].x, host[cell].y, host[cell].z, host[cell].w};
         const int n = (int)(w4[0] & 255u);
-        if (n < 2 || n > 15) continue;
+        if (n < 1 || n > 15) continue;
         list.clear();
         for (int i = 1; i <= n; ++i) list.push_back((int)((w4[i >> 2] >> (8 * (i & 3))) & 255u));
         const double lo[3] = {(double)((cell & 31) * 8), (double)(((cell >> 5) & 31) * 8), (double)((cell >> 10) * 8)};
         prune_list(lo, 8.0, list);
-        if ((int)list.size() < n) {
-            host[cell] = pack(list);
-            pruned_any = true;
-        }
+        host[cell] = pack(list, lo, 8.0);  // (re-packed even when nothing was dropped: the padding)
+        pruned_any = true;
     }
     for (int cell = 0; cell < kEdCells; ++cell)
         if ((host[cell].x & 255u) == 255u) {
@@ -832,7 +852,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
         stack.pop_back();
         uint4 entry;
         if (wk.from.size() <= 15) {
-            entry = pack(wk.from);
+            entry = pack(wk.from, wk.lo, wk.size);
         } else if (wk.size <= 1.0) {
             entry = make_uint4(255u, 0u, 0u, 0u);  // a unit cube that still sees more than 15 entries: scan the palette
         } else {
@@ -894,7 +914,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
             const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
             box_list(all, lo, 16.0, list);
             prune_list(lo, 16.0, list);
-            l16[cell] = list.size() <= 15 ? pack(list) : make_uint4(255u, 0u, 0u, 0u);
+            l16[cell] = list.size() <= 15 ? pack(list, lo, 16.0) : make_uint4(255u, 0u, 0u, 0u);
         }
         uint4 *d_l16 = cells + kEdCells + nodes.size() * (d_nodes ? 1 : 0);
         e = hipMemcpy(d_l16, l16.data(), sizeof(uint4) * 4096, hipMemcpyHostToDevice);
