@@ -211,6 +211,66 @@ def test_fit_palette_under_one_rank_nccl_group(be, orc):
     assert np.abs(init.cpu().numpy() - init_h).max() == 0.0
 
 
+def _two_rank_fit_worker(rank, world, port, h, w, K, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dither_pie_amd import kmeans, sharding
+        from oracle import oracle as orc
+        torch.cuda.set_device(0)
+        img = orc.rnd(h, w, 77)
+        lo, hi = sharding.shard_range(h, rank, world)
+        band = torch.from_numpy(np.ascontiguousarray(img[lo:hi])).cuda()
+        pal, centers, inertia, n_iter = kmeans.fit_palette(band.reshape(-1, 3), K, 42, n_total=h * w, offset=lo * w)
+        # C4's second half and C5's partition with the real kernels: the band with global coordinates, a block of frames
+        from dither_pie_amd.dithering_lib import DitherMode, ImageDitherer
+        d4 = ImageDitherer(K, DitherMode.BLUE_NOISE, pal, False, {"size": 32, "seed": 7})
+        whole = sharding.gather_bands(sharding.dither_band(d4, band, lo), h)
+        frames = np.stack([orc.rnd(40, 56, 500 + i) for i in range(5)])
+        d5 = ImageDitherer(16, DitherMode.BAYER, orc.generate_uniform_palette(16), False, {"size": "4x4"})
+        flo, fhi = sharding.my_frame_block(5)
+        video = sharding.gather_frames(sharding.dither_frames_sharded(d5, torch.from_numpy(frames[flo:fhi]).cuda()), 5)
+        q.put((rank, pal, np.asarray(centers), float(inertia), int(n_iter), whole.cpu().numpy(), video.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_palette_two_ranks_real_kernel_equals_one_rank(be, orc):
+    """The sharded paths with the REAL kernels on two ranks (two processes sharing this GPU; the collectives run through a
+    gloo group on device tensors -- RCCL itself needs one GPU per rank): C4 = seeding sample gathered from both bands,
+    k-means++ kernel on each rank, Lloyd passes + all-reduce + device-side update, then the blue-noise dither of each band
+    with global coordinates, gathered; C5 = contiguous frame blocks, gathered.  Byte-identical to the single-rank results."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from dither_pie_amd import kmeans
+    h, w, K = 301, 333, 12
+    img = orc.rnd(h, w, 77)
+    pal1, c1, i1, n1 = kmeans.fit_palette(torch.from_numpy(img).cuda().reshape(-1, 3), K, 42)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_fit_worker, args=(r, 2, port, h, w, K, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref_img = orc.apply_dithering(img, pal1, "blue_noise", {"size": 32, "seed": 7})
+    frames = np.stack([orc.rnd(40, 56, 500 + i) for i in range(5)])
+    ref_video = np.stack([orc.apply_dithering(f, orc.generate_uniform_palette(16), "bayer", {"size": "4x4"}) for f in frames])
+    for rank, pal, c, i, n, whole, video in res:
+        assert pal == pal1 and np.array_equal(c, np.asarray(c1)) and i == float(i1) and n == int(n1), rank
+        assert np.array_equal(whole, ref_img) and np.array_equal(video, ref_video), rank
+
+
 # ------------------------------------------------------------------------------------------------ C5 / C1 / C2
 def test_c5_1080p_frames_in_a_batch(d, orc):
     import torch
