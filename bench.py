@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary 1080p / error-diffusion lines")
     ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="(testing the N > 1 code path on a one-GPU box) every rank uses cuda:0 and the collectives run over "
+                         "gloo; the numbers of such a run mean nothing")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -170,6 +173,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun even a single rank uses RCCL
@@ -181,7 +186,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            if args.rehearse_on_one_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -281,6 +289,8 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
         "rccl_world_size": dist.get_world_size() if distributed else 1,
+        **({"rehearsal": "all ranks on cuda:0, gloo collectives: code-path check only, the numbers mean nothing"}
+           if args.rehearse_on_one_gpu else {}),
         "config": {"workload": "C2: Bayer 8x8 + 256-colour nearest palette palr(256,7), 3840x2160 RGB, "
                                f"{args.frames} distinct frames rnd(2160,3840,1234+i) per GPU resident in HBM, frames sharded per rank",
                    "frames_per_gpu": args.frames, "h": H4K, "w": W4K, "colors": 256, "matrix": "8x8",
