@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ditherpie_hip.h"
@@ -148,6 +149,11 @@ struct dp_palette {
     std::vector<uint8_t> lut_host; // 256 or empty
     bool float_accel;              // a float palette the cell-table accelerator handles
     int device;
+    // the candidate tables of the diffusion kernels (dev.ed_*) are built at the first diffusion call with the palette
+    // (host.cpp: ensure_ed_tables): ordered-only users -- one palette per image in the CLI -- never pay for them
+    std::vector<double> pts_host;  // K*3 float64 (KD-tree points)
+    bool ed_tried;
+    std::mutex ed_mutex;
 };
 
 struct dp_thresholds {

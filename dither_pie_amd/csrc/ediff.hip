@@ -783,6 +783,23 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
         }
         list.swap(keep);
     };
+    // the palette entry nearest to each corner of the cube: bit d of the index set = the corner's coordinate d is 255
+    int corner_entry[8];
+    for (int c = 0; c < 8; ++c) {
+        double best = std::numeric_limits<double>::infinity();
+        corner_entry[c] = 0;
+        for (int j = 0; j < K; ++j) {
+            double d2 = 0.0;
+            for (int d = 0; d < 3; ++d) {
+                const double m = pts[3 * j + d] - ((c >> d) & 1 ? 255.0 : 0.0);
+                d2 += m * m;
+            }
+            if (d2 < best) {
+                best = d2;
+                corner_entry[c] = j;
+            }
+        }
+    }
     // count byte + up to 15 index bytes.  Lists of up to 12 entries are padded to a multiple of 4 positions with an entry that is
     // NOT on the list (the one farthest from the box): the key scan of nearest_color_cells evaluates whole groups of four
     // without per-position tests; an unlisted entry is never the nearest of a point of the box, and should float32
@@ -791,18 +808,24 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
         uint32_t w[4] = {(uint32_t)list.size(), 0u, 0u, 0u};
         for (size_t n = 1; n <= list.size(); ++n) w[n >> 2] |= (uint32_t)list[n - 1] << (8 * (n & 3));
         if (lo && !list.empty() && list.size() <= 12 && (int)list.size() < K) {
-            int filler = -1;
-            double far_d = -1.0;
-            for (int j = 0; j < K; ++j) {
-                if (std::find(list.begin(), list.end(), j) != list.end()) continue;
-                double d2 = 0.0;
-                for (int d = 0; d < 3; ++d) {
-                    const double m = pts[3 * j + d] - (lo[d] + 0.5 * size);
-                    d2 += m * m;
-                }
-                if (d2 > far_d) {
-                    far_d = d2;
-                    filler = j;
+            // (any unlisted entry will do; a far one keeps it out of the margin: the entry nearest to the cube corner
+            // opposite to the box, unless that one is listed -- then the farthest by scan)
+            const int oct = (lo[0] + 0.5 * size < 128.0 ? 1 : 0) | (lo[1] + 0.5 * size < 128.0 ? 2 : 0) | (lo[2] + 0.5 * size < 128.0 ? 4 : 0);
+            int filler = corner_entry[oct];
+            if (std::find(list.begin(), list.end(), filler) != list.end()) {
+                filler = -1;
+                double far_d = -1.0;
+                for (int j = 0; j < K; ++j) {
+                    if (std::find(list.begin(), list.end(), j) != list.end()) continue;
+                    double d2 = 0.0;
+                    for (int d = 0; d < 3; ++d) {
+                        const double m = pts[3 * j + d] - (lo[d] + 0.5 * size);
+                        d2 += m * m;
+                    }
+                    if (d2 > far_d) {
+                        far_d = d2;
+                        filler = j;
+                    }
                 }
             }
             const size_t upto = (list.size() + 3) / 4 * 4;

@@ -379,15 +379,24 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
         p->pal_host.assign(pal_f32, pal_f32 + 3 * K);
         if (lut_in) p->lut_host.assign(lut_in, lut_in + 256);
     }
-    if (K > 8 && K <= 256) {
-        // candidate lists of the error-diffusion kernels (a 512 KB table, one small kernel)
-        const int rc = build_ed_cells(p->dev, pts.data(), &p->ed_blob);
-        if (rc != DP_OK) {
-            dp_palette_destroy(p);
-            return rc;
-        }
-    }
+    p->pts_host = pts;  // for the candidate tables of the diffusion kernels, built when first needed (ensure_ed_tables)
+    p->ed_tried = false;
     *out = p;
+    return DP_OK;
+}
+
+// The candidate lists of the diffusion kernels (a 512 KB table from one small kernel, sharpened and padded on the host,
+// plus the 16^3 tables: 3 / 5 / 19 ms at 16 / 64 / 256 colours): built once, at the first diffusion call with the palette.
+static int ensure_ed_tables(const dp_palette *pal_c)
+{
+    dp_palette *p = const_cast<dp_palette *>(pal_c);
+    std::lock_guard<std::mutex> lock(p->ed_mutex);
+    if (p->ed_tried) return DP_OK;
+    p->ed_tried = true;
+    if (p->dev.K > 8 && p->dev.K <= 256) {
+        const int rc = build_ed_cells(p->dev, p->pts_host.data(), &p->ed_blob);
+        if (rc != DP_OK) return rc;
+    }
     return DP_OK;
 }
 
@@ -732,6 +741,8 @@ static int error_diffusion_common(const uint8_t *in_dev, uint8_t *out_dev, int64
                   dp_error_diffusion_workspace_bytes(n_frames, h, w));
         return DP_EWORKSPACE;
     }
+    const int rc_tab = ensure_ed_tables(pal);
+    if (rc_tab != DP_OK) return rc_tab;
     return launch_error_diffusion(in_dev, out_dev, n_frames, h, w, pal->dev, dx, dy, wq, ntaps, serpentine,
                                   workspace_dev, workspace_bytes, (hipStream_t)stream, wq64);
 }
@@ -752,6 +763,8 @@ int dp_variable_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_
                   dp_error_diffusion_workspace_bytes(n_frames, h, w));
         return DP_EWORKSPACE;
     }
+    const int rc_tab = ensure_ed_tables(pal);
+    if (rc_tab != DP_OK) return rc_tab;
     return launch_variable_diffusion(in_dev, out_dev, n_frames, h, w, pal->dev, model, p0, p1, serpentine ? 1 : 0,
                                      gate_dev, coef_dev, workspace_dev, (hipStream_t)stream);
 }
