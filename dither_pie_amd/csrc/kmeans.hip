@@ -12,12 +12,21 @@
 // every field fits) and leave the workgroup as int64 atomics.  All totals are integers: any rank count and any
 // reduction order give identical results.
 //
+// kmeans_cells_build_kernel + kmeans_cells_kernel (K <= 255, images of 2^19 pixels and more): the same pass over
+// per-cell candidate lists rebuilt from the current centres in front of every pass -- a pixel scores the 1..7 centres
+// that can be nearest somewhere in its 16x16x16 cell instead of all K; totals through wave-level sums where a wave's
+// pixels share a label and one packed LDS atomic per pixel elsewhere.  Same labels, same int64 totals.
+//
 // kmeans_update_kernel: the centre update of one Lloyd iteration on the device (means, squared shift, sklearn's
 // tolerance test, "assignments unchanged" test, inertia), so that the host loop launches iterations back to back and
 // reads the status back only every few iterations.
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "dp_internal.h"
+#include "wave_util.hip.h"
 
 namespace dp {
 namespace {
@@ -355,6 +364,362 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_kernel(const uint8_t *__re
     flush();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Lloyd pass over per-cell candidate lists (K <= 255, large n): the product path for big images.
+// kmeans_cells_build_kernel (one launch in front of every pass, four lanes per cell): for every cell of the 16x16x16 colour grid, the centres
+// that can be nearest to SOME point of the cell -- first those whose smallest distance to the cell's box does not exceed
+// the smallest "largest distance" of any centre, then a pairwise test: j leaves the list if another listed k is closer
+// on the whole box (|x-c_k|^2 - |x-c_j|^2 is linear in x: its maximum over the box is at a corner).  float32 with a
+// slack of 1.0 on quantities below 4e5 (errors < 0.25): a superset of the exact sets, 1.6 entries on average for 32
+// centres of uniform data, 6 at most.  8 bytes per cell: {n, e0 .. e6}, unused positions name entry K, a dummy whose
+// score is above every real one; a cell with more than 7 candidates holds n = 2 and dummies only, which the pass below
+// reads as a near tie.
+// kmeans_cells_kernel: as kmeans_step_kernel, but a pixel scores only its cell's candidates -- the wave runs to the
+// longest list among its lanes (4 rounds on uniform random pixels, 1-2 on images), 7 instructions per pixel and round
+// (byte -> LDS offset, three v_fma_f32, key, v_med3_i32, v_min_i32; the key's tag is the list position).  Two keys
+// within the float32 error bound, or a dummy-only cell, go to the float64 scan over all K as before: labels and int64
+// totals are the reference's.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCellsBlock = 512;
+constexpr int kCellsWaves = kCellsBlock / 64;
+constexpr int kCellsMaxK = 255;
+constexpr int kCellsGrid = 4096;
+constexpr int64_t kCellsMinPixels = 1 << 19;  // below this the table build and its 32 KB copy per workgroup do not pay
+constexpr float kDummyScore = 1048000.0f;  // above every real score (< 2^19 + 390152), below 2^20
+
+// (four lanes per cell: each takes every fourth centre in the two bound passes and every fourth survivor in the
+// pairwise pass; the survivors meet in a bit mask in LDS, so the list comes out in ascending order whoever found what)
+constexpr int kBuildThreads = 256;
+constexpr int kBuildCells = kBuildThreads / 4;
+__global__ __launch_bounds__(kBuildThreads) void kmeans_cells_build_kernel(const double *__restrict__ centers, const int K,
+                                                                           uint2 *__restrict__ cells)
+{
+    __shared__ float4 s_c[kCellsMaxK + 1];
+    __shared__ uint32_t s_mask[kBuildCells][8];  // survivors of the bound test, by centre
+    __shared__ uint32_t s_keep[kBuildCells];     // survivors of the pairwise test, by position among the former
+    for (int i = threadIdx.x; i < K; i += kBuildThreads) {
+        const float x = (float)centers[3 * i], y = (float)centers[3 * i + 1], z = (float)centers[3 * i + 2];
+        s_c[i] = make_float4(x, y, z, x * x + y * y + z * z);
+    }
+    const int cl = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    if (sub == 0) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s_mask[cl][w] = 0u;
+    }
+    __syncthreads();
+    const int cell = blockIdx.x * kBuildCells + cl;  // g' | r' << 4 | b' << 8 (what kmeans_cells_kernel's multiply yields)
+    const float lo0 = (float)(((cell >> 4) & 15) << 4), lo1 = (float)((cell & 15) << 4), lo2 = (float)(((cell >> 8) & 15) << 4);
+    const float hi0 = lo0 + 15.f, hi1 = lo1 + 15.f, hi2 = lo2 + 15.f;
+    float U = __int_as_float(0x7f800000);
+    for (int j = sub; j < K; j += 4) {
+        const float4 c = s_c[j];
+        const float f0 = fmaxf(fabsf(c.x - lo0), fabsf(c.x - hi0)), f1 = fmaxf(fabsf(c.y - lo1), fabsf(c.y - hi1)),
+                    f2 = fmaxf(fabsf(c.z - lo2), fabsf(c.z - hi2));
+        U = fminf(U, f0 * f0 + f1 * f1 + f2 * f2);
+    }
+    U = fminf(U, __shfl_xor(U, 1));
+    U = fminf(U, __shfl_xor(U, 2));
+    U += 1.0f;
+    for (int j = sub; j < K; j += 4) {
+        const float4 c = s_c[j];
+        const float n0 = fmaxf(fmaxf(lo0 - c.x, c.x - hi0), 0.f), n1 = fmaxf(fmaxf(lo1 - c.y, c.y - hi1), 0.f),
+                    n2 = fmaxf(fmaxf(lo2 - c.z, c.z - hi2), 0.f);
+        if (n0 * n0 + n1 * n1 + n2 * n2 <= U) atomicOr(&s_mask[cl][j >> 5], 1u << (j & 31));
+    }
+    __syncthreads();
+    // the survivors in ascending order (every lane of the cell reads the same list)
+    uint8_t surv[16];
+    int cnt = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        uint32_t m = s_mask[cl][w];
+        while (m) {
+            const int bit = __ffs((int)m) - 1;
+            m &= m - 1u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q == cnt) surv[q] = (uint8_t)(32 * w + bit);
+            ++cnt;
+        }
+    }
+    if (sub == 0) s_keep[cl] = cnt <= 16 ? ((1u << cnt) - 1u) : 0u;
+    __syncthreads();
+    if (cnt <= 16) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            if (a < cnt && (a & 3) == sub) {
+                const float4 cj = s_c[surv[a]];
+                bool drop = false;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    if (b < cnt && b != a && !drop) {
+                        const float4 ck = s_c[surv[b]];
+                        // max over the box of |x-ck|^2 - |x-cj|^2 = 2 x.(cj - ck) + |ck|^2 - |cj|^2
+                        const float d0 = cj.x - ck.x, d1 = cj.y - ck.y, d2 = cj.z - ck.z;
+                        const float m = 2.f * ((d0 > 0.f ? hi0 : lo0) * d0 + (d1 > 0.f ? hi1 : lo1) * d1 + (d2 > 0.f ? hi2 : lo2) * d2) + (ck.w - cj.w);
+                        drop = m < -1.0f;
+                    }
+                }
+                if (drop) atomicAnd(&s_keep[cl], ~(1u << a));
+            }
+        }
+    }
+    __syncthreads();
+    if (sub != 0) return;
+    const uint32_t keep = s_keep[cl];
+    const int n = __popc(keep);
+    uint32_t w0, w1;
+    const uint32_t dummy = (uint32_t)K;
+    if (cnt > 16 || n > 7) {
+        w0 = 2u | (dummy << 8) | (dummy << 16) | (dummy << 24);
+        w1 = dummy * 0x01010101u;
+    } else {
+        uint32_t e[7];
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+            if (a < cnt && ((keep >> a) & 1u)) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (q == k) e[q] = surv[a];
+                ++k;
+            }
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+            if (q >= n) e[q] = dummy;
+        w0 = (uint32_t)n | (e[0] << 8) | (e[1] << 16) | (e[2] << 24);
+        w1 = e[3] | (e[4] << 8) | (e[5] << 16) | (e[6] << 24);
+    }
+    cells[cell] = make_uint2(w0, w1);
+}
+
+template <bool SQ>
+__global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint8_t *__restrict__ px, const int64_t n,
+                                                                   const double *__restrict__ centers, const int K,
+                                                                   const uint2 *__restrict__ cells,
+                                                                   unsigned long long *__restrict__ sums,
+                                                                   unsigned long long *__restrict__ counts,
+                                                                   unsigned long long *__restrict__ sumsq)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint2 *s_cells = reinterpret_cast<uint2 *>(smem);                                  // 4096 x {n, e0..e6}
+    float4 *s_c4 = reinterpret_cast<float4 *>(s_cells + kCellsGrid);                    // K + 1: {-2c, |c|^2 + BIAS}
+    double *s_c = reinterpret_cast<double *>(s_c4 + K + 1);                             // 3 K float64 (near ties)
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 3 * K);    // [waves][K][2 or 3]
+    constexpr int kW = SQ ? 3 : 2;
+    unsigned long long *s_l1 = s_acc + (size_t)kCellsWaves * K * kW;                    // [waves][K] packed r18|g18|b18|n10
+    for (int i = threadIdx.x; i < kCellsGrid; i += kCellsBlock) s_cells[i] = cells[i];
+    for (int i = threadIdx.x; i <= K; i += kCellsBlock) {
+        if (i < K) {
+            const double c0 = centers[3 * i], c1 = centers[3 * i + 1], c2 = centers[3 * i + 2];
+            s_c[3 * i] = c0;
+            s_c[3 * i + 1] = c1;
+            s_c[3 * i + 2] = c2;
+            s_c4[i] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2),
+                                  (float)(c0 * c0 + c1 * c1 + c2 * c2 + (double)kScoreBias));
+        } else {
+            s_c4[i] = make_float4(0.f, 0.f, 0.f, kDummyScore);
+        }
+    }
+    for (int i = threadIdx.x; i < kCellsWaves * K * (kW + 1); i += kCellsBlock) s_acc[i] = 0;
+    __syncthreads();
+    unsigned long long *acc = s_acc + (size_t)(threadIdx.x >> 6) * K * kW;
+    unsigned long long *l1 = s_l1 + (size_t)(threadIdx.x >> 6) * K;
+    const int lane = threadIdx.x & 63;
+
+    const int64_t n_groups = (n + 3) / 4;
+    const bool aligned = ((uintptr_t)px & 3) == 0;
+    uint32_t since_flush = 0, since_l1 = 0;
+    // a wave's packed first-level totals into its wide ones (both private to the wave: plain read-modify-write)
+    auto flush_l1 = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int i = lane; i < K; i += 64) {
+            const unsigned long long v = l1[i];
+            if (v) {
+                l1[i] = 0;
+                acc[i * kW] += (v & 0x3ffffull) | (((v >> 18) & 0x3ffffull) << 28);
+                acc[i * kW + 1] += ((v >> 36) & 0x3ffffull) | ((v >> 54) << 28);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    auto flush = [&]() {
+        flush_l1();
+        since_l1 = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < K; i += kCellsBlock) {
+            unsigned long long rg = 0, bn = 0, sq = 0;
+#pragma unroll
+            for (int w = 0; w < kCellsWaves; ++w) {
+                unsigned long long *a = s_acc + ((size_t)w * K + i) * kW;
+                rg += a[0];
+                bn += a[1];
+                a[0] = a[1] = 0;
+                if (SQ) {
+                    sq += a[2];
+                    a[2] = 0;
+                }
+            }
+            // (a wave's fields hold < 2^16 pixels: summed over the 8 waves r and g stay below 2^27 < 2^28)
+            if (bn >> 28) {
+                atomicAdd(&sums[3 * i], rg & 0xfffffffull);
+                atomicAdd(&sums[3 * i + 1], rg >> 28);
+                atomicAdd(&sums[3 * i + 2], bn & 0xfffffffull);
+                atomicAdd(&counts[i], bn >> 28);
+                if (SQ) atomicAdd(&sumsq[i], sq);
+            }
+        }
+        __syncthreads();
+    };
+    const unsigned char *c4_bytes = reinterpret_cast<const unsigned char *>(s_c4);
+    const unsigned char *cell_bytes = reinterpret_cast<const unsigned char *>(s_cells);
+    // the next round's twelve bytes are in flight while this round runs (full, aligned groups; the others load in place)
+    auto fetch = [&](const int64_t gi) -> uint3 {
+        if (aligned && gi * 4 + 4 <= n) return reinterpret_cast<const uint3 *>(px)[gi];
+        return make_uint3(0u, 0u, 0u);
+    };
+    uint3 w_next = fetch((int64_t)blockIdx.x * kCellsBlock + threadIdx.x);
+    for (int64_t g0 = (int64_t)blockIdx.x * kCellsBlock; g0 < n_groups; g0 += (int64_t)gridDim.x * kCellsBlock) {
+        const int64_t gi = g0 + threadIdx.x;
+        const int64_t p0 = gi * 4;
+        const int cnt = gi < n_groups ? (int)min<int64_t>(4, n - p0) : 0;
+        uint32_t v[4] = {0u, 0u, 0u, 0u};
+        const uint3 w = w_next;
+        w_next = fetch(gi + (int64_t)gridDim.x * kCellsBlock);
+        if (aligned && cnt == 4) {
+            v[0] = w.x & 0xffffffu;
+            v[1] = __builtin_amdgcn_perm(w.y, w.x, 0x0c050403u);
+            v[2] = __builtin_amdgcn_perm(w.z, w.y, 0x0c040302u);
+            v[3] = w.z >> 8;
+        } else {
+            for (int q = 0; q < cnt; ++q) {
+                const uint8_t *b = px + (p0 + q) * 3;
+                v[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+            }
+        }
+        float fr[4], fg[4], fb[4];
+        int k0[4], k1[4];
+        uint2 L[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            fr[q] = (float)(v[q] & 255u);
+            fg[q] = (float)((v[q] >> 8) & 255u);
+            fb[q] = (float)(v[q] >> 16);
+            // byte offset of the cell's list, (g' | r' << 4 | b' << 8) * 8: the high nibbles r' << 4 | g' << 12 | b' << 20
+            // times 2^20 + 2^8 (mod 2^32) = r' << 12 | g' << 20 | r' << 24 | b' << 28, bits 16..19 clear
+            const uint32_t off = (uint32_t)__umul24(v[q] & 0xf0f0f0u, 0x100100u) >> 17;  // (HIP's __umul24 returns int)
+            L[q] = *reinterpret_cast<const uint2 *>(cell_bytes + off);
+            k0[q] = k1[q] = 0x7fffffff;
+        }
+        const int nmax = (int)max(max(L[0].x & 255u, L[1].x & 255u), max(L[2].x & 255u, L[3].x & 255u));
+        uint32_t four = 4u;
+        asm volatile("" : "+v"(four));  // (SDWA takes no inline constant)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            if (__ballot(i < nmax) == 0ull) break;  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t word = (i + 1) < 4 ? L[q].x : L[q].y;
+                uint32_t eoff;  // (byte (i + 1) of the list) << 4 in one instruction
+                if (((i + 1) & 3) == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(eoff) : "v"(four), "v"(word));
+                else if (((i + 1) & 3) == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(eoff) : "v"(four), "v"(word));
+                else if (((i + 1) & 3) == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(eoff) : "v"(four), "v"(word));
+                else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(eoff) : "v"(four), "v"(word));
+                const float4 c = *reinterpret_cast<const float4 *>(c4_bytes + eoff);
+                float t = c.w;  // three v_fmac_f32 (kept apart: packed pairs would cost moves)
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(fr[q]), "v"(c.x));
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(fg[q]), "v"(c.y));
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(fb[q]), "v"(c.z));
+                const int key = (int)((__float_as_uint(t) << 8) + (uint32_t)i);
+                k1[q] = med3_s32(k0[q], k1[q], key);
+                k0[q] = min(k0[q], key);
+            }
+        }
+        int lab[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lab[q] = 0;
+            if (q < cnt) {
+                const uint32_t r = v[q] & 255u, g = (v[q] >> 8) & 255u, b = v[q] >> 16;
+                // the winner's list position is the key's tag: byte (tag + 1) of the list
+                lab[q] = (int)__builtin_amdgcn_perm(L[q].y, L[q].x, 0x0c0c0c00u + (uint32_t)(k0[q] & 255) + 1u);
+                // scores within 0.15 of their exact value, keys 256 apart per ulp of 0.0625 (see kmeans_step_kernel):
+                // a gap of more than 6 ulp settles the order among the listed centres, and an unlisted one is farther
+                // than some listed one on the whole cell.  A list of one leaves k1 at a dummy's key, far away; the
+                // dummies of an overfull cell tie with each other.
+                if (k1[q] - k0[q] <= (6 << 8) + 255) {
+                    const double x0 = (double)r, x1 = (double)g, x2 = (double)b;
+                    double bd = __longlong_as_double(0x7ff0000000000000LL);
+                    for (int j = 0; j < K; ++j) {
+                        const double a = __dsub_rn(x0, s_c[3 * j]), c = __dsub_rn(x1, s_c[3 * j + 1]),
+                                     e = __dsub_rn(x2, s_c[3 * j + 2]);
+                        const double d = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(c, c)), __dmul_rn(e, e));
+                        if (d < bd) {
+                            bd = d;
+                            lab[q] = j;
+                        }
+                    }
+                }
+            }
+        }
+        // Totals.  Images are coherent: most of a wave's 256 consecutive pixels carry one or two labels, and 256 LDS
+        // atomics on one address serialise.  So: rounds that take the label of the first pixel not yet accounted for,
+        // sum its pixels over the wave (packed r | g << 16 and b; v_add_u32_dpp reductions) and let one lane add the
+        // totals; a round that found fewer than 32 pixels is the last one, and what is left goes through one packed
+        // 64-bit LDS atomic per pixel (r, g, b in 18 bits each, the count in 10: flushed every 768 pixels).
+        uint32_t rem = (1u << cnt) - 1u;
+        // (not worth a round when fewer than 24 lanes share lane 0's first label: uniform random pixels, many clusters)
+        const int first_label = __builtin_amdgcn_readfirstlane(lab[0]);
+        const int n_rounds = __popcll(__ballot(lab[0] == first_label)) >= 24 ? 8 : 0;
+        for (int round = 0; round < n_rounds; ++round) {
+            const unsigned long long has = __ballot(rem != 0u);
+            if (has == 0ull) break;
+            const int src = __ffsll((long long)has) - 1;
+            const int mine = (rem & 1u) ? lab[0] : (rem & 2u) ? lab[1] : (rem & 4u) ? lab[2] : lab[3];
+            const int l = __builtin_amdgcn_readlane(mine, src);
+            uint32_t rg = 0, bb = 0, sq = 0;
+            int found = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool sel = ((rem >> q) & 1u) && lab[q] == l;
+                const uint32_t r = v[q] & 255u, g = (v[q] >> 8) & 255u, b = v[q] >> 16;
+                rg += sel ? (r | (g << 16)) : 0u;
+                bb += sel ? b : 0u;
+                if (SQ) sq += sel ? (r * r + g * g + b * b) : 0u;
+                rem &= sel ? ~(1u << q) : ~0u;
+                found += __popcll(__ballot(sel));
+            }
+            rg = wave_sum_to_lane63(rg);
+            bb = wave_sum_to_lane63(bb);
+            if (SQ) sq = wave_sum_to_lane63(sq);
+            if (lane == 63) {
+                atomicAdd(&acc[l * kW], (unsigned long long)(rg & 0xffffu) | ((unsigned long long)(rg >> 16) << 28));
+                atomicAdd(&acc[l * kW + 1], (unsigned long long)bb | ((unsigned long long)found << 28));
+                if (SQ) atomicAdd(&acc[l * kW + 2], (unsigned long long)sq);
+            }
+            if (found < 32) break;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if ((rem >> q) & 1u) {
+                const uint32_t r = v[q] & 255u, g = (v[q] >> 8) & 255u, b = v[q] >> 16;
+                atomicAdd(&l1[lab[q]], (unsigned long long)(r | (g << 18)) | ((unsigned long long)((b << 4) | (1u << 22)) << 32));
+                if (SQ) atomicAdd(&acc[lab[q] * kW + 2], (unsigned long long)(r * r + g * g + b * b));
+            }
+        }
+        if (++since_l1 == 3) {  // wave-uniform: 768 pixels at most in the packed fields
+            flush_l1();
+            since_l1 = 0;
+        }
+        since_flush += kCellsBlock;
+        if (since_flush >= (uint32_t)kGroupsPerFlush) {  // block-uniform
+            flush();
+            since_flush = 0;
+        }
+    }
+    flush();
+}
+
 // status words (float64) of the device-side Lloyd loop
 enum { kStDone = 0, kStIter = 1, kStInertia = 2, kStShift = 3, kStTolAbs = 4, kStQTotal = 5, kStWords = 8 };
 
@@ -587,6 +952,24 @@ __global__ __launch_bounds__(kPpThreads) void kmeans_pp_kernel(const uint8_t *__
 
 }  // namespace
 
+// 32 KB of cell lists per (device, stream) that has run a pass: launches on one stream are ordered, so a pass never
+// sees another pass's lists; kept until the library is unloaded.
+static uint2 *cells_scratch(const int dev, hipStream_t s)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, uint2 *> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({dev, s});
+    if (it != cache.end()) return it->second;
+    void *p = nullptr;
+    if (hipMalloc(&p, sizeof(uint2) * kCellsGrid) != hipSuccess) {
+        set_error("dp_kmeans_step_u8: hipMalloc of the cell lists failed");
+        return nullptr;
+    }
+    cache[{dev, s}] = static_cast<uint2 *>(p);
+    return static_cast<uint2 *>(p);
+}
+
 int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int K, int64_t *sums, int64_t *counts,
                        int64_t *sumsq, hipStream_t s)
 {
@@ -629,6 +1012,37 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
         prof_end(pm, s);
         DP_HIP(hipGetLastError());
         return DP_OK;
+    }
+    {
+        // big images: per-cell candidate lists, rebuilt from the current centres in front of every pass
+        // (DP_KMEANS_CELLS=0 keeps the full scan, =1 takes the lists at any size: tests)
+        const char *e = getenv("DP_KMEANS_CELLS");
+        const bool force = e && e[0] == '1', off = e && e[0] == '0';
+        const size_t csmem = sizeof(uint2) * kCellsGrid + sizeof(float4) * (K + 1) + sizeof(double) * 3 * K +
+                             sizeof(unsigned long long) * kCellsWaves * K * (kw + 1);
+        if (!off && !want_mfma && K <= kCellsMaxK && (force || n >= kCellsMinPixels) && csmem <= 150 * 1024) {
+            uint2 *cells = cells_scratch(dev, s);
+            if (!cells) return DP_EHIP;
+            hipLaunchKernelGGL(kmeans_cells_build_kernel, dim3(kCellsGrid / kBuildCells), dim3(kBuildThreads), 0, s, centers, K, cells);
+            const int64_t cwant = (groups + kCellsBlock - 1) / kCellsBlock;
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (csmem + 1024)));  // 3 x 8 waves: 6 per SIMD
+            const unsigned cblocks = (unsigned)std::min<int64_t>(cwant, (int64_t)cus * per_cu);
+            if (sumsq) {
+                auto kern = kmeans_cells_kernel<true>;
+                DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)csmem));
+                hipLaunchKernelGGL(kern, dim3(cblocks), dim3(kCellsBlock), csmem, s, px, n, centers, K, cells,
+                                   reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
+                                   reinterpret_cast<unsigned long long *>(sumsq));
+            } else {
+                auto kern = kmeans_cells_kernel<false>;
+                DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)csmem));
+                hipLaunchKernelGGL(kern, dim3(cblocks), dim3(kCellsBlock), csmem, s, px, n, centers, K, cells,
+                                   reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr);
+            }
+            prof_end(pm, s);
+            DP_HIP(hipGetLastError());
+            return DP_OK;
+        }
     }
     const bool keys = K <= 256 && !getenv("DP_KMEANS_NO_KEYS");
 #define DP_KM(SQF, KF)                                                                                                    \

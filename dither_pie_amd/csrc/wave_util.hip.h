@@ -30,6 +30,28 @@ __device__ __forceinline__ float wave_min_to_all(const float vf)
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)v, 63));
 }
 
+// Sum of a 32-bit value over the 64 lanes, valid in lane 63 only: the same row_shr / row_bcast ladder with
+// v_add_u32_dpp (a lane without a source keeps its value, which is what a prefix sum wants there).
+__device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return v;
+}
+
 // Value of lane (lane ^ mask) -- the butterfly exchange of wave-wide reductions over pairs (value, position), for which
 // no fused DPP minimum exists; one ds_bpermute_b32 (LDS crossbar, no memory).
 __device__ __forceinline__ uint32_t lane_xor_u32(const uint32_t v, const int mask)

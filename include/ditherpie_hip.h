@@ -23,7 +23,7 @@
  *     mutates the palette: finish it before another thread launches with that palette.
  *   - environment variables read by the library are experiment / test switches only (DP_DEBUG_ACCEL, DP_FORCE_TABLE,
  *     DP_NO_WARP, DP_NO_FAST, DP_FAST_ALL, DP_FAST_DBG, DP_ED_ONE_WG, DP_ED_WAVES, DP_ED_TEST_GIVEUP,
- *     DP_GATE_CHUNK_BYTES, DP_GATE_TWO_PASS, DP_KMEANS_MFMA, DP_KMEANS_NO_KEYS; INTEGRATION.md lists what each does); production
+ *     DP_GATE_CHUNK_BYTES, DP_GATE_TWO_PASS, DP_KMEANS_MFMA, DP_KMEANS_NO_KEYS, DP_KMEANS_CELLS; INTEGRATION.md lists what each does); production
  *     callers set none of them.
  */
 #ifndef DITHERPIE_HIP_H
@@ -176,7 +176,10 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
  * sums_dev[K*3], member counts counts_dev[K] and squared norms sumsq_dev[K] (sum of r^2+g^2+b^2),
  * all overwritten.  Being integers, the totals all-reduce exactly across ranks (RCCL, any order);
  * the caller updates the centres and derives the inertia
- *   sum_k ( sumsq_k - 2 c_k . sums_k + counts_k |c_k|^2 ). */
+ *   sum_k ( sumsq_k - 2 c_k . sums_k + counts_k |c_k|^2 ).
+ * Images of 2^19 pixels and more with K <= 255 go through per-cell candidate lists that the call rebuilds from
+ * centers_dev first (one small extra launch; 32 KB of library-owned device memory per (device, stream) that has
+ * run such a pass, kept until the library is unloaded); same totals. */
 int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
                       int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
 /* (sumsq_dev may be NULL: the squared norms are then not accumulated -- their total is a constant of the data, only

@@ -163,6 +163,50 @@ def test_kmeans_matrix_core_kernel_totals(be, orc, monkeypatch, K):
     assert torch.equal(s, s2) and torch.equal(n, n2) and torch.equal(q, q2)
 
 
+@pytest.mark.parametrize("K,kind", [(1, "random"), (2, "lattice"), (5, "random"), (16, "clustered"), (32, "lattice"), (33, "data"),
+                                    (100, "clustered"), (200, "data"), (255, "random"), (8, "duplicates")])
+def test_kmeans_cell_list_kernel_totals(be, orc, monkeypatch, K, kind):
+    """The Lloyd pass over per-cell candidate lists (kmeans_cells_kernel, what images above 2^19 pixels take; forced here
+    with DP_KMEANS_CELLS=1): integer totals equal the oracle's and the full-scan kernel's -- ragged pixel count, an
+    unaligned pixel pointer, centres on the integer lattice (exact ties between clusters), centres crowded into one
+    corner of the cube (cells with more candidates than a list holds), duplicated centres, smooth content (whole waves
+    with one label: the wave-level sums) and uniform noise (the packed LDS atomics)."""
+    import torch
+    rs = np.random.RandomState(100 + K)
+    noise = orc.rnd(411, 1031, 17 + K).reshape(-1, 3)
+    yy, xx = np.mgrid[0:300, 0:1031]
+    smooth = np.stack([xx * 255 // 1030, yy * 255 // 299, (xx + yy) * 255 // 1329], -1).reshape(-1, 3)
+    smooth = np.clip(smooth + rs.randint(-3, 4, smooth.shape), 0, 255).astype(np.uint8)
+    flat = np.concatenate([noise, smooth])[: len(noise) + len(smooth) - 3]
+    if kind == "random":
+        centers = rs.rand(K, 3) * 255.0
+    elif kind == "lattice":
+        centers = np.round(rs.rand(K, 3) * 255.0)
+    elif kind == "clustered":
+        centers = 20.0 + rs.rand(K, 3) * 30.0
+    elif kind == "data":
+        centers = flat[rs.randint(0, len(flat), K)].astype(np.float64) + 0.25
+    else:
+        centers = np.repeat(np.round(rs.rand(K // 2, 3) * 255.0), 2, axis=0)
+    s_ref, n_ref, _ = orc.kmeans_step(flat, centers)
+    buf = torch.zeros(len(flat) * 3 + 1, dtype=torch.uint8, device="cuda")
+    for offset in (0, 1):  # 4-byte aligned, then not
+        px = buf[offset:offset + len(flat) * 3].view(-1, 3)
+        px.copy_(torch.from_numpy(np.ascontiguousarray(flat)))
+        monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+        s, n, q = be.kmeans_step(px, torch.from_numpy(centers))
+        monkeypatch.setenv("DP_KMEANS_CELLS", "0")
+        s2, n2, q2 = be.kmeans_step(px, torch.from_numpy(centers))
+        monkeypatch.delenv("DP_KMEANS_CELLS")
+        assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(n.cpu().numpy(), n_ref), (K, kind, offset)
+        assert torch.equal(s, s2) and torch.equal(n, n2) and torch.equal(q, q2), (K, kind, offset)
+        tot = torch.zeros(5 * K, dtype=torch.int64, device="cuda")
+        monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+        be.kmeans_step_into(px, torch.from_numpy(centers).cuda(), tot, want_sq=False)  # the instance without squared norms
+        monkeypatch.delenv("DP_KMEANS_CELLS")
+        assert np.array_equal(tot[:3 * K].cpu().numpy().reshape(K, 3), s_ref) and np.array_equal(tot[3 * K:4 * K].cpu().numpy(), n_ref)
+
+
 @pytest.mark.parametrize("n,K,seed", [(10000, 32, 42), (10000, 256, 1), (9999, 16, 7), (517, 8, 3), (64, 64, 5), (40, 5, 11), (16384, 2, 2), (3, 1, 0)])
 def test_kmeans_plusplus_kernel_equals_host_seeding(be, n, K, seed):
     """dp_kmeans_plusplus_u8 (one workgroup, integer arithmetic) picks the centres sklearn's float64 code picks: compared
