@@ -210,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
 //   kernel has a larger fixed part (one dword load per pixel and lane pair, LDS atomics from half-filled waves).
 // ---------------------------------------------------------------------------------------------------------------
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int kNearKeys = (12 << 8) | 255;
 constexpr int kMfmaMaxK = 256;
 constexpr int kTiles = 4;  // tiles of 32 pixels a wave takes per round
@@ -571,7 +572,8 @@ __global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint
         }
         __syncthreads();
     };
-    const unsigned char *c4_bytes = reinterpret_cast<const unsigned char *>(s_c4);
+    // the candidate reads below address s_c4 by its LDS offset
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)s_c4 != kCellsGrid * 8u) __builtin_trap();
     const unsigned char *cell_bytes = reinterpret_cast<const unsigned char *>(s_cells);
     // the next round's twelve bytes are in flight while this round runs (full, aligned groups; the others load in place)
     auto fetch = [&](const int64_t gi) -> uint3 {
@@ -617,22 +619,39 @@ __global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             if (__ballot(i < nmax) == 0ull) break;  // wave-uniform
+            // (byte (i + 1) of each list) << 4 in one instruction, the four records in flight together, then per pixel three
+            // v_fmac_f32 (kept apart: packed pairs would cost moves), the key with the list position as tag, v_med3 + v_min
+            uint32_t eo[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t word = (i + 1) < 4 ? L[q].x : L[q].y;
-                uint32_t eoff;  // (byte (i + 1) of the list) << 4 in one instruction
-                if (((i + 1) & 3) == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(eoff) : "v"(four), "v"(word));
-                else if (((i + 1) & 3) == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(eoff) : "v"(four), "v"(word));
-                else if (((i + 1) & 3) == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(eoff) : "v"(four), "v"(word));
-                else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(eoff) : "v"(four), "v"(word));
-                const float4 c = *reinterpret_cast<const float4 *>(c4_bytes + eoff);
-                float t = c.w;  // three v_fmac_f32 (kept apart: packed pairs would cost moves)
-                asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(fr[q]), "v"(c.x));
-                asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(fg[q]), "v"(c.y));
-                asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(fb[q]), "v"(c.z));
-                const int key = (int)((__float_as_uint(t) << 8) + (uint32_t)i);
-                k1[q] = med3_s32(k0[q], k1[q], key);
-                k0[q] = min(k0[q], key);
+                if (((i + 1) & 3) == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(eo[q]) : "v"(four), "v"(word));
+                else if (((i + 1) & 3) == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(eo[q]) : "v"(four), "v"(word));
+                else if (((i + 1) & 3) == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(eo[q]) : "v"(four), "v"(word));
+                else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(eo[q]) : "v"(four), "v"(word));
+            }
+            floatx4 c0, c1, c2, c3;
+            // (s_c4 starts kCellsGrid * 8 = 32768 bytes into the workgroup's LDS; the kernel has no static LDS)
+            asm volatile(
+                "ds_read_b128 %0, %4 offset:32768\n\t"
+                "ds_read_b128 %1, %5 offset:32768\n\t"
+                "ds_read_b128 %2, %6 offset:32768\n\t"
+                "ds_read_b128 %3, %7 offset:32768\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+                : "v"(eo[0]), "v"(eo[1]), "v"(eo[2]), "v"(eo[3])
+                : "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const floatx4 c = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3;
+                float t = c[3];
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(fr[q]), "v"(c[0]));
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(fg[q]), "v"(c[1]));
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(fb[q]), "v"(c[2]));
+                int key;
+                asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(key) : "v"(t), "n"(i));
+                asm("v_med3_i32 %0, %1, %0, %2" : "+v"(k1[q]) : "v"(k0[q]), "v"(key));
+                asm("v_min_i32 %0, %0, %1" : "+v"(k0[q]) : "v"(key));
             }
         }
         int lab[4];
