@@ -12,8 +12,8 @@
 // every field fits) and leave the workgroup as int64 atomics.  All totals are integers: any rank count and any
 // reduction order give identical results.
 //
-// kmeans_cells_build_kernel + kmeans_cells_kernel (K <= 255, images of 2^19 pixels and more): the same pass over
-// per-cell candidate lists rebuilt from the current centres in front of every pass -- a pixel scores the 1..7 centres
+// kmeans_cells_build[16]_kernel + kmeans_cells_kernel (K <= 256, images of 2^19 pixels and more): the same pass over
+// per-cell candidate lists rebuilt from the current centres in front of every pass -- a pixel scores the 1..7 (K > 64: 1..15) centres
 // that can be nearest somewhere in its 16x16x16 cell instead of all K; totals through wave-level sums where a wave's
 // pixels share a label and one packed LDS atomic per pixel elsewhere.  Same labels, same int64 totals.
 //
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_kernel(const uint8_t *__re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Lloyd pass over per-cell candidate lists (K <= 255, large n): the product path for big images.
+// Lloyd pass over per-cell candidate lists (K <= 256, large n): the product path for big images.
 // kmeans_cells_build_kernel (one launch in front of every pass, four lanes per cell): for every cell of the 16x16x16 colour grid, the centres
 // that can be nearest to SOME point of the cell -- first those whose smallest distance to the cell's box does not exceed
 // the smallest "largest distance" of any centre, then a pairwise test: j leaves the list if another listed k is closer
@@ -381,9 +381,9 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_kernel(const uint8_t *__re
 // within the float32 error bound, or a dummy-only cell, go to the float64 scan over all K as before: labels and int64
 // totals are the reference's.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kCellsBlock = 512;
-constexpr int kCellsWaves = kCellsBlock / 64;
-constexpr int kCellsMaxK = 255;
+constexpr int kCellsMaxK8 = 64;     // 8-byte lists up to here (K <= 255 would work; longer lists pay off above)
+constexpr int kCellsMaxK = 256;
+constexpr uint32_t kC4Bytes16 = 16u * 257u;  // the centre records in front of the 16-byte lists
 constexpr int kCellsGrid = 4096;
 constexpr int64_t kCellsMinPixels = 1 << 19;  // below this the table build and its 32 KB copy per workgroup do not pay
 constexpr float kDummyScore = 1048000.0f;  // above every real score (< 2^19 + 390152), below 2^20
@@ -393,9 +393,9 @@ constexpr float kDummyScore = 1048000.0f;  // above every real score (< 2^19 + 3
 constexpr int kBuildThreads = 256;
 constexpr int kBuildCells = kBuildThreads / 4;
 __global__ __launch_bounds__(kBuildThreads) void kmeans_cells_build_kernel(const double *__restrict__ centers, const int K,
-                                                                           uint2 *__restrict__ cells)
+                                                                           uint32_t *__restrict__ cells)
 {
-    __shared__ float4 s_c[kCellsMaxK + 1];
+    __shared__ float4 s_c[kCellsMaxK];
     __shared__ uint32_t s_mask[kBuildCells][8];  // survivors of the bound test, by centre
     __shared__ uint32_t s_keep[kBuildCells];     // survivors of the pairwise test, by position among the former
     for (int i = threadIdx.x; i < K; i += kBuildThreads) {
@@ -491,26 +491,153 @@ __global__ __launch_bounds__(kBuildThreads) void kmeans_cells_build_kernel(const
         w0 = (uint32_t)n | (e[0] << 8) | (e[1] << 16) | (e[2] << 24);
         w1 = e[3] | (e[4] << 8) | (e[5] << 16) | (e[6] << 24);
     }
-    cells[cell] = make_uint2(w0, w1);
+    cells[2 * cell] = w0;
+    cells[2 * cell + 1] = w1;
 }
 
-template <bool SQ>
-__global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint8_t *__restrict__ px, const int64_t n,
+// The same for 16-byte lists {n, e0 .. e14} (K <= 256): up to 32 survivors of the bound test go through the pairwise test
+// (in LDS, loops instead of unrolled registers); unused positions name a centre that is NOT on the list and lies far
+// from the cell -- the one with the largest distance to the box among those the bound test rejected, else one the
+// pairwise test rejected (either way more than 1.0 behind some listed centre everywhere in the cell, so it neither wins
+// nor looks like a near tie); a cell with more than 15 candidates holds n = 2 and the same entry twice, which ties.
+__global__ __launch_bounds__(kBuildThreads) void kmeans_cells_build16_kernel(const double *__restrict__ centers, const int K,
+                                                                             uint32_t *__restrict__ cells)
+{
+    __shared__ float4 s_c[kCellsMaxK];
+    __shared__ uint32_t s_mask[kBuildCells][8];
+    __shared__ uint32_t s_keep[kBuildCells];
+    __shared__ uint8_t s_surv[kBuildCells][32];
+    for (int i = threadIdx.x; i < K; i += kBuildThreads) {
+        const float x = (float)centers[3 * i], y = (float)centers[3 * i + 1], z = (float)centers[3 * i + 2];
+        s_c[i] = make_float4(x, y, z, x * x + y * y + z * z);
+    }
+    const int cl = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    if (sub == 0) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s_mask[cl][w] = 0u;
+    }
+    __syncthreads();
+    const int cell = blockIdx.x * kBuildCells + cl;
+    const float lo0 = (float)(((cell >> 4) & 15) << 4), lo1 = (float)((cell & 15) << 4), lo2 = (float)(((cell >> 8) & 15) << 4);
+    const float hi0 = lo0 + 15.f, hi1 = lo1 + 15.f, hi2 = lo2 + 15.f;
+    float U = __int_as_float(0x7f800000);
+    for (int j = sub; j < K; j += 4) {
+        const float4 c = s_c[j];
+        const float f0 = fmaxf(fabsf(c.x - lo0), fabsf(c.x - hi0)), f1 = fmaxf(fabsf(c.y - lo1), fabsf(c.y - hi1)),
+                    f2 = fmaxf(fabsf(c.z - lo2), fabsf(c.z - hi2));
+        U = fminf(U, f0 * f0 + f1 * f1 + f2 * f2);
+    }
+    U = fminf(U, __shfl_xor(U, 1));
+    U = fminf(U, __shfl_xor(U, 2));
+    U += 1.0f;
+    float far_d = -1.f;  // the rejected centre farthest from the box
+    int far_j = -1;
+    for (int j = sub; j < K; j += 4) {
+        const float4 c = s_c[j];
+        const float n0 = fmaxf(fmaxf(lo0 - c.x, c.x - hi0), 0.f), n1 = fmaxf(fmaxf(lo1 - c.y, c.y - hi1), 0.f),
+                    n2 = fmaxf(fmaxf(lo2 - c.z, c.z - hi2), 0.f);
+        const float dmin = n0 * n0 + n1 * n1 + n2 * n2;
+        if (dmin <= U) atomicOr(&s_mask[cl][j >> 5], 1u << (j & 31));
+        else if (dmin > far_d) {
+            far_d = dmin;
+            far_j = j;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+        const float od = __shfl_xor(far_d, m);
+        const int oj = __shfl_xor(far_j, m);
+        if (od > far_d || (od == far_d && oj > far_j)) {  // (any total order: the four lanes must agree)
+            far_d = od;
+            far_j = oj;
+        }
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int w = 0; w < 8; ++w) {
+        uint32_t m = s_mask[cl][w];
+        while (m) {
+            const int bit = __ffs((int)m) - 1;
+            m &= m - 1u;
+            if (cnt < 32 && sub == 0) s_surv[cl][cnt] = (uint8_t)(32 * w + bit);
+            ++cnt;
+        }
+    }
+    if (sub == 0) s_keep[cl] = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+    __syncthreads();
+    if (cnt <= 32) {
+        for (int a = sub; a < cnt; a += 4) {
+            const float4 cj = s_c[s_surv[cl][a]];
+            bool drop = false;
+            for (int b = 0; b < cnt && !drop; ++b) {
+                if (b == a) continue;
+                const float4 ck = s_c[s_surv[cl][b]];
+                const float d0 = cj.x - ck.x, d1 = cj.y - ck.y, d2 = cj.z - ck.z;
+                const float m = 2.f * ((d0 > 0.f ? hi0 : lo0) * d0 + (d1 > 0.f ? hi1 : lo1) * d1 + (d2 > 0.f ? hi2 : lo2) * d2) + (ck.w - cj.w);
+                drop = m < -1.0f;
+            }
+            if (drop) atomicAnd(&s_keep[cl], ~(1u << a));
+        }
+    }
+    __syncthreads();
+    if (sub != 0) return;
+    const uint32_t keep = s_keep[cl];
+    const int n = __popc(keep);
+    uint32_t bytes[16];
+    if (cnt > 32 || n > 15) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bytes[q] = 0u;
+        bytes[0] = 2u;
+    } else {
+        uint32_t filler = far_j >= 0 ? (uint32_t)far_j : 0u;
+        if (far_j < 0)
+            for (int a = 0; a < cnt; ++a)
+                if (!((keep >> a) & 1u)) {
+                    filler = s_surv[cl][a];
+                    break;
+                }
+#pragma unroll
+        for (int q = 1; q < 16; ++q) bytes[q] = filler;
+        bytes[0] = (uint32_t)n;
+        int k = 1;
+        for (int a = 0; a < cnt; ++a)
+            if ((keep >> a) & 1u) {
+                const uint32_t v = s_surv[cl][a];
+#pragma unroll
+                for (int q = 1; q < 16; ++q)
+                    if (q == k) bytes[q] = v;
+                ++k;
+            }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        cells[4 * cell + w] = bytes[4 * w] | (bytes[4 * w + 1] << 8) | (bytes[4 * w + 2] << 16) | (bytes[4 * w + 3] << 24);
+}
+
+// W = 2: 8-byte lists {n, e0..e6} padded with the dummy entry K (K <= 255), 512 threads, 6 waves per SIMD, wide totals per
+// wave.  W = 4 (K > 64): 16-byte lists {n, e0..e14} padded with a real centre that is not on the list and far from the
+// cell (K <= 256), 1024 threads, wide totals per workgroup (LDS atomics), the centre records first in LDS.
+template <bool SQ, int W>
+__global__ __launch_bounds__(W == 2 ? 512 : 1024, W == 2 ? 6 : 4) void kmeans_cells_kernel(const uint8_t *__restrict__ px, const int64_t n,
                                                                    const double *__restrict__ centers, const int K,
-                                                                   const uint2 *__restrict__ cells,
+                                                                   const uint32_t *__restrict__ cells,
                                                                    unsigned long long *__restrict__ sums,
                                                                    unsigned long long *__restrict__ counts,
                                                                    unsigned long long *__restrict__ sumsq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint2 *s_cells = reinterpret_cast<uint2 *>(smem);                                  // 4096 x {n, e0..e6}
-    float4 *s_c4 = reinterpret_cast<float4 *>(s_cells + kCellsGrid);                    // K + 1: {-2c, |c|^2 + BIAS}
-    double *s_c = reinterpret_cast<double *>(s_c4 + K + 1);                             // 3 K float64 (near ties)
-    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 3 * K);    // [waves][K][2 or 3]
+    constexpr int kCellsBlock = W == 2 ? 512 : 1024;
+    constexpr int kCellsWaves = kCellsBlock / 64;
+    constexpr int kAccSets = W == 2 ? kCellsWaves : 1;  // wide totals: per wave, or one set per workgroup
+    constexpr uint32_t kC4Off = W == 2 ? kCellsGrid * 8u : 0u, kCellOff = W == 2 ? 0u : kC4Bytes16;
+    uint32_t *s_cells = reinterpret_cast<uint32_t *>(smem + kCellOff);                  // 4096 x {n, e0..}
+    float4 *s_c4 = reinterpret_cast<float4 *>(smem + kC4Off);                           // {-2c, |c|^2 + BIAS} (W = 2: + dummy)
+    double *s_c = reinterpret_cast<double *>(smem + (W == 2 ? kC4Off + 16u * (K + 1) : kCellOff + kCellsGrid * 16u));  // 3 K float64
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 3 * K);    // [sets][K][2 or 3]
     constexpr int kW = SQ ? 3 : 2;
-    unsigned long long *s_l1 = s_acc + (size_t)kCellsWaves * K * kW;                    // [waves][K] packed r18|g18|b18|n10
-    for (int i = threadIdx.x; i < kCellsGrid; i += kCellsBlock) s_cells[i] = cells[i];
-    for (int i = threadIdx.x; i <= K; i += kCellsBlock) {
+    unsigned long long *s_l1 = s_acc + (size_t)kAccSets * K * kW;                       // [waves][K] packed r18|g18|b18|n10
+    for (int i = threadIdx.x; i < kCellsGrid * W; i += kCellsBlock) s_cells[i] = cells[i];
+    for (int i = threadIdx.x; i < K + (W == 2 ? 1 : 0); i += kCellsBlock) {
         if (i < K) {
             const double c0 = centers[3 * i], c1 = centers[3 * i + 1], c2 = centers[3 * i + 2];
             s_c[3 * i] = c0;
@@ -522,24 +649,31 @@ __global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint
             s_c4[i] = make_float4(0.f, 0.f, 0.f, kDummyScore);
         }
     }
-    for (int i = threadIdx.x; i < kCellsWaves * K * (kW + 1); i += kCellsBlock) s_acc[i] = 0;
+    for (int i = threadIdx.x; i < (kAccSets * kW + kCellsWaves) * K; i += kCellsBlock) s_acc[i] = 0;
     __syncthreads();
-    unsigned long long *acc = s_acc + (size_t)(threadIdx.x >> 6) * K * kW;
+    unsigned long long *acc = s_acc + (W == 2 ? (size_t)(threadIdx.x >> 6) * K * kW : (size_t)0);
     unsigned long long *l1 = s_l1 + (size_t)(threadIdx.x >> 6) * K;
     const int lane = threadIdx.x & 63;
 
     const int64_t n_groups = (n + 3) / 4;
     const bool aligned = ((uintptr_t)px & 3) == 0;
     uint32_t since_flush = 0, since_l1 = 0;
-    // a wave's packed first-level totals into its wide ones (both private to the wave: plain read-modify-write)
+    // a wave's packed first-level totals into the wide ones (W = 2: both private to the wave, plain read-modify-write)
     auto flush_l1 = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int i = lane; i < K; i += 64) {
             const unsigned long long v = l1[i];
             if (v) {
                 l1[i] = 0;
-                acc[i * kW] += (v & 0x3ffffull) | (((v >> 18) & 0x3ffffull) << 28);
-                acc[i * kW + 1] += ((v >> 36) & 0x3ffffull) | ((v >> 54) << 28);
+                const unsigned long long rg = (v & 0x3ffffull) | (((v >> 18) & 0x3ffffull) << 28);
+                const unsigned long long bn = ((v >> 36) & 0x3ffffull) | ((v >> 54) << 28);
+                if (W == 2) {
+                    acc[i * kW] += rg;
+                    acc[i * kW + 1] += bn;
+                } else {
+                    atomicAdd(&acc[i * kW], rg);
+                    atomicAdd(&acc[i * kW + 1], bn);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -551,7 +685,7 @@ __global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint
         for (int i = threadIdx.x; i < K; i += kCellsBlock) {
             unsigned long long rg = 0, bn = 0, sq = 0;
 #pragma unroll
-            for (int w = 0; w < kCellsWaves; ++w) {
+            for (int w = 0; w < kAccSets; ++w) {
                 unsigned long long *a = s_acc + ((size_t)w * K + i) * kW;
                 rg += a[0];
                 bn += a[1];
@@ -561,7 +695,8 @@ __global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint
                     a[2] = 0;
                 }
             }
-            // (a wave's fields hold < 2^16 pixels: summed over the 8 waves r and g stay below 2^27 < 2^28)
+            // (W = 2: a wave's fields hold < 2^16 pixels, summed over the 8 waves r and g stay below 2^27; W = 4: the
+            // workgroup's one set sees 2^16 pixels between flushes: below 2^24)
             if (bn >> 28) {
                 atomicAdd(&sums[3 * i], rg & 0xfffffffull);
                 atomicAdd(&sums[3 * i + 1], rg >> 28);
@@ -572,8 +707,8 @@ __global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint
         }
         __syncthreads();
     };
-    // the candidate reads below address s_c4 by its LDS offset
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)s_c4 != kCellsGrid * 8u) __builtin_trap();
+    // the candidate reads below address s_c4 by its LDS offset (the kernel has no static LDS)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)s_c4 != kC4Off) __builtin_trap();
     const unsigned char *cell_bytes = reinterpret_cast<const unsigned char *>(s_cells);
     // the next round's twelve bytes are in flight while this round runs (full, aligned groups; the others load in place)
     auto fetch = [&](const int64_t gi) -> uint3 {
@@ -601,7 +736,7 @@ __global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint
         }
         float fr[4], fg[4], fb[4];
         int k0[4], k1[4];
-        uint2 L[4];
+        uint32_t L[4][W];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             fr[q] = (float)(v[q] & 255u);
@@ -609,37 +744,47 @@ __global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint
             fb[q] = (float)(v[q] >> 16);
             // byte offset of the cell's list, (g' | r' << 4 | b' << 8) * 8: the high nibbles r' << 4 | g' << 12 | b' << 20
             // times 2^20 + 2^8 (mod 2^32) = r' << 12 | g' << 20 | r' << 24 | b' << 28, bits 16..19 clear
-            const uint32_t off = (uint32_t)__umul24(v[q] & 0xf0f0f0u, 0x100100u) >> 17;  // (HIP's __umul24 returns int)
-            L[q] = *reinterpret_cast<const uint2 *>(cell_bytes + off);
+            // (W = 4: times 16, one bit further up)
+            const uint32_t off = (uint32_t)__umul24(v[q] & 0xf0f0f0u, 0x100100u) >> (W == 2 ? 17 : 16);  // (HIP's __umul24 returns int)
+            if (W == 2) {
+                const uint2 t = *reinterpret_cast<const uint2 *>(cell_bytes + off);
+                L[q][0] = t.x;
+                L[q][1] = t.y;
+            } else {
+                const uint4 t = *reinterpret_cast<const uint4 *>(cell_bytes + off);
+                L[q][0] = t.x;
+                L[q][1] = t.y;
+                L[q][W - 2] = t.z;
+                L[q][W - 1] = t.w;
+            }
             k0[q] = k1[q] = 0x7fffffff;
         }
-        const int nmax = (int)max(max(L[0].x & 255u, L[1].x & 255u), max(L[2].x & 255u, L[3].x & 255u));
+        const int nmax = (int)max(max(L[0][0] & 255u, L[1][0] & 255u), max(L[2][0] & 255u, L[3][0] & 255u));
         uint32_t four = 4u;
         asm volatile("" : "+v"(four));  // (SDWA takes no inline constant)
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < 4 * W - 1; ++i) {
             if (__ballot(i < nmax) == 0ull) break;  // wave-uniform
             // (byte (i + 1) of each list) << 4 in one instruction, the four records in flight together, then per pixel three
             // v_fmac_f32 (kept apart: packed pairs would cost moves), the key with the list position as tag, v_med3 + v_min
             uint32_t eo[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t word = (i + 1) < 4 ? L[q].x : L[q].y;
+                const uint32_t word = L[q][(i + 1) >> 2];
                 if (((i + 1) & 3) == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(eo[q]) : "v"(four), "v"(word));
                 else if (((i + 1) & 3) == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(eo[q]) : "v"(four), "v"(word));
                 else if (((i + 1) & 3) == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(eo[q]) : "v"(four), "v"(word));
                 else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(eo[q]) : "v"(four), "v"(word));
             }
             floatx4 c0, c1, c2, c3;
-            // (s_c4 starts kCellsGrid * 8 = 32768 bytes into the workgroup's LDS; the kernel has no static LDS)
             asm volatile(
-                "ds_read_b128 %0, %4 offset:32768\n\t"
-                "ds_read_b128 %1, %5 offset:32768\n\t"
-                "ds_read_b128 %2, %6 offset:32768\n\t"
-                "ds_read_b128 %3, %7 offset:32768\n\t"
+                "ds_read_b128 %0, %4 offset:%8\n\t"
+                "ds_read_b128 %1, %5 offset:%8\n\t"
+                "ds_read_b128 %2, %6 offset:%8\n\t"
+                "ds_read_b128 %3, %7 offset:%8\n\t"
                 "s_waitcnt lgkmcnt(0)"
                 : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
-                : "v"(eo[0]), "v"(eo[1]), "v"(eo[2]), "v"(eo[3])
+                : "v"(eo[0]), "v"(eo[1]), "v"(eo[2]), "v"(eo[3]), "n"(kC4Off)
                 : "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -661,11 +806,14 @@ __global__ __launch_bounds__(kCellsBlock, 6) void kmeans_cells_kernel(const uint
             if (q < cnt) {
                 const uint32_t r = v[q] & 255u, g = (v[q] >> 8) & 255u, b = v[q] >> 16;
                 // the winner's list position is the key's tag: byte (tag + 1) of the list
-                lab[q] = (int)__builtin_amdgcn_perm(L[q].y, L[q].x, 0x0c0c0c00u + (uint32_t)(k0[q] & 255) + 1u);
+                const uint32_t pos = (uint32_t)(k0[q] & 255) + 1u;
+                if (W == 2) lab[q] = (int)__builtin_amdgcn_perm(L[q][1], L[q][0], 0x0c0c0c00u + pos);
+                else lab[q] = (int)__builtin_amdgcn_perm(pos & 8u ? L[q][W - 1] : L[q][1], pos & 8u ? L[q][W - 2] : L[q][0], 0x0c0c0c00u + (pos & 7u));
                 // scores within 0.15 of their exact value, keys 256 apart per ulp of 0.0625 (see kmeans_step_kernel):
                 // a gap of more than 6 ulp settles the order among the listed centres, and an unlisted one is farther
-                // than some listed one on the whole cell.  A list of one leaves k1 at a dummy's key, far away; the
-                // dummies of an overfull cell tie with each other.
+                // than some listed one on the whole cell.  A list of one leaves k1 at the key of a dummy or of a far
+                // unlisted centre (more than 1.0 behind a listed one everywhere in the cell); the two equal entries of an
+                // overfull cell tie with each other.
                 if (k1[q] - k0[q] <= (6 << 8) + 255) {
                     const double x0 = (double)r, x1 = (double)g, x2 = (double)b;
                     double bd = __longlong_as_double(0x7ff0000000000000LL);
@@ -971,22 +1119,22 @@ __global__ __launch_bounds__(kPpThreads) void kmeans_pp_kernel(const uint8_t *__
 
 }  // namespace
 
-// 32 KB of cell lists per (device, stream) that has run a pass: launches on one stream are ordered, so a pass never
+// 64 KB of cell lists per (device, stream) that has run a pass: launches on one stream are ordered, so a pass never
 // sees another pass's lists; kept until the library is unloaded.
-static uint2 *cells_scratch(const int dev, hipStream_t s)
+static uint32_t *cells_scratch(const int dev, hipStream_t s)
 {
     static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, uint2 *> cache;
+    static std::map<std::pair<int, hipStream_t>, uint32_t *> cache;
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find({dev, s});
     if (it != cache.end()) return it->second;
     void *p = nullptr;
-    if (hipMalloc(&p, sizeof(uint2) * kCellsGrid) != hipSuccess) {
+    if (hipMalloc(&p, (size_t)16 * kCellsGrid) != hipSuccess) {
         set_error("dp_kmeans_step_u8: hipMalloc of the cell lists failed");
         return nullptr;
     }
-    cache[{dev, s}] = static_cast<uint2 *>(p);
-    return static_cast<uint2 *>(p);
+    cache[{dev, s}] = static_cast<uint32_t *>(p);
+    return static_cast<uint32_t *>(p);
 }
 
 int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int K, int64_t *sums, int64_t *counts,
@@ -1037,27 +1185,33 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
         // (DP_KMEANS_CELLS=0 keeps the full scan, =1 takes the lists at any size: tests)
         const char *e = getenv("DP_KMEANS_CELLS");
         const bool force = e && e[0] == '1', off = e && e[0] == '0';
-        const size_t csmem = sizeof(uint2) * kCellsGrid + sizeof(float4) * (K + 1) + sizeof(double) * 3 * K +
-                             sizeof(unsigned long long) * kCellsWaves * K * (kw + 1);
+        const bool wide = K > kCellsMaxK8;  // 16-byte lists, 1024 threads, one set of wide totals per workgroup
+        const int cblock = wide ? 1024 : 512, cwaves = cblock / 64;
+        const size_t csmem = wide ? (size_t)kC4Bytes16 + 16 * kCellsGrid + sizeof(double) * 3 * K + sizeof(unsigned long long) * K * (kw + cwaves)
+                                  : (size_t)8 * kCellsGrid + sizeof(float4) * (K + 1) + sizeof(double) * 3 * K +
+                                        sizeof(unsigned long long) * cwaves * K * (kw + 1);
         if (!off && !want_mfma && K <= kCellsMaxK && (force || n >= kCellsMinPixels) && csmem <= 150 * 1024) {
-            uint2 *cells = cells_scratch(dev, s);
+            uint32_t *cells = cells_scratch(dev, s);
             if (!cells) return DP_EHIP;
-            hipLaunchKernelGGL(kmeans_cells_build_kernel, dim3(kCellsGrid / kBuildCells), dim3(kBuildThreads), 0, s, centers, K, cells);
-            const int64_t cwant = (groups + kCellsBlock - 1) / kCellsBlock;
-            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (csmem + 1024)));  // 3 x 8 waves: 6 per SIMD
+            if (wide) hipLaunchKernelGGL(kmeans_cells_build16_kernel, dim3(kCellsGrid / kBuildCells), dim3(kBuildThreads), 0, s, centers, K, cells);
+            else hipLaunchKernelGGL(kmeans_cells_build_kernel, dim3(kCellsGrid / kBuildCells), dim3(kBuildThreads), 0, s, centers, K, cells);
+            const int64_t cwant = (groups + cblock - 1) / cblock;
+            const int per_cu = wide ? 1 : (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (csmem + 1024)));  // 3 x 8 waves: 6 per SIMD
             const unsigned cblocks = (unsigned)std::min<int64_t>(cwant, (int64_t)cus * per_cu);
+#define DP_KMC(SQF, WF)                                                                                                   \
+    do {                                                                                                                 \
+        auto kern = kmeans_cells_kernel<SQF, WF>;                                                                        \
+        DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)csmem)); \
+        hipLaunchKernelGGL(kern, dim3(cblocks), dim3(cblock), csmem, s, px, n, centers, K, cells,                        \
+                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), \
+                           reinterpret_cast<unsigned long long *>(sumsq));                                              \
+    } while (0)
             if (sumsq) {
-                auto kern = kmeans_cells_kernel<true>;
-                DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)csmem));
-                hipLaunchKernelGGL(kern, dim3(cblocks), dim3(kCellsBlock), csmem, s, px, n, centers, K, cells,
-                                   reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
-                                   reinterpret_cast<unsigned long long *>(sumsq));
+                if (wide) DP_KMC(true, 4); else DP_KMC(true, 2);
             } else {
-                auto kern = kmeans_cells_kernel<false>;
-                DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)csmem));
-                hipLaunchKernelGGL(kern, dim3(cblocks), dim3(kCellsBlock), csmem, s, px, n, centers, K, cells,
-                                   reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr);
+                if (wide) DP_KMC(false, 4); else DP_KMC(false, 2);
             }
+#undef DP_KMC
             prof_end(pm, s);
             DP_HIP(hipGetLastError());
             return DP_OK;

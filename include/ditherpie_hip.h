@@ -177,8 +177,8 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
  * all overwritten.  Being integers, the totals all-reduce exactly across ranks (RCCL, any order);
  * the caller updates the centres and derives the inertia
  *   sum_k ( sumsq_k - 2 c_k . sums_k + counts_k |c_k|^2 ).
- * Images of 2^19 pixels and more with K <= 255 go through per-cell candidate lists that the call rebuilds from
- * centers_dev first (one small extra launch; 32 KB of library-owned device memory per (device, stream) that has
+ * Images of 2^19 pixels and more with K <= 256 go through per-cell candidate lists that the call rebuilds from
+ * centers_dev first (one small extra launch; 64 KB of library-owned device memory per (device, stream) that has
  * run such a pass, kept until the library is unloaded); same totals. */
 int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
                       int64_t *counts_dev, int64_t *sumsq_dev, void *stream);

@@ -164,7 +164,8 @@ def test_kmeans_matrix_core_kernel_totals(be, orc, monkeypatch, K):
 
 
 @pytest.mark.parametrize("K,kind", [(1, "random"), (2, "lattice"), (5, "random"), (16, "clustered"), (32, "lattice"), (33, "data"),
-                                    (100, "clustered"), (200, "data"), (255, "random"), (8, "duplicates")])
+                                    (64, "random"), (65, "lattice"), (100, "clustered"), (200, "data"), (255, "random"), (256, "data"),
+                                    (256, "clustered"), (8, "duplicates"), (130, "duplicates")])
 def test_kmeans_cell_list_kernel_totals(be, orc, monkeypatch, K, kind):
     """The Lloyd pass over per-cell candidate lists (kmeans_cells_kernel, what images above 2^19 pixels take; forced here
     with DP_KMEANS_CELLS=1): integer totals equal the oracle's and the full-scan kernel's -- ragged pixel count, an

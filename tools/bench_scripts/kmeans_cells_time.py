@@ -11,7 +11,7 @@ yy, xx = torch.meshgrid(torch.arange(4320, device='cuda'), torch.arange(7680, de
 smooth = torch.stack([(xx * 255 // 7679), (yy * 255 // 4319), ((xx + yy) * 255 // (7679 + 4319))], -1).to(torch.uint8).reshape(-1, 3)
 smooth = (smooth.to(torch.int16) + torch.randint(-6, 7, smooth.shape, device='cuda', generator=g).to(torch.int16)).clamp(0, 255).to(torch.uint8).contiguous()
 for name, px in (("uniform random", rnd), ("smooth + grain", smooth)):
-    for K in ([int(a) for a in sys.argv[1:]] or [1, 2, 8, 16, 32, 64, 128, 255]):
+    for K in ([int(a) for a in sys.argv[1:]] or [1, 2, 8, 16, 32, 64, 128, 256]):
         c = torch.from_numpy(np.random.RandomState(1).rand(K, 3) * 255.0).cuda()
         # a few Lloyd steps so that the centres look like k-means centres of this data
         for _ in range(3):
