@@ -1119,12 +1119,17 @@ __global__ __launch_bounds__(kPpThreads) void kmeans_pp_kernel(const uint8_t *__
 
 }  // namespace
 
-// 64 KB of cell lists per (device, stream) that has run a pass: launches on one stream are ordered, so a pass never
-// sees another pass's lists; kept until the library is unloaded.
-static uint32_t *cells_scratch(const int dev, hipStream_t s)
+// 64 KB of cell lists per (device, stream) that has run a pass, kept until the library is unloaded.  Launches on one
+// stream are ordered, so a pass never sees another pass's lists as long as a call's two launches (lists, pass) are
+// enqueued together: the entry's mutex is held across them (two host threads may share a stream).
+struct CellsScratch {
+    uint32_t *ptr = nullptr;
+    std::mutex launch_mu;
+};
+static CellsScratch *cells_scratch(const int dev, hipStream_t s)
 {
     static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, uint32_t *> cache;
+    static std::map<std::pair<int, hipStream_t>, CellsScratch *> cache;
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find({dev, s});
     if (it != cache.end()) return it->second;
@@ -1133,8 +1138,10 @@ static uint32_t *cells_scratch(const int dev, hipStream_t s)
         set_error("dp_kmeans_step_u8: hipMalloc of the cell lists failed");
         return nullptr;
     }
-    cache[{dev, s}] = static_cast<uint32_t *>(p);
-    return static_cast<uint32_t *>(p);
+    CellsScratch *e = new CellsScratch;
+    e->ptr = static_cast<uint32_t *>(p);
+    cache[{dev, s}] = e;
+    return e;
 }
 
 int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int K, int64_t *sums, int64_t *counts,
@@ -1191,8 +1198,10 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
                                   : (size_t)8 * kCellsGrid + sizeof(float4) * (K + 1) + sizeof(double) * 3 * K +
                                         sizeof(unsigned long long) * cwaves * K * (kw + 1);
         if (!off && !want_mfma && K <= kCellsMaxK && (force || n >= kCellsMinPixels) && csmem <= 150 * 1024) {
-            uint32_t *cells = cells_scratch(dev, s);
-            if (!cells) return DP_EHIP;
+            CellsScratch *scratch = cells_scratch(dev, s);
+            if (!scratch) return DP_EHIP;
+            std::lock_guard<std::mutex> launch_lock(scratch->launch_mu);
+            uint32_t *cells = scratch->ptr;
             if (wide) hipLaunchKernelGGL(kmeans_cells_build16_kernel, dim3(kCellsGrid / kBuildCells), dim3(kBuildThreads), 0, s, centers, K, cells);
             else hipLaunchKernelGGL(kmeans_cells_build_kernel, dim3(kCellsGrid / kBuildCells), dim3(kBuildThreads), 0, s, centers, K, cells);
             const int64_t cwant = (groups + cblock - 1) / cblock;

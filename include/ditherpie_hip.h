@@ -179,7 +179,8 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
  *   sum_k ( sumsq_k - 2 c_k . sums_k + counts_k |c_k|^2 ).
  * Images of 2^19 pixels and more with K <= 256 go through per-cell candidate lists that the call rebuilds from
  * centers_dev first (one small extra launch; 64 KB of library-owned device memory per (device, stream) that has
- * run such a pass, kept until the library is unloaded); same totals. */
+ * run such a pass, kept until the library is unloaded; a call enqueues its two launches under that entry's mutex, so
+ * host threads that share a stream cannot interleave them); same totals. */
 int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
                       int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
 /* (sumsq_dev may be NULL: the squared norms are then not accumulated -- their total is a constant of the data, only

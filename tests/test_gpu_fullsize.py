@@ -400,6 +400,38 @@ def test_two_threads_share_a_stream(d, orc):
     assert not errors, errors
 
 
+def test_two_threads_share_a_stream_for_lloyd_passes(be, orc, monkeypatch):
+    """dp_kmeans_step_u8 with per-cell candidate lists keeps the lists in library-owned memory per (device, stream): two
+    threads on the default stream with different centres (ctypes drops the GIL) must not see each other's lists."""
+    import torch
+    monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+    px_np = orc.rnd(600, 1000, 77).reshape(-1, 3)
+    px = torch.from_numpy(px_np).cuda()
+    sets = []
+    for i, K in enumerate([32, 7, 100, 32]):
+        c = np.random.RandomState(300 + i).rand(K, 3) * 255.0
+        sets.append((torch.from_numpy(c).cuda(), orc.kmeans_step(px_np, c)))
+    errors = []
+
+    def worker(order):
+        try:
+            for rep in range(40):
+                for j in order:
+                    c, (s_ref, n_ref, _) = sets[j]
+                    s, n, _q = be.kmeans_step(px, c)
+                    if not (np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(n.cpu().numpy(), n_ref)):
+                        errors.append((j, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(o,)) for o in ([0, 1, 2, 3], [3, 2, 1, 0])]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_frames_over_devices_in_process(d, orc):
     """sharding.process_on_devices: contiguous frame blocks, one worker thread and stream per device entry (the one GPU
     of the test box named twice), result equal to the single-call result and in frame order."""
