@@ -400,6 +400,42 @@ def test_two_threads_share_a_stream(d, orc):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_kmeans_cell_list_fuzz(be, orc, monkeypatch, seed):
+    """Random cluster counts (1..256), centre layouts, pixel counts and content through the candidate-list pass: the
+    int64 totals equal the oracle's float64 labelling every time."""
+    import torch
+    rs = np.random.RandomState(1000 + seed)
+    monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+    for case in range(12):
+        K = int(rs.choice([1, 2, 3, 7, 16, 31, 32, 64, 65, 129, 255, 256]))
+        n = int(rs.choice([1, 3, 255, 257, 4096, 50001, 200003]))
+        kind = rs.randint(0, 4)
+        if kind == 0:      # noise
+            px = rs.randint(0, 256, (n, 3)).astype(np.uint8)
+        elif kind == 1:    # a ramp with grain: long runs of one label
+            t = np.arange(n)
+            px = np.clip(np.stack([t * 255 // max(n - 1, 1), 255 - t * 255 // max(n - 1, 1), (t // 7) % 256], -1) + rs.randint(-2, 3, (n, 3)), 0, 255).astype(np.uint8)
+        elif kind == 2:    # a few distinct colours only
+            px = rs.randint(0, 256, (5, 3)).astype(np.uint8)[rs.randint(0, 5, n)]
+        else:              # dark content: everything in one corner of the cube
+            px = rs.randint(0, 40, (n, 3)).astype(np.uint8)
+        ckind = rs.randint(0, 4)
+        if ckind == 0:
+            centers = rs.rand(K, 3) * 255.0
+        elif ckind == 1:
+            centers = np.round(rs.rand(K, 3) * 255.0)
+        elif ckind == 2:
+            centers = px[rs.randint(0, n, K)].astype(np.float64) + rs.choice([0.0, 0.5, 0.25])
+        else:
+            centers = 5.0 + rs.rand(K, 3) * 20.0
+        s_ref, n_ref, _ = orc.kmeans_step(px, centers)
+        s, cnt, q = be.kmeans_step(torch.from_numpy(px).cuda(), torch.from_numpy(centers))
+        assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(cnt.cpu().numpy(), n_ref), (seed, case, K, n, kind, ckind)
+        x64 = px.astype(np.int64)
+        assert int(q.sum().item()) == int((x64 * x64).sum())
+
+
 def test_two_threads_share_a_stream_for_lloyd_passes(be, orc, monkeypatch):
     """dp_kmeans_step_u8 with per-cell candidate lists keeps the lists in library-owned memory per (device, stream): two
     threads on the default stream with different centres (ctypes drops the GIL) must not see each other's lists."""
