@@ -645,6 +645,10 @@ constexpr int kLeanLdsWords = 160 * 1024 / 4;
 constexpr int kLeanQueue = 128;                                         // entries per wave
 constexpr int kLeanQueueWords = (kCellBlock / 64) * kLeanQueue;         // 8 KB at the top of LDS
 constexpr int kLeanTabBytes = (kLeanLdsWords - kLeanQueueWords) * 4;    // table + thresholds must fit below
+constexpr int kLeanHalfLdsWords = 80 * 1024 / 4;                        // HALF instances: two workgroups per CU
+constexpr int kLeanHalfQueue = 112;                                     // entries per wave: drained from 48 up (47 + 64 at most)
+constexpr int kLeanHalfDrain = 48;
+constexpr int kLeanHalfTabBytes = (kLeanHalfLdsWords - (kCellBlock / 64) * kLeanHalfQueue) * 4;
 constexpr int kWarpLutBytes = 768;                                      // tables over warped cells: the three maps ...
 constexpr int kWarpLutAt = kLeanTabBytes - kWarpLutBytes;               // ... sit right below the queue
 
@@ -922,7 +926,10 @@ __device__ __forceinline__ uint32_t lean_pixel_full(const uint32_t entry, const 
 
 // ADAPT: compiled with the deep mode (see below); the launcher picks it for palettes crowded into few cells, whose
 // pixels tend to sit in split cells -- the plain instantiation keeps its scalar registers for the lean loop
-template <int MODE, int BW, bool ADAPT, bool WARP>
+// HALF (4-entry blocks on plain cells, not adaptive): the workgroup declares 80 KB of LDS instead of all 160 -- the
+// 64 KB table, thresholds and queue fit -- so that two workgroups share a CU (8 waves per SIMD; these instances need fewer
+// than 64 VGPRs) and a wave's LDS waits are covered twice as often.
+template <int MODE, int BW, bool ADAPT, bool WARP, bool HALF = false>
 __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t *__restrict__ in,
                                                                   uint8_t *__restrict__ out,
                                                                   unsigned long long *__restrict__ flags,
@@ -930,7 +937,9 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
                                                                   const float sx, const float sy, const float sc,
                                                                   const uint32_t n_tiles)
 {
-    __shared__ __align__(16) uint32_t smem[kLeanLdsWords];  // static: LDS addresses need no base register
+    static_assert(!HALF || (BW == 4 && !ADAPT && !WARP), "HALF: 4-entry blocks on plain cells only");
+    constexpr int kLdsWords = HALF ? kLeanHalfLdsWords : kLeanLdsWords;
+    __shared__ __align__(16) uint32_t smem[kLdsWords];  // static: LDS addresses need no base register
     for (int i = threadIdx.x * 4; i < pal.tab_words; i += kCellBlock * 4) {
         uint4 v = *reinterpret_cast<const uint4 *>(&pal.cell_tab[i]);
         // The LDS copy of a marker block (marker word + equal entries) carries the marker TWICE: should the marker's key
@@ -948,7 +957,9 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
     __syncthreads();
     const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(smem);
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t *s_queue = smem + (kLeanLdsWords - kLeanQueueWords) + (threadIdx.x >> 6) * kLeanQueue;
+    constexpr int kQueue = HALF ? kLeanHalfQueue : kLeanQueue;
+    constexpr uint32_t kDrainAt = HALF ? kLeanHalfDrain : 64;  // (HALF: partly filled drains, so that the queue can be shorter)
+    uint32_t *s_queue = smem + (kLdsWords - (kCellBlock / 64) * kQueue) + (threadIdx.x >> 6) * kQueue;
     uint32_t qcount = 0;  // wave-uniform
     bool deep = false;    // wave-uniform: resolve every pixel completely in place (see below)
     const uint3 *in3 = reinterpret_cast<const uint3 *>(in);
@@ -1178,10 +1189,12 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
             if (rmask != 0u)
                 s_queue[__builtin_amdgcn_mbcnt_hi((uint32_t)(rb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rb, qcount))] = (gidx << 4) | rmask;
             qcount += (uint32_t)__popcll(rb);
-            while (qcount >= 64u) {
-                qcount -= 64u;
+            while (qcount >= kDrainAt) {
+                const uint32_t nq = HALF ? (qcount < 64u ? qcount : 64u) : 64u;
+                qcount -= nq;
                 __threadfence_block();  // the group stores that are about to be overwritten
-                const uint32_t rest = lean_pixel_full<MODE, BW, WARP>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
+                uint32_t rest = 0u;
+                if (!HALF || lane < nq) rest = lean_pixel_full<MODE, BW, WARP>(s_queue[qcount + lane], in, out, flags, g, pal, thr, smem, sx, sy, sc);
                 const unsigned long long mb = __ballot(rest != 0u);  // groups with a further deferred pixel go back
                 if (mb != 0ull) {
                     if (rest != 0u)
@@ -2284,7 +2297,10 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
             n_words = n_tiles * (kCellBlock / 64) * 4;
             const size_t lds = sizeof(uint32_t) * ((size_t)pal.tab_words + 256);  // launch_cell (plain table) only
-            const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus());
+            // 4-entry blocks on plain cells that leave half of LDS free: two workgroups per CU (DP_LEAN_NO_HALF=1: one)
+            const bool half = lean_ok && small && !warp && !getenv("DP_LEAN_NO_HALF") &&
+                              lean_tab_bytes + (mode == DP_MODE_MATRIX && int_lean ? (size_t)thr.th_h * thr.tw_pad * 4 : 0) <= (size_t)kLeanHalfTabBytes;
+            const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus() * (half ? 2u : 1u));
             {
                 const uint64_t adv = ((uint64_t)cgrid * kCellBlock * 4u) % (uint64_t)hw;
                 g.adv_y = (uint32_t)(adv / (uint64_t)w);
@@ -2311,6 +2327,9 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         if (warp && small) DP_LEAN_K(M, 4, false, true);                                                                 \
         else if (warp && adapt) DP_LEAN_K(M, 8, true, true);                                                             \
         else if (warp) DP_LEAN_K(M, 8, false, true);                                                                     \
+        else if (small && half)                                                                                          \
+            hipLaunchKernelGGL((ordered_lean_kernel<M, 4, false, false, true>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, \
+                               pal4, thr, sx, sy, ign_scale, n_tiles);                                                   \
         else if (small) DP_LEAN_K(M, 4, false, false);                                                                   \
         else if (adapt) DP_LEAN_K(M, 8, true, false);                                                                    \
         else DP_LEAN_K(M, 8, false, false);                                                                              \

@@ -23,7 +23,7 @@
  *     mutates the palette: finish it before another thread launches with that palette.
  *   - environment variables read by the library are experiment / test switches only (DP_DEBUG_ACCEL, DP_FORCE_TABLE,
  *     DP_NO_WARP, DP_NO_FAST, DP_FAST_ALL, DP_FAST_DBG, DP_ED_ONE_WG, DP_ED_WAVES, DP_ED_TEST_GIVEUP,
- *     DP_GATE_CHUNK_BYTES, DP_GATE_TWO_PASS, DP_KMEANS_MFMA, DP_KMEANS_NO_KEYS, DP_KMEANS_CELLS; INTEGRATION.md lists what each does); production
+ *     DP_GATE_CHUNK_BYTES, DP_GATE_TWO_PASS, DP_KMEANS_MFMA, DP_KMEANS_NO_KEYS, DP_KMEANS_CELLS, DP_LEAN_NO_HALF; INTEGRATION.md lists what each does); production
  *     callers set none of them.
  */
 #ifndef DITHERPIE_HIP_H
