@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "dp_internal.h"
@@ -717,6 +718,27 @@ size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w)
     return (size_t)n_frames * (size_t)w * 4 * sizeof(float) * 4 + 512 + (size_t)n_frames * 256;
 }
 
+// The per-cell loops of build_ed_cells are independent: split them over a few host threads (the tables of a new palette are
+// built at its first diffusion call, i.e. in front of a user's image).
+template <class F>
+static void parallel_cells(const int n, F &&body)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
+    if (n < 1024 || nt == 1) {
+        body(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int chunk = (n + (int)nt - 1) / (int)nt;
+    for (unsigned t = 1; t < nt; ++t) {
+        const int lo = (int)t * chunk, hi = std::min(n, lo + chunk);
+        if (lo < hi) th.emplace_back([&body, lo, hi]() { body(lo, hi); });
+    }
+    body(0, std::min(n, chunk));
+    for (auto &t : th) t.join();
+}
+
 int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
 {
     *blob_out = nullptr;
@@ -844,18 +866,20 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     std::vector<int> all(K), list;
     for (int j = 0; j < K; ++j) all[j] = j;
     // the kernel's lists (the geometric criterion), sharpened by the pairwise test
-    bool pruned_any = false;
-    for (int cell = 0; cell < kEdCells; ++cell) {
-        const uint32_t w4[4] = {host[cell].x, host[cell].y, host[cell].z, host[cell].w};
-        const int n = (int)(w4[0] & 255u);
-        if (n < 1 || n > 15) continue;
-        list.clear();
-        for (int i = 1; i <= n; ++i) list.push_back((int)((w4[i >> 2] >> (8 * (i & 3))) & 255u));
-        const double lo[3] = {(double)((cell & 31) * 8), (double)(((cell >> 5) & 31) * 8), (double)((cell >> 10) * 8)};
-        prune_list(lo, 8.0, list);
-        host[cell] = pack(list, lo, 8.0);  // (re-packed even when nothing was dropped: the padding)
-        pruned_any = true;
-    }
+    const bool pruned_any = true;
+    parallel_cells(kEdCells, [&](const int c0, const int c1) {
+        std::vector<int> list;
+        for (int cell = c0; cell < c1; ++cell) {
+            const uint32_t w4[4] = {host[cell].x, host[cell].y, host[cell].z, host[cell].w};
+            const int n = (int)(w4[0] & 255u);
+            if (n < 1 || n > 15) continue;
+            list.clear();
+            for (int i = 1; i <= n; ++i) list.push_back((int)((w4[i >> 2] >> (8 * (i & 3))) & 255u));
+            const double lo[3] = {(double)((cell & 31) * 8), (double)(((cell >> 5) & 31) * 8), (double)((cell >> 10) * 8)};
+            prune_list(lo, 8.0, list);
+            host[cell] = pack(list, lo, 8.0);  // (re-packed even when nothing was dropped: the padding)
+        }
+    });
     for (int cell = 0; cell < kEdCells; ++cell)
         if ((host[cell].x & 255u) == 255u) {
             Work wk;
@@ -933,12 +957,15 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
         // lists of the 16x16x16 cells in the format of the 8x8x8 table, for the LDS of the wavefront kernel's few-frames
         // variant (one wave per SIMD: the read of the 8x8x8 table from L2 is half of a step's latency there)
         std::vector<uint4> l16(4096);
-        for (int cell = 0; cell < 4096; ++cell) {
-            const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
-            box_list(all, lo, 16.0, list);
-            prune_list(lo, 16.0, list);
-            l16[cell] = list.size() <= 15 ? pack(list, lo, 16.0) : make_uint4(255u, 0u, 0u, 0u);
-        }
+        parallel_cells(4096, [&](const int c0, const int c1) {
+            std::vector<int> list;
+            for (int cell = c0; cell < c1; ++cell) {
+                const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
+                box_list(all, lo, 16.0, list);
+                prune_list(lo, 16.0, list);
+                l16[cell] = list.size() <= 15 ? pack(list, lo, 16.0) : make_uint4(255u, 0u, 0u, 0u);
+            }
+        });
         uint4 *d_l16 = cells + kEdCells + nodes.size() * (d_nodes ? 1 : 0);
         e = hipMemcpy(d_l16, l16.data(), sizeof(uint4) * 4096, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -952,7 +979,9 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     if (K <= 16) {
         // lists of the 16x16x16 cells for the wavefront kernel's LDS: count | up to 7 indices, one nibble each
         std::vector<uint32_t> coarse(4096);
-        for (int cell = 0; cell < 4096; ++cell) {
+        parallel_cells(4096, [&](const int c0, const int c1) {
+        std::vector<int> list;
+        for (int cell = c0; cell < c1; ++cell) {
             const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
             box_list(all, lo, 16.0, list);
             prune_list(lo, 16.0, list);
@@ -983,6 +1012,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
             }
             coarse[cell] = word;
         }
+        });
         uint32_t *d_coarse = reinterpret_cast<uint32_t *>(cells + kEdCells + nodes.size() * (d_nodes ? 1 : 0));
         e = hipMemcpy(d_coarse, coarse.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -999,7 +1029,9 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
         // unbounded in a direction in which |x - c_k|^2 - |x - c_j|^2 grows, k cannot dominate j.
         std::vector<uint32_t> ext(4096);
         const double kInf = std::numeric_limits<double>::infinity();
-        for (int cell = 0; cell < 4096; ++cell) {
+        parallel_cells(4096, [&](const int c0, const int c1) {
+        std::vector<int> list;
+        for (int cell = c0; cell < c1; ++cell) {
             const int ci[3] = {cell & 15, (cell >> 4) & 15, cell >> 8};
             double blo[3], bhi[3];
             for (int d = 0; d < 3; ++d) {
@@ -1044,6 +1076,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
             }
             ext[cell] = word;
         }
+        });
         e = hipMemcpy(d_coarse + 4096, ext.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipFree(cells);

@@ -70,8 +70,8 @@ int dp_device_info(int *n_devices, char *arch_buf, size_t arch_buf_len);
  * nth_element order) on the host, uploads it, and picks the exact-integer fast path when every
  * palette value is an integer in [0,255] and lut_in is NULL.  Costs ~0.05 ms (0.1 ms at 1024 colours).
  * The candidate tables of the diffusion kernels (9..256 colours) are NOT built here: the first
- * dp_error_diffusion_* / dp_variable_diffusion_u8 call with the palette builds them on the host (3 ms at
- * 16 colours, 8 ms at 256, under a per-palette mutex, so concurrent first calls are safe) and uploads them
+ * dp_error_diffusion_* / dp_variable_diffusion_u8 call with the palette builds them on the host (up to 8
+ * threads: 1.4 ms at 16 colours, 1.9 ms at 256; under a per-palette mutex, so concurrent first calls are safe) and uploads them
  * synchronously; ordered-only users never pay for them. */
 int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, const uint8_t *lut_in,
                       dp_palette **out);
