@@ -308,8 +308,9 @@ def ign_thresholds(h, w, scale=1.0, seed=0, y0=0, x0=0, device="cuda"):
     return out
 
 
-def kmeans_step(px, centers):
-    """px: CUDA uint8 [...,3]; centers: CUDA float64 [K,3] -> (sums [K,3], counts [K], sumsq [K]) int64"""
+def kmeans_step(px, centers, mean=None):
+    """px: CUDA uint8 [...,3]; centers: CUDA float64 [K,3]; mean: CUDA float64 [3] or None (sklearn's tie rule, see
+    include/ditherpie_hip.h) -> (sums [K,3], counts [K], sumsq [K]) int64"""
     if not (px.is_cuda and px.dtype == torch.uint8 and px.shape[-1] == 3):
         raise TypeError("px must be a CUDA uint8 tensor [...,3]")
     px = px.contiguous()
@@ -319,18 +320,23 @@ def kmeans_step(px, centers):
     counts = torch.empty((K,), dtype=torch.int64, device=px.device)
     sumsq = torch.empty((K,), dtype=torch.int64, device=px.device)
     with torch.cuda.device(px.device):
-        check(_lib.load().dp_kmeans_step_u8(px.data_ptr(), px.numel() // 3, centers.data_ptr(), K, sums.data_ptr(),
+        if mean is not None:
+            mean = mean.to(device=px.device, dtype=torch.float64).contiguous()
+        check(_lib.load().dp_kmeans_step_u8(px.data_ptr(), px.numel() // 3, centers.data_ptr(),
+                                            mean.data_ptr() if mean is not None else None, K, sums.data_ptr(),
                                             counts.data_ptr(), sumsq.data_ptr(), _stream()))
     return sums, counts, sumsq
 
 
-def kmeans_step_into(px, centers, totals, want_sq=True):
+def kmeans_step_into(px, centers, totals, want_sq=True, mean=None):
     """One Lloyd pass written into the planar totals buffer `totals` (int64 [5K]: sums [K,3] | counts [K] | squared
-    norms [K]); with want_sq=False the last part is left alone.  No allocation, nothing read back."""
+    norms [K]); with want_sq=False the last part is left alone.  No allocation, nothing read back.  mean: float64 [3]
+    tensor on the device (already contiguous) or None."""
     K = centers.shape[0]
     base = totals.data_ptr()
     with torch.cuda.device(px.device):
-        check(_lib.load().dp_kmeans_step_u8(px.data_ptr(), px.numel() // 3, centers.data_ptr(), K, base, base + 8 * 3 * K,
+        check(_lib.load().dp_kmeans_step_u8(px.data_ptr(), px.numel() // 3, centers.data_ptr(),
+                                            mean.data_ptr() if mean is not None else None, K, base, base + 8 * 3 * K,
                                             (base + 8 * 4 * K) if want_sq else None, _stream()))
 
 

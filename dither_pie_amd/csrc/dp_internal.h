@@ -191,7 +191,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
                            const int32_t *dx, const int32_t *dy, const float *wq, int ntaps, int serpentine,
                            void *ws, size_t ws_bytes, hipStream_t s, const double *wq64 = nullptr);
 size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w);
-int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int K, int64_t *sums, int64_t *counts,
+int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, const double *mean, int K, int64_t *sums, int64_t *counts,
                        int64_t *sumsq, hipStream_t s);
 int launch_kmeans_pp(const uint8_t *sample, int n, int K, int first, const double *uniforms, int n_trials, int *out_ids,
                      double *out_centers, hipStream_t s);

@@ -792,14 +792,14 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
                                 (hipStream_t)stream);
 }
 
-int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
-                      int64_t *counts_dev, int64_t *sumsq_dev, void *stream)
+int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, const double *mean_dev, int K,
+                      int64_t *sums_dev, int64_t *counts_dev, int64_t *sumsq_dev, void *stream)
 {
     if ((!px_dev && n > 0) || n < 0 || !centers_dev || K < 1 || K > 1024 || !sums_dev || !counts_dev) {
         set_error("dp_kmeans_step_u8: bad argument");
         return DP_EINVAL;
     }
-    return launch_kmeans_step(px_dev, n, centers_dev, K, sums_dev, counts_dev, sumsq_dev, (hipStream_t)stream);
+    return launch_kmeans_step(px_dev, n, centers_dev, mean_dev, K, sums_dev, counts_dev, sumsq_dev, (hipStream_t)stream);
 }
 
 int dp_kmeans_update(const int64_t *totals_dev, double *centers_dev, int64_t *prev_dev, double *status_dev, int K,

@@ -40,6 +40,64 @@ __device__ __forceinline__ int med3_s32(const int a, const int b, const int c)
     return max(min(a, b), min(max(a, b), c));  // selected as one v_med3_i32
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The float64 decision behind the float32 ranking (near ties only).  Centre records in LDS: 4 doubles {c0, c1, c2, cn}.
+//   mean == nullptr: direct distances ((x0-c0)^2 + (x1-c1)^2) + (x2-c2)^2, lowest index on exact ties.
+//   mean != nullptr: sklearn's own expression (KMeans.fit -> _k_means_lloyd.pyx::_update_chunk_dense, as
+//     dithering_lib.py:1854-1856 runs it): data and centres mean-centred in float64, v_j = |c'_j|^2 - 2 x'.c'_j with
+//     |c'|^2 = (fl(c0'^2) + fl(c2'^2)) + fl(c1'^2) (numpy einsum over three elements in 512-bit lanes) and
+//     x'.c' = fma(x2', c2', fma(x1', c1', fl(x0' c0'))) (the OpenBLAS dgemm micro-kernel), first minimum.  It orders like
+//     the distance except where two centres are EXACTLY equidistant (k-means++ seeds are data points: integer centres
+//     tie on up to 1 % of a structured image's pixels in the first pass), where its rounding decides -- reproducibly,
+//     and that is what the reference's palette then depends on (tests/golden kmx_*).  Rounding error < 1e-9 against a
+//     near-tie window of 0.25: every sample whose label the expression could change comes through here.
+__device__ __forceinline__ void stage_centre_f64(double *rec, const double c0, const double c1, const double c2, const double *mean)
+{
+    if (mean) {
+        const double a = __dsub_rn(c0, mean[0]), b = __dsub_rn(c1, mean[1]), c = __dsub_rn(c2, mean[2]);
+        rec[0] = a;
+        rec[1] = b;
+        rec[2] = c;
+        rec[3] = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(c, c)), __dmul_rn(b, b));
+    } else {
+        rec[0] = c0;
+        rec[1] = c1;
+        rec[2] = c2;
+        rec[3] = 0.0;
+    }
+}
+
+__device__ __forceinline__ int label_f64(const double *s_c, const int K, const double *mean, const uint32_t r, const uint32_t g,
+                                         const uint32_t b, int lab)
+{
+    double bd = __longlong_as_double(0x7ff0000000000000LL);
+    if (mean) {
+        const double y0 = __dsub_rn((double)r, mean[0]), y1 = __dsub_rn((double)g, mean[1]), y2 = __dsub_rn((double)b, mean[2]);
+        for (int j = 0; j < K; ++j) {
+            double acc = __dmul_rn(y0, s_c[4 * j]);
+            acc = __fma_rn(y1, s_c[4 * j + 1], acc);
+            acc = __fma_rn(y2, s_c[4 * j + 2], acc);
+            const double v = __dsub_rn(s_c[4 * j + 3], __dmul_rn(2.0, acc));
+            if (v < bd) {
+                bd = v;
+                lab = j;
+            }
+        }
+    } else {
+        const double x0 = (double)r, x1 = (double)g, x2 = (double)b;
+        for (int j = 0; j < K; ++j) {
+            const double a = __dsub_rn(x0, s_c[4 * j]), c = __dsub_rn(x1, s_c[4 * j + 1]), e = __dsub_rn(x2, s_c[4 * j + 2]);
+            const double d = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(c, c)), __dmul_rn(e, e));
+            if (d < bd) {
+                bd = d;
+                lab = j;
+            }
+        }
+    }
+    return lab;
+}
+
+
 // KEYS (K <= 256): the scores carry a bias of 2^19 + 195076, which puts every one of them into [2^19, 2^20) -- one
 // exponent, so the float bits shifted left by 8 order like the scores and leave room for the centre's index:
 // key = bits << 8 | j (v_lshl_or_b32), the two smallest keys by v_med3_i32 + v_min_i32 -- 6 instructions per pixel and
@@ -49,7 +107,7 @@ constexpr float kScoreBias = 524288.0f + 195076.0f;
 
 template <bool SQ, bool KEYS>
 __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__restrict__ px, const int64_t n,
-                                                             const double *__restrict__ centers, const int K,
+                                                             const double *__restrict__ centers, const double *__restrict__ mean, const int K,
                                                              unsigned long long *__restrict__ sums,
                                                              unsigned long long *__restrict__ counts,
                                                              unsigned long long *__restrict__ sumsq)
@@ -57,13 +115,11 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
     extern __shared__ __align__(16) unsigned char smem[];
     float4 *s_c4 = reinterpret_cast<float4 *>(smem);                                    // K: {-2c, |c|^2} float32
     double *s_c = reinterpret_cast<double *>(s_c4 + K);                                  // K*3 float64 (near ties)
-    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 3 * K);     // [waves][K][2 or 3]
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 4 * K);     // [waves][K][2 or 3]
     constexpr int kW = SQ ? 3 : 2;
     for (int i = threadIdx.x; i < K; i += kBlock) {
         const double c0 = centers[3 * i], c1 = centers[3 * i + 1], c2 = centers[3 * i + 2];
-        s_c[3 * i] = c0;
-        s_c[3 * i + 1] = c1;
-        s_c[3 * i + 2] = c2;
+        stage_centre_f64(s_c + 4 * i, c0, c1, c2, mean);
         s_c4[i] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2),
                               (float)(c0 * c0 + c1 * c1 + c2 * c2 + (KEYS ? (double)kScoreBias : 0.0)));
     }
@@ -159,19 +215,7 @@ __global__ __launch_bounds__(kBlock) void kmeans_step_kernel(const uint8_t *__re
                 // within 0.15), keys 256 apart per ulp of 0.0625: a gap of more than 6 ulp settles the order (K == 1
                 // leaves k1 at its initial value, far away, and the label is 0 either way)
                 const bool near_tie = KEYS ? (k1[q] - k0[q] <= (6 << 8) + 255) : !(b1[q] - b0[q] > 0.25f + 1e-6f * fabsf(b1[q]));
-                if (near_tie) {
-                    const double x0 = (double)r, x1 = (double)g, x2 = (double)b;
-                    double bd = __longlong_as_double(0x7ff0000000000000LL);
-                    for (int j = 0; j < K; ++j) {
-                        const double a = __dsub_rn(x0, s_c[3 * j]), c = __dsub_rn(x1, s_c[3 * j + 1]),
-                                     e = __dsub_rn(x2, s_c[3 * j + 2]);
-                        const double d = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(c, c)), __dmul_rn(e, e));
-                        if (d < bd) {
-                            bd = d;
-                            lab = j;
-                        }
-                    }
-                }
+                if (near_tie) lab = label_f64(s_c, K, mean, r, g, b, lab);
                 atomicAdd(&acc[lab * kW], (unsigned long long)r | ((unsigned long long)g << 28));
                 atomicAdd(&acc[lab * kW + 1], (unsigned long long)b | (1ull << 28));
                 if (SQ) atomicAdd(&acc[lab * kW + 2], (unsigned long long)(r * r + g * g + b * b));
@@ -217,7 +261,7 @@ constexpr int kTiles = 4;  // tiles of 32 pixels a wave takes per round
 
 template <bool SQ>
 __global__ __launch_bounds__(kBlock) void kmeans_mfma_kernel(const uint8_t *__restrict__ px, const int64_t n,
-                                                             const double *__restrict__ centers, const int K,
+                                                             const double *__restrict__ centers, const double *__restrict__ mean, const int K,
                                                              unsigned long long *__restrict__ sums,
                                                              unsigned long long *__restrict__ counts,
                                                              unsigned long long *__restrict__ sumsq)
@@ -226,14 +270,12 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_kernel(const uint8_t *__re
     extern __shared__ __align__(16) unsigned char smem[];
     const int KB = (K + 31) >> 5, KP = KB * 32;  // blocks of 32 centre rows (rows >= K: a score no pixel reaches)
     float4 *s_c4 = reinterpret_cast<float4 *>(smem);                                  // KP: {-2c, |c|^2 + BIAS}
-    double *s_c = reinterpret_cast<double *>(s_c4 + KP);                               // 3 KP float64 (near ties)
-    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 3 * KP);  // [waves][KP][2 or 3]
+    double *s_c = reinterpret_cast<double *>(s_c4 + KP);                               // 4 KP float64 (near ties)
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 4 * KP);  // [waves][KP][2 or 3]
     for (int i = threadIdx.x; i < KP; i += kBlock) {
         if (i < K) {
             const double c0 = centers[3 * i], c1 = centers[3 * i + 1], c2 = centers[3 * i + 2];
-            s_c[3 * i] = c0;
-            s_c[3 * i + 1] = c1;
-            s_c[3 * i + 2] = c2;
+            stage_centre_f64(s_c + 4 * i, c0, c1, c2, mean);
             s_c4[i] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2),
                                   (float)(c0 * c0 + c1 * c1 + c2 * c2 + (double)kScoreBias));
         } else {
@@ -338,18 +380,8 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_kernel(const uint8_t *__re
             const int64_t p = p0 + 32 * t;
             const uint32_t cr = w[t] & 255u, cg = (w[t] >> 8) & 255u, cbl = (w[t] >> 16) & 255u;
             if (p < n) {
-                if (k1 - k0 <= kNearKeys || lab >= K) {  // a near tie (or K == 1): float64, lowest index on exact ties
-                    const double x0 = (double)cr, x1d = (double)cg, x2d = (double)cbl;
-                    double bd = __longlong_as_double(0x7ff0000000000000LL);
-                    for (int q = 0; q < K; ++q) {
-                        const double a = __dsub_rn(x0, s_c[3 * q]), c = __dsub_rn(x1d, s_c[3 * q + 1]), e = __dsub_rn(x2d, s_c[3 * q + 2]);
-                        const double d = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(c, c)), __dmul_rn(e, e));
-                        if (d < bd) {
-                            bd = d;
-                            lab = q;
-                        }
-                    }
-                }
+                // a near tie (or K == 1): float64
+                if (k1 - k0 <= kNearKeys || lab >= K) lab = label_f64(s_c, K, mean, cr, cg, cbl, 0);
                 // lanes j add r | g << 28, lanes j + 32 add b | count << 28 (and nobody else touches this pixel)
                 const unsigned long long v = h ? ((unsigned long long)cbl | (1ull << 28)) : ((unsigned long long)cr | ((unsigned long long)cg << 28));
                 atomicAdd(&acc[lab * kW + h], v);
@@ -619,7 +651,7 @@ __global__ __launch_bounds__(kBuildThreads) void kmeans_cells_build16_kernel(con
 // cell (K <= 256), 1024 threads, wide totals per workgroup (LDS atomics), the centre records first in LDS.
 template <bool SQ, int W>
 __global__ __launch_bounds__(W == 2 ? 512 : 1024, W == 2 ? 6 : 4) void kmeans_cells_kernel(const uint8_t *__restrict__ px, const int64_t n,
-                                                                   const double *__restrict__ centers, const int K,
+                                                                   const double *__restrict__ centers, const double *__restrict__ mean, const int K,
                                                                    const uint32_t *__restrict__ cells,
                                                                    unsigned long long *__restrict__ sums,
                                                                    unsigned long long *__restrict__ counts,
@@ -632,17 +664,15 @@ __global__ __launch_bounds__(W == 2 ? 512 : 1024, W == 2 ? 6 : 4) void kmeans_ce
     constexpr uint32_t kC4Off = W == 2 ? kCellsGrid * 8u : 0u, kCellOff = W == 2 ? 0u : kC4Bytes16;
     uint32_t *s_cells = reinterpret_cast<uint32_t *>(smem + kCellOff);                  // 4096 x {n, e0..}
     float4 *s_c4 = reinterpret_cast<float4 *>(smem + kC4Off);                           // {-2c, |c|^2 + BIAS} (W = 2: + dummy)
-    double *s_c = reinterpret_cast<double *>(smem + (W == 2 ? kC4Off + 16u * (K + 1) : kCellOff + kCellsGrid * 16u));  // 3 K float64
-    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 3 * K);    // [sets][K][2 or 3]
+    double *s_c = reinterpret_cast<double *>(smem + (W == 2 ? kC4Off + 16u * (K + 1) : kCellOff + kCellsGrid * 16u));  // 4 K float64
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_c + 4 * K);    // [sets][K][2 or 3]
     constexpr int kW = SQ ? 3 : 2;
     unsigned long long *s_l1 = s_acc + (size_t)kAccSets * K * kW;                       // [waves][K] packed r18|g18|b18|n10
     for (int i = threadIdx.x; i < kCellsGrid * W; i += kCellsBlock) s_cells[i] = cells[i];
     for (int i = threadIdx.x; i < K + (W == 2 ? 1 : 0); i += kCellsBlock) {
         if (i < K) {
             const double c0 = centers[3 * i], c1 = centers[3 * i + 1], c2 = centers[3 * i + 2];
-            s_c[3 * i] = c0;
-            s_c[3 * i + 1] = c1;
-            s_c[3 * i + 2] = c2;
+            stage_centre_f64(s_c + 4 * i, c0, c1, c2, mean);
             s_c4[i] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2),
                                   (float)(c0 * c0 + c1 * c1 + c2 * c2 + (double)kScoreBias));
         } else {
@@ -814,19 +844,7 @@ __global__ __launch_bounds__(W == 2 ? 512 : 1024, W == 2 ? 6 : 4) void kmeans_ce
                 // than some listed one on the whole cell.  A list of one leaves k1 at the key of a dummy or of a far
                 // unlisted centre (more than 1.0 behind a listed one everywhere in the cell); the two equal entries of an
                 // overfull cell tie with each other.
-                if (k1[q] - k0[q] <= (6 << 8) + 255) {
-                    const double x0 = (double)r, x1 = (double)g, x2 = (double)b;
-                    double bd = __longlong_as_double(0x7ff0000000000000LL);
-                    for (int j = 0; j < K; ++j) {
-                        const double a = __dsub_rn(x0, s_c[3 * j]), c = __dsub_rn(x1, s_c[3 * j + 1]),
-                                     e = __dsub_rn(x2, s_c[3 * j + 2]);
-                        const double d = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(c, c)), __dmul_rn(e, e));
-                        if (d < bd) {
-                            bd = d;
-                            lab[q] = j;
-                        }
-                    }
-                }
+                if (k1[q] - k0[q] <= (6 << 8) + 255) lab[q] = label_f64(s_c, K, mean, r, g, b, lab[q]);
             }
         }
         // Totals.  Images are coherent: most of a wave's 256 consecutive pixels carry one or two labels, and 256 LDS
@@ -1144,8 +1162,8 @@ static CellsScratch *cells_scratch(const int dev, hipStream_t s)
     return e;
 }
 
-int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int K, int64_t *sums, int64_t *counts,
-                       int64_t *sumsq, hipStream_t s)
+int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, const double *mean, int K, int64_t *sums,
+                       int64_t *counts, int64_t *sumsq, hipStream_t s)
 {
     if (counts == sums + 3 * (size_t)K && (sumsq == nullptr || sumsq == counts + K)) {
         // one planar totals buffer (the device-side Lloyd loop, dp_kmeans_update): one memset instead of three launches
@@ -1163,7 +1181,7 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
     const unsigned blocks = (unsigned)std::min<int64_t>(want, (int64_t)cus * 8);  // persistent: 8 workgroups of 4 waves per CU
     ProfMark *pm = prof_begin(s);
     const size_t kw = sumsq ? 3 : 2;
-    const size_t smem = sizeof(float4) * K + sizeof(double) * 3 * K + sizeof(unsigned long long) * kWavesPerBlock * K * kw;
+    const size_t smem = sizeof(float4) * K + sizeof(double) * 4 * K + sizeof(unsigned long long) * kWavesPerBlock * K * kw;
     if (smem > 64 * 1024) {
         set_error("dp_kmeans_step_u8: too many clusters for the LDS accumulators");
         return DP_EUNSUPPORTED;
@@ -1173,15 +1191,15 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
         // scores on the matrix cores: a wave takes 128 pixels per round, 4 workgroups of 4 waves per CU
         constexpr int kRoundPx = kWavesPerBlock * kTiles * 32;
         const int KP = ((K + 31) / 32) * 32;
-        const size_t msmem = sizeof(float4) * KP + sizeof(double) * 3 * KP + sizeof(unsigned long long) * kWavesPerBlock * KP * kw;
+        const size_t msmem = sizeof(float4) * KP + sizeof(double) * 4 * KP + sizeof(unsigned long long) * kWavesPerBlock * KP * kw;
         const int64_t rounds = (n + kRoundPx - 1) / kRoundPx;
         const unsigned mblocks = (unsigned)std::min<int64_t>(rounds, (int64_t)cus * 4);
         if (sumsq)
-            hipLaunchKernelGGL(kmeans_mfma_kernel<true>, dim3(mblocks), dim3(kBlock), msmem, s, px, n, centers, K,
+            hipLaunchKernelGGL(kmeans_mfma_kernel<true>, dim3(mblocks), dim3(kBlock), msmem, s, px, n, centers, mean, K,
                                reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
                                reinterpret_cast<unsigned long long *>(sumsq));
         else
-            hipLaunchKernelGGL(kmeans_mfma_kernel<false>, dim3(mblocks), dim3(kBlock), msmem, s, px, n, centers, K,
+            hipLaunchKernelGGL(kmeans_mfma_kernel<false>, dim3(mblocks), dim3(kBlock), msmem, s, px, n, centers, mean, K,
                                reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr);
         prof_end(pm, s);
         DP_HIP(hipGetLastError());
@@ -1194,8 +1212,8 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
         const bool force = e && e[0] == '1', off = e && e[0] == '0';
         const bool wide = K > kCellsMaxK8;  // 16-byte lists, 1024 threads, one set of wide totals per workgroup
         const int cblock = wide ? 1024 : 512, cwaves = cblock / 64;
-        const size_t csmem = wide ? (size_t)kC4Bytes16 + 16 * kCellsGrid + sizeof(double) * 3 * K + sizeof(unsigned long long) * K * (kw + cwaves)
-                                  : (size_t)8 * kCellsGrid + sizeof(float4) * (K + 1) + sizeof(double) * 3 * K +
+        const size_t csmem = wide ? (size_t)kC4Bytes16 + 16 * kCellsGrid + sizeof(double) * 4 * K + sizeof(unsigned long long) * K * (kw + cwaves)
+                                  : (size_t)8 * kCellsGrid + sizeof(float4) * (K + 1) + sizeof(double) * 4 * K +
                                         sizeof(unsigned long long) * cwaves * K * (kw + 1);
         if (!off && !want_mfma && K <= kCellsMaxK && (force || n >= kCellsMinPixels) && csmem <= 150 * 1024) {
             CellsScratch *scratch = cells_scratch(dev, s);
@@ -1211,7 +1229,7 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
     do {                                                                                                                 \
         auto kern = kmeans_cells_kernel<SQF, WF>;                                                                        \
         DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)csmem)); \
-        hipLaunchKernelGGL(kern, dim3(cblocks), dim3(cblock), csmem, s, px, n, centers, K, cells,                        \
+        hipLaunchKernelGGL(kern, dim3(cblocks), dim3(cblock), csmem, s, px, n, centers, mean, K, cells,                        \
                            reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), \
                            reinterpret_cast<unsigned long long *>(sumsq));                                              \
     } while (0)
@@ -1228,7 +1246,7 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, int 
     }
     const bool keys = K <= 256 && !getenv("DP_KMEANS_NO_KEYS");
 #define DP_KM(SQF, KF)                                                                                                    \
-    hipLaunchKernelGGL((kmeans_step_kernel<SQF, KF>), dim3(blocks), dim3(kBlock), smem, s, px, n, centers, K,            \
+    hipLaunchKernelGGL((kmeans_step_kernel<SQF, KF>), dim3(blocks), dim3(kBlock), smem, s, px, n, centers, mean, K,            \
                        reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),   \
                        reinterpret_cast<unsigned long long *>(sumsq))
     if (sumsq) {

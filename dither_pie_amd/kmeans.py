@@ -26,13 +26,25 @@ import numpy as np
 SAMPLE = 10000
 
 
-def kmeans_plusplus(sample_u8, K, rs):
-    """sklearn's _kmeans_plusplus on a small pixel sample; rs: numpy RandomState. -> float64 [K,3]"""
+def first_center_draw(n, rs):
+    """sklearn draws the first centre with `random_state.choice(n_samples, p=sample_weight / sample_weight.sum())`
+    (sklearn/cluster/_kmeans.py, _kmeans_plusplus; unit weights in KMeans.fit as dithering_lib.py:1854-1856 calls it):
+    ONE random_sample() looked up in the normalised cumulative sum with side='right' - not the masked-rejection
+    integers of `choice(n)`, which leave the MT19937 stream somewhere else for every later draw."""
+    w = np.ones(n, dtype=np.float64)
+    return int(rs.choice(n, p=w / w.sum()))
+
+
+def kmeans_plusplus(sample_u8, K, rs, return_indices=False):
+    """sklearn's _kmeans_plusplus on a small pixel sample; rs: numpy RandomState. -> float64 [K,3]
+    (return_indices: also the K sample indices picked)"""
     X = np.asarray(sample_u8, dtype=np.float64).reshape(-1, 3)
     n = X.shape[0]
     n_trials = 2 + int(np.log(K))
     centers = np.empty((K, 3), np.float64)
-    centers[0] = X[rs.choice(n)]
+    ids = np.empty(K, np.int64)
+    ids[0] = first_center_draw(n, rs)
+    centers[0] = X[ids[0]]
     closest = ((X - centers[0]) ** 2).sum(axis=1)
     pot = closest.sum()
     for c in range(1, K):
@@ -44,7 +56,8 @@ def kmeans_plusplus(sample_u8, K, rs):
         best = int(np.argmin(pots))
         pot, closest = pots[best], d[best]
         centers[c] = X[picks[best]]
-    return centers
+        ids[c] = picks[best]
+    return (centers, ids) if return_indices else centers
 
 
 def kmeans_plusplus_device(sample, K, rs):
@@ -58,12 +71,12 @@ def kmeans_plusplus_device(sample, K, rs):
     n = sample.reshape(-1, 3).shape[0]
     n_trials = 2 + int(np.log(K))
     if n <= backend.KMEANS_PP_MAX_SAMPLE and n_trials <= 8 and K <= n:
-        first = int(rs.choice(n))
+        first = first_center_draw(n, rs)
         uniforms = np.stack([rs.uniform(size=n_trials) for _ in range(1, K)]) if K > 1 else np.zeros((0, n_trials))
         return backend.kmeans_plusplus(sample, K, first, uniforms)[1]
     X = sample.reshape(-1, 3).to(torch.float64)
     centers = torch.empty((K, 3), dtype=torch.float64, device=X.device)
-    centers[0] = X[int(rs.choice(n))]
+    centers[0] = X[first_center_draw(n, rs)]
     closest = ((X - centers[0]) ** 2).sum(dim=1)
     pot = closest.sum()
     for c in range(1, K):
@@ -88,8 +101,20 @@ def _all_reduce_totals(totals, group):
 CHECK_EVERY = 8  # iterations launched back to back between two looks at the status words
 
 
-def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None):
+def _check_centres_in_cube(c):
+    """dp_kmeans_step_u8's float32 ranking is valid for centres inside the colour cube only (include/ditherpie_hip.h)."""
+    lo, hi = float(c.min()), float(c.max())
+    if not (lo >= 0.0 and hi <= 255.0):   # also catches NaN
+        raise ValueError(f"k-means centres must lie within [0, 255] per channel (got {lo}..{hi})")
+
+
+def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sklearn_ties=True):
     """Lloyd iterations over the uint8 pixels `px` ([...,3] tensor on the GPU).
+
+    sklearn_ties: a pass "zero" (one centre: the totals of all pixels, all-reduced like any other pass) gives the data
+    mean KMeans.fit subtracts, and every pass labels equidistant pixels as sklearn's float64 expression on the centred
+    data does (dp_kmeans_step_u8's mean_dev) - what makes fits of <= 10 000 pixels, where the reference is
+    deterministic (dithering_lib.py:1845-1857), equal the reference's also on structured images.  False: lowest index.
 
     Each iteration is three stream-ordered steps with no host synchronisation: the pass over the pixels
     (dp_kmeans_step_u8: labels + exact integer totals), ONE all-reduce of the planar int64 totals when a process group is
@@ -99,7 +124,7 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None):
     the same rules run on the host.  Returns (centers float64 [K,3] numpy, inertia, n_iter)."""
     import torch
     if step_fn is not None:
-        return _lloyd_host(px, init_centers, max_iter, tol, group, step_fn)
+        return _lloyd_host(px, init_centers, max_iter, tol, group, step_fn, sklearn_ties)
     from . import backend
     flat = px.reshape(-1, 3)
     if not flat.is_contiguous():
@@ -109,15 +134,22 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None):
         centers = init_centers.to(device=dev, dtype=torch.float64).reshape(-1, 3).contiguous().clone()
     else:
         centers = torch.as_tensor(np.array(init_centers, dtype=np.float64).reshape(-1, 3)).to(dev).contiguous()
+    _check_centres_in_cube(centers)
     K = centers.shape[0]
-    totals = torch.zeros(5 * K, dtype=torch.int64, device=dev)
+    totals = torch.zeros(5 * max(K, 1), dtype=torch.int64, device=dev)
     prev = torch.zeros(4 * K, dtype=torch.int64, device=dev)
     status = torch.zeros(8, dtype=torch.float64, device=dev)
+    mean = None
+    if sklearn_ties:
+        t0 = torch.zeros(4, dtype=torch.int64, device=dev)
+        backend.kmeans_step_into(flat, torch.zeros((1, 3), dtype=torch.float64, device=dev), t0, want_sq=False)
+        _all_reduce_totals(t0, group)
+        mean = (t0[:3].to(torch.float64) / t0[3].to(torch.float64)).contiguous()   # exact sums: sum / n rounded once
     launched = 0
     while True:
         for _ in range(CHECK_EVERY):
             first = launched == 0
-            backend.kmeans_step_into(flat, centers, totals, want_sq=first)
+            backend.kmeans_step_into(flat, centers, totals, want_sq=first, mean=mean)
             _all_reduce_totals(totals if first else totals[:4 * K], group)
             backend.kmeans_update(totals, centers, prev, status, tol, max_iter)
             launched += 1
@@ -129,19 +161,26 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None):
     return centers.cpu().numpy(), float(st[2]), int(st[1])
 
 
-def _lloyd_host(px, init_centers, max_iter, tol, group, step_fn):
-    """The same iteration with the centre update on the host side of `step_fn` (CPU tests of the N>1 logic)."""
+def _lloyd_host(px, init_centers, max_iter, tol, group, step_fn, sklearn_ties=True):
+    """The same iteration with the centre update on the host side of `step_fn(px, centers, mean)` (CPU tests of the
+    N>1 logic)."""
     import torch
     centers = torch.as_tensor(np.array(init_centers, dtype=np.float64).reshape(-1, 3))
+    _check_centres_in_cube(centers)
     K = centers.shape[0]
     dev = None
     tol_abs = None
     prev = None
     inertia = float("nan")
     n_iter = 0
+    mean = None
+    if sklearn_ties:   # pass zero: one centre, the totals of every pixel over all ranks
+        s0, n0, _ = step_fn(px, torch.zeros((1, 3), dtype=torch.float64), None)
+        t0 = _all_reduce_totals(torch.cat([s0.reshape(3), n0.reshape(1)]).contiguous(), group)
+        mean = (t0[:3].to(torch.float64) / t0[3].to(torch.float64)).contiguous()
 
     def totals_for(c):
-        sums, counts, sumsq = step_fn(px, c)
+        sums, counts, sumsq = step_fn(px, c, mean)
         t = torch.cat([sums.reshape(K, 3), counts.reshape(K, 1), sumsq.reshape(K, 1)], dim=1).contiguous()
         return _all_reduce_totals(t, group)
 
@@ -157,8 +196,8 @@ def _lloyd_host(px, init_centers, max_iter, tol, group, step_fn):
         s, n = totals[:, :3].double(), totals[:, 3].double()
         if tol_abs is None:  # sklearn: tol * mean of the per-channel variances (from the exact totals)
             N = n.sum()
-            mean = s.sum(0) / N
-            tol_abs = tol * float(((totals[:, 4].double().sum() / N - (mean * mean).sum()) / 3.0).item())
+            mu = s.sum(0) / N
+            tol_abs = tol * float(((totals[:, 4].double().sum() / N - (mu * mu).sum()) / 3.0).item())
         new = torch.where((n > 0).unsqueeze(1), s / n.clamp(min=1.0).unsqueeze(1), centers)
         shift = ((new - centers) ** 2).sum()
         same = torch.zeros((), dtype=torch.float64, device=dev) if prev is None else \

@@ -172,7 +172,7 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
 
 /* k-means palette extraction ---------------------------------------------------------------------
  * One Lloyd pass of the KMeans fit at dithering_lib.py:1854-1856 over n uint8 RGB pixels: nearest
- * centre in float64 (lowest index on ties) and exact int64 per-cluster totals: channel sums
+ * centre in float64 and exact int64 per-cluster totals: channel sums
  * sums_dev[K*3], member counts counts_dev[K] and squared norms sumsq_dev[K] (sum of r^2+g^2+b^2),
  * all overwritten.  Being integers, the totals all-reduce exactly across ranks (RCCL, any order);
  * the caller updates the centres and derives the inertia
@@ -180,12 +180,22 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
  * Images of 2^19 pixels and more with K <= 256 go through per-cell candidate lists that the call rebuilds from
  * centers_dev first (one small extra launch; 64 KB of library-owned device memory per (device, stream) that has
  * run such a pass, kept until the library is unloaded; a call enqueues its two launches under that entry's mutex, so
- * host threads that share a stream cannot interleave them); same totals. */
-int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, int K, int64_t *sums_dev,
-                      int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
-/* (sumsq_dev may be NULL: the squared norms are then not accumulated -- their total is a constant of the data, only
- * the first pass of a fit needs it.)
- *
+ * host threads that share a stream cannot interleave them); same totals.
+ *   centers_dev  K*3 float64.  PRECONDITION: every coordinate within [0, 255] (means of uint8 pixels and k-means++
+ *                seeds always are): the float32 ranking in front of the float64 decision packs biased scores into one
+ *                binary exponent and is only valid for centres inside the colour cube.  kmeans.lloyd() checks
+ *                caller-supplied initial centres; the C ABI does not (the values are on the device).
+ *   mean_dev     3 float64 or NULL.  Given (the mean of ALL the fit's pixels, sum / n per channel), a pixel that is
+ *                equidistant from two centres gets the label sklearn gives it: the argmin of sklearn's own float64
+ *                expression |c'|^2 - 2 x'.c' on mean-centred data (KMeans.fit centres the data; rounding decides exact
+ *                ties, reproducibly -- see label_f64 in kmeans.hip for the operation order).  With it a fit of <= 10 000
+ *                pixels, where the reference is deterministic, reproduces the reference's centres to 1e-12 on every
+ *                fixture incl. structured images (tests/golden kmx_*).  NULL: lowest index on exact ties.
+ *   sumsq_dev    may be NULL: the squared norms are then not accumulated -- their total is a constant of the data, only
+ *                the first pass of a fit needs it. */
+int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, const double *mean_dev, int K,
+                      int64_t *sums_dev, int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
+/*
  * The centre update of one Lloyd iteration ON THE DEVICE, so that a host loop can launch iterations back to back
  * (pass, all-reduce of the totals across ranks, update) and look at the status only every few iterations -- sklearn's
  * _kmeans_single_lloyd as dithering_lib.py:1854-1856 runs it: empty clusters keep their centre, stop when the

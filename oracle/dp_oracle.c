@@ -826,24 +826,77 @@ int orc_blue_noise(int size, uint32_t seed, float *out)
 /* ------------------------------------------------------------------ */
 /* one Lloyd pass on uint8 pixels: nearest centre in f64 (lowest index */
 /* on ties, as sklearn's argmin), exact integer sums and counts        */
+/*                                                                      */
+/* mean == NULL: distances as ((x0-c0)^2 + (x1-c1)^2) + (x2-c2)^2.     */
+/* mean != NULL: the label of a sample is decided as sklearn decides   */
+/* it (sklearn/cluster/_k_means_lloyd.pyx, _update_chunk_dense, reached */
+/* from KMeans.fit, dithering_lib.py:1854-1856): the data and the      */
+/* centres are mean-centred in float64 (KMeans.fit: X -= X.mean(0)),   */
+/* v_j = |c'_j|^2 - 2 x'.c'_j with                                      */
+/*   |c'|^2 = (fl(c0'^2) + fl(c2'^2)) + fl(c1'^2)   numpy einsum        */
+/*            "ij,ij->i" on three elements with 512-bit lanes           */
+/*            (row_norms): products rounded, halves added first         */
+/*   x'.c'  = fma(x2', c2', fma(x1', c1', fl(x0' c0')))   the OpenBLAS  */
+/*            dgemm micro-kernels (Haswell / SkylakeX): one fused       */
+/*            multiply-add chain over the three features                */
+/*   v      = fl(|c'|^2 - 2 acc)   (alpha = -2 is exact)                */
+/* and the first minimum wins.  In exact arithmetic v_j orders like the */
+/* distance, so this only matters for samples equidistant from two      */
+/* centres (k-means++ seeds are data points: integer centres tie on 0.3 */
+/* to 1 % of the pixels of a structured image in the first iteration),  */
+/* where rounding decides -- and decides identically on every x86 with  */
+/* FMA and AVX-512, which is what generated tests/golden (kmx_*: 213    */
+/* tied samples, all reproduced).  The formula's rounding error is      */
+/* below 1e-9, so it is evaluated only where the two best exact         */
+/* distances are within 1e-6 of each other; sklearn evaluates it        */
+/* everywhere, with the same argmin.                                    */
 /* ------------------------------------------------------------------ */
-void orc_kmeans_step(const uint8_t *px, long n, const double *centers, int K, int64_t *sums,
-                     int64_t *counts, double *inertia)
+void orc_kmeans_step_sk(const uint8_t *px, long n, const double *centers, int K, const double *mean, int64_t *sums,
+                        int64_t *counts, double *inertia)
 {
     memset(sums, 0, sizeof(int64_t) * 3 * (size_t)K);
     memset(counts, 0, sizeof(int64_t) * (size_t)K);
+    double *cc = NULL, *cn = NULL;
+    if (mean) {
+        cc = (double *)malloc(sizeof(double) * 3 * (size_t)K);
+        cn = (double *)malloc(sizeof(double) * (size_t)K);
+        for (int j = 0; j < K; j++) {
+            for (int c = 0; c < 3; c++) cc[3 * j + c] = centers[3 * j + c] - mean[c];
+            const double p0 = cc[3 * j] * cc[3 * j], p1 = cc[3 * j + 1] * cc[3 * j + 1], p2 = cc[3 * j + 2] * cc[3 * j + 2];
+            cn[j] = (p0 + p2) + p1;
+        }
+    }
     double tot = 0.0;
     for (long i = 0; i < n; i++) {
         double x0 = px[3 * i], x1 = px[3 * i + 1], x2 = px[3 * i + 2];
         int best = 0;
-        double bd = INFINITY;
+        double bd = INFINITY, sd = INFINITY;
         for (int j = 0; j < K; j++) {
             double a = x0 - centers[3 * j], b = x1 - centers[3 * j + 1], c = x2 - centers[3 * j + 2];
             double d = (a * a + b * b) + c * c;
             if (d < bd) {
+                sd = bd;
                 bd = d;
                 best = j;
+            } else if (d < sd) {
+                sd = d;
             }
+        }
+        if (mean && sd - bd <= 1e-6) {
+            const double y0 = x0 - mean[0], y1 = x1 - mean[1], y2 = x2 - mean[2];
+            double bv = INFINITY;
+            for (int j = 0; j < K; j++) {
+                double acc = y0 * cc[3 * j];
+                acc = fma(y1, cc[3 * j + 1], acc);
+                acc = fma(y2, cc[3 * j + 2], acc);
+                const double v = cn[j] - 2.0 * acc;
+                if (v < bv) {
+                    bv = v;
+                    best = j;
+                }
+            }
+            const double a = x0 - centers[3 * best], b = x1 - centers[3 * best + 1], c = x2 - centers[3 * best + 2];
+            bd = (a * a + b * b) + c * c;
         }
         sums[3 * best] += px[3 * i];
         sums[3 * best + 1] += px[3 * i + 1];
@@ -851,8 +904,19 @@ void orc_kmeans_step(const uint8_t *px, long n, const double *centers, int K, in
         counts[best]++;
         tot += bd;
     }
+    free(cc);
+    free(cn);
     *inertia = tot;
 }
+
+void orc_kmeans_step(const uint8_t *px, long n, const double *centers, int K, int64_t *sums,
+                     int64_t *counts, double *inertia)
+{
+    orc_kmeans_step_sk(px, n, centers, K, NULL, sums, counts, inertia);
+}
+
+/* ------------------------------------------------------------------ */
+
 
 /* ------------------------------------------------------------------ */
 /* variable-weight diffusers (pure-Python branches of the reference)   */

@@ -64,6 +64,8 @@ def lib():
         L.orc_uniform_filter1d_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int]
         L.orc_kmeans_step.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
+        L.orc_kmeans_step_sk.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -454,26 +456,41 @@ def generate_uniform_palette(n):
 
 
 # ----------------------------------------------------------------------------- k-means
-def kmeans_step(px, centers):
-    """one Lloyd pass: (int64 sums [K,3], int64 counts [K], inertia)."""
+def kmeans_step(px, centers, mean=None):
+    """one Lloyd pass: (int64 sums [K,3], int64 counts [K], inertia).  mean (float64 [3], the data mean KMeans.fit
+    subtracts): equidistant samples are labelled by sklearn's own float64 expression (orc_kmeans_step_sk); None:
+    lowest index by direct distances."""
     px = np.ascontiguousarray(px, dtype=np.uint8).reshape(-1, 3)
     centers = np.ascontiguousarray(centers, dtype=np.float64)
     K = centers.shape[0]
     sums = np.zeros((K, 3), np.int64)
     counts = np.zeros(K, np.int64)
     inertia = C.c_double(0)
-    lib().orc_kmeans_step(_p(px), px.shape[0], _p(centers), K, _p(sums), _p(counts), C.byref(inertia))
+    if mean is not None:
+        mean = np.ascontiguousarray(mean, dtype=np.float64).reshape(3)
+    lib().orc_kmeans_step_sk(_p(px), px.shape[0], _p(centers), K, _p(mean) if mean is not None else None, _p(sums),
+                             _p(counts), C.byref(inertia))
     return sums, counts, inertia.value
 
 
-def kmeans_plusplus(px, K, rs):
+def data_mean(px):
+    """X.mean(axis=0) of the uint8 samples as KMeans.fit computes it: the column sums are integers below 2^53, so every
+    summation order gives sum / n rounded once."""
+    px = np.asarray(px).reshape(-1, 3)
+    return px.sum(axis=0, dtype=np.int64).astype(np.float64) / float(px.shape[0])
+
+
+def kmeans_plusplus(px, K, rs, return_indices=False):
     """sklearn.cluster._kmeans._kmeans_plusplus restated on the uint8 pixel sample (f64 arithmetic,
-    direct (x-c)^2 distances); rs is a numpy RandomState."""
+    direct (x-c)^2 distances); rs is a numpy RandomState.  Pinned by the km*_init_idx fixtures (sklearn's own picks
+    for RandomState(42) on the three reference k-means inputs, tests/golden/make_golden.py)."""
     X = np.asarray(px, dtype=np.float64).reshape(-1, 3)
     n = X.shape[0]
     trials = 2 + int(np.log(K))
     centers = np.empty((K, 3), np.float64)
-    cid = rs.choice(n)
+    w = np.ones(n, np.float64)
+    cid = rs.choice(n, p=w / w.sum())  # sklearn: choice(n_samples, p=sample_weight / sample_weight.sum())
+    ids = [int(cid)]
     centers[0] = X[cid]
     closest = ((X - centers[0]) ** 2).sum(1)
     pot = closest.sum()
@@ -488,21 +505,25 @@ def kmeans_plusplus(px, K, rs):
         pot = pots[b]
         closest = dc[b]
         centers[c] = X[cand[b]]
-    return centers
+        ids.append(int(cand[b]))
+    return (centers, np.array(ids)) if return_indices else centers
 
 
-def kmeans_lloyd(px, init_centers, max_iter=300, tol=1e-4):
+def kmeans_lloyd(px, init_centers, max_iter=300, tol=1e-4, sklearn_ties=True):
     """sklearn _kmeans_single_lloyd semantics on exact integer sums:
     stop on unchanged labels (detected through unchanged sums/counts) or squared centre shift
-    <= tol * mean(var(X)); empty clusters keep their previous centre."""
+    <= tol * mean(var(X)); empty clusters keep their previous centre.  sklearn_ties: equidistant samples are labelled
+    by sklearn's float64 expression on the mean-centred data (orc_kmeans_step_sk) - with it the 11 sklearn fixtures
+    (km*, kmx_*) are reproduced to 2e-13 with equal iteration counts; without it (lowest index) three of them drift."""
     px = np.ascontiguousarray(px, dtype=np.uint8).reshape(-1, 3)
     X = px.astype(np.float64)
     tol_abs = float(np.mean(np.var(X, axis=0)) * tol)
     centers = np.array(init_centers, dtype=np.float64)
+    mean = data_mean(px) if sklearn_ties else None
     prev = None
     n_iter = 0
     for n_iter in range(1, max_iter + 1):
-        sums, counts, _ = kmeans_step(px, centers)
+        sums, counts, _ = kmeans_step(px, centers, mean)
         new = centers.copy()
         nz = counts > 0
         new[nz] = sums[nz] / counts[nz, None]

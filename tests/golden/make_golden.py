@@ -151,11 +151,65 @@ for v in ED_VARIANTS:
                       ("U", 16), ("grad", 64, 96), False, True))
 
 
+# More k-means palettes from the reference where it is deterministic (<= 10 000 pixels, dithering_lib.py:1845-1857):
+# (name, input spec, K, random_state).  Recorded per case: the reference palette, sklearn's own k-means++ picks for that
+# random_state on the mean-centred data (what KMeans.fit seeds with), its centres, inertia and iteration count.
+KM_EXTRA = [
+    ("kmx_smooth_k4", ("imgl", 64, 96, 21, "smooth"), 4, 42),
+    ("kmx_dark_k16", ("imgl", 90, 110, 22, "dark"), 16, 42),
+    ("kmx_smooth_k64", ("imgl", 100, 100, 23, "smooth"), 64, 42),
+    ("kmx_rnd_k2", ("rnd", 50, 60, 24), 2, 42),
+    ("kmx_rnd_k16_rs7", ("rnd", 70, 70, 25), 16, 7),
+    ("kmx_grad_k32_rs123", ("grad", 99, 101), 32, 123),
+    ("kmx_exact10000_k8", ("rnd", 100, 100, 26), 8, 42),
+    ("kmx_fewcolours_k8", ("grad", 16, 20), 8, 42),
+]
+
+
+def append_kmeans_extra(kat, npz):
+    from sklearn.cluster import KMeans, kmeans_plusplus
+    import video_processor as vp
+    done = kat["misc"].setdefault("kmeans_extra", {})
+    for nm, ispec, K, rs in KM_EXTRA:
+        if nm in done:
+            continue
+        arr = make_input(ispec)
+        pal = dl.ColorReducer.generate_kmeans_palette(Image.fromarray(arr), K, random_state=rs)
+        X = arr.reshape(-1, 3).astype(np.float64)
+        _, init_idx = kmeans_plusplus(X - X.mean(axis=0), K, random_state=rs)
+        km = KMeans(n_clusters=K, random_state=rs).fit(arr.reshape(-1, 3))
+        km2 = KMeans(n_clusters=K, init=X[init_idx], n_init=1).fit(arr.reshape(-1, 3))
+        assert np.allclose(km.cluster_centers_, km2.cluster_centers_, atol=1e-9), "init replay mismatch"
+        assert [tuple(c) for c in km.cluster_centers_.astype(int)] == [tuple(int(v) for v in c) for c in pal]
+        npz[f"{nm}_palette"] = np.array(pal, np.int32)
+        npz[f"{nm}_init_idx"] = np.asarray(init_idx, np.int32)
+        npz[f"{nm}_centers"] = km.cluster_centers_
+        done[nm] = dict(input=list(ispec), K=K, random_state=rs, inertia=float(km.inertia_), n_iter=int(km.n_iter_))
+        print(nm, km.n_iter_, km.inertia_, flush=True)
+    # examples/image_pixelized.json as dither_cli.process_single_image runs it (dither_cli.py:516, 423, 546-566): regular
+    # pixelization to max_size 64, k-means 16 (random_state=42) of the pixelized image, error diffusion with its defaults,
+    # use_gamma, final NEAREST resize x8 - on a synthetic 400x300 stand-in for the absent test_300.png
+    if "pixelized_example" not in kat["misc"]:
+        src = Image.fromarray(imgl(300, 400, 27, "smooth"))
+        small = vp.pixelize_regular(src, 64)
+        pal = dl.ColorReducer.generate_kmeans_palette(small, 16, random_state=42)
+        d = dl.ImageDitherer(16, dl.DitherMode("error_diffusion"), [tuple(int(v) for v in c) for c in pal], True, {})
+        out = d.apply_dithering(small)
+        big = out.resize((out.width * 8, out.height * 8), Image.Resampling.NEAREST)
+        kat["misc"]["pixelized_example"] = dict(input=["imgl", 300, 400, 27, "smooth"], max_size=64, K=16, multiplier=8,
+                                                small_size=list(small.size), palette=[[int(v) for v in c] for c in pal],
+                                                h_small=H(np.array(small)), h_out=H(np.array(out)), h_big=H(np.array(big)))
+        npz["pixelized_example_out"] = np.array(out)
+        print("pixelized_example", small.size, H(np.array(out)), flush=True)
+
+
 def append_new():
-    """Adds the cases of CASES that kat.json does not hold yet (and their median-cut palettes) without touching the rest."""
+    """Adds the cases of CASES that kat.json does not hold yet (and their median-cut palettes) and the KM_EXTRA k-means
+    fixtures without touching the rest."""
     with open(os.path.join(HERE, "kat.json")) as f:
         kat = json.load(f)
     npz = dict(np.load(os.path.join(HERE, "small.npz")))
+    append_kmeans_extra(kat, npz)
     have = {c["name"] for c in kat["cases"]}
     for name, mode, params, pspec, ispec, gamma, keep in CASES:
         if name in have:

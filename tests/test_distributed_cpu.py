@@ -18,17 +18,17 @@ def _free_port():
     return p
 
 
-def _oracle_step(px, centers):
+def _oracle_step(px, centers, mean=None):
+    """-> (sums [K,3], counts [K], squared norms [K]); only the TOTAL of the squared norms is ever used (tolerance and
+    inertia), so they are booked on cluster 0."""
     import torch
     from oracle import oracle as orc
     p = px.reshape(-1, 3).cpu().numpy()
     c = centers.cpu().numpy()
-    sums, counts, _ = orc.kmeans_step(p, c)
+    sums, counts, _ = orc.kmeans_step(p, c, None if mean is None else mean.cpu().numpy())
     sq = np.zeros(len(c), np.int64)
     x = p.astype(np.int64)
-    d = ((x[:, None, :] - c[None, :, :]) ** 2).sum(2)
-    lab = d.argmin(1)
-    np.add.at(sq, lab, (x * x).sum(1))
+    sq[0] = int((x * x).sum())
     return torch.from_numpy(sums), torch.from_numpy(counts), torch.from_numpy(sq)
 
 

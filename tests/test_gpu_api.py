@@ -122,6 +122,62 @@ def test_kmeans_gpu_matches_sklearn_fixture_and_oracle(d, orc, gold, kat):
         assert diff.max() <= 1 and (diff > 0).mean() <= 0.05
 
 
+def test_generate_kmeans_palette_equals_reference_on_small_images(d, orc, gold, kat):
+    """ColorReducer.generate_kmeans_palette against the REFERENCE's own palettes (dithering_lib.py:1845-1857) on the 11
+    images of <= 10 000 pixels in tests/golden, where the reference is deterministic: device seeding (sklearn's draw
+    order), Lloyd over the pixels with sklearn's labelling of equidistant pixels, astype(int).  Equal up to A.6's rounding
+    noise at integer boundaries (+-1 on <= 5 % of the entries; in fact equal)."""
+    import torch
+    from conftest import case_input
+    from dither_pie_amd import kmeans
+    cases = []
+    for nm in ("km8", "km16", "km32"):
+        m = kat["misc"][nm]
+        cases.append((nm, ["rnd", m["h"], m["w"], m["seed"]] if m["kind"] == "rnd" else ["grad", m["h"], m["w"]], m["K"], 42, m))
+    for nm, m in sorted(kat["misc"]["kmeans_extra"].items()):
+        cases.append((nm, m["input"], m["K"], m["random_state"], m))
+    assert len(cases) == 11
+    for nm, spec, K, rs, m in cases:
+        arr = case_input(orc, spec)
+        pal = d.ColorReducer.generate_kmeans_palette(Image.fromarray(arr), K, random_state=rs)
+        assert len(pal) == K and all(isinstance(v, int) for c in pal for v in c)
+        diff = np.abs(np.array(pal) - gold[f"{nm}_palette"])
+        assert diff.max() <= 1 and (diff > 0).mean() <= 0.05, (nm, int(diff.max()))
+        _, centers, inertia, n_iter = kmeans.fit_palette(torch.from_numpy(arr).cuda().reshape(-1, 3), K, rs)
+        assert n_iter == m["n_iter"], nm
+        assert np.abs(centers - gold[f"{nm}_centers"]).max() < 1e-9, nm
+        assert abs(inertia - m["inertia"]) <= 1e-9 * m["inertia"], nm
+
+
+def test_pixelized_example_end_to_end(d, orc, kat, gold):
+    """examples/image_pixelized.json as dither_cli.process_single_image runs it (dither_cli.py:516, 423, 546-566) - the
+    reference's one shipped k-means configuration - on a synthetic 400x300 stand-in for the absent test_300.png: regular
+    pixelization to max_size 64 (86x64 = 5504 pixels: the deterministic regime), k-means 16 with random_state 42 of the
+    pixelized image, error diffusion with its defaults, use_gamma, final NEAREST resize x8.  Palette and every output
+    byte equal the reference's."""
+    from dither_pie_amd import video_processor as v
+    m = kat["misc"]["pixelized_example"]
+    src = Image.fromarray(orc.imgl(*m["input"][1:]))
+    small = v.pixelize_regular(src, m["max_size"])
+    assert list(small.size) == m["small_size"] and orc.H(np.array(small)) == m["h_small"]
+    pal = d.ColorReducer.generate_kmeans_palette(small, m["K"], random_state=42)
+    assert [list(c) for c in pal] == m["palette"]
+    out = d.ImageDitherer(m["K"], d.DitherMode("error_diffusion"), pal, True, {}).apply_dithering(small)
+    assert np.array_equal(np.array(out), gold["pixelized_example_out"])
+    big = out.resize((out.width * m["multiplier"], out.height * m["multiplier"]), Image.Resampling.NEAREST)
+    assert orc.H(np.array(big)) == m["h_big"]
+
+
+def test_lloyd_rejects_centres_outside_the_cube(d):
+    import torch
+    from dither_pie_amd import kmeans
+    px = torch.zeros((64, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        kmeans.lloyd(px, np.array([[0.0, 0.0, 0.0], [300.0, 1.0, 1.0]]))
+    with pytest.raises(ValueError):
+        kmeans.lloyd(px, np.array([[0.0, -1.0, 0.0]]))
+
+
 def test_generate_kmeans_palette_quality_and_determinism(d, orc):
     """A.6 (ii): inertia over the full image <= 1.01 x the inertia of an sklearn-style fit on a 10k sample."""
     arr = np.concatenate([orc.grad(150, 200), orc.rnd(150, 200, 3) // 2 + 60], axis=0)

@@ -210,9 +210,11 @@ def test_kmeans_cell_list_kernel_totals(be, orc, monkeypatch, K, kind):
 
 @pytest.mark.parametrize("n,K,seed", [(10000, 32, 42), (10000, 256, 1), (9999, 16, 7), (517, 8, 3), (64, 64, 5), (40, 5, 11), (16384, 2, 2), (3, 1, 0)])
 def test_kmeans_plusplus_kernel_equals_host_seeding(be, n, K, seed):
-    """dp_kmeans_plusplus_u8 (one workgroup, integer arithmetic) picks the centres sklearn's float64 code picks: compared
-    with the numpy statement of _kmeans_plusplus that the sklearn fixtures pin (tests/test_oracle_golden.py), on random
-    samples, on samples full of duplicates (zero distances, equal potentials) and at the LDS capacity."""
+    """dp_kmeans_plusplus_u8 (one workgroup, integer arithmetic) against the product's numpy statement of sklearn's
+    _kmeans_plusplus (kmeans.kmeans_plusplus) on random samples, on samples full of duplicates (zero distances, equal
+    potentials) and at the LDS capacity.  This is kernel == host statement; that the statement (and the kernel) pick what
+    sklearn picks is pinned separately, against sklearn's own indices: test_oracle_golden.py::
+    test_kmeans_plusplus_picks_sklearns_seeds (host) and test_kmeans_plusplus_kernel_picks_sklearns_seeds below."""
     import torch
     from dither_pie_amd import kmeans
     rs = np.random.RandomState(seed)
@@ -222,6 +224,65 @@ def test_kmeans_plusplus_kernel_equals_host_seeding(be, n, K, seed):
     host = kmeans.kmeans_plusplus(sample, K, np.random.RandomState(seed))
     dev = kmeans.kmeans_plusplus_device(torch.from_numpy(sample).cuda(), K, np.random.RandomState(seed))
     assert np.array_equal(dev.cpu().numpy(), host)
+
+
+def _km_fixture_cases(kat):
+    out = []
+    for nm in ("km8", "km16", "km32"):
+        m = kat["misc"][nm]
+        out.append((nm, ["rnd", m["h"], m["w"], m["seed"]] if m["kind"] == "rnd" else ["grad", m["h"], m["w"]], m["K"], 42, m))
+    for nm, m in sorted(kat["misc"]["kmeans_extra"].items()):
+        out.append((nm, m["input"], m["K"], m["random_state"], m))
+    return out
+
+
+def test_kmeans_plusplus_kernel_picks_sklearns_seeds(be, orc, gold, kat):
+    """The seeding kernel picks exactly the sample indices sklearn's _kmeans_plusplus picked (km*_init_idx, kmx_*_init_idx:
+    produced by sklearn itself in make_golden.py) on all 11 reference k-means inputs - first centre drawn as
+    RandomState.choice(n, p=uniform), the trials' uniforms in sklearn's order."""
+    import torch
+    from conftest import case_input
+    from dither_pie_amd import kmeans
+    for nm, spec, K, rs_seed, _ in _km_fixture_cases(kat):
+        px = case_input(orc, spec).reshape(-1, 3)
+        n = len(px)
+        rs = np.random.RandomState(rs_seed)
+        n_trials = 2 + int(np.log(K))
+        first = kmeans.first_center_draw(n, rs)
+        uniforms = np.stack([rs.uniform(size=n_trials) for _ in range(1, K)]) if K > 1 else np.zeros((0, n_trials))
+        ids, centers = be.kmeans_plusplus(torch.from_numpy(px).cuda(), K, first, uniforms)
+        assert np.array_equal(ids.cpu().numpy(), gold[f"{nm}_init_idx"]), nm
+        assert np.array_equal(centers.cpu().numpy(), px[gold[f"{nm}_init_idx"]].astype(np.float64)), nm
+
+
+@pytest.mark.parametrize("variant,K", [("scan", 16), ("scan", 300), ("cells", 16), ("cells", 100), ("mfma", 40)])
+def test_kmeans_pass_sklearn_tie_rule(be, orc, monkeypatch, variant, K):
+    """dp_kmeans_step_u8 with mean_dev: pixels equidistant from two centres get the label of sklearn's float64
+    expression on mean-centred data (the oracle's orc_kmeans_step_sk, pinned by the kmx_* fixtures), in every kernel
+    that has a float64 decision (full scan with and without keys, both candidate-list widths, the matrix-core kernel).
+    Centres are data points of a structured image, as in the first pass after k-means++: ~1 % exact ties."""
+    import torch
+    yy, xx = np.mgrid[0:257, 0:403]
+    img = np.stack([xx % 256, yy % 256, ((xx + yy) // 2) % 256], -1).astype(np.uint8)
+    flat = np.ascontiguousarray(np.concatenate([img.reshape(-1, 3), orc.rnd(64, 403, K).reshape(-1, 3) // 8 * 8])[:-1])
+    rs = np.random.RandomState(K)
+    centers = flat[rs.randint(0, len(flat), K)].astype(np.float64)
+    mean = orc.data_mean(flat)
+    s_ref, n_ref, _ = orc.kmeans_step(flat, centers, mean)
+    s_low, n_low, _ = orc.kmeans_step(flat, centers)
+    assert not np.array_equal(n_ref, n_low), "the input has to tell the two tie rules apart"
+    px = torch.from_numpy(flat).cuda()
+    if variant == "cells":
+        monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+    elif variant == "mfma":
+        monkeypatch.setenv("DP_KMEANS_MFMA", "1")
+    else:
+        monkeypatch.setenv("DP_KMEANS_CELLS", "0")
+    s, n, q = be.kmeans_step(px, torch.from_numpy(centers), torch.from_numpy(mean))
+    s0, n0, _ = be.kmeans_step(px, torch.from_numpy(centers))
+    assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(n.cpu().numpy(), n_ref)
+    assert np.array_equal(s0.cpu().numpy(), s_low) and np.array_equal(n0.cpu().numpy(), n_low)
+    assert int(q.sum()) == int((flat.astype(np.int64) ** 2).sum())
 
 
 def test_fit_palette_under_one_rank_nccl_group(be, orc):

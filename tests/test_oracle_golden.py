@@ -168,6 +168,59 @@ def test_kmeans_lloyd_matches_sklearn_from_same_init(orc, gold, kat, nm):
     assert diff.max() <= 1 and (diff > 0).mean() <= 0.05  # rounding noise at integer boundaries
 
 
+def _km_cases(kat):
+    """the 11 k-means fixtures the reference produced (<= 10 000 pixels: deterministic there), as
+    (name, input spec, K, random_state, meta)"""
+    out = []
+    for nm in ("km8", "km16", "km32"):
+        m = kat["misc"][nm]
+        spec = ["rnd", m["h"], m["w"], m["seed"]] if m["kind"] == "rnd" else ["grad", m["h"], m["w"]]
+        out.append((nm, spec, m["K"], 42, m))
+    for nm, m in sorted(kat["misc"]["kmeans_extra"].items()):
+        out.append((nm, m["input"], m["K"], m["random_state"], m))
+    return out
+
+
+def test_kmeans_plusplus_picks_sklearns_seeds(orc, gold, kat):
+    """The restated k-means++ (oracle) AND the product's host statement pick exactly the sample indices sklearn's own
+    _kmeans_plusplus picked for the same RandomState (km*_init_idx / kmx_*_init_idx were produced by sklearn in
+    make_golden.py and replayed there against KMeans.fit): this pins the draw order of the MT19937 stream, incl. the first
+    centre's choice(n, p=uniform)."""
+    from dither_pie_amd import kmeans
+    cases = _km_cases(kat)
+    assert len(cases) == 11
+    for nm, spec, K, rs, _ in cases:
+        px = case_input(orc, spec).reshape(-1, 3)
+        _, ids = orc.kmeans_plusplus(px, K, np.random.RandomState(rs), return_indices=True)
+        assert np.array_equal(ids, gold[f"{nm}_init_idx"]), nm
+        _, ids = kmeans.kmeans_plusplus(px, K, np.random.RandomState(rs), return_indices=True)
+        assert np.array_equal(ids, gold[f"{nm}_init_idx"]), nm
+
+
+def test_kmeans_fit_reproduces_reference_palette(orc, gold, kat):
+    """Seeding + Lloyd of the oracle against ColorReducer.generate_kmeans_palette of the reference itself
+    (dithering_lib.py:1845-1857) on images of <= 10 000 pixels: same iteration count, centres to 1e-9, the truncated
+    palette equal except at integer boundaries (A.6) - incl. the structured images where equidistant pixels have to be
+    labelled the way sklearn's float64 expression labels them (kmx_dark_k16, kmx_grad_k32_rs123, kmx_smooth_k64 drift by
+    up to 4 levels with a lowest-index rule)."""
+    worst = 0
+    for nm, spec, K, rs, m in _km_cases(kat):
+        px = case_input(orc, spec).reshape(-1, 3)
+        init = orc.kmeans_plusplus(px, K, np.random.RandomState(rs))
+        centers, inertia, n_iter = orc.kmeans_lloyd(px, init)
+        assert n_iter == m["n_iter"], nm
+        assert np.abs(centers - gold[f"{nm}_centers"]).max() < 1e-9, nm
+        assert abs(inertia - m["inertia"]) <= 1e-9 * m["inertia"], nm
+        diff = np.abs(centers.astype(int) - gold[f"{nm}_palette"])
+        assert diff.max() <= 1 and (diff > 0).mean() <= 0.05, nm
+        worst = max(worst, int(diff.max()))
+    # and the lowest-index rule is really NOT what the reference does (the fixtures can tell the two apart)
+    nm, spec, K, rs, m = next(c for c in _km_cases(kat) if c[0] == "kmx_grad_k32_rs123")
+    px = case_input(orc, spec).reshape(-1, 3)
+    c2, _, n2 = orc.kmeans_lloyd(px, px[gold[f"{nm}_init_idx"]].astype(np.float64), sklearn_ties=False)
+    assert n2 != m["n_iter"] or np.abs(c2 - gold[f"{nm}_centers"]).max() > 1e-3
+
+
 def test_scipy_statement_agrees_with_golden_and_c_oracle(orc, gold):
     """three-way agreement: reference output (golden) == C restatement == scipy/numpy statement"""
     pytest.importorskip("scipy.spatial")
