@@ -81,8 +81,10 @@ class Palette:
 
     def build_accel(self):
         """Build the LDS cell table + tie codes (synchronous, idempotent; a no-op for palettes that do
-        not qualify).  Thread-safe: concurrent callers wait until the one build has finished, so nobody launches
-        with a half-built accelerator."""
+        not qualify).  Thread-safe: concurrent builders wait for the one build; threads that are launching with the
+        palette meanwhile are safe because the library builds into a private copy of the device record and publishes it
+        with one assignment, and every launch works on a snapshot of that record (host.cpp: snapshot / publish) - such a
+        launch simply still runs without the accelerator."""
         if self._accel_done:
             return
         with self._accel_lock:
@@ -201,9 +203,13 @@ class _Launch:
                 del _ws_cache[k]  # (a thread still inside that entry keeps its own references)
         self.ent = ent
         ent[1].acquire()
-        t = ent[0]
-        if t is None or t.numel() < self.nbytes or t.numel() > _WS_SHRINK * max(self.nbytes, 1 << 20):
-            t = ent[0] = torch.empty(max(self.nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        try:
+            t = ent[0]
+            if t is None or t.numel() < self.nbytes or t.numel() > _WS_SHRINK * max(self.nbytes, 1 << 20):
+                t = ent[0] = torch.empty(max(self.nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        except BaseException:   # out of memory on a grow: __exit__ will not run, the stream's lock must not stay held
+            ent[1].release()
+            raise
         return t
 
     def __exit__(self, *exc):

@@ -148,11 +148,7 @@ __global__ __launch_bounds__(256) void accel_scan_kernel(const PalDev pal, uint3
 }
 
 
-// T(x)-union masks for arbitrary axis-aligned boxes of colours (used below the 8x8x8 level)
-struct Box {
-    int r0, g0, b0, size;
-};
-
+// T(x)-union masks for arbitrary axis-aligned boxes of colours (used below the 8x8x8 level; Box: host_logic.h)
 template <int MW>
 __global__ __launch_bounds__(64) void accel_box_kernel(const PalDev pal, const Box *__restrict__ boxes,
                                                        uint32_t *__restrict__ masks)
@@ -380,302 +376,7 @@ __global__ __launch_bounds__(64) void accel_box_float_kernel(const PalDev pal, c
 
 namespace {
 
-constexpr int kCells = 4096;
-constexpr int kWideCap = 512;   // such lists per table at most
-constexpr int kNearSlots = 6;  // entries of an 8-entry block that the nearest-only path of ordered_fast_kernel reads
-constexpr int kTabCapWords = (160 * 1024 - 2048) / 4;  // LDS budget of the dither kernels
-constexpr int kTabMaxWords = 1 << 20;                 // largest table built (4 MB); what exceeds LDS stays in global memory
-// words the lean kernels stage when the table is larger than LDS: the 4096 cell blocks + the first split nodes
-constexpr int kTabStageWords = 4096 * 8 + 88 * 64;
-
-struct TableStats {
-    int n_split = 0, n_slow = 0, max_cnt = 0, max_near = 0, n_near_overflow = 0;
-    bool wide_overflow = false;
-    std::vector<Box> node_box;  // the box each split node covers, by node index
-    int n_split_cells = 0;  // 16^3 cells that are split (the pixels of these cells leave the main path of the kernels)
-    bool too_big = false;
-};
-
-// Turns the per-cell membership masks into the LDS table: [4096 cells][8 words], then [n_split][8 sub-cells][8].
-// coord4[j]: integer coordinates r | g<<8 | b<<16 of entry j (used to choose padding entries); word[j]: what a
-// block stores for entry j.  box_masks(boxes, out) computes the membership masks (8 words each) of further boxes.
-// nmasks (optional): the nearest sets N(cell) of the 4096 cells.  With them a cell whose N has more than `ns` members is
-// split like an overflowing one, and perm[slot] receives, for every unsplit cell block, the order in which the fast
-// ordered kernel stages the block's entries into LDS -- the members of N first (field k, 3 bits for bw = 8, 2 bits
-// for bw = 4: which entry of the index-ordered block goes to LDS slot k; bits 28..31: |N|); 0xffffffff = split cell.
-// The table itself stays in palette-index order (the tie codes are defined on that order).
-// wide (with perm): for every SPLIT cell the whole list T(cell) in index order, padded to kWideList entries -- the fast
-// kernel resolves the pixels of split cells on it (one block read instead of a descent through the octree);
-// perm[slot] = 0xff000000 | list number.  A cell with a longer list sets st.wide_overflow (no fast kernel then).
-template <class BoxMasks>
-int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int bw, const int cap_words, const int K,
-                   const std::vector<uint32_t> &coord4, const std::vector<uint32_t> &word, BoxMasks box_masks,
-                   std::vector<uint32_t> &tab, TableStats &st, const uint32_t *nmasks = nullptr, const int ns = 0,
-                   std::vector<uint32_t> *perm = nullptr, std::vector<uint32_t> *wide = nullptr)
-{
-    // bw: entries per block (8, or 4 for small palettes); a split node is 8 child blocks
-    tab.assign((size_t)kCells * bw, 0u);
-    std::vector<int> list, extra;
-    std::vector<uint64_t> dkey;
-    // members of a mask, padded to bw with the unused entries nearest to (cr,cg,cb); false if more than bw
-    auto make_block = [&](const uint32_t *mask, int cr, int cg, int cb, uint32_t *out8) {
-        list.clear();
-        extra.clear();
-        for (int j = 0; j < K; ++j) ((mask[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
-        st.max_cnt = std::max(st.max_cnt, (int)list.size());
-        if (list.size() > (size_t)bw) return false;
-        if (list.size() < (size_t)bw) {
-            // pad with the unused entries nearest to the centre (any real entry is harmless)
-            const size_t need = (size_t)bw - list.size();
-            dkey.resize(extra.size());
-            for (size_t q = 0; q < extra.size(); ++q) {
-                const uint32_t c = coord4[extra[q]];
-                const int r = c & 255, g = (c >> 8) & 255, b = (c >> 16) & 255;
-                dkey[q] = ((uint64_t)((r - cr) * (r - cr) + (g - cg) * (g - cg) + (b - cb) * (b - cb)) << 16) | (uint64_t)extra[q];
-            }
-            std::partial_sort(dkey.begin(), dkey.begin() + need, dkey.end());
-            for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
-            std::sort(list.begin(), list.end());  // key ties must break towards the lower palette index
-        }
-        for (int i = 0; i < bw; ++i) out8[i] = word[list[i]];
-        return true;
-    };
-    // pending splits below the 8^3 level: (block position in tab, box) resolved level by level
-    struct Pending {
-        size_t pos;
-        Box box;
-    };
-    std::vector<Pending> pending;
-    // turn the block at `pos` into a split node with 8 children of half size; children masks come
-    // either from `child_masks` (8 x 8 words) or, if null, are requested for the next round
-    auto split = [&](size_t pos, const Box &bx, const uint32_t *child_masks) {
-        const size_t base = tab.size();
-        if (base + 8 * (size_t)bw > (size_t)cap_words) {
-            st.too_big = true;
-            return;
-        }
-        tab.resize(base + 8 * (size_t)bw, 0u);
-        tab[pos] = 0x80000000u | (uint32_t)((base - (size_t)kCells * bw) / (8 * (size_t)bw));
-        ++st.n_split;
-        st.node_box.push_back(bx);
-        const int hs = bx.size / 2;
-        for (int sidx = 0; sidx < 8; ++sidx) {
-            Box c{bx.r0 + ((sidx >> 2) & 1) * hs, bx.g0 + ((sidx >> 1) & 1) * hs, bx.b0 + (sidx & 1) * hs, hs};
-            const size_t cpos = base + (size_t)sidx * bw;
-            if (child_masks) {
-                uint32_t blk[8];
-                if (make_block(child_masks + (size_t)mw * sidx, c.r0 + hs / 2, c.g0 + hs / 2, c.b0 + hs / 2, blk))
-                    std::copy(blk, blk + bw, tab.begin() + cpos);
-                else
-                    pending.push_back({cpos, c});
-            } else {
-                pending.push_back({cpos, c});
-            }
-        }
-    };
-    if (perm) perm->assign(kCells, 0xffffffffu);
-    for (int cell = 0; cell < kCells && !st.too_big; ++cell) {
-        const uint32_t *m = &masks[(size_t)cell * 9 * mw];
-        const int r0 = (cell >> 8) * 16, g0 = ((cell >> 4) & 15) * 16, b0 = (cell & 15) * 16;
-        uint32_t blk[8];
-        const size_t slot = (size_t)cell_slot(cell >> 8, (cell >> 4) & 15, cell & 15);
-        bool fits = make_block(m, r0 + 8, g0 + 8, b0 + 8, blk);
-        bool near_overflow = false;
-        if (fits && nmasks) {
-            // `list` holds the block's entries in index order: the nearest set first
-            const uint32_t *nm = nmasks + (size_t)cell * mw;
-            const int fb = bw == 8 ? 3 : 2;
-            uint32_t pw = 0;
-            int k = 0, n_near = 0;
-            for (int pass = 0; pass < 2; ++pass)
-                for (int i = 0; i < bw; ++i) {
-                    const int j = list[i];
-                    const bool near = (nm[j >> 5] >> (j & 31)) & 1u;
-                    if (near == (pass == 0)) {
-                        pw |= (uint32_t)i << (fb * k++);
-                        n_near += near;
-                    }
-                }
-            // a nearest set larger than the nearest-only path of the fast kernel reads: the cell keeps its block in the table,
-            // but the fast kernel treats it as split (staging order = flat list below)
-            near_overflow = n_near > ns;
-            if (!near_overflow && perm) (*perm)[slot] = pw | ((uint32_t)n_near << 28);
-            st.max_near = std::max(st.max_near, n_near);
-            st.n_near_overflow += near_overflow;
-        }
-        if (fits) std::copy(blk, blk + bw, tab.begin() + slot * bw);
-        if (!fits || near_overflow) {
-            if (perm && wide) {
-                // the cell's whole list, index order, padded with the unused entries nearest to the centre
-                list.clear();
-                extra.clear();
-                for (int j = 0; j < K; ++j) ((m[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
-                if (K <= kWideList) {
-                    // the whole palette (the kernel reads min(K, kWideList) entries)
-                    (*perm)[slot] = 0xff000000u | (uint32_t)(wide->size() / kWideList);
-                    for (int i = 0; i < kWideList; ++i) wide->push_back(i < K ? word[i] : 0u);
-                } else if ((int)list.size() > kWideList) {
-                    st.wide_overflow = true;
-                } else {
-                    const size_t need = (size_t)kWideList - list.size();
-                    dkey.resize(extra.size());
-                    for (size_t q = 0; q < extra.size(); ++q) {
-                        const uint32_t c = coord4[extra[q]];
-                        const int r = c & 255, g = (c >> 8) & 255, b = (c >> 16) & 255;
-                        dkey[q] = ((uint64_t)((r - r0 - 8) * (r - r0 - 8) + (g - g0 - 8) * (g - g0 - 8) + (b - b0 - 8) * (b - b0 - 8)) << 16) | (uint64_t)extra[q];
-                    }
-                    std::partial_sort(dkey.begin(), dkey.begin() + need, dkey.end());
-                    for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
-                    std::sort(list.begin(), list.end());
-                    (*perm)[slot] = 0xff000000u | (uint32_t)(wide->size() / kWideList);
-                    for (int i = 0; i < kWideList; ++i) wide->push_back(word[list[i]]);
-                }
-            }
-        }
-        if (!fits) {
-            split(slot * bw, Box{r0, g0, b0, 16}, m + mw);
-            ++st.n_split_cells;
-        }
-    }
-    // deeper levels: boxes that still hold more than 8 members are split again; a single colour that still
-    // overflows is left to the fix-up pass
-    while (!pending.empty() && !st.too_big) {
-        std::vector<Pending> todo;
-        todo.swap(pending);
-        std::vector<Pending> kids;  // children whose masks we need this round
-        for (const Pending &pd : todo) {
-            if (pd.box.size == 1) {
-                tab[pd.pos] = 0xC0000000u;
-                ++st.n_slow;
-                continue;
-            }
-            const size_t before = pending.size();
-            split(pd.pos, pd.box, nullptr);
-            if (st.too_big) break;
-            for (size_t q = before; q < pending.size(); ++q) kids.push_back(pending[q]);
-            pending.resize(before);
-        }
-        if (st.too_big || kids.empty()) break;
-        std::vector<Box> boxes(kids.size());
-        for (size_t q = 0; q < kids.size(); ++q) boxes[q] = kids[q].box;
-        std::vector<uint32_t> bm(kids.size() * (size_t)mw);
-        const int rc = box_masks(boxes, bm);
-        if (rc != DP_OK) return rc;
-        for (size_t q = 0; q < kids.size(); ++q) {
-            const Box &c = kids[q].box;
-            uint32_t blk[8];
-            if (make_block(&bm[q * (size_t)mw], c.r0 + c.size / 2, c.g0 + c.size / 2, c.b0 + c.size / 2, blk))
-                std::copy(blk, blk + bw, tab.begin() + kids[q].pos);
-            else
-                pending.push_back(kids[q]);
-        }
-    }
-    return DP_OK;
-}
-
-// Tables larger than LDS: the kernels stage the cell blocks and the FIRST split nodes, the rest is read from global
-// memory.  Put the nodes of the most crowded boxes first -- a palette extracted from an image crowds its colours where
-// the image's pixels are, so those are the nodes the pixels visit.
-void crowded_nodes_first(std::vector<uint32_t> &tab, const TableStats &st, const int bw, const std::vector<uint32_t> &coord4)
-{
-    const size_t n = st.node_box.size();
-    if (n < 2) return;
-    std::vector<int> score(n, 0);
-    for (size_t k = 0; k < n; ++k) {
-        const Box &b = st.node_box[k];
-        for (const uint32_t c : coord4) {
-            const int r = c & 255, g = (c >> 8) & 255, bl = (c >> 16) & 255;
-            score[k] += (r >= b.r0 && r < b.r0 + b.size && g >= b.g0 && g < b.g0 + b.size && bl >= b.b0 && bl < b.b0 + b.size);
-        }
-    }
-    std::vector<uint32_t> order(n), where(n);
-    for (size_t k = 0; k < n; ++k) order[k] = (uint32_t)k;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
-    for (size_t k = 0; k < n; ++k) where[order[k]] = (uint32_t)k;
-    const size_t base = (size_t)kCells * bw, node_words = 8 * (size_t)bw;
-    std::vector<uint32_t> moved(tab.size());
-    std::copy(tab.begin(), tab.begin() + base, moved.begin());
-    for (size_t k = 0; k < n; ++k)
-        std::copy(tab.begin() + base + k * node_words, tab.begin() + base + (k + 1) * node_words,
-                  moved.begin() + base + where[k] * node_words);
-    for (uint32_t &w : moved)
-        if ((w >> 30) == 2u) w = 0x80000000u | where[w & 0xffffffu];  // split markers: the child node's new index
-    tab.swap(moved);
-}
-
-// The per-channel maps of a warped table (see accel_scan_warp_kernel).
-struct WarpMaps {
-    uint8_t lut[3][256];  // colour value -> warped coordinate
-    int lo[3][257];       // lo[c][u]: the smallest value whose warped coordinate is >= u (256 when there is none)
-};
-
-// 16 cells per channel, cell i starting at the palette's coordinate of rank K*i/16 (boundaries kept strictly
-// increasing); inside a cell of w values, value number k sits at sub-position k*16/w.
-void make_warp(const std::vector<uint32_t> &coord4, WarpMaps &wm)
-{
-    const size_t K = coord4.size();
-    for (int c = 0; c < 3; ++c) {
-        std::vector<int> v(K);
-        for (size_t j = 0; j < K; ++j) v[j] = (coord4[j] >> (8 * c)) & 255;
-        std::sort(v.begin(), v.end());
-        int a[17];
-        a[0] = 0;
-        a[16] = 256;
-        for (int i = 1; i < 16; ++i) {
-            int q = v[K * (size_t)i / 16];
-            q = std::max(q, a[i - 1] + 1);
-            q = std::min(q, 256 - (16 - i));
-            a[i] = q;
-        }
-        for (int i = 0; i < 16; ++i) {
-            const int w = a[i + 1] - a[i];
-            for (int x = a[i]; x < a[i + 1]; ++x) wm.lut[c][x] = (uint8_t)(16 * i + ((x - a[i]) * 16) / w);
-        }
-        int x = 0;
-        for (int u = 0; u <= 256; ++u) {
-            while (x < 256 && (int)wm.lut[c][x] < u) ++x;
-            wm.lo[c][u] = x;
-        }
-    }
-}
-
-// the palette entries and, for each entry, the points a quarter and half of the way to its four nearest other entries
-std::vector<uint32_t> mass_points(const std::vector<uint32_t> &coord4)
-{
-    std::vector<uint32_t> out(coord4);
-    const size_t K = coord4.size();
-    constexpr int kNear = 4;
-    for (size_t j = 0; j < K && K > (size_t)kNear; ++j) {
-        const int r = coord4[j] & 255, g = (coord4[j] >> 8) & 255, b = (coord4[j] >> 16) & 255;
-        uint64_t best[kNear];
-        for (uint64_t &v : best) v = ~0ull;
-        for (size_t k = 0; k < K; ++k) {
-            if (k == j) continue;
-            const int dr = (int)(coord4[k] & 255) - r, dg = (int)((coord4[k] >> 8) & 255) - g, db = (int)((coord4[k] >> 16) & 255) - b;
-            uint64_t key = ((uint64_t)(dr * dr + dg * dg + db * db) << 32) | k;
-            for (uint64_t &v : best)
-                if (key < v) std::swap(key, v);
-        }
-        for (const uint64_t key : best) {
-            const uint32_t c = coord4[key & 0xffffffffu];
-            const int cr = c & 255, cg = (c >> 8) & 255, cb = (c >> 16) & 255;
-            for (const int q : {1, 2})  // quarters of the way
-                out.push_back((uint32_t)(r + (cr - r) * q / 4) | ((uint32_t)(g + (cg - g) * q / 4) << 8) | ((uint32_t)(b + (cb - b) * q / 4) << 16));
-        }
-    }
-    return out;
-}
-
-// how many of the given points (coordinates as the table sees them) sit in split cells
-int entries_in_split_cells(const std::vector<uint32_t> &tab, const int bw, const std::vector<uint32_t> &coord4)
-{
-    int n = 0;
-    for (const uint32_t c : coord4) {
-        const size_t slot = (size_t)cell_slot((c & 255) >> 4, ((c >> 8) & 255) >> 4, ((c >> 16) & 255) >> 4);
-        n += (int)(tab[slot * bw] >> 31);
-    }
-    return n;
-}
+// (assemble_table, crowded_nodes_first, make_warp, mass_points, entries_in_split_cells and their constants: host_logic.h)
 
 // runs `launch(d_boxes, d_masks, n)` over a list of boxes and brings the masks back
 template <class B, class Launch>

@@ -9,16 +9,15 @@
 #include <vector>
 
 #include "../../include/ditherpie_hip.h"
+#include "host_logic.h"
 
 namespace dp {
 
-constexpr int kLeafSize = 10;     // scipy.spatial.KDTree default (dithering_lib.py:339)
 constexpr int kQueueSmall = 64;   // traversal queue entries: every balanced tree of K <= 256 has <= 51 inner nodes
 constexpr int kQueueLarge = 256;  // ... larger palettes (K <= 1024) and degenerate trees use the large instantiation
 constexpr int kQueueTiles = 65536;  // wave tiles (256 px) with a flagged pixel that the fix-up pass visits directly (queue in the workspace)
 constexpr int kIdxBits = 10;      // palette index bits packed under the distance key (brute-force kernels)
 constexpr int kLocalBits = 8;     // byte offset of a candidate inside its block (cell-table kernel)
-constexpr int kWideList = 16;     // entries of the flat candidate list of a split cell (ordered_fast_kernel, accel.hip)
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
@@ -28,17 +27,6 @@ int hip_fail(hipError_t e, const char *what);
         hipError_t e__ = (call);                       \
         if (e__ != hipSuccess) return dp::hip_fail(e__, #call); \
     } while (0)
-
-// KD-tree as scipy builds it; node 0 is the root, children follow in pre-order.
-struct HostTree {
-    int K = 0;
-    std::vector<double> pts;  // K*3
-    std::vector<int32_t> indices;
-    std::vector<int32_t> split_dim, start, end, less, greater;
-    std::vector<double> split;
-    double mins[3], maxes[3];
-};
-void build_tree(const double *pts, int K, HostTree &t);
 
 // Device view of a prepared palette (plain pointers; passed to kernels by value).
 struct PalDev {
@@ -130,10 +118,6 @@ struct ThrDev {
     double inv_h, inv_w;
 };
 
-// Position of a 16x16x16 cell in the LDS table: the kernels form it as r' | b'<<4 | g'<<8 (x & 0xf0f0f0,
-// OR-ed with itself shifted left by 12, bits 16..27), three operations fewer than r'<<8 | g'<<4 | b'.
-inline int cell_slot(int rc, int gc, int bc) { return rc | (bc << 4) | (gc << 8); }
-
 }  // namespace dp
 
 struct dp_palette {
@@ -153,7 +137,12 @@ struct dp_palette {
     // (host.cpp: ensure_ed_tables): ordered-only users -- one palette per image in the CLI -- never pay for them
     std::vector<double> pts_host;  // K*3 float64 (KD-tree points)
     bool ed_tried;
-    std::mutex ed_mutex;
+    // `dev` is what the kernels are launched with.  The accelerator and the diffusion tables are added to it lazily,
+    // possibly while other host threads are launching with the same palette (ctypes drops the GIL): builders serialise
+    // on build_mu, fill a private copy and publish it with one assignment under dev_mu; every launch works on a
+    // by-value snapshot taken under dev_mu (host.cpp: snapshot / publish).  Pointers of an older snapshot stay valid
+    // until dp_palette_destroy.
+    std::mutex build_mu, dev_mu;
 };
 
 struct dp_thresholds {

@@ -99,7 +99,7 @@ __device__ __forceinline__ float clamp255(const float v) { return __builtin_amdg
 // the smallest of all entries' largest distances to the box.  Whatever the float32 scan below decides among the
 // listed entries is then validated exactly as in the full scan (the true nearest entry, and every entry tied with
 // it, is on the list).  ~3 entries per cell for 256 random colours, at most 15 stored.
-constexpr int kEdCells = 32 * 32 * 32;
+// (kEdCells = 32^3: host_logic.h)
 
 __global__ __launch_bounds__(256) void ed_cells_kernel(const PalDev pal, uint4 *__restrict__ cells)
 {
@@ -718,375 +718,50 @@ size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w)
     return (size_t)n_frames * (size_t)w * 4 * sizeof(float) * 4 + 512 + (size_t)n_frames * 256;
 }
 
-// The per-cell loops of build_ed_cells are independent: split them over a few host threads (the tables of a new palette are
-// built at its first diffusion call, i.e. in front of a user's image).
-template <class F>
-static void parallel_cells(const int n, F &&body)
-{
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
-    if (n < 1024 || nt == 1) {
-        body(0, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    const int chunk = (n + (int)nt - 1) / (int)nt;
-    for (unsigned t = 1; t < nt; ++t) {
-        const int lo = (int)t * chunk, hi = std::min(n, lo + chunk);
-        if (lo < hi) th.emplace_back([&body, lo, hi]() { body(lo, hi); });
-    }
-    body(0, std::min(n, chunk));
-    for (auto &t : th) t.join();
-}
-
 int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
 {
     *blob_out = nullptr;
     const int K = dev.K;
+    static_assert(sizeof(U4) == sizeof(uint4), "U4 mirrors uint4");
     uint4 *cells = nullptr;
     constexpr size_t kCoarseQuads = 4096;  // room for a 16^3-cell table behind the lists (and the nodes): 4096 words or 4096 quads
     DP_HIP(hipMalloc((void **)&cells, sizeof(uint4) * (kEdCells + kCoarseQuads)));
     hipLaunchKernelGGL(ed_cells_kernel, dim3(kEdCells / 256), dim3(256), 0, 0, dev, cells);
     hipError_t e = hipGetLastError();
-    std::vector<uint4> host(kEdCells);
+    std::vector<U4> host(kEdCells);
     if (e == hipSuccess) e = hipMemcpy(host.data(), cells, sizeof(uint4) * kEdCells, hipMemcpyDeviceToHost);
     if (e != hipSuccess) {
         (void)hipFree(cells);
         return hip_fail(e, "error-diffusion candidate lists");
     }
-    // Cells whose list overflowed (palettes extracted from an image crowd their colours into a few cells) are refined
-    // on the host: 8 children of half the size, down to unit cubes; a child's list is a subset of its parent's.
-    std::vector<uint4> nodes;
-    auto box_list = [&](const std::vector<int> &from, const double lo[3], const double size, std::vector<int> &list) {
-        double bound = std::numeric_limits<double>::infinity();
-        for (int j : from) {
-            double far2 = 0.0;
-            for (int k = 0; k < 3; ++k) {
-                const double c = pts[3 * j + k];
-                const double m = std::max(std::fabs(c - lo[k]), std::fabs(c - (lo[k] + size)));
-                far2 += m * m;
-            }
-            bound = std::min(bound, far2);
-        }
-        bound = bound * (1.0 + 1e-12) + 1e-9;
-        list.clear();
-        for (int j : from) {
-            double near2 = 0.0;
-            for (int k = 0; k < 3; ++k) {
-                const double c = pts[3 * j + k];
-                const double m = std::max(std::max(lo[k] - c, c - (lo[k] + size)), 0.0);
-                near2 += m * m;
-            }
-            if (near2 <= bound) list.push_back(j);
-        }
-    };
-    // A sharper (still conservative) list for a box: entry j is dropped if some other listed entry k is closer to EVERY
-    // point of the box, i.e. the box lies strictly on k's side of the bisector of j and k:
-    //   max over the box of |x - c_k|^2 - |x - c_j|^2 = max of 2 x.(c_j - c_k) + |c_k|^2 - |c_j|^2 < 0   (linear in x).
-    // The true nearest entry of a point of the box is dominated by nobody, so it stays listed, with everything tied with it.
-    auto prune_list = [&](const double lo[3], const double size, std::vector<int> &list) {
-        std::vector<int> keep;
-        for (int j : list) {
-            bool dominated = false;
-            for (int k : list) {
-                if (k == j) continue;
-                double mx = 0.0;
-                for (int d = 0; d < 3; ++d) {
-                    const double a = 2.0 * (pts[3 * j + d] - pts[3 * k + d]);
-                    mx += std::max(a * lo[d], a * (lo[d] + size));
-                    mx += pts[3 * k + d] * pts[3 * k + d] - pts[3 * j + d] * pts[3 * j + d];
-                }
-                if (mx < -1e-9 * (1.0 + std::fabs(mx))) {
-                    dominated = true;
-                    break;
-                }
-            }
-            if (!dominated) keep.push_back(j);
-        }
-        list.swap(keep);
-    };
-    // the palette entry nearest to each corner of the cube: bit d of the index set = the corner's coordinate d is 255
-    int corner_entry[8];
-    for (int c = 0; c < 8; ++c) {
-        double best = std::numeric_limits<double>::infinity();
-        corner_entry[c] = 0;
-        for (int j = 0; j < K; ++j) {
-            double d2 = 0.0;
-            for (int d = 0; d < 3; ++d) {
-                const double m = pts[3 * j + d] - ((c >> d) & 1 ? 255.0 : 0.0);
-                d2 += m * m;
-            }
-            if (d2 < best) {
-                best = d2;
-                corner_entry[c] = j;
-            }
-        }
-    }
-    // count byte + up to 15 index bytes.  Lists of up to 12 entries are padded to a multiple of 4 positions with an entry that is
-    // NOT on the list (the one farthest from the box): the key scan of nearest_color_cells evaluates whole groups of four
-    // without per-position tests; an unlisted entry is never the nearest of a point of the box, and should float32
-    // rounding bring it within the margin of the nearest, the exact scan -- which honours the count -- decides.
-    auto pack = [&](const std::vector<int> &list, const double *lo = nullptr, const double size = 0.0) {
-        uint32_t w[4] = {(uint32_t)list.size(), 0u, 0u, 0u};
-        for (size_t n = 1; n <= list.size(); ++n) w[n >> 2] |= (uint32_t)list[n - 1] << (8 * (n & 3));
-        if (lo && !list.empty() && list.size() <= 12 && (int)list.size() < K) {
-            // (any unlisted entry will do; a far one keeps it out of the margin: the entry nearest to the cube corner
-            // opposite to the box, unless that one is listed -- then the farthest by scan)
-            const int oct = (lo[0] + 0.5 * size < 128.0 ? 1 : 0) | (lo[1] + 0.5 * size < 128.0 ? 2 : 0) | (lo[2] + 0.5 * size < 128.0 ? 4 : 0);
-            int filler = corner_entry[oct];
-            if (std::find(list.begin(), list.end(), filler) != list.end()) {
-                filler = -1;
-                double far_d = -1.0;
-                for (int j = 0; j < K; ++j) {
-                    if (std::find(list.begin(), list.end(), j) != list.end()) continue;
-                    double d2 = 0.0;
-                    for (int d = 0; d < 3; ++d) {
-                        const double m = pts[3 * j + d] - (lo[d] + 0.5 * size);
-                        d2 += m * m;
-                    }
-                    if (d2 > far_d) {
-                        far_d = d2;
-                        filler = j;
-                    }
-                }
-            }
-            const size_t upto = (list.size() + 3) / 4 * 4;
-            for (size_t n = list.size() + 1; n <= upto && filler >= 0; ++n) w[n >> 2] |= (uint32_t)filler << (8 * (n & 3));
-        }
-        return make_uint4(w[0], w[1], w[2], w[3]);
-    };
-    struct Work {
-        size_t slot;      // index into `nodes` (or, with top == true, into `host`)
-        bool top;
-        double lo[3];
-        double size;
-        std::vector<int> from;
-    };
-    std::vector<Work> stack;
-    std::vector<int> all(K), list;
-    for (int j = 0; j < K; ++j) all[j] = j;
-    // the kernel's lists (the geometric criterion), sharpened by the pairwise test
-    const bool pruned_any = true;
-    parallel_cells(kEdCells, [&](const int c0, const int c1) {
-        std::vector<int> list;
-        for (int cell = c0; cell < c1; ++cell) {
-            const uint32_t w4[4] = {host[cell].x, host[cell].y, host[cell].z, host[cell].w};
-            const int n = (int)(w4[0] & 255u);
-            if (n < 1 || n > 15) continue;
-            list.clear();
-            for (int i = 1; i <= n; ++i) list.push_back((int)((w4[i >> 2] >> (8 * (i & 3))) & 255u));
-            const double lo[3] = {(double)((cell & 31) * 8), (double)(((cell >> 5) & 31) * 8), (double)((cell >> 10) * 8)};
-            prune_list(lo, 8.0, list);
-            host[cell] = pack(list, lo, 8.0);  // (re-packed even when nothing was dropped: the padding)
-        }
-    });
-    for (int cell = 0; cell < kEdCells; ++cell)
-        if ((host[cell].x & 255u) == 255u) {
-            Work wk;
-            wk.slot = (size_t)cell;
-            wk.top = true;
-            wk.lo[0] = (double)((cell & 31) * 8);
-            wk.lo[1] = (double)(((cell >> 5) & 31) * 8);
-            wk.lo[2] = (double)((cell >> 10) * 8);
-            wk.size = 8.0;
-            box_list(all, wk.lo, 8.0, wk.from);  // the cell's full list
-            prune_list(wk.lo, 8.0, wk.from);
-            stack.push_back(std::move(wk));
-        }
-    bool give_up = false;
-    while (!stack.empty() && !give_up) {
-        Work wk = std::move(stack.back());
-        stack.pop_back();
-        uint4 entry;
-        if (wk.from.size() <= 15) {
-            entry = pack(wk.from, wk.lo, wk.size);
-        } else if (wk.size <= 1.0) {
-            entry = make_uint4(255u, 0u, 0u, 0u);  // a unit cube that still sees more than 15 entries: scan the palette
-        } else {
-            const size_t node = nodes.size() / 8;
-            if (node >= (1u << 22)) {
-                give_up = true;
-                break;
-            }
-            nodes.resize(nodes.size() + 8, make_uint4(255u, 0u, 0u, 0u));
-            entry = make_uint4(254u | ((uint32_t)node << 8), 0u, 0u, 0u);
-            const double hs = wk.size * 0.5;
-            for (int sub = 0; sub < 8; ++sub) {
-                Work ch;
-                ch.slot = node * 8 + (size_t)sub;
-                ch.top = false;
-                ch.lo[0] = wk.lo[0] + ((sub & 1) ? hs : 0.0);
-                ch.lo[1] = wk.lo[1] + ((sub & 2) ? hs : 0.0);
-                ch.lo[2] = wk.lo[2] + ((sub & 4) ? hs : 0.0);
-                ch.size = hs;
-                box_list(wk.from, ch.lo, hs, ch.from);
-                prune_list(ch.lo, hs, ch.from);
-                stack.push_back(std::move(ch));
-            }
-        }
-        if (wk.top) host[wk.slot] = entry;
-        else nodes[wk.slot] = entry;
-    }
-    uint4 *d_nodes = nullptr;
-    if (!give_up && !nodes.empty()) {
-        // one allocation: cells, then the nodes
+    // Everything between the kernel's geometric lists and the finished tables is host work (host_logic.h): the pairwise
+    // sharpening, the refinement of overflowing cells (palettes extracted from an image crowd their colours into a few
+    // cells) into an octree down to unit cubes, the 16^3-cell lists for LDS.
+    EdTables tb;
+    ed_tables_refine(pts, K, host, tb);
+    if (!tb.nodes.empty()) {  // one allocation: cells, then the nodes, then the 16^3-cell table(s)
         uint4 *both = nullptr;
-        e = hipMalloc((void **)&both, sizeof(uint4) * (kEdCells + nodes.size() + kCoarseQuads));
-        if (e == hipSuccess) e = hipMemcpy(both, host.data(), sizeof(uint4) * kEdCells, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(both + kEdCells, nodes.data(), sizeof(uint4) * nodes.size(), hipMemcpyHostToDevice);
+        e = hipMalloc((void **)&both, sizeof(uint4) * (kEdCells + tb.nodes.size() + kCoarseQuads));
         (void)hipFree(cells);
-        if (e != hipSuccess) {
-            if (both) (void)hipFree(both);
-            return hip_fail(e, "error-diffusion candidate lists");
-        }
         cells = both;
-        d_nodes = both + kEdCells;
-    } else if (!give_up && pruned_any) {
-        e = hipMemcpy(cells, host.data(), sizeof(uint4) * kEdCells, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(cells);
-            return hip_fail(e, "error-diffusion candidate lists");
-        }
+        if (e != hipSuccess) return hip_fail(e, "error-diffusion candidate lists");
+        e = hipMemcpy(cells + kEdCells, tb.nodes.data(), sizeof(uint4) * tb.nodes.size(), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMemcpy(cells, host.data(), sizeof(uint4) * kEdCells, hipMemcpyHostToDevice);
+    uint4 *tail = cells + kEdCells + tb.nodes.size();
+    if (e == hipSuccess && !tb.l16.empty()) e = hipMemcpy(tail, tb.l16.data(), sizeof(uint4) * 4096, hipMemcpyHostToDevice);
+    uint32_t *d_coarse = reinterpret_cast<uint32_t *>(tail);
+    if (e == hipSuccess && !tb.coarse.empty()) e = hipMemcpy(d_coarse, tb.coarse.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !tb.ext.empty()) e = hipMemcpy(d_coarse + 4096, tb.ext.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(cells);
+        return hip_fail(e, "error-diffusion candidate lists");
     }
     dev.ed_cells = cells;
-    dev.ed_nodes = d_nodes;
-    dev.ed_coarse = nullptr;
-    dev.ed_lists16 = nullptr;
-    dev.ed_coarse_ext = nullptr;
-    if (K > 16) {
-        // lists of the 16x16x16 cells in the format of the 8x8x8 table, for the LDS of the wavefront kernel's few-frames
-        // variant (one wave per SIMD: the read of the 8x8x8 table from L2 is half of a step's latency there)
-        std::vector<uint4> l16(4096);
-        parallel_cells(4096, [&](const int c0, const int c1) {
-            std::vector<int> list;
-            for (int cell = c0; cell < c1; ++cell) {
-                const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
-                box_list(all, lo, 16.0, list);
-                prune_list(lo, 16.0, list);
-                l16[cell] = list.size() <= 15 ? pack(list, lo, 16.0) : make_uint4(255u, 0u, 0u, 0u);
-            }
-        });
-        uint4 *d_l16 = cells + kEdCells + nodes.size() * (d_nodes ? 1 : 0);
-        e = hipMemcpy(d_l16, l16.data(), sizeof(uint4) * 4096, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(cells);
-            dev.ed_cells = nullptr;
-            dev.ed_nodes = nullptr;
-            return hip_fail(e, "error-diffusion candidate lists");
-        }
-        dev.ed_lists16 = d_l16;
-    }
-    if (K <= 16) {
-        // lists of the 16x16x16 cells for the wavefront kernel's LDS: count | up to 7 indices, one nibble each
-        std::vector<uint32_t> coarse(4096);
-        parallel_cells(4096, [&](const int c0, const int c1) {
-        std::vector<int> list;
-        for (int cell = c0; cell < c1; ++cell) {
-            const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
-            box_list(all, lo, 16.0, list);
-            prune_list(lo, 16.0, list);
-            uint32_t word = 15u;
-            if (list.size() <= 7) {
-                word = (uint32_t)list.size();
-                for (size_t n = 0; n < list.size(); ++n) word |= (uint32_t)list[n] << (4 * (n + 1));
-                // The unused positions name the entry farthest from the cell that is not on the list (K > 8 > list size:
-                // there is one).  The key scan of nearest_color_cells evaluates every position of a group of 4 (or 7)
-                // without a per-position validity test; an entry that is not listed can never be the nearest one, and
-                // if it comes within the margin of the nearest the exact scan (which honours the count) decides.
-                int filler = -1;
-                double far_d = -1.0;
-                for (int j = 0; j < K; ++j) {
-                    if (std::find(list.begin(), list.end(), j) != list.end()) continue;
-                    double near2 = 0.0;
-                    for (int k = 0; k < 3; ++k) {
-                        const double c = pts[3 * j + k];
-                        const double m = std::max(std::max(lo[k] - c, c - (lo[k] + 16.0)), 0.0);
-                        near2 += m * m;
-                    }
-                    if (near2 > far_d) {
-                        far_d = near2;
-                        filler = j;
-                    }
-                }
-                for (size_t n = list.size(); n < 7 && filler >= 0; ++n) word |= (uint32_t)filler << (4 * (n + 1));
-            }
-            coarse[cell] = word;
-        }
-        });
-        uint32_t *d_coarse = reinterpret_cast<uint32_t *>(cells + kEdCells + nodes.size() * (d_nodes ? 1 : 0));
-        e = hipMemcpy(d_coarse, coarse.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(cells);
-            dev.ed_cells = nullptr;
-            dev.ed_nodes = nullptr;
-            return hip_fail(e, "error-diffusion candidate lists");
-        }
-        dev.ed_coarse = d_coarse;
-        // The same table for query points that are NOT clamped to the cube (the perceptual / hybrid / adaptive-variance
-        // diffusers of vardiff.hip): a point is looked up in the cell of its clamped coordinates, so the outermost cells
-        // stand for everything beyond them -- their boxes are unbounded on that side.  With an unbounded box the geometric
-        // criterion lists everybody; the pairwise test alone decides (K <= 16: 256 pairs per cell): over a box that is
-        // unbounded in a direction in which |x - c_k|^2 - |x - c_j|^2 grows, k cannot dominate j.
-        std::vector<uint32_t> ext(4096);
-        const double kInf = std::numeric_limits<double>::infinity();
-        parallel_cells(4096, [&](const int c0, const int c1) {
-        std::vector<int> list;
-        for (int cell = c0; cell < c1; ++cell) {
-            const int ci[3] = {cell & 15, (cell >> 4) & 15, cell >> 8};
-            double blo[3], bhi[3];
-            for (int d = 0; d < 3; ++d) {
-                blo[d] = ci[d] == 0 ? -kInf : (double)(ci[d] * 16);
-                bhi[d] = ci[d] == 15 ? kInf : (double)(ci[d] * 16 + 16);
-            }
-            list.clear();
-            for (int j = 0; j < K; ++j) {
-                bool dominated = false;
-                for (int k = 0; k < K && !dominated; ++k) {
-                    if (k == j) continue;
-                    double mx = 0.0;
-                    for (int d = 0; d < 3; ++d) {
-                        const double a = 2.0 * (pts[3 * j + d] - pts[3 * k + d]);
-                        if (a > 0.0) mx += bhi[d] == kInf ? kInf : a * bhi[d];
-                        else if (a < 0.0) mx += blo[d] == -kInf ? kInf : a * blo[d];
-                        mx += pts[3 * k + d] * pts[3 * k + d] - pts[3 * j + d] * pts[3 * j + d];
-                    }
-                    if (mx < -1e-9 * (1.0 + std::fabs(mx))) dominated = true;
-                }
-                if (!dominated) list.push_back(j);
-            }
-            uint32_t word = 15u;
-            if (list.size() <= 7) {
-                word = (uint32_t)list.size();
-                for (size_t n = 0; n < list.size(); ++n) word |= (uint32_t)list[n] << (4 * (n + 1));
-                int filler = -1;
-                double far_d = -1.0;
-                for (int j = 0; j < K; ++j) {  // unused positions: the unlisted entry farthest from the cell's inner corner
-                    if (std::find(list.begin(), list.end(), j) != list.end()) continue;
-                    double d2 = 0.0;
-                    for (int d = 0; d < 3; ++d) {
-                        const double m = pts[3 * j + d] - (double)(ci[d] * 16 + 8);
-                        d2 += m * m;
-                    }
-                    if (d2 > far_d) {
-                        far_d = d2;
-                        filler = j;
-                    }
-                }
-                for (size_t n = list.size(); n < 7 && filler >= 0; ++n) word |= (uint32_t)filler << (4 * (n + 1));
-            }
-            ext[cell] = word;
-        }
-        });
-        e = hipMemcpy(d_coarse + 4096, ext.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(cells);
-            dev.ed_cells = nullptr;
-            dev.ed_nodes = nullptr;
-            dev.ed_coarse = nullptr;
-            return hip_fail(e, "error-diffusion candidate lists");
-        }
-        dev.ed_coarse_ext = d_coarse + 4096;
-    }
+    dev.ed_nodes = tb.nodes.empty() ? nullptr : cells + kEdCells;
+    dev.ed_lists16 = tb.l16.empty() ? nullptr : tail;
+    dev.ed_coarse = tb.coarse.empty() ? nullptr : d_coarse;
+    dev.ed_coarse_ext = tb.ext.empty() ? nullptr : d_coarse + 4096;
     *blob_out = cells;
     return DP_OK;
 }

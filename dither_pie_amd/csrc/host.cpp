@@ -26,108 +26,7 @@ int hip_fail(hipError_t e, const char *what)
     return e == hipErrorOutOfMemory ? DP_ENOMEM : DP_EHIP;
 }
 
-// ---------------------------------------------------------------------------------------------
-// scipy.spatial.KDTree(points) with its defaults (leafsize=10, compact_nodes, balanced_tree), the
-// structure behind every palette search of the reference (dithering_lib.py:339, 358, 554, 655).
-// The permutation std::nth_element leaves behind decides scipy's tie order, so the same standard
-// algorithm (libstdc++ introselect) is used here, with scipy's coordinate-only comparator.
-// ---------------------------------------------------------------------------------------------
-namespace {
-struct Builder {
-    HostTree &t;
-    const double *P;
-
-    double coord(int i, int d) const { return P[(size_t)i * 3 + d]; }
-
-    // two-pointer partition of indices[s,e) by coord < split; returns the first index of the >= part
-    int split_range(int s, int e, int d, double split)
-    {
-        int lo = s, hi = e - 1;
-        while (lo <= hi) {
-            if (coord(t.indices[lo], d) < split)
-                ++lo;
-            else if (coord(t.indices[hi], d) >= split)
-                --hi;
-            else
-                std::swap(t.indices[lo++], t.indices[hi--]);
-        }
-        return lo;
-    }
-
-    int add_node(int s, int e)
-    {
-        int id = (int)t.split_dim.size();
-        t.split_dim.push_back(-1);
-        t.split.push_back(0.0);
-        t.start.push_back(s);
-        t.end.push_back(e);
-        t.less.push_back(-1);
-        t.greater.push_back(-1);
-        return id;
-    }
-
-    int build(int s, int e)
-    {
-        const int id = add_node(s, e);
-        if (e - s <= kLeafSize) return id;
-
-        double lo[3], hi[3];
-        for (int d = 0; d < 3; ++d) lo[d] = hi[d] = coord(t.indices[s], d);
-        for (int j = s + 1; j < e; ++j)
-            for (int d = 0; d < 3; ++d) {
-                const double v = coord(t.indices[j], d);
-                hi[d] = hi[d] > v ? hi[d] : v;
-                lo[d] = lo[d] < v ? lo[d] : v;
-            }
-        int dim = 0;
-        double extent = 0;
-        for (int d = 0; d < 3; ++d)
-            if (hi[d] - lo[d] > extent) {
-                dim = d;
-                extent = hi[d] - lo[d];
-            }
-        if (hi[dim] == lo[dim]) return id;  // all points coincide
-
-        int32_t *first = t.indices.data() + s;
-        const int half = (e - s) / 2;
-        std::nth_element(first, first + half, first + (e - s),
-                         [&](int32_t a, int32_t b) { return coord(a, dim) < coord(b, dim); });
-        double split = coord(t.indices[s + half], dim);
-        int cut = split_range(s, e, dim, split);
-        if (cut == s) {
-            // nothing lies strictly below the median value: cut just above the minimum instead
-            double mn = coord(t.indices[s], dim);
-            for (int j = s + 1; j < e; ++j) mn = std::min(mn, coord(t.indices[j], dim));
-            split = std::nextafter(mn, std::numeric_limits<double>::infinity());
-            cut = split_range(s, e, dim, split);
-        }
-        t.split_dim[id] = dim;
-        t.split[id] = split;
-        const int l = build(s, cut);
-        const int g = build(cut, e);
-        t.less[id] = l;
-        t.greater[id] = g;
-        return id;
-    }
-};
-}  // namespace
-
-void build_tree(const double *pts, int K, HostTree &t)
-{
-    t = HostTree();
-    t.K = K;
-    t.pts.assign(pts, pts + (size_t)K * 3);
-    t.indices.resize(K);
-    std::iota(t.indices.begin(), t.indices.end(), 0);
-    for (int d = 0; d < 3; ++d) t.mins[d] = t.maxes[d] = pts[d];
-    for (int j = 1; j < K; ++j)
-        for (int d = 0; d < 3; ++d) {
-            t.mins[d] = std::min(t.mins[d], pts[(size_t)j * 3 + d]);
-            t.maxes[d] = std::max(t.maxes[d], pts[(size_t)j * 3 + d]);
-        }
-    Builder b{t, t.pts.data()};
-    b.build(0, K);
-}
+// (the KD-tree construction -- build_tree -- lives in host_logic.h: pure C++, also built under the CPU sanitizers)
 
 // ---- profiling ------------------------------------------------------------------------------
 static thread_local bool g_prof = false;
@@ -387,15 +286,30 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
 
 // The candidate lists of the diffusion kernels (a 512 KB table from one small kernel, sharpened and padded on the host,
 // plus the 16^3 tables: 3 / 5 / 19 ms at 16 / 64 / 256 colours): built once, at the first diffusion call with the palette.
+static dp::PalDev snapshot(const dp_palette *pal_c)
+{
+    dp_palette *p = const_cast<dp_palette *>(pal_c);
+    std::lock_guard<std::mutex> lock(p->dev_mu);
+    return p->dev;
+}
+
+static void publish(dp_palette *p, const dp::PalDev &d)
+{
+    std::lock_guard<std::mutex> lock(p->dev_mu);
+    p->dev = d;
+}
+
 static int ensure_ed_tables(const dp_palette *pal_c)
 {
     dp_palette *p = const_cast<dp_palette *>(pal_c);
-    std::lock_guard<std::mutex> lock(p->ed_mutex);
+    std::lock_guard<std::mutex> lock(p->build_mu);
     if (p->ed_tried) return DP_OK;
     p->ed_tried = true;
     if (p->dev.K > 8 && p->dev.K <= 256) {
-        const int rc = build_ed_cells(p->dev, p->pts_host.data(), &p->ed_blob);
+        dp::PalDev d = snapshot(p);
+        const int rc = build_ed_cells(d, p->pts_host.data(), &p->ed_blob);
         if (rc != DP_OK) return rc;
+        publish(p, d);
     }
     return DP_OK;
 }
@@ -427,13 +341,20 @@ int dp_palette_build_accel(dp_palette *p)
         set_error("dp_palette_build_accel: NULL palette");
         return DP_EINVAL;
     }
+    std::lock_guard<std::mutex> lock(p->build_mu);
     if (p->accel_tried || !(p->same_out || p->float_accel)) return DP_OK;
     p->accel_tried = true;
+    // built into a private copy and published whole: a thread launching with this palette meanwhile sees either the
+    // palette without the accelerator or with all of it, never a table pointer without its sizes
+    dp::PalDev d = snapshot(p);
+    int rc;
     if (p->float_accel)
-        return build_accel_float(p->dev, p->pal_host.data(), p->lut_host.empty() ? nullptr : p->lut_host.data(),
-                                 &p->accel_blob, &p->accel_bytes);
-    // cell lists + tie codes: integer palettes whose output bytes are the palette colours themselves
-    return build_accel(p->dev, p->p4_host, &p->accel_blob, &p->accel_bytes);
+        rc = build_accel_float(d, p->pal_host.data(), p->lut_host.empty() ? nullptr : p->lut_host.data(), &p->accel_blob,
+                               &p->accel_bytes);
+    else  // cell lists + tie codes: integer palettes whose output bytes are the palette colours themselves
+        rc = build_accel(d, p->p4_host, &p->accel_blob, &p->accel_bytes);
+    if (rc == DP_OK) publish(p, d);
+    return rc;
 }
 
 int dp_palette_accel_info(const dp_palette *p, int *pool_entries, int *max_cell)
@@ -442,10 +363,9 @@ int dp_palette_accel_info(const dp_palette *p, int *pool_entries, int *max_cell)
         set_error("dp_palette_accel_info: NULL palette");
         return DP_EINVAL;
     }
-    if (pool_entries)
-        *pool_entries = p->dev.cell_tab ? p->dev.tab_words
-                                        : (p->dev.cell_tab4 ? p->dev.tab4_words : (p->dev.ftab ? p->dev.ftab_words : 0));
-    if (max_cell) *max_cell = (p->dev.cell_tab || p->dev.cell_tab4 || p->dev.ftab) ? p->dev.max_cell : 0;
+    const dp::PalDev d = snapshot(p);
+    if (pool_entries) *pool_entries = d.cell_tab ? d.tab_words : (d.cell_tab4 ? d.tab4_words : (d.ftab ? d.ftab_words : 0));
+    if (max_cell) *max_cell = (d.cell_tab || d.cell_tab4 || d.ftab) ? d.max_cell : 0;
     return DP_OK;
 }
 
@@ -673,7 +593,7 @@ int dp_ordered_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int
                   dp_ordered_workspace_bytes(n_frames, h, w));
         return DP_EWORKSPACE;
     }
-    return launch_ordered(in_dev, out_dev, n_frames, h, w, y0, x0, pal->dev, mode, thr ? &thr->dev : nullptr,
+    return launch_ordered(in_dev, out_dev, n_frames, h, w, y0, x0, snapshot(pal), mode, thr ? &thr->dev : nullptr,
                           ign_scale, ign_seed, workspace_dev, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -743,7 +663,7 @@ static int error_diffusion_common(const uint8_t *in_dev, uint8_t *out_dev, int64
     }
     const int rc_tab = ensure_ed_tables(pal);
     if (rc_tab != DP_OK) return rc_tab;
-    return launch_error_diffusion(in_dev, out_dev, n_frames, h, w, pal->dev, dx, dy, wq, ntaps, serpentine,
+    return launch_error_diffusion(in_dev, out_dev, n_frames, h, w, snapshot(pal), dx, dy, wq, ntaps, serpentine,
                                   workspace_dev, workspace_bytes, (hipStream_t)stream, wq64);
 }
 
@@ -765,7 +685,7 @@ int dp_variable_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_
     }
     const int rc_tab = ensure_ed_tables(pal);
     if (rc_tab != DP_OK) return rc_tab;
-    return launch_variable_diffusion(in_dev, out_dev, n_frames, h, w, pal->dev, model, p0, p1, serpentine ? 1 : 0,
+    return launch_variable_diffusion(in_dev, out_dev, n_frames, h, w, snapshot(pal), model, p0, p1, serpentine ? 1 : 0,
                                      gate_dev, coef_dev, workspace_dev, (hipStream_t)stream);
 }
 
@@ -788,7 +708,7 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
         set_error("dp_variance_gate_u8: workspace too small (need %zu bytes)", variance_gate_ws_bytes(n_frames, h, w));
         return DP_EWORKSPACE;
     }
-    return launch_variance_gate(in_dev, gate_dev, n_frames, h, w, pal->dev, var_threshold, window_radius, workspace_dev,
+    return launch_variance_gate(in_dev, gate_dev, n_frames, h, w, snapshot(pal), var_threshold, window_radius, workspace_dev,
                                 (hipStream_t)stream);
 }
 

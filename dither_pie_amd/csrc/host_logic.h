@@ -1,0 +1,785 @@
+// Host-side logic of libditherpie_hip.so that never touches the GPU: the scipy-order KD-tree build, the assembly of
+// the search accelerator's cell table from membership masks, and the candidate tables of the diffusion kernels (with
+// their multi-threaded per-cell loops).  Pure C++17, no HIP headers: included by the .hip / .cpp translation units through
+// dp_internal.h AND compiled on its own under AddressSanitizer + UBSan and under ThreadSanitizer
+// (`make host_asan host_tsan` -> build/host_asan, build/host_tsan from host_sanitize.cpp; run by
+// tests/test_host_sanitizers.py in the CPU tier).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "../../include/ditherpie_hip.h"
+
+namespace dp {
+
+constexpr int kLeafSize = 10;     // scipy.spatial.KDTree default (dithering_lib.py:339)
+constexpr int kWideList = 16;     // entries of the flat candidate list of a split cell (ordered_fast_kernel, accel.hip)
+
+// KD-tree as scipy builds it; node 0 is the root, children follow in pre-order.
+struct HostTree {
+    int K = 0;
+    std::vector<double> pts;  // K*3
+    std::vector<int32_t> indices;
+    std::vector<int32_t> split_dim, start, end, less, greater;
+    std::vector<double> split;
+    double mins[3], maxes[3];
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// scipy.spatial.KDTree(points) with its defaults (leafsize=10, compact_nodes, balanced_tree), the
+// structure behind every palette search of the reference (dithering_lib.py:339, 358, 554, 655).
+// The permutation std::nth_element leaves behind decides scipy's tie order, so the same standard
+// algorithm (libstdc++ introselect) is used here, with scipy's coordinate-only comparator.
+// ---------------------------------------------------------------------------------------------
+namespace kd_detail {
+struct Builder {
+    HostTree &t;
+    const double *P;
+
+    double coord(int i, int d) const { return P[(size_t)i * 3 + d]; }
+
+    // two-pointer partition of indices[s,e) by coord < split; returns the first index of the >= part
+    int split_range(int s, int e, int d, double split)
+    {
+        int lo = s, hi = e - 1;
+        while (lo <= hi) {
+            if (coord(t.indices[lo], d) < split)
+                ++lo;
+            else if (coord(t.indices[hi], d) >= split)
+                --hi;
+            else
+                std::swap(t.indices[lo++], t.indices[hi--]);
+        }
+        return lo;
+    }
+
+    int add_node(int s, int e)
+    {
+        int id = (int)t.split_dim.size();
+        t.split_dim.push_back(-1);
+        t.split.push_back(0.0);
+        t.start.push_back(s);
+        t.end.push_back(e);
+        t.less.push_back(-1);
+        t.greater.push_back(-1);
+        return id;
+    }
+
+    int build(int s, int e)
+    {
+        const int id = add_node(s, e);
+        if (e - s <= kLeafSize) return id;
+
+        double lo[3], hi[3];
+        for (int d = 0; d < 3; ++d) lo[d] = hi[d] = coord(t.indices[s], d);
+        for (int j = s + 1; j < e; ++j)
+            for (int d = 0; d < 3; ++d) {
+                const double v = coord(t.indices[j], d);
+                hi[d] = hi[d] > v ? hi[d] : v;
+                lo[d] = lo[d] < v ? lo[d] : v;
+            }
+        int dim = 0;
+        double extent = 0;
+        for (int d = 0; d < 3; ++d)
+            if (hi[d] - lo[d] > extent) {
+                dim = d;
+                extent = hi[d] - lo[d];
+            }
+        if (hi[dim] == lo[dim]) return id;  // all points coincide
+
+        int32_t *first = t.indices.data() + s;
+        const int half = (e - s) / 2;
+        std::nth_element(first, first + half, first + (e - s),
+                         [&](int32_t a, int32_t b) { return coord(a, dim) < coord(b, dim); });
+        double split = coord(t.indices[s + half], dim);
+        int cut = split_range(s, e, dim, split);
+        if (cut == s) {
+            // nothing lies strictly below the median value: cut just above the minimum instead
+            double mn = coord(t.indices[s], dim);
+            for (int j = s + 1; j < e; ++j) mn = std::min(mn, coord(t.indices[j], dim));
+            split = std::nextafter(mn, std::numeric_limits<double>::infinity());
+            cut = split_range(s, e, dim, split);
+        }
+        t.split_dim[id] = dim;
+        t.split[id] = split;
+        const int l = build(s, cut);
+        const int g = build(cut, e);
+        t.less[id] = l;
+        t.greater[id] = g;
+        return id;
+    }
+};
+}  // namespace kd_detail
+
+inline void build_tree(const double *pts, int K, HostTree &t)
+{
+    t = HostTree();
+    t.K = K;
+    t.pts.assign(pts, pts + (size_t)K * 3);
+    t.indices.resize(K);
+    std::iota(t.indices.begin(), t.indices.end(), 0);
+    for (int d = 0; d < 3; ++d) t.mins[d] = t.maxes[d] = pts[d];
+    for (int j = 1; j < K; ++j)
+        for (int d = 0; d < 3; ++d) {
+            t.mins[d] = std::min(t.mins[d], pts[(size_t)j * 3 + d]);
+            t.maxes[d] = std::max(t.maxes[d], pts[(size_t)j * 3 + d]);
+        }
+    kd_detail::Builder b{t, t.pts.data()};
+    b.build(0, K);
+}
+
+
+// Position of a 16x16x16 cell in the LDS table: the kernels form it as r' | b'<<4 | g'<<8 (x & 0xf0f0f0,
+// OR-ed with itself shifted left by 12, bits 16..27), three operations fewer than r'<<8 | g'<<4 | b'.
+inline int cell_slot(int rc, int gc, int bc) { return rc | (bc << 4) | (gc << 8); }
+
+
+// an axis-aligned box of colours (the accelerator's octree below the 16^3 cells)
+struct Box {
+    int r0, g0, b0, size;
+};
+
+
+constexpr int kCells = 4096;
+constexpr int kWideCap = 512;   // such lists per table at most
+constexpr int kNearSlots = 6;  // entries of an 8-entry block that the nearest-only path of ordered_fast_kernel reads
+constexpr int kTabCapWords = (160 * 1024 - 2048) / 4;  // LDS budget of the dither kernels
+constexpr int kTabMaxWords = 1 << 20;                 // largest table built (4 MB); what exceeds LDS stays in global memory
+// words the lean kernels stage when the table is larger than LDS: the 4096 cell blocks + the first split nodes
+constexpr int kTabStageWords = 4096 * 8 + 88 * 64;
+
+struct TableStats {
+    int n_split = 0, n_slow = 0, max_cnt = 0, max_near = 0, n_near_overflow = 0;
+    bool wide_overflow = false;
+    std::vector<Box> node_box;  // the box each split node covers, by node index
+    int n_split_cells = 0;  // 16^3 cells that are split (the pixels of these cells leave the main path of the kernels)
+    bool too_big = false;
+};
+
+// Turns the per-cell membership masks into the LDS table: [4096 cells][8 words], then [n_split][8 sub-cells][8].
+// coord4[j]: integer coordinates r | g<<8 | b<<16 of entry j (used to choose padding entries); word[j]: what a
+// block stores for entry j.  box_masks(boxes, out) computes the membership masks (8 words each) of further boxes.
+// nmasks (optional): the nearest sets N(cell) of the 4096 cells.  With them a cell whose N has more than `ns` members is
+// split like an overflowing one, and perm[slot] receives, for every unsplit cell block, the order in which the fast
+// ordered kernel stages the block's entries into LDS -- the members of N first (field k, 3 bits for bw = 8, 2 bits
+// for bw = 4: which entry of the index-ordered block goes to LDS slot k; bits 28..31: |N|); 0xffffffff = split cell.
+// The table itself stays in palette-index order (the tie codes are defined on that order).
+// wide (with perm): for every SPLIT cell the whole list T(cell) in index order, padded to kWideList entries -- the fast
+// kernel resolves the pixels of split cells on it (one block read instead of a descent through the octree);
+// perm[slot] = 0xff000000 | list number.  A cell with a longer list sets st.wide_overflow (no fast kernel then).
+template <class BoxMasks>
+int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int bw, const int cap_words, const int K,
+                   const std::vector<uint32_t> &coord4, const std::vector<uint32_t> &word, BoxMasks box_masks,
+                   std::vector<uint32_t> &tab, TableStats &st, const uint32_t *nmasks = nullptr, const int ns = 0,
+                   std::vector<uint32_t> *perm = nullptr, std::vector<uint32_t> *wide = nullptr)
+{
+    // bw: entries per block (8, or 4 for small palettes); a split node is 8 child blocks
+    tab.assign((size_t)kCells * bw, 0u);
+    std::vector<int> list, extra;
+    std::vector<uint64_t> dkey;
+    // members of a mask, padded to bw with the unused entries nearest to (cr,cg,cb); false if more than bw
+    auto make_block = [&](const uint32_t *mask, int cr, int cg, int cb, uint32_t *out8) {
+        list.clear();
+        extra.clear();
+        for (int j = 0; j < K; ++j) ((mask[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
+        st.max_cnt = std::max(st.max_cnt, (int)list.size());
+        if (list.size() > (size_t)bw) return false;
+        if (list.size() < (size_t)bw) {
+            // pad with the unused entries nearest to the centre (any real entry is harmless)
+            const size_t need = (size_t)bw - list.size();
+            dkey.resize(extra.size());
+            for (size_t q = 0; q < extra.size(); ++q) {
+                const uint32_t c = coord4[extra[q]];
+                const int r = c & 255, g = (c >> 8) & 255, b = (c >> 16) & 255;
+                dkey[q] = ((uint64_t)((r - cr) * (r - cr) + (g - cg) * (g - cg) + (b - cb) * (b - cb)) << 16) | (uint64_t)extra[q];
+            }
+            std::partial_sort(dkey.begin(), dkey.begin() + need, dkey.end());
+            for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
+            std::sort(list.begin(), list.end());  // key ties must break towards the lower palette index
+        }
+        for (int i = 0; i < bw; ++i) out8[i] = word[list[i]];
+        return true;
+    };
+    // pending splits below the 8^3 level: (block position in tab, box) resolved level by level
+    struct Pending {
+        size_t pos;
+        Box box;
+    };
+    std::vector<Pending> pending;
+    // turn the block at `pos` into a split node with 8 children of half size; children masks come
+    // either from `child_masks` (8 x 8 words) or, if null, are requested for the next round
+    auto split = [&](size_t pos, const Box &bx, const uint32_t *child_masks) {
+        const size_t base = tab.size();
+        if (base + 8 * (size_t)bw > (size_t)cap_words) {
+            st.too_big = true;
+            return;
+        }
+        tab.resize(base + 8 * (size_t)bw, 0u);
+        tab[pos] = 0x80000000u | (uint32_t)((base - (size_t)kCells * bw) / (8 * (size_t)bw));
+        ++st.n_split;
+        st.node_box.push_back(bx);
+        const int hs = bx.size / 2;
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            Box c{bx.r0 + ((sidx >> 2) & 1) * hs, bx.g0 + ((sidx >> 1) & 1) * hs, bx.b0 + (sidx & 1) * hs, hs};
+            const size_t cpos = base + (size_t)sidx * bw;
+            if (child_masks) {
+                uint32_t blk[8];
+                if (make_block(child_masks + (size_t)mw * sidx, c.r0 + hs / 2, c.g0 + hs / 2, c.b0 + hs / 2, blk))
+                    std::copy(blk, blk + bw, tab.begin() + cpos);
+                else
+                    pending.push_back({cpos, c});
+            } else {
+                pending.push_back({cpos, c});
+            }
+        }
+    };
+    if (perm) perm->assign(kCells, 0xffffffffu);
+    for (int cell = 0; cell < kCells && !st.too_big; ++cell) {
+        const uint32_t *m = &masks[(size_t)cell * 9 * mw];
+        const int r0 = (cell >> 8) * 16, g0 = ((cell >> 4) & 15) * 16, b0 = (cell & 15) * 16;
+        uint32_t blk[8];
+        const size_t slot = (size_t)cell_slot(cell >> 8, (cell >> 4) & 15, cell & 15);
+        bool fits = make_block(m, r0 + 8, g0 + 8, b0 + 8, blk);
+        bool near_overflow = false;
+        if (fits && nmasks) {
+            // `list` holds the block's entries in index order: the nearest set first
+            const uint32_t *nm = nmasks + (size_t)cell * mw;
+            const int fb = bw == 8 ? 3 : 2;
+            uint32_t pw = 0;
+            int k = 0, n_near = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int i = 0; i < bw; ++i) {
+                    const int j = list[i];
+                    const bool near = (nm[j >> 5] >> (j & 31)) & 1u;
+                    if (near == (pass == 0)) {
+                        pw |= (uint32_t)i << (fb * k++);
+                        n_near += near;
+                    }
+                }
+            // a nearest set larger than the nearest-only path of the fast kernel reads: the cell keeps its block in the table,
+            // but the fast kernel treats it as split (staging order = flat list below)
+            near_overflow = n_near > ns;
+            if (!near_overflow && perm) (*perm)[slot] = pw | ((uint32_t)n_near << 28);
+            st.max_near = std::max(st.max_near, n_near);
+            st.n_near_overflow += near_overflow;
+        }
+        if (fits) std::copy(blk, blk + bw, tab.begin() + slot * bw);
+        if (!fits || near_overflow) {
+            if (perm && wide) {
+                // the cell's whole list, index order, padded with the unused entries nearest to the centre
+                list.clear();
+                extra.clear();
+                for (int j = 0; j < K; ++j) ((m[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
+                if (K <= kWideList) {
+                    // the whole palette (the kernel reads min(K, kWideList) entries)
+                    (*perm)[slot] = 0xff000000u | (uint32_t)(wide->size() / kWideList);
+                    for (int i = 0; i < kWideList; ++i) wide->push_back(i < K ? word[i] : 0u);
+                } else if ((int)list.size() > kWideList) {
+                    st.wide_overflow = true;
+                } else {
+                    const size_t need = (size_t)kWideList - list.size();
+                    dkey.resize(extra.size());
+                    for (size_t q = 0; q < extra.size(); ++q) {
+                        const uint32_t c = coord4[extra[q]];
+                        const int r = c & 255, g = (c >> 8) & 255, b = (c >> 16) & 255;
+                        dkey[q] = ((uint64_t)((r - r0 - 8) * (r - r0 - 8) + (g - g0 - 8) * (g - g0 - 8) + (b - b0 - 8) * (b - b0 - 8)) << 16) | (uint64_t)extra[q];
+                    }
+                    std::partial_sort(dkey.begin(), dkey.begin() + need, dkey.end());
+                    for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
+                    std::sort(list.begin(), list.end());
+                    (*perm)[slot] = 0xff000000u | (uint32_t)(wide->size() / kWideList);
+                    for (int i = 0; i < kWideList; ++i) wide->push_back(word[list[i]]);
+                }
+            }
+        }
+        if (!fits) {
+            split(slot * bw, Box{r0, g0, b0, 16}, m + mw);
+            ++st.n_split_cells;
+        }
+    }
+    // deeper levels: boxes that still hold more than 8 members are split again; a single colour that still
+    // overflows is left to the fix-up pass
+    while (!pending.empty() && !st.too_big) {
+        std::vector<Pending> todo;
+        todo.swap(pending);
+        std::vector<Pending> kids;  // children whose masks we need this round
+        for (const Pending &pd : todo) {
+            if (pd.box.size == 1) {
+                tab[pd.pos] = 0xC0000000u;
+                ++st.n_slow;
+                continue;
+            }
+            const size_t before = pending.size();
+            split(pd.pos, pd.box, nullptr);
+            if (st.too_big) break;
+            for (size_t q = before; q < pending.size(); ++q) kids.push_back(pending[q]);
+            pending.resize(before);
+        }
+        if (st.too_big || kids.empty()) break;
+        std::vector<Box> boxes(kids.size());
+        for (size_t q = 0; q < kids.size(); ++q) boxes[q] = kids[q].box;
+        std::vector<uint32_t> bm(kids.size() * (size_t)mw);
+        const int rc = box_masks(boxes, bm);
+        if (rc != DP_OK) return rc;
+        for (size_t q = 0; q < kids.size(); ++q) {
+            const Box &c = kids[q].box;
+            uint32_t blk[8];
+            if (make_block(&bm[q * (size_t)mw], c.r0 + c.size / 2, c.g0 + c.size / 2, c.b0 + c.size / 2, blk))
+                std::copy(blk, blk + bw, tab.begin() + kids[q].pos);
+            else
+                pending.push_back(kids[q]);
+        }
+    }
+    return DP_OK;
+}
+
+// Tables larger than LDS: the kernels stage the cell blocks and the FIRST split nodes, the rest is read from global
+// memory.  Put the nodes of the most crowded boxes first -- a palette extracted from an image crowds its colours where
+// the image's pixels are, so those are the nodes the pixels visit.
+inline void crowded_nodes_first(std::vector<uint32_t> &tab, const TableStats &st, const int bw, const std::vector<uint32_t> &coord4)
+{
+    const size_t n = st.node_box.size();
+    if (n < 2) return;
+    std::vector<int> score(n, 0);
+    for (size_t k = 0; k < n; ++k) {
+        const Box &b = st.node_box[k];
+        for (const uint32_t c : coord4) {
+            const int r = c & 255, g = (c >> 8) & 255, bl = (c >> 16) & 255;
+            score[k] += (r >= b.r0 && r < b.r0 + b.size && g >= b.g0 && g < b.g0 + b.size && bl >= b.b0 && bl < b.b0 + b.size);
+        }
+    }
+    std::vector<uint32_t> order(n), where(n);
+    for (size_t k = 0; k < n; ++k) order[k] = (uint32_t)k;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
+    for (size_t k = 0; k < n; ++k) where[order[k]] = (uint32_t)k;
+    const size_t base = (size_t)kCells * bw, node_words = 8 * (size_t)bw;
+    std::vector<uint32_t> moved(tab.size());
+    std::copy(tab.begin(), tab.begin() + base, moved.begin());
+    for (size_t k = 0; k < n; ++k)
+        std::copy(tab.begin() + base + k * node_words, tab.begin() + base + (k + 1) * node_words,
+                  moved.begin() + base + where[k] * node_words);
+    for (uint32_t &w : moved)
+        if ((w >> 30) == 2u) w = 0x80000000u | where[w & 0xffffffu];  // split markers: the child node's new index
+    tab.swap(moved);
+}
+
+// The per-channel maps of a warped table (see accel_scan_warp_kernel).
+struct WarpMaps {
+    uint8_t lut[3][256];  // colour value -> warped coordinate
+    int lo[3][257];       // lo[c][u]: the smallest value whose warped coordinate is >= u (256 when there is none)
+};
+
+// 16 cells per channel, cell i starting at the palette's coordinate of rank K*i/16 (boundaries kept strictly
+// increasing); inside a cell of w values, value number k sits at sub-position k*16/w.
+inline void make_warp(const std::vector<uint32_t> &coord4, WarpMaps &wm)
+{
+    const size_t K = coord4.size();
+    for (int c = 0; c < 3; ++c) {
+        std::vector<int> v(K);
+        for (size_t j = 0; j < K; ++j) v[j] = (coord4[j] >> (8 * c)) & 255;
+        std::sort(v.begin(), v.end());
+        int a[17];
+        a[0] = 0;
+        a[16] = 256;
+        for (int i = 1; i < 16; ++i) {
+            int q = v[K * (size_t)i / 16];
+            q = std::max(q, a[i - 1] + 1);
+            q = std::min(q, 256 - (16 - i));
+            a[i] = q;
+        }
+        for (int i = 0; i < 16; ++i) {
+            const int w = a[i + 1] - a[i];
+            for (int x = a[i]; x < a[i + 1]; ++x) wm.lut[c][x] = (uint8_t)(16 * i + ((x - a[i]) * 16) / w);
+        }
+        int x = 0;
+        for (int u = 0; u <= 256; ++u) {
+            while (x < 256 && (int)wm.lut[c][x] < u) ++x;
+            wm.lo[c][u] = x;
+        }
+    }
+}
+
+// the palette entries and, for each entry, the points a quarter and half of the way to its four nearest other entries
+inline std::vector<uint32_t> mass_points(const std::vector<uint32_t> &coord4)
+{
+    std::vector<uint32_t> out(coord4);
+    const size_t K = coord4.size();
+    constexpr int kNear = 4;
+    for (size_t j = 0; j < K && K > (size_t)kNear; ++j) {
+        const int r = coord4[j] & 255, g = (coord4[j] >> 8) & 255, b = (coord4[j] >> 16) & 255;
+        uint64_t best[kNear];
+        for (uint64_t &v : best) v = ~0ull;
+        for (size_t k = 0; k < K; ++k) {
+            if (k == j) continue;
+            const int dr = (int)(coord4[k] & 255) - r, dg = (int)((coord4[k] >> 8) & 255) - g, db = (int)((coord4[k] >> 16) & 255) - b;
+            uint64_t key = ((uint64_t)(dr * dr + dg * dg + db * db) << 32) | k;
+            for (uint64_t &v : best)
+                if (key < v) std::swap(key, v);
+        }
+        for (const uint64_t key : best) {
+            const uint32_t c = coord4[key & 0xffffffffu];
+            const int cr = c & 255, cg = (c >> 8) & 255, cb = (c >> 16) & 255;
+            for (const int q : {1, 2})  // quarters of the way
+                out.push_back((uint32_t)(r + (cr - r) * q / 4) | ((uint32_t)(g + (cg - g) * q / 4) << 8) | ((uint32_t)(b + (cb - b) * q / 4) << 16));
+        }
+    }
+    return out;
+}
+
+// how many of the given points (coordinates as the table sees them) sit in split cells
+inline int entries_in_split_cells(const std::vector<uint32_t> &tab, const int bw, const std::vector<uint32_t> &coord4)
+{
+    int n = 0;
+    for (const uint32_t c : coord4) {
+        const size_t slot = (size_t)cell_slot((c & 255) >> 4, ((c >> 8) & 255) >> 4, ((c >> 16) & 255) >> 4);
+        n += (int)(tab[slot * bw] >> 31);
+    }
+    return n;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Candidate tables of the diffusion kernels (ediff.hip / vardiff.hip): everything that happens on the host between the
+// download of ed_cells_kernel's geometric lists and the upload of the finished tables.
+// ---------------------------------------------------------------------------------------------
+struct U4 {  // layout of HIP's uint4
+    uint32_t x, y, z, w;
+};
+inline U4 make_u4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return U4{x, y, z, w}; }
+
+constexpr int kEdCells = 32 * 32 * 32;
+
+// The per-cell loops below are independent: split them over a few host threads (the tables of a new palette are built
+// at its first diffusion call, i.e. in front of a user's image).  Each thread writes only the cells of its own range.
+template <class F>
+inline void parallel_cells(const int n, F &&body)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
+    if (n < 1024 || nt == 1) {
+        body(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int chunk = (n + (int)nt - 1) / (int)nt;
+    for (unsigned t = 1; t < nt; ++t) {
+        const int lo = (int)t * chunk, hi = std::min(n, lo + chunk);
+        if (lo < hi) th.emplace_back([&body, lo, hi]() { body(lo, hi); });
+    }
+    body(0, std::min(n, chunk));
+    for (auto &t : th) t.join();
+}
+
+struct EdTables {
+    std::vector<U4> nodes;         // refinement of overflowing 8^3 cells (8 entries per node); empty if none / given up
+    bool give_up = false;          // more than 2^22 nodes: the overflowing cells keep count 255 (scan the palette)
+    std::vector<U4> l16;           // K > 16: lists of the 16^3 cells in the 8^3 table's format
+    std::vector<uint32_t> coarse;  // K <= 16: lists of the 16^3 cells, count | 7 index nibbles
+    std::vector<uint32_t> ext;     // K <= 16: the same over the extended grid (outermost cells = half-spaces)
+};
+
+// cells [kEdCells]: in = the kernel's lists (count byte | up to 15 index bytes, count 255 = overflow), out = sharpened,
+// padded, overflowing cells refined into `nodes`.  pts: K*3 float64 palette coordinates.
+inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &host, EdTables &out)
+{
+    std::vector<U4> &nodes = out.nodes;
+    nodes.clear();
+    auto box_list = [&](const std::vector<int> &from, const double lo[3], const double size, std::vector<int> &list) {
+        double bound = std::numeric_limits<double>::infinity();
+        for (int j : from) {
+            double far2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double c = pts[3 * j + k];
+                const double m = std::max(std::fabs(c - lo[k]), std::fabs(c - (lo[k] + size)));
+                far2 += m * m;
+            }
+            bound = std::min(bound, far2);
+        }
+        bound = bound * (1.0 + 1e-12) + 1e-9;
+        list.clear();
+        for (int j : from) {
+            double near2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double c = pts[3 * j + k];
+                const double m = std::max(std::max(lo[k] - c, c - (lo[k] + size)), 0.0);
+                near2 += m * m;
+            }
+            if (near2 <= bound) list.push_back(j);
+        }
+    };
+    // A sharper (still conservative) list for a box: entry j is dropped if some other listed entry k is closer to EVERY
+    // point of the box, i.e. the box lies strictly on k's side of the bisector of j and k:
+    //   max over the box of |x - c_k|^2 - |x - c_j|^2 = max of 2 x.(c_j - c_k) + |c_k|^2 - |c_j|^2 < 0   (linear in x).
+    // The true nearest entry of a point of the box is dominated by nobody, so it stays listed, with everything tied with it.
+    auto prune_list = [&](const double lo[3], const double size, std::vector<int> &list) {
+        std::vector<int> keep;
+        for (int j : list) {
+            bool dominated = false;
+            for (int k : list) {
+                if (k == j) continue;
+                double mx = 0.0;
+                for (int d = 0; d < 3; ++d) {
+                    const double a = 2.0 * (pts[3 * j + d] - pts[3 * k + d]);
+                    mx += std::max(a * lo[d], a * (lo[d] + size));
+                    mx += pts[3 * k + d] * pts[3 * k + d] - pts[3 * j + d] * pts[3 * j + d];
+                }
+                if (mx < -1e-9 * (1.0 + std::fabs(mx))) {
+                    dominated = true;
+                    break;
+                }
+            }
+            if (!dominated) keep.push_back(j);
+        }
+        list.swap(keep);
+    };
+    // the palette entry nearest to each corner of the cube: bit d of the index set = the corner's coordinate d is 255
+    int corner_entry[8];
+    for (int c = 0; c < 8; ++c) {
+        double best = std::numeric_limits<double>::infinity();
+        corner_entry[c] = 0;
+        for (int j = 0; j < K; ++j) {
+            double d2 = 0.0;
+            for (int d = 0; d < 3; ++d) {
+                const double m = pts[3 * j + d] - ((c >> d) & 1 ? 255.0 : 0.0);
+                d2 += m * m;
+            }
+            if (d2 < best) {
+                best = d2;
+                corner_entry[c] = j;
+            }
+        }
+    }
+    // count byte + up to 15 index bytes.  Lists of up to 12 entries are padded to a multiple of 4 positions with an entry that is
+    // NOT on the list (the one farthest from the box): the key scan of nearest_color_cells evaluates whole groups of four
+    // without per-position tests; an unlisted entry is never the nearest of a point of the box, and should float32
+    // rounding bring it within the margin of the nearest, the exact scan -- which honours the count -- decides.
+    auto pack = [&](const std::vector<int> &list, const double *lo = nullptr, const double size = 0.0) {
+        uint32_t w[4] = {(uint32_t)list.size(), 0u, 0u, 0u};
+        for (size_t n = 1; n <= list.size(); ++n) w[n >> 2] |= (uint32_t)list[n - 1] << (8 * (n & 3));
+        if (lo && !list.empty() && list.size() <= 12 && (int)list.size() < K) {
+            // (any unlisted entry will do; a far one keeps it out of the margin: the entry nearest to the cube corner
+            // opposite to the box, unless that one is listed -- then the farthest by scan)
+            const int oct = (lo[0] + 0.5 * size < 128.0 ? 1 : 0) | (lo[1] + 0.5 * size < 128.0 ? 2 : 0) | (lo[2] + 0.5 * size < 128.0 ? 4 : 0);
+            int filler = corner_entry[oct];
+            if (std::find(list.begin(), list.end(), filler) != list.end()) {
+                filler = -1;
+                double far_d = -1.0;
+                for (int j = 0; j < K; ++j) {
+                    if (std::find(list.begin(), list.end(), j) != list.end()) continue;
+                    double d2 = 0.0;
+                    for (int d = 0; d < 3; ++d) {
+                        const double m = pts[3 * j + d] - (lo[d] + 0.5 * size);
+                        d2 += m * m;
+                    }
+                    if (d2 > far_d) {
+                        far_d = d2;
+                        filler = j;
+                    }
+                }
+            }
+            const size_t upto = (list.size() + 3) / 4 * 4;
+            for (size_t n = list.size() + 1; n <= upto && filler >= 0; ++n) w[n >> 2] |= (uint32_t)filler << (8 * (n & 3));
+        }
+        return make_u4(w[0], w[1], w[2], w[3]);
+    };
+    struct Work {
+        size_t slot;      // index into `nodes` (or, with top == true, into `host`)
+        bool top;
+        double lo[3];
+        double size;
+        std::vector<int> from;
+    };
+    std::vector<Work> stack;
+    std::vector<int> all(K);
+    for (int j = 0; j < K; ++j) all[j] = j;
+    // the kernel's lists (the geometric criterion), sharpened by the pairwise test
+    parallel_cells(kEdCells, [&](const int c0, const int c1) {
+        std::vector<int> list;
+        for (int cell = c0; cell < c1; ++cell) {
+            const uint32_t w4[4] = {host[cell].x, host[cell].y, host[cell].z, host[cell].w};
+            const int n = (int)(w4[0] & 255u);
+            if (n < 1 || n > 15) continue;
+            list.clear();
+            for (int i = 1; i <= n; ++i) list.push_back((int)((w4[i >> 2] >> (8 * (i & 3))) & 255u));
+            const double lo[3] = {(double)((cell & 31) * 8), (double)(((cell >> 5) & 31) * 8), (double)((cell >> 10) * 8)};
+            prune_list(lo, 8.0, list);
+            host[cell] = pack(list, lo, 8.0);  // (re-packed even when nothing was dropped: the padding)
+        }
+    });
+    for (int cell = 0; cell < kEdCells; ++cell)
+        if ((host[cell].x & 255u) == 255u) {
+            Work wk;
+            wk.slot = (size_t)cell;
+            wk.top = true;
+            wk.lo[0] = (double)((cell & 31) * 8);
+            wk.lo[1] = (double)(((cell >> 5) & 31) * 8);
+            wk.lo[2] = (double)((cell >> 10) * 8);
+            wk.size = 8.0;
+            box_list(all, wk.lo, 8.0, wk.from);  // the cell's full list
+            prune_list(wk.lo, 8.0, wk.from);
+            stack.push_back(std::move(wk));
+        }
+    bool give_up = false;
+    std::vector<U4> top_saved;  // the overflowing cells' entries before refinement (restored if the refinement is abandoned)
+    while (!stack.empty() && !give_up) {
+        Work wk = std::move(stack.back());
+        stack.pop_back();
+        U4 entry;
+        if (wk.from.size() <= 15) {
+            entry = pack(wk.from, wk.lo, wk.size);
+        } else if (wk.size <= 1.0) {
+            entry = make_u4(255u, 0u, 0u, 0u);  // a unit cube that still sees more than 15 entries: scan the palette
+        } else {
+            const size_t node = nodes.size() / 8;
+            if (node >= (1u << 22)) {
+                give_up = true;
+                break;
+            }
+            nodes.resize(nodes.size() + 8, make_u4(255u, 0u, 0u, 0u));
+            entry = make_u4(254u | ((uint32_t)node << 8), 0u, 0u, 0u);
+            const double hs = wk.size * 0.5;
+            for (int sub = 0; sub < 8; ++sub) {
+                Work ch;
+                ch.slot = node * 8 + (size_t)sub;
+                ch.top = false;
+                ch.lo[0] = wk.lo[0] + ((sub & 1) ? hs : 0.0);
+                ch.lo[1] = wk.lo[1] + ((sub & 2) ? hs : 0.0);
+                ch.lo[2] = wk.lo[2] + ((sub & 4) ? hs : 0.0);
+                ch.size = hs;
+                box_list(wk.from, ch.lo, hs, ch.from);
+                prune_list(ch.lo, hs, ch.from);
+                stack.push_back(std::move(ch));
+            }
+        }
+        if (wk.top) host[wk.slot] = entry;
+        else nodes[wk.slot] = entry;
+    }
+    out.give_up = give_up;
+    if (give_up) {
+        // abandoned: no cell may point into the node array any more
+        for (int cell = 0; cell < kEdCells; ++cell)
+            if ((host[cell].x & 255u) == 254u) host[cell] = make_u4(255u, 0u, 0u, 0u);
+        nodes.clear();
+    }
+    out.l16.clear();
+    out.coarse.clear();
+    out.ext.clear();
+    if (K > 16) {
+        // lists of the 16x16x16 cells in the format of the 8x8x8 table, for the LDS of the wavefront kernel's few-frames
+        // variant (one wave per SIMD: the read of the 8x8x8 table from L2 is half of a step's latency there)
+        std::vector<U4> &l16 = out.l16;
+        l16.resize(4096);
+        parallel_cells(4096, [&](const int c0, const int c1) {
+            std::vector<int> list;
+            for (int cell = c0; cell < c1; ++cell) {
+                const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
+                box_list(all, lo, 16.0, list);
+                prune_list(lo, 16.0, list);
+                l16[cell] = list.size() <= 15 ? pack(list, lo, 16.0) : make_u4(255u, 0u, 0u, 0u);
+            }
+        });
+    }
+    if (K <= 16) {
+        // lists of the 16x16x16 cells for the wavefront kernel's LDS: count | up to 7 indices, one nibble each
+        std::vector<uint32_t> &coarse = out.coarse;
+        coarse.resize(4096);
+        parallel_cells(4096, [&](const int c0, const int c1) {
+            std::vector<int> list;
+            for (int cell = c0; cell < c1; ++cell) {
+                const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
+                box_list(all, lo, 16.0, list);
+                prune_list(lo, 16.0, list);
+                uint32_t word = 15u;
+                if (list.size() <= 7) {
+                    word = (uint32_t)list.size();
+                    for (size_t n = 0; n < list.size(); ++n) word |= (uint32_t)list[n] << (4 * (n + 1));
+                    // The unused positions name the entry farthest from the cell that is not on the list (K > 8 > list size:
+                    // there is one).  The key scan of nearest_color_cells evaluates every position of a group of 4 (or 7)
+                    // without a per-position validity test; an entry that is not listed can never be the nearest one, and
+                    // if it comes within the margin of the nearest the exact scan (which honours the count) decides.
+                    int filler = -1;
+                    double far_d = -1.0;
+                    for (int j = 0; j < K; ++j) {
+                        if (std::find(list.begin(), list.end(), j) != list.end()) continue;
+                        double near2 = 0.0;
+                        for (int k = 0; k < 3; ++k) {
+                            const double c = pts[3 * j + k];
+                            const double m = std::max(std::max(lo[k] - c, c - (lo[k] + 16.0)), 0.0);
+                            near2 += m * m;
+                        }
+                        if (near2 > far_d) {
+                            far_d = near2;
+                            filler = j;
+                        }
+                    }
+                    for (size_t n = list.size(); n < 7 && filler >= 0; ++n) word |= (uint32_t)filler << (4 * (n + 1));
+                }
+                coarse[cell] = word;
+            }
+        });
+        // The same table for query points that are NOT clamped to the cube (the perceptual / hybrid / adaptive-variance
+        // diffusers of vardiff.hip): a point is looked up in the cell of its clamped coordinates, so the outermost cells
+        // stand for everything beyond them -- their boxes are unbounded on that side.  With an unbounded box the geometric
+        // criterion lists everybody; the pairwise test alone decides (K <= 16: 256 pairs per cell): over a box that is
+        // unbounded in a direction in which |x - c_k|^2 - |x - c_j|^2 grows, k cannot dominate j.
+        std::vector<uint32_t> &ext = out.ext;
+        ext.resize(4096);
+        const double kInf = std::numeric_limits<double>::infinity();
+        parallel_cells(4096, [&](const int c0, const int c1) {
+            std::vector<int> list;
+            for (int cell = c0; cell < c1; ++cell) {
+                const int ci[3] = {cell & 15, (cell >> 4) & 15, cell >> 8};
+                double blo[3], bhi[3];
+                for (int d = 0; d < 3; ++d) {
+                    blo[d] = ci[d] == 0 ? -kInf : (double)(ci[d] * 16);
+                    bhi[d] = ci[d] == 15 ? kInf : (double)(ci[d] * 16 + 16);
+                }
+                list.clear();
+                for (int j = 0; j < K; ++j) {
+                    bool dominated = false;
+                    for (int k = 0; k < K && !dominated; ++k) {
+                        if (k == j) continue;
+                        double mx = 0.0;
+                        for (int d = 0; d < 3; ++d) {
+                            const double a = 2.0 * (pts[3 * j + d] - pts[3 * k + d]);
+                            if (a > 0.0) mx += bhi[d] == kInf ? kInf : a * bhi[d];
+                            else if (a < 0.0) mx += blo[d] == -kInf ? kInf : a * blo[d];
+                            mx += pts[3 * k + d] * pts[3 * k + d] - pts[3 * j + d] * pts[3 * j + d];
+                        }
+                        if (mx < -1e-9 * (1.0 + std::fabs(mx))) dominated = true;
+                    }
+                    if (!dominated) list.push_back(j);
+                }
+                uint32_t word = 15u;
+                if (list.size() <= 7) {
+                    word = (uint32_t)list.size();
+                    for (size_t n = 0; n < list.size(); ++n) word |= (uint32_t)list[n] << (4 * (n + 1));
+                    int filler = -1;
+                    double far_d = -1.0;
+                    for (int j = 0; j < K; ++j) {  // unused positions: the unlisted entry farthest from the cell's inner corner
+                        if (std::find(list.begin(), list.end(), j) != list.end()) continue;
+                        double d2 = 0.0;
+                        for (int d = 0; d < 3; ++d) {
+                            const double m = pts[3 * j + d] - (double)(ci[d] * 16 + 8);
+                            d2 += m * m;
+                        }
+                        if (d2 > far_d) {
+                            far_d = d2;
+                            filler = j;
+                        }
+                    }
+                    for (size_t n = list.size(); n < 7 && filler >= 0; ++n) word |= (uint32_t)filler << (4 * (n + 1));
+                }
+                ext[cell] = word;
+            }
+        });
+    }
+}
+
+}  // namespace dp

@@ -9,9 +9,11 @@ frames are processed IN PROCESS in batches that stay resident in HBM between the
 ffmpeg/ffprobe remain external subprocesses as in the reference (same libx264 re-encode with audio/subtitle
 copy), but frames travel as rawvideo rgb24 through pipes into pinned host buffers instead of PNG files on
 disk (PNG encode/decode dominates a processed frame in the reference); the PNG-file
-exchange of the reference remains available (`use_pipes=False`) with its failure policy: a frame that fails
-is retried twice, then copied from the nearest good frame.  Either way the call returns False on any other
-error and progress_callback(fraction, message) gets the same milestones (0.0, 0.05, 0.1 ... 0.9, 1.0).
+exchange of the reference remains available (`use_pipes=False`).  Both keep the reference's failure policy
+(video_processor.py:325-336, 53-96): a batch that fails is retried frame by frame (three attempts each), a frame that
+still fails is replaced by the nearest good output frame (the previous one first) and the video goes on; the call
+returns False only when ffmpeg fails or no frame could be processed.  progress_callback(fraction, message) gets the
+same milestones (0.0, 0.05, 0.1 ... 0.9, 1.0).
 """
 from __future__ import annotations
 
@@ -219,24 +221,91 @@ class VideoProcessor:
                 failed.append(f)
         return failed
 
+    ATTEMPTS = 3  # the first try plus the reference's two retries (video_processor.py:325-336)
+
+    def _batch_with_retries(self, host_frames, run):
+        """The reference's failure policy for one batch (video_processor.py:304-346): the whole batch in one go; if that
+        raises, every frame on its own, up to ATTEMPTS times; a frame that keeps failing is reported as None and the
+        caller substitutes a neighbour.  run(frames [k,H,W,3]) -> [k,H',W',3].
+        -> (out tensor [n,...] or None, per-frame list or None): exactly one of the two is set."""
+        try:
+            return run(host_frames), None
+        except Exception as e:  # noqa: BLE001 - "a frame that errors must not abort the video"
+            print(f"Batch failed ({e}); retrying frame by frame", file=sys.stderr)
+        outs = []
+        for i in range(host_frames.shape[0]):
+            o = None
+            for attempt in range(self.ATTEMPTS):
+                try:
+                    o = run(host_frames[i:i + 1])[0].cpu()
+                    break
+                except Exception as e:  # noqa: BLE001
+                    print(f"Error processing frame {i} of the batch (attempt {attempt + 1}): {e}", file=sys.stderr)
+            outs.append(o)
+        return None, outs
+
+    def _probe_rotation(self, video_path: str) -> int:
+        """Display rotation of the first video stream in degrees (0 when there is none): ffmpeg auto-rotates while
+        decoding - the reference's plain `ffmpeg -i input frame_%05d.png` (video_processor.py:208-217) does - so the
+        piped frames have the ROTATED geometry."""
+        try:
+            r = subprocess.run(["ffprobe", "-v", "error", "-select_streams", "v:0", "-show_entries",
+                                "stream_tags=rotate:stream_side_data=rotation", "-of",
+                                "default=nokey=1:noprint_wrappers=1", video_path], capture_output=True, text=True, check=True)
+            for line in r.stdout.split("\n"):
+                try:
+                    return int(round(float(line.strip()))) % 360
+                except ValueError:
+                    continue
+        except Exception as e:  # noqa: BLE001
+            print(f"Warning: Could not probe rotation: {e}", file=sys.stderr)
+        return 0
+
     def _stream_through_pipes(self, input_path, output_path, ditherer, method, max_size, batch_size,
-                              final_resize_multiplier, info) -> int:
-        """decode -> GPU -> encode through two ffmpeg rawvideo pipes; returns the number of frames written."""
+                              final_resize_multiplier, info, run=None) -> int:
+        """decode -> GPU -> encode through two ffmpeg rawvideo pipes; returns the number of frames written.
+        Failure policy as in the reference: a batch that fails is retried frame by frame, a frame that still fails is
+        replaced by the nearest good output frame (the previous one first, video_processor.py:53-96) and the video goes
+        on; the call fails only when ffmpeg does or when no frame at all could be processed.  `run` (tests): the batch
+        function, default process_frames on the configured devices."""
         import torch
         w, h, fps = int(info["width"]), int(info["height"]), info["fps"]
+        if self._probe_rotation(input_path) in (90, 270):
+            w, h = h, w  # ffprobe reports the coded size; the decoder below rotates as the reference's extraction does
         frame_bytes = w * h * 3
         total_hint = info.get("frame_count") or 0
-        # the byte stream is sliced into frames of exactly w x h: make the decoder's geometry explicit (no rotation
-        # from display-matrix metadata, output forced to the probed size)
-        devs = self._devices()
+        devs = self._devices() if run is None else [None]
         batch_size = batch_size * len(devs)  # one batch per device in flight
-        dec = subprocess.Popen(["ffmpeg", "-v", "error", "-noautorotate", "-i", input_path, "-f", "rawvideo", "-pix_fmt",
+        if run is None:
+            def run(x):
+                if len(devs) > 1 and x.shape[0] > 1:
+                    from . import sharding
+                    return sharding.process_on_devices(
+                        x, lambda y: process_frames(y, ditherer, method, max_size, final_resize_multiplier), devs)
+                with torch.cuda.device(devs[0]):
+                    return process_frames(x.cuda(non_blocking=True), ditherer, method, max_size, final_resize_multiplier)
+        # the byte stream is sliced into frames of exactly w x h: the decoder's output size is made explicit
+        dec = subprocess.Popen(["ffmpeg", "-v", "error", "-i", input_path, "-f", "rawvideo", "-pix_fmt",
                                 "rgb24", "-s", f"{w}x{h}", "pipe:1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         enc = None
         done = 0
-        stage = torch.empty(batch_size * frame_bytes, dtype=torch.uint8, pin_memory=True)
+        pin = torch.cuda.is_available()
+        stage = torch.empty(batch_size * frame_bytes, dtype=torch.uint8, pin_memory=pin)
         view = memoryview(stage.numpy())
         out_host = None
+        last_good = None      # the newest good output frame (host tensor): what a failed frame is replaced with
+        leading = 0           # frames that failed before any frame succeeded: they take the first good frame
+        substituted = 0
+
+        def open_encoder(shape):
+            oh, ow = int(shape[0]), int(shape[1])
+            return subprocess.Popen(
+                ["ffmpeg", "-y", "-v", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{ow}x{oh}",
+                 "-framerate", f"{fps:.5f}", "-i", "pipe:0", "-i", input_path, "-map", "0:v:0", "-map", "1:a?",
+                 "-map", "1:s?", "-c:v", "libx264", "-preset", "medium", "-crf", "18", "-pix_fmt", "yuv420p",
+                 "-c:a", "copy", "-c:s", "copy", output_path],
+                stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
         try:
             while True:
                 got = 0
@@ -252,32 +321,47 @@ class VideoProcessor:
                 if n_frames == 0:
                     break
                 host_frames = stage[:n_frames * frame_bytes].view(n_frames, h, w, 3)
-                if len(devs) > 1:
-                    from . import sharding
-                    out = sharding.process_on_devices(
-                        host_frames, lambda x: process_frames(x, ditherer, method, max_size, final_resize_multiplier), devs)
+                out, per_frame = self._batch_with_retries(host_frames, run)
+                if out is not None:  # the usual case: one copy into the pinned buffer, one write
+                    if enc is None:
+                        enc = open_encoder(out.shape[1:])
+                    if out_host is None:
+                        out_host = torch.empty((batch_size,) + tuple(out.shape[1:]), dtype=torch.uint8, pin_memory=pin)
+                    out_host[:n_frames].copy_(out, non_blocking=True)
+                    if out.is_cuda:
+                        torch.cuda.current_stream(out.device).synchronize()
+                    for _ in range(leading):
+                        enc.stdin.write(memoryview(out_host[0].numpy()).cast("B"))
+                    leading = 0
+                    enc.stdin.write(memoryview(out_host[:n_frames].numpy()).cast("B"))
+                    last_good = out_host[n_frames - 1].clone()
                 else:
-                    with torch.cuda.device(devs[0]):
-                        out = process_frames(host_frames.cuda(non_blocking=True), ditherer, method, max_size,
-                                             final_resize_multiplier)
-                if enc is None:
-                    oh, ow = int(out.shape[1]), int(out.shape[2])
-                    enc = subprocess.Popen(
-                        ["ffmpeg", "-y", "-v", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{ow}x{oh}",
-                         "-framerate", f"{fps:.5f}", "-i", "pipe:0", "-i", input_path, "-map", "0:v:0", "-map", "1:a?",
-                         "-map", "1:s?", "-c:v", "libx264", "-preset", "medium", "-crf", "18", "-pix_fmt", "yuv420p",
-                         "-c:a", "copy", "-c:s", "copy", output_path],
-                        stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                    out_host = torch.empty((batch_size,) + tuple(out.shape[1:]), dtype=torch.uint8, pin_memory=True)
-                out_host[:n_frames].copy_(out, non_blocking=True)
-                if out.is_cuda:
-                    torch.cuda.current_stream(out.device).synchronize()
-                enc.stdin.write(memoryview(out_host[:n_frames].numpy()).cast("B"))
+                    for i, o in enumerate(per_frame):
+                        if o is not None:
+                            last_good = o
+                        else:
+                            substituted += 1
+                            if last_good is not None:
+                                o = last_good  # the previous good frame first (video_processor.py:66-77)
+                            else:  # nothing before it: the next good frame, of this batch or of a later one
+                                o = next((q for q in per_frame[i + 1:] if q is not None), None)
+                                if o is None:
+                                    leading += 1
+                                    continue
+                        if enc is None:
+                            enc = open_encoder(o.shape)
+                        buf = memoryview(np.ascontiguousarray(o.numpy())).cast("B")
+                        for _ in range(leading + 1):
+                            enc.stdin.write(buf)
+                        leading = 0
                 done += n_frames
                 frac = done / total_hint if total_hint else 0.5
                 self._report_progress(0.1 + 0.8 * min(frac, 1.0), f"Processed {done}/{total_hint or '?'} frames")
                 if got < batch_size * frame_bytes:
                     break
+            if substituted:
+                print(f"Fixed {substituted} failed frames by copying from nearest frames", file=sys.stderr)
+            self._report_progress(0.9, "Finishing the encode...")
         finally:
             if dec.stdout:
                 dec.stdout.close()
@@ -290,6 +374,8 @@ class VideoProcessor:
             raise RuntimeError(f"ffmpeg failed (decoder {rc_dec}, encoder {rc_enc})")
         if done == 0:
             raise ValueError("No frames extracted from video")
+        if last_good is None:
+            raise RuntimeError("no frame of the video could be processed")
         return done
 
     def process_video_streaming(self, input_path: str, output_path: str, ditherer: ImageDitherer,
@@ -303,13 +389,14 @@ class VideoProcessor:
                 use_pipes = False  # frame size unknown: the PNG-file exchange below does not depend on it
         if use_pipes:
             try:
+                # the reference's milestones (0.0, 0.05, 0.1 ... 0.9, 1.0; video_processor.py:199-384) with messages that
+                # say what this path does at them: decode, processing and encode run concurrently through the pipes
                 self._report_progress(0.0, "Initializing video processing...")
-                self._report_progress(0.05, "Extracting frames...")
+                self._report_progress(0.05, "Starting the decoder...")
                 method, max_size = (None, 64) if pixelize_func is None else pixelize_func
                 self._report_progress(0.1, "Processing frames...")
                 self._stream_through_pipes(input_path, output_path, ditherer, method, max_size, max(1, batch_size),
-                                           final_resize_multiplier, info)
-                self._report_progress(0.9, "Encoding final video...")
+                                           final_resize_multiplier, info)   # reports 0.9 before it waits for the encoder
                 self._report_progress(1.0, "Video processing complete!")
                 return True
             except Exception as e:  # noqa: BLE001

@@ -52,3 +52,37 @@ def case_palette(orc, spec):
     if spec[0] == "list":
         return [tuple(c) for c in spec[1]]
     raise ValueError(spec)
+
+
+def fake_ffmpeg_tools(tmp_path, monkeypatch, frames, rotation=None, coded=None):
+    """Stand-ins for ffmpeg / ffprobe on PATH (there is no ffmpeg in the image): the decoder emits `frames` as rgb24, the
+    encoder stores `-s` and the bytes it receives, ffprobe answers the queries get_video_info / _probe_rotation make."""
+    import stat
+    import sys
+    n, h, w = frames.shape[:3]
+    cw, ch = coded if coded else (w, h)
+    raw = tmp_path / "input.raw"
+    raw.write_bytes(frames.tobytes())
+    fake_ffmpeg = tmp_path / "ffmpeg"
+    fake_ffmpeg.write_text(f"""#!{sys.executable}
+import sys
+a = sys.argv[1:]
+if "pipe:1" in a:      # decoder: raw frames to stdout; it must have been asked for the displayed geometry
+    assert a[a.index("-s") + 1] == "{w}x{h}", a
+    assert "-noautorotate" not in a
+    sys.stdout.buffer.write(open({str(raw)!r}, "rb").read())
+elif "pipe:0" in a:    # encoder: keep the size argument and the bytes
+    open(a[-1], "wb").write(a[a.index("-s") + 1].encode() + b"\\n" + sys.stdin.buffer.read())
+else:
+    sys.exit(2)
+""")
+    fake_ffprobe = tmp_path / "ffprobe"
+    fake_ffprobe.write_text(f"""#!{sys.executable}
+import sys
+e = sys.argv[sys.argv.index("-show_entries") + 1]
+print({{"stream=r_frame_rate": "25/1", "stream=width,height": "{cw}\\n{ch}", "stream=duration,nb_frames": "0.44\\n{n}",
+       "stream_tags=rotate:stream_side_data=rotation": {("" if rotation is None else str(rotation))!r}}}[e])
+""")
+    for f in (fake_ffmpeg, fake_ffprobe):
+        f.chmod(f.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv("PATH", str(tmp_path) + ":" + os.environ["PATH"])

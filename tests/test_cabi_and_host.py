@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, fake_ffmpeg_tools as _fake_ffmpeg_tools
 
 
 @pytest.fixture(scope="module")
@@ -249,3 +249,77 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "from oracle" not in src and "import oracle" not in src and "dp_oracle" not in src, f
+
+
+@pytest.mark.parametrize("bad,expect", [
+    ({3}, [0, 1, 2, 2, 4, 5, 6, 7, 8, 9, 10]),                 # one frame: the previous good output frame
+    ({0, 1}, [2, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10]),              # nothing before them: the next good one
+    ({0, 1, 2, 3, 4, 5}, [6, 6, 6, 6, 6, 6, 6, 7, 8, 9, 10]),  # a whole batch and more at the head of the video
+    ({4, 5, 6, 7, 10}, [0, 1, 2, 3, 3, 3, 3, 3, 8, 9, 9]),     # a whole batch in the middle, and the last frame
+])
+def test_pipe_path_keeps_the_reference_failure_policy(tmp_path, monkeypatch, bad, expect):
+    """video_processor.py:325-336, 53-96, 473-475 on the rawvideo-pipe path: a batch that raises is retried frame by
+    frame (3 attempts), a frame that keeps failing is replaced by the nearest good OUTPUT frame (previous first) and the
+    video continues with True.  The batch function is a stand-in that inverts a frame and raises on chosen ones (the
+    device path is exercised in tests/test_gpu_api.py); frames carry their index so that substitutions are visible."""
+    import torch
+    from dither_pie_amd import video_processor as v
+    n, h, w = 11, 6, 8
+    frames = np.zeros((n, h, w, 3), np.uint8)
+    for i in range(n):
+        frames[i] = i
+    _fake_ffmpeg_tools(tmp_path, monkeypatch, frames)
+    attempts = {}
+
+    def run(x):
+        ids = [int(f[0, 0, 0]) for f in x]
+        for i in ids:
+            attempts[i] = attempts.get(i, 0) + 1
+            if i in bad:
+                raise RuntimeError(f"injected failure on frame {i}")
+        return 255 - x.clone()
+
+    seen = []
+    vp = v.VideoProcessor(progress_callback=lambda f, m: seen.append((f, m)))
+    info = vp.get_video_info("in.mp4")
+    out_path = tmp_path / "out.bin"
+    done = vp._stream_through_pipes("in.mp4", str(out_path), None, None, 64, 4, None, info, run=run)
+    assert done == n
+    size, body = out_path.read_bytes().split(b"\n", 1)
+    assert size == f"{w}x{h}".encode()
+    got = np.frombuffer(body, np.uint8).reshape(n, h, w, 3)
+    assert [255 - int(f[0, 0, 0]) for f in got] == expect
+    for i in bad:   # 1 try inside its batch (unless an earlier frame of the batch raised first) + 3 on its own
+        assert attempts[i] in (v.VideoProcessor.ATTEMPTS, v.VideoProcessor.ATTEMPTS + 1)
+    assert seen[-1][0] == 0.9
+
+
+def test_pipe_path_fails_only_when_nothing_succeeds(tmp_path, monkeypatch):
+    from dither_pie_amd import video_processor as v
+    frames = np.zeros((5, 4, 4, 3), np.uint8)
+    _fake_ffmpeg_tools(tmp_path, monkeypatch, frames)
+    vp = v.VideoProcessor()
+
+    def run(x):
+        raise RuntimeError("always")
+
+    with pytest.raises(RuntimeError, match="no frame"):
+        vp._stream_through_pipes("in.mp4", str(tmp_path / "o.bin"), None, None, 64, 2, None, vp.get_video_info("in.mp4"), run=run)
+
+
+@pytest.mark.parametrize("rotation,swap", [(None, False), ("90", True), ("-90.000000", True), ("180", False), ("270", True)])
+def test_pipe_path_follows_rotation_metadata(tmp_path, monkeypatch, rotation, swap):
+    """Phone footage: ffprobe reports the CODED size plus a rotate tag / display matrix; ffmpeg rotates while decoding
+    (the reference's plain extraction, video_processor.py:208-217, does), so the pipe must be sliced with the displayed
+    geometry.  The decoder stand-in asserts it was asked for exactly that and was not told -noautorotate."""
+    from dither_pie_amd import video_processor as v
+    n, h, w = 3, 6, 10   # displayed
+    frames = np.arange(n * h * w * 3, dtype=np.uint32).astype(np.uint8).reshape(n, h, w, 3)
+    _fake_ffmpeg_tools(tmp_path, monkeypatch, frames, rotation=rotation, coded=(h, w) if swap else (w, h))
+    vp = v.VideoProcessor()
+    info = vp.get_video_info("in.mp4")
+    assert (info["width"], info["height"]) == ((h, w) if swap else (w, h))
+    out_path = tmp_path / "o.bin"
+    assert vp._stream_through_pipes("in.mp4", str(out_path), None, None, 64, 2, None, info, run=lambda x: x.clone()) == n
+    size, body = out_path.read_bytes().split(b"\n", 1)
+    assert size == f"{w}x{h}".encode() and body == frames.tobytes()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 from PIL import Image
 
-from conftest import GOLDEN, case_input, case_palette
+from conftest import GOLDEN, case_input, case_palette, fake_ffmpeg_tools
 
 pytestmark = pytest.mark.gpu
 
@@ -243,28 +243,7 @@ def test_video_streaming_through_rawvideo_pipes(d, orc, tmp_path, monkeypatch):
     n, w, h = 11, 64, 48
     rs = np.random.RandomState(5)
     frames = rs.randint(0, 256, (n, h, w, 3)).astype(np.uint8)
-    raw = tmp_path / "input.raw"
-    raw.write_bytes(frames.tobytes())
-    fake_ffmpeg = tmp_path / "ffmpeg"
-    fake_ffmpeg.write_text(f"""#!{sys.executable}
-import sys
-a = sys.argv[1:]
-if "pipe:1" in a:      # decoder: raw frames to stdout
-    sys.stdout.buffer.write(open({str(raw)!r}, "rb").read())
-elif "pipe:0" in a:    # encoder: keep the size argument and the bytes
-    open(a[-1], "wb").write(a[a.index("-s") + 1].encode() + b"\\n" + sys.stdin.buffer.read())
-else:
-    sys.exit(2)
-""")
-    fake_ffprobe = tmp_path / "ffprobe"
-    fake_ffprobe.write_text(f"""#!{sys.executable}
-import sys
-e = sys.argv[sys.argv.index("-show_entries") + 1]
-print({{"stream=r_frame_rate": "25/1", "stream=width,height": "{w}\\n{h}", "stream=duration,nb_frames": "0.44\\n{n}"}}[e])
-""")
-    for f in (fake_ffmpeg, fake_ffprobe):
-        f.chmod(f.stat().st_mode | stat.S_IXUSR)
-    monkeypatch.setenv("PATH", str(tmp_path) + ":" + __import__("os").environ["PATH"])
+    fake_ffmpeg_tools(tmp_path, monkeypatch, frames)
     it = d.ImageDitherer(16, d.DitherMode.BAYER, orc.palr(16, 3), False, {"size": "4x4"})
     seen = []
     vp = v.VideoProcessor(progress_callback=lambda f_, m: seen.append(f_))
@@ -278,6 +257,37 @@ print({{"stream=r_frame_rate": "25/1", "stream=width,height": "{w}\\n{h}", "stre
     got = np.frombuffer(body, np.uint8).reshape(ref.shape)
     assert np.array_equal(got, ref)
     assert seen[0] == 0.0 and seen[-1] == 1.0 and all(b >= a for a, b in zip(seen, seen[1:]))
+
+
+@pytest.mark.gpu
+def test_video_pipes_survive_failing_frames_on_the_device_path(d, orc, tmp_path, monkeypatch):
+    """The failure policy of the pipe path (video_processor.py:325-336, 53-96) around the REAL kernels: a ditherer that
+    raises whenever a marked frame is in its batch.  The batch is retried frame by frame, the marked frames are replaced
+    by the previous good output frame, every other frame equals process_frames(), the call returns True."""
+    import torch
+    from dither_pie_amd import video_processor as v
+    n, w, h = 10, 64, 48
+    frames = np.random.RandomState(6).randint(0, 255, (n, h, w, 3)).astype(np.uint8)
+    bad = {2, 7}
+    for i in range(n):
+        frames[i, 0, 0, 0] = 255 if i in bad else 0
+    fake_ffmpeg_tools(tmp_path, monkeypatch, frames)
+
+    class Flaky(d.ImageDitherer):
+        def apply_dithering_frames(self, x, *a, **k):
+            if bool((x[:, 0, 0, 0] == 255).any()):
+                raise RuntimeError("injected device-side failure")
+            return super().apply_dithering_frames(x, *a, **k)
+
+    it = Flaky(16, d.DitherMode.BAYER, orc.palr(16, 3), False, {"size": "4x4"})
+    out_path = tmp_path / "out.bin"
+    assert v.VideoProcessor().process_video_streaming(str(tmp_path / "in.mp4"), str(out_path), it, None, batch_size=4) is True
+    size, body = out_path.read_bytes().split(b"\n", 1)
+    good = d.ImageDitherer(16, d.DitherMode.BAYER, orc.palr(16, 3), False, {"size": "4x4"})
+    ref = v.process_frames(torch.from_numpy(frames).cuda(), good, None, 64, None).cpu().numpy()
+    got = np.frombuffer(body, np.uint8).reshape(ref.shape)
+    for i in range(n):
+        assert np.array_equal(got[i], ref[i - 1] if i in bad else ref[i]), i
 
 
 def test_distinct_colours_on_device_match_numpy():

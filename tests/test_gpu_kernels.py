@@ -692,3 +692,40 @@ def test_variance_gate_in_chunks_of_frames(be, orc, monkeypatch):
     for i in range(len(frames)):
         ref, _ = orc.variance_gate(frames[i], 250.0, 2)
         assert np.array_equal(gates[i], ref), i
+
+
+def test_accelerator_built_while_other_threads_launch(be, orc):
+    """Host threads sharing one palette (the GUI's preview threads, process_on_devices(devices=[0, 0])): one of them
+    crosses the break-even point and builds the accelerator while the others are inside dp_ordered_u8 with the GIL
+    dropped.  The library publishes the finished device record whole and launches work on snapshots, so every result is
+    right whichever side of the build a launch fell on."""
+    import threading
+    import torch
+    pal = orc.palr(256)
+    arr = orc.rnd(270, 480, 3)
+    ref = orc.apply_dithering(arr, pal, "bayer", {"size": "8x8"})
+    thr = be.Thresholds.from_matrix(orc.bayer_matrix("8x8"))
+    for rep in range(3):
+        P = be.Palette(*orc.prepare_palette(pal, False))
+        P.accel_break_even_pixels = lambda: 6 * 270 * 480   # the build lands in the middle of the launches below
+        x = torch.from_numpy(arr).cuda()
+        errs = []
+
+        def work():
+            try:
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    for _ in range(8):
+                        out = be.ordered(x, P, be.MODE_MATRIX, thr=thr)
+                        if not np.array_equal(out.cpu().numpy(), ref):
+                            errs.append("mismatch")
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        ts = [threading.Thread(target=work) for _ in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        assert P._accel_done and P.accel_entries > 0
