@@ -1,0 +1,82 @@
+"""CPU tier: the host logic of libditherpie_hip.so (dither_pie_amd/csrc/host_logic.h: scipy-order KD-tree build,
+accelerator table assembly, diffusion candidate tables with their multi-threaded per-cell loops) compiled WITHOUT HIP
+behind dither_pie_amd/csrc/host_sanitize.cpp, once with -fsanitize=address,undefined and once with -fsanitize=thread
+(`make -C dither_pie_amd/csrc host_asan host_tsan`), and run on the golden cKDTree palettes.  A sanitizer report makes
+the process exit non-zero (halt_on_error), a failed self-check exits 1."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "dither_pie_amd", "csrc")
+ENV = dict(os.environ, ASAN_OPTIONS="halt_on_error=1:detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+           TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+
+
+@pytest.fixture(scope="module")
+def tools():
+    subprocess.check_call(["make", "-s", "-C", CSRC, "host_asan", "host_tsan"])
+    return {k: os.path.join(CSRC, "build", "host_" + k) for k in ("asan", "tsan")}
+
+
+def _run(tool, cmd, pts, tmp_path, *extra):
+    f = tmp_path / "pts.f64"
+    np.ascontiguousarray(pts, dtype=np.float64).tofile(f)
+    r = subprocess.run([tool, cmd, str(f), str(len(pts)), *map(str, extra)], capture_output=True, text=True, env=ENV,
+                       timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_kdtree_build_under_sanitizers_matches_scipy(tools, gold, kat, tmp_path, san):
+    """build_tree (libstdc++ nth_element on raw index arithmetic) on all 11 golden palettes, incl. duplicates, a flat one
+    and a float one: same indices / nodes / splits as scipy's cKDTree, nothing for ASan / UBSan / TSan to report."""
+    for nm in kat["misc"]["tree_palettes"]:
+        pts = gold[f"tree_{nm}_pts"]
+        lines = _run(tools[san], "kdtree", pts, tmp_path).strip().split("\n")
+        assert lines[0].split()[0] == "indices"
+        assert np.array_equal(np.array(lines[0].split()[1:], np.int32), gold[f"tree_{nm}_indices"]), nm
+        n = int(lines[1].split()[1])
+        rows = [l.split() for l in lines[2:2 + n]]
+        nodes = np.array([[int(v) for v in r[:5]] for r in rows], np.int32)
+        splits = np.array([float(r[5]) for r in rows])
+        assert np.array_equal(nodes, gold[f"tree_{nm}_nodes"]), nm
+        inner = nodes[:, 0] >= 0
+        assert np.array_equal(splits[inner], gold[f"tree_{nm}_splits"][inner]), nm
+
+
+def _crowded(K, seed):
+    rs = np.random.RandomState(seed)
+    return np.clip(np.round(40 + rs.randn(K, 3) * 9), 0, 255)
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_diffusion_tables_under_sanitizers(tools, gold, tmp_path, san):
+    """ed_tables_refine with its up-to-8-thread per-cell loops: random / uniform-grid / float (gamma) / crowded palettes
+    (the crowded ones overflow cells and go through the octree refinement); the harness checks on 40 000 points that the
+    true nearest entries are on every list a kernel would search."""
+    cases = [gold["tree_p256_pts"], gold["tree_p32_pts"], gold["tree_p11_pts"], gold["tree_U16_pts"], gold["tree_lin256_pts"],
+             gold["tree_dup40_pts"], _crowded(200, 1), _crowded(16, 2)]
+    if san == "tsan":
+        cases = [cases[0], cases[3], cases[6]]
+    for pts in cases:
+        out = _run(tools[san], "edtables", pts, tmp_path)
+        assert " bad=0" in out, out
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_accelerator_table_assembly_under_sanitizers(tools, gold, tmp_path, san):
+    """assemble_table / crowded_nodes_first / make_warp / mass_points / entries_in_split_cells from brute-force
+    membership masks (the harness scans all 2^24 colours as accel_scan_kernel does): a random, a uniform-grid and a
+    crowded palette, 8- and 4-entry blocks; every sampled colour finds all of T(x) in the block it reaches."""
+    cases = [(gold["tree_p32_pts"], 8), (gold["tree_U16_pts"], 4), (_crowded(40, 3), 8)]
+    if san == "tsan":
+        cases = cases[2:]
+    for pts, bw in cases:
+        out = _run(tools[san], "accel", pts, tmp_path, bw)
+        assert " bad=0 " in out and "warp_bad=0" in out, out
