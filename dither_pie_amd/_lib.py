@@ -11,8 +11,12 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DP_LIB_PATH: another build of the same library (A/B measurements of kernel variants: tools/bench_scripts/ab_kernel.py)
-LIB_PATH = os.environ.get("DP_LIB_PATH") or os.path.join(_HERE, "libditherpie_hip.so")
+# Two builds of the same sources (csrc/Makefile): libditherpie_hip.so -- the product, which reads no environment variable --
+# and libditherpie_hip_exp.so (-DDP_EXPERIMENTS), in which the DP_* switches that force a table / kernel / schedule are
+# compiled in.  DITHER_PIE_EXPERIMENTS=1 (set by tests/conftest.py and tools/bench_scripts) selects the latter.
+# DP_LIB_PATH: another build altogether (A/B measurements of kernel variants: tools/bench_scripts/ab_kernel.py)
+EXPERIMENTS = os.environ.get("DITHER_PIE_EXPERIMENTS", "") not in ("", "0")
+LIB_PATH = os.environ.get("DP_LIB_PATH") or os.path.join(_HERE, "libditherpie_hip_exp.so" if EXPERIMENTS else "libditherpie_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_OK, DP_EINVAL, DP_EUNSUPPORTED, DP_EHIP, DP_ENOMEM, DP_EWORKSPACE = range(6)
@@ -70,7 +74,7 @@ def build(force=False):
     """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
-    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC])
     return LIB_PATH
 
 

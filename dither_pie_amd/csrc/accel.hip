@@ -416,8 +416,9 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     //         table over warped cells [max] | the three warp maps [768 bytes] | staging orders of the 8- and the
     //         4-entry table [2 x 4096 words]
     //         | the flat lists of their split cells [2 x kWideCap x kWideList words]
+    //         | the compact (one byte per entry) copy of the crowded table [kCompactMaxWords]
     const size_t bytes = sizeof(uint32_t) * (3 * kCodeWords + 2 * kTabMaxWords + kTabCapWords) + sizeof(uint4) * kExcCap + 16 + 768 +
-                         sizeof(uint32_t) * (2 * kCells + 2 * kWideCap * kWideList);
+                         sizeof(uint32_t) * (2 * kCells + 2 * kWideCap * kWideList + kCompactMaxWords);
     DP_HIP(hipMalloc((void **)&blob, bytes));
     struct DevFree {  // frees the scan masks on every way out
         void *p = nullptr;
@@ -484,7 +485,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         // Single colours with more than 4 equidistant entries (marked slow; uniform grids have them) are resolved by
         // the deferred path with a scan of the whole (small) palette.
         use4 = !st4.too_big && st4.n_split_cells <= kCells * 4 / 100;
-        if (getenv("DP_DEBUG_ACCEL"))
+        if (exp_env("DP_DEBUG_ACCEL"))
             fprintf(stderr, "accel K=%d: 4-entry table: %d split cells, %d split nodes, %d slow, %zu words, too_big=%d -> use=%d\n", K,
                     st4.n_split_cells, st4.n_split, st4.n_slow, tab4.size(), (int)st4.too_big, (int)use4);
     }
@@ -496,7 +497,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
             (void)hipFree(blob);
             return rc;
         }
-        if (getenv("DP_DEBUG_ACCEL"))
+        if (exp_env("DP_DEBUG_ACCEL"))
             fprintf(stderr, "accel K=%d: 8-entry table: %d split cells, %d split nodes, %d slow, %zu words (%s), longest list %d, too_big=%d\n",
                     K, st.n_split_cells, st.n_split, st.n_slow, tab.size(), tab.size() <= (size_t)kTabCapWords ? "all in LDS" : "deep nodes in global memory",
                     st.max_cnt, (int)st.too_big);
@@ -518,7 +519,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     // table keeps them on the main path
     if (use4 && ok8 && m4 * 20 > n_mass && m8 * 2 <= m4) use4 = false;
     // experiments: DP_FORCE_TABLE = u4 | u8 | w4 | w8 picks the table regardless of the estimates (when it exists)
-    const char *force_env = getenv("DP_FORCE_TABLE");
+    const char *force_env = exp_env("DP_FORCE_TABLE");
     const std::string force = force_env ? force_env : "";
     if (force == "u4") use4 = K <= 64 && !st4.too_big;
     else if (!force.empty() && ok8) use4 = false;
@@ -539,7 +540,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     bool w_spilled = false;
     uint32_t *d_wtab = d_exc_count + 4 + kTabCapWords;
     uint8_t *d_lut = reinterpret_cast<uint8_t *>(d_wtab + kTabMaxWords);
-    if (K >= 8 && (try_warp || force[0] == 'w') && force[0] != 'u' && !getenv("DP_NO_WARP")) {
+    if (K >= 8 && (try_warp || force[0] == 'w') && force[0] != 'u' && !exp_env("DP_NO_WARP")) {
         make_warp(p4_host, wm);
         auto warped = [&](const uint32_t c) {
             return (uint32_t)wm.lut[0][c & 255] | ((uint32_t)wm.lut[1][(c >> 8) & 255] << 8) | ((uint32_t)wm.lut[2][(c >> 16) & 255] << 16);
@@ -604,14 +605,14 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
                 if (w_spilled) crowded_nodes_first(wtab, wst, 8, coordw);
             }
         }
-        if (getenv("DP_DEBUG_ACCEL"))
+        if (exp_env("DP_DEBUG_ACCEL"))
             fprintf(stderr, "accel K=%d: mass in split cells: plain 4-entry %d, plain 8-entry %d of %d (in use: %d-entry, %d cells%s); warped 4-entry %d, "
                     "warped %d-entry table: %d, %d split cells, %d nodes, %d slow, %zu words%s\n",
                     K, m4, m8, n_mass, use4 ? 4 : 8, u_cells, u_spilled ? ", spilled" : "", w4_mass, wbw, w_mass, wst.n_split_cells, wst.n_split,
                     wst.n_slow, wtab.size(), w_spilled ? " (deep nodes in global memory)" : "");
         // no real gain (less than half of the mass brought back, or less than 2 % of it): stay with the plain cells
         if (wbw != 0 && (w_mass * 2 > u_mass || (u_mass - w_mass) * 50 < n_mass) && !(u_spilled && !w_spilled) && force.empty()) wbw = 0;
-    } else if (getenv("DP_DEBUG_ACCEL")) {
+    } else if (exp_env("DP_DEBUG_ACCEL")) {
         fprintf(stderr, "accel K=%d: mass in split cells: plain 4-entry %d, plain 8-entry %d of %d (in use: %d-entry, %d cells)\n", K, m4, m8, n_mass,
                 use4 ? 4 : 8, u_cells);
     }
@@ -638,8 +639,8 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     dev.cell_perm = dev.cell_perm4 = nullptr;
     dev.near_slots = 0;
     const bool fast8 = have8 && !st.too_big && !st.wide_overflow && !use4 && wbw == 0 && !dev.adapt && tab.size() <= (size_t)kTabCapWords &&
-                       wide8.size() <= (size_t)kWideCap * kWideList && !getenv("DP_NO_FAST");
-    if (getenv("DP_DEBUG_ACCEL") && have8)
+                       wide8.size() <= (size_t)kWideCap * kWideList && !exp_env("DP_NO_FAST");
+    if (exp_env("DP_DEBUG_ACCEL") && have8)
         fprintf(stderr, "accel K=%d: fast kernel on the 8-entry table: %s (%d cells with a nearest set above %d entries, %zu flat lists)\n", K,
                 fast8 ? "yes" : "no", st.n_near_overflow, kNearSlots, wide8.size() / kWideList);
     if (!fast8) perm8.clear();
@@ -659,7 +660,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
         dev.cell_perm = d_perm8;
         dev.near_slots = kNearSlots;
     }
-    if (use4 && wbw == 0 && !perm4.empty() && !st4.wide_overflow && wide4.size() <= (size_t)kWideCap * kWideList && !getenv("DP_NO_FAST")) {
+    if (use4 && wbw == 0 && !perm4.empty() && !st4.wide_overflow && wide4.size() <= (size_t)kWideCap * kWideList && !exp_env("DP_NO_FAST")) {
         e = hipMemcpy(d_perm4, perm4.data(), sizeof(uint32_t) * kCells, hipMemcpyHostToDevice);
         if (e == hipSuccess && !wide4.empty()) e = hipMemcpy(d_wide4, wide4.data(), sizeof(uint32_t) * wide4.size(), hipMemcpyHostToDevice);
         dev.cell_wide4 = d_wide4;
@@ -674,6 +675,29 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     dev.tab_words = 0;
     dev.tab_total = 0;
     if (have8 && !st.too_big && tab.size() > (size_t)kTabCapWords) crowded_nodes_first(tab, st, 8, p4_host);
+    // Crowded palettes: the table the adaptive lean kernel would run on (8-entry blocks over warped or plain cells), one
+    // byte per entry, for ordered_compact_kernel (everything in LDS, no deferral)
+    dev.comp_tab = nullptr;
+    dev.comp_words = dev.comp_warp = 0;
+    {
+        const bool from_warp = wbw == 8 && dev.warp_adapt != 0;
+        const bool from_plain = wbw == 0 && dev.adapt != 0 && have8 && !st.too_big;
+        const std::vector<uint32_t> &src = from_warp ? wtab : tab;
+        if (K <= 256 && (from_warp || from_plain) && src.size() / 4 <= (size_t)kCompactMaxWords && !exp_env("DP_NO_COMPACT")) {
+            const std::vector<uint32_t> ct = compact_table(src, p4_host);
+            uint32_t *d_comp = d_wide4 + kWideCap * kWideList;
+            e = hipMemcpy(d_comp, ct.data(), sizeof(uint32_t) * ct.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(blob);
+                return hip_fail(e, "accelerator upload (compact table)");
+            }
+            dev.comp_tab = d_comp;
+            dev.comp_words = (int)ct.size();
+            dev.comp_warp = from_warp ? 1 : 0;
+            if (exp_env("DP_DEBUG_ACCEL"))
+                fprintf(stderr, "accel K=%d: compact table over %s cells: %zu bytes\n", K, from_warp ? "warped" : "plain", ct.size() * 4);
+        }
+    }
     if (have8 && !st.too_big) {
         e = hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -20,6 +21,19 @@ constexpr int kIdxBits = 10;      // palette index bits packed under the distanc
 constexpr int kLocalBits = 8;     // byte offset of a candidate inside its block (cell-table kernel)
 
 void set_error(const char *fmt, ...);
+
+// Experiment switches (DP_* environment variables: forcing a table, a kernel or a schedule for tests, A/B measurements and
+// tools/bench_scripts).  Only the library variant built with -DDP_EXPERIMENTS (libditherpie_hip_exp.so, what tests and
+// tools load) looks at the environment; the default library (libditherpie_hip.so) has no getenv() on any path.
+inline const char *exp_env(const char *name)
+{
+#ifdef DP_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 int hip_fail(hipError_t e, const char *what);
 
 #define DP_HIP(call)                                   \
@@ -74,6 +88,11 @@ struct PalDev {
     int warp_words, warp_total; // staged / all words (as tab_words / tab_total)
     int warp_bw;
     int warp_adapt;
+    // crowded palettes: the table the adaptive lean kernel would use (plain or warped 8-entry blocks), one BYTE per entry
+    // (index into p4; accel.hip: compact_table) -- ordered_compact_kernel keeps all of it in LDS; nullptr when absent
+    const uint32_t *comp_tab;
+    int comp_words;             // (4096 + 8 * nodes) * 2
+    int comp_warp;              // its cells are the warped ones (warp_lut)
     int n_split;
     int n_slow_blocks;
     int n_split_cells;          // 16^3 cells of cell_tab that are split (a palette crowded into few cells has many)

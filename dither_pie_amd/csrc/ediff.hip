@@ -813,7 +813,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         }
         const int n_bands = (h + 63) / 64;
         int nw = n_bands < kMaxWaves ? n_bands : kMaxWaves;
-        if (const char *e = getenv("DP_ED_WAVES")) {  // experiments: waves per one-workgroup frame
+        if (const char *e = exp_env("DP_ED_WAVES")) {  // experiments: waves per one-workgroup frame
             const int v = atoi(e);
             if (v >= 1 && v <= kMaxWaves && v <= n_bands) nw = v;
         }
@@ -827,7 +827,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         {
             const size_t prog_off = ((size_t)n_frames * (size_t)w * 48 + 255) & ~(size_t)255;
             const size_t prog_bytes = (size_t)n_frames * kEdProgWords * sizeof(uint32_t);
-            if (n_frames * 2 <= cus && n_bands >= 4 && w >= 64 && prog_off + prog_bytes <= ws_bytes && !getenv("DP_ED_ONE_WG")) {
+            if (n_frames * 2 <= cus && n_bands >= 4 && w >= 64 && prog_off + prog_bytes <= ws_bytes && !exp_env("DP_ED_ONE_WG")) {
                 const int nwt = n_bands < 32 ? n_bands : 32;
                 while (G * 2 <= 16 && n_frames * (G * 2) <= cus && G * 2 <= nwt) G *= 2;
                 if (G > 1) {
@@ -841,7 +841,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         // frame's give-up flag and ends.  The repair launch right behind it (same stream, one workgroup per frame,
         // G = 1, frames without the flag return immediately) does those frames again, so the call never reports success
         // over partly written frames.
-        const int test_giveup = getenv("DP_ED_TEST_GIVEUP") ? 1 : 0;
+        const int test_giveup = exp_env("DP_ED_TEST_GIVEUP") ? 1 : 0;
         const int nw1 = n_bands < kMaxWaves ? n_bands : kMaxWaves;
 #define DP_EDW(C, N, X)                                                                                                   \
     do {                                                                                                                 \

@@ -251,6 +251,8 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.n_wide = d.n_wide4 = 0;
     d.adapt = 0;
     d.warp_tab = nullptr;
+    d.comp_tab = nullptr;
+    d.comp_words = d.comp_warp = 0;
     d.warp_lut = nullptr;
     d.warp_words = d.warp_total = d.warp_bw = d.warp_adapt = 0;
     d.n_split = d.n_slow_blocks = 0;

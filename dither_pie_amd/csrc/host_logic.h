@@ -11,6 +11,7 @@
 #include <limits>
 #include <numeric>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/ditherpie_hip.h"
@@ -428,6 +429,43 @@ inline std::vector<uint32_t> mass_points(const std::vector<uint32_t> &coord4)
             for (const int q : {1, 2})  // quarters of the way
                 out.push_back((uint32_t)(r + (cr - r) * q / 4) | ((uint32_t)(g + (cg - g) * q / 4) << 8) | ((uint32_t)(b + (cb - b) * q / 4) << 16));
         }
+    }
+    return out;
+}
+
+// One byte per entry: the table `tab` of 8-entry blocks (4096 cell blocks, then 8 blocks per split node; entries = packed
+// colours in palette-index order, a block whose first word has bit 31 set = marker) with every colour replaced by the
+// index of its palette entry, two words per block.  Entries of equal colour (duplicated palette entries) get their indices
+// in ascending order, as the index-ordered block has them.  Marker blocks become {marker, 0xffffffff} with the marker
+// 0x80000000 | byte offset of the node's eight blocks in THIS table (split) or 0xC0000000 (too many candidates).
+constexpr int kCompactMaxWords = 36 * 1024;  // 144 KB: what ordered_compact_kernel can hold next to records, maps, thresholds
+inline std::vector<uint32_t> compact_table(const std::vector<uint32_t> &tab, const std::vector<uint32_t> &coord4)
+{
+    std::vector<std::pair<uint32_t, uint32_t>> by_colour(coord4.size());
+    for (size_t j = 0; j < coord4.size(); ++j) by_colour[j] = {coord4[j], (uint32_t)j};
+    std::sort(by_colour.begin(), by_colour.end());  // ascending index among equal colours
+    std::vector<uint32_t> out(tab.size() / 4);
+    for (size_t b = 0; b + 8 <= tab.size(); b += 8) {
+        if (tab[b] >> 31) {
+            const bool split = (tab[b] >> 30) == 2u;
+            out[b / 4] = split ? (0x80000000u | (uint32_t)((4096u + (tab[b] & 0xffffffu) * 8u) * 8u)) : 0xC0000000u;
+            out[b / 4 + 1] = 0xffffffffu;
+            continue;
+        }
+        uint32_t w[2] = {0u, 0u};
+        for (int i = 0; i < 8; ++i) {
+            int nth = 0;  // how many earlier entries of the block have this colour
+            for (int k = 0; k < i; ++k) nth += tab[b + k] == tab[b + i];
+            auto it = std::lower_bound(by_colour.begin(), by_colour.end(), std::make_pair(tab[b + i], 0u));
+            uint32_t idx = 0u;
+            if (it != by_colour.end() && it->first == tab[b + i]) {
+                if ((size_t)(it - by_colour.begin()) + nth < by_colour.size() && (it + nth)->first == tab[b + i]) it += nth;
+                idx = it->second;
+            }
+            w[i >> 2] |= idx << (8 * (i & 3));
+        }
+        out[b / 4] = w[0];
+        out[b / 4 + 1] = w[1];
     }
     return out;
 }

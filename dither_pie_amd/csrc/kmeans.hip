@@ -1186,7 +1186,7 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, cons
         set_error("dp_kmeans_step_u8: too many clusters for the LDS accumulators");
         return DP_EUNSUPPORTED;
     }
-    const bool want_mfma = getenv("DP_KMEANS_MFMA") != nullptr;  // measured slower at every K: opt-in only
+    const bool want_mfma = exp_env("DP_KMEANS_MFMA") != nullptr;  // measured slower at every K: opt-in only
     if (want_mfma && K <= kMfmaMaxK) {
         // scores on the matrix cores: a wave takes 128 pixels per round, 4 workgroups of 4 waves per CU
         constexpr int kRoundPx = kWavesPerBlock * kTiles * 32;
@@ -1208,7 +1208,7 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, cons
     {
         // big images: per-cell candidate lists, rebuilt from the current centres in front of every pass
         // (DP_KMEANS_CELLS=0 keeps the full scan, =1 takes the lists at any size: tests)
-        const char *e = getenv("DP_KMEANS_CELLS");
+        const char *e = exp_env("DP_KMEANS_CELLS");
         const bool force = e && e[0] == '1', off = e && e[0] == '0';
         const bool wide = K > kCellsMaxK8;  // 16-byte lists, 1024 threads, one set of wide totals per workgroup
         const int cblock = wide ? 1024 : 512, cwaves = cblock / 64;
@@ -1244,7 +1244,7 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, cons
             return DP_OK;
         }
     }
-    const bool keys = K <= 256 && !getenv("DP_KMEANS_NO_KEYS");
+    const bool keys = K <= 256 && !exp_env("DP_KMEANS_NO_KEYS");
 #define DP_KM(SQF, KF)                                                                                                    \
     hipLaunchKernelGGL((kmeans_step_kernel<SQF, KF>), dim3(blocks), dim3(kBlock), smem, s, px, n, centers, mean, K,            \
                        reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),   \

@@ -1229,6 +1229,328 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// ordered_compact_kernel: crowded integer palettes (extracted from the image itself: median cut, k-means).
+//
+// Such a palette puts its colours where the pixels are, so most PIXELS sit in cells whose candidate set is larger
+// than a block: the octree below the 16^3 cells is the main path, not the exception.  With 4-byte entries the octree
+// of a 256-colour median-cut palette (550 nodes x 256 B) does not fit LDS next to the 4096 cell blocks, the lean
+// kernel reads its deeper nodes from global memory and spends 61 % of its wave cycles waiting (round 2: 1.61 ms for
+// 24 4K frames).  Here the SAME table (same cells -- plain or warped --, same node numbering, same block positions:
+// host_logic.h compact_table) is held with ONE BYTE per entry, the index of the palette entry: 8 bytes per block, 64
+// per node, the whole octree in 35 KB.  The palette itself sits in LDS as 256 records {colour, |p|^2 << 8 | index}
+// (2 KB), so a candidate's key is TWO instructions -- v_dot4_u32_u8 (x.p) and v_mad_i32_i24 (-512 x.p + record) --
+// plus one v_lshlrev_b32_sdwa for the record's address, against four in the lean kernel; the key's low byte is the
+// palette index, which orders equal distances exactly as the block position does (blocks are in index order).
+// Everything fits less than half of LDS: two workgroups share a CU (8 waves per SIMD) and nothing on the per-pixel
+// path leaves the CU except the tie codes.  Every pixel is resolved in place (no deferral queue): cell block, descent
+// while the block is a split marker, eight keys, top three, exact decision, tie codes / exception list / float64
+// replay as resolve_pixel does.  A tie between the second and third candidate only matters when the decision takes
+// the second one, so the tie-code words are requested for fewer pixels, and those of a lane's four pixels together.
+// Compact block: two words of four index bytes; second word 0xffffffff = marker, first word then
+// 0x80000000 | byte offset of the split node's eight blocks, or 0xC0000000 (a single colour with more than eight
+// candidates: fix-up pass).
+// ---------------------------------------------------------------------------------------------
+constexpr int kCompactHalfWords = 80 * 1024 / 4;
+constexpr uint32_t kCompactRecBytes = 256 * 8;                           // LDS: records at 0 ...
+constexpr uint32_t kCompactLutAt = kCompactRecBytes;                     // ... the three warp maps ...
+constexpr uint32_t kCompactTabAt = kCompactLutAt + kWarpLutBytes;        // ... the table, then integer thresholds
+
+// keys of eight palette records and the three smallest (see cand8); r_k = {colour, |p|^2 << 8 | index}
+__device__ __forceinline__ void cand8r(const uint32_t x, const uint2 r0, const uint2 r1, const uint2 r2, const uint2 r3,
+                                       const uint2 r4, const uint2 r5, const uint2 r6, const uint2 r7, const int neg2, int &m0,
+                                       int &m1, int &m2)
+{
+    int n0, n1, n2, n3, n4, n5, n6, n7;
+    asm volatile(
+        "v_dot4_u32_u8 %[n0], %[x], %[c0], 0\n\t"
+        "v_dot4_u32_u8 %[n1], %[x], %[c1], 0\n\t"
+        "v_dot4_u32_u8 %[n2], %[x], %[c2], 0\n\t"
+        "v_dot4_u32_u8 %[n3], %[x], %[c3], 0\n\t"
+        "v_dot4_u32_u8 %[n4], %[x], %[c4], 0\n\t"
+        "v_dot4_u32_u8 %[n5], %[x], %[c5], 0\n\t"
+        "v_dot4_u32_u8 %[n6], %[x], %[c6], 0\n\t"
+        "v_dot4_u32_u8 %[n7], %[x], %[c7], 0\n\t"
+        "v_mad_i32_i24 %[n0], %[n0], %[ng], %[k0]\n\t"
+        "v_mad_i32_i24 %[n1], %[n1], %[ng], %[k1]\n\t"
+        "v_mad_i32_i24 %[n2], %[n2], %[ng], %[k2]\n\t"
+        "v_mad_i32_i24 %[n3], %[n3], %[ng], %[k3]\n\t"
+        "v_mad_i32_i24 %[n4], %[n4], %[ng], %[k4]\n\t"
+        "v_mad_i32_i24 %[n5], %[n5], %[ng], %[k5]\n\t"
+        "v_mad_i32_i24 %[n6], %[n6], %[ng], %[k6]\n\t"
+        "v_mad_i32_i24 %[n7], %[n7], %[ng], %[k7]\n\t"
+        "v_min3_i32 %[m0], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m1], %[n0], %[n1], %[n2]\n\t"
+        "v_max3_i32 %[m2], %[n0], %[n1], %[n2]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n3]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n3]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n3]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n4]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n4]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n4]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n5]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n5]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n5]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n6]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n6]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n6]\n\t"
+        "v_med3_i32 %[m2], %[m1], %[m2], %[n7]\n\t"
+        "v_med3_i32 %[m1], %[m0], %[m1], %[n7]\n\t"
+        "v_min_i32 %[m0], %[m0], %[n7]\n\t"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [n4] "=&v"(n4), [n5] "=&v"(n5),
+          [n6] "=&v"(n6), [n7] "=&v"(n7), [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2)
+        : [x] "v"(x), [c0] "v"(r0.x), [c1] "v"(r1.x), [c2] "v"(r2.x), [c3] "v"(r3.x), [c4] "v"(r4.x), [c5] "v"(r5.x),
+          [c6] "v"(r6.x), [c7] "v"(r7.x), [k0] "v"(r0.y), [k1] "v"(r1.y), [k2] "v"(r2.y), [k3] "v"(r3.y), [k4] "v"(r4.y),
+          [k5] "v"(r5.y), [k6] "v"(r6.y), [k7] "v"(r7.y), [ng] "s"(neg2));
+}
+
+// byte k of `word` times 8 (the LDS address of palette record number byte k): one SDWA shift; `three` holds 3
+template <int BYTE>
+__device__ __forceinline__ uint32_t rec_addr(const uint32_t word, const uint32_t three)
+{
+    uint32_t a;
+    if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(three), "v"(word));
+    else if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(three), "v"(word));
+    else if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(three), "v"(word));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(three), "v"(word));
+    return a;
+}
+
+// Which of the three nearest candidates (0, 1, 2 by (distance, index)) is written: two bits per (tie code, decision).
+// k=2 codes (accel.hip): 0 (c0,c1)  1 (c1,c0)  2 (c0,c2)  3 (c2,c0)  4 (c1,c2)  5 (c2,c1); field 2*code + (nearest ? 0 : 1)
+constexpr uint32_t kPickTable = (0u << 0) | (1u << 2) | (1u << 4) | (0u << 6) | (0u << 8) | (2u << 10) | (2u << 12) | (0u << 14) |
+                                (1u << 16) | (2u << 18) | (2u << 20) | (1u << 22);
+
+template <int MODE, bool WARP, bool HALF>
+__global__ __launch_bounds__(kCellBlock, HALF ? 8 : 4) void ordered_compact_kernel(const uint8_t *__restrict__ in,
+                                                                     uint8_t *__restrict__ out,
+                                                                     unsigned long long *__restrict__ flags,
+                                                                     const Geo g, const PalDev pal, const ThrDev thr,
+                                                                     const float sx, const float sy, const float sc,
+                                                                     const uint32_t n_tiles)
+{
+    constexpr int kLdsWords = HALF ? kCompactHalfWords : kLeanLdsWords;
+    __shared__ __align__(16) uint32_t smem[kLdsWords];
+    const uint32_t thr_at = kCompactTabAt / 4 + (uint32_t)pal.comp_words;  // (words)
+    for (int i = threadIdx.x; i < pal.K; i += kCellBlock) {
+        const uint32_t c = pal.p4[i];
+        smem[2 * i] = c;
+        smem[2 * i + 1] = (__builtin_amdgcn_udot4(c, c, 0u, false) << kLocalBits) | (uint32_t)i;
+    }
+    if (WARP && threadIdx.x < kWarpLutBytes / 4) smem[kCompactLutAt / 4 + threadIdx.x] = reinterpret_cast<const uint32_t *>(pal.warp_lut)[threadIdx.x];
+    for (int i = threadIdx.x; i < pal.comp_words; i += kCellBlock) smem[kCompactTabAt / 4 + i] = pal.comp_tab[i];
+    if (MODE == 1) {
+        const int n = thr.th_h * thr.tw_pad;
+        for (int i = threadIdx.x; i < n; i += kCellBlock) smem[thr_at + i] = thr.mpad[i];
+    }
+    __syncthreads();
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(smem);
+    const uint8_t *s_lut = s_bytes + kCompactLutAt;
+    const uint8_t *s_tab = s_bytes + kCompactTabAt;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint3 *in3 = reinterpret_cast<const uint3 *>(in);
+    uint3 *out3 = reinterpret_cast<uint3 *>(out);
+    const uint32_t n_full = g.n_px >> 2;
+    uint32_t three;
+    asm volatile("v_mov_b32 %0, 3" : "=v"(three));  // (kept in a register: SDWA takes no inline constant here)
+
+    // the block that decides a colour: its cell's, or the leaf reached by one colour bit per level
+    auto find_block = [&](const uint32_t x, uint32_t &lo, uint32_t &hi, bool &stuck) {
+        uint32_t xc = x;
+        if (WARP) xc = (uint32_t)s_lut[x & 255u] | ((uint32_t)s_lut[256u + ((x >> 8) & 255u)] << 8) | ((uint32_t)s_lut[512u + (x >> 16)] << 16);
+        const uint32_t t = xc & 0xf0f0f0u, y = t | (t << 12);
+        uint2 b = *reinterpret_cast<const uint2 *>(s_tab + ((y >> 13) & 0x7ff8u));  // slot (r' | b'<<4 | g'<<8) x 8 bytes
+        stuck = false;
+        for (int bit = 3; b.y == 0xffffffffu; --bit) {
+            if ((b.x & 0x40000000u) || bit < 0) {
+                stuck = true;
+                break;
+            }
+            // child number r<<2 | g<<1 | b from bit `bit` of the three coordinates, times 8 bytes: the three bits land on
+            // bits 18, 17, 16 of the product (no carries: all partial products are distinct powers of two)
+            const uint32_t sub8 = (__umul24((xc >> bit) & 0x010101u, 0x40201u) >> 13) & 0x38u;
+            b = *reinterpret_cast<const uint2 *>(s_tab + ((b.x & 0xffffffu) | sub8));
+        }
+        lo = b.x;
+        hi = b.y;
+    };
+    auto keys_of = [&](const uint32_t x, const uint32_t lo, const uint32_t hi, int &m0, int &m1, int &m2) {
+        const uint2 r0 = *reinterpret_cast<const uint2 *>(s_bytes + rec_addr<0>(lo, three));
+        const uint2 r1 = *reinterpret_cast<const uint2 *>(s_bytes + rec_addr<1>(lo, three));
+        const uint2 r2 = *reinterpret_cast<const uint2 *>(s_bytes + rec_addr<2>(lo, three));
+        const uint2 r3 = *reinterpret_cast<const uint2 *>(s_bytes + rec_addr<3>(lo, three));
+        const uint2 r4 = *reinterpret_cast<const uint2 *>(s_bytes + rec_addr<0>(hi, three));
+        const uint2 r5 = *reinterpret_cast<const uint2 *>(s_bytes + rec_addr<1>(hi, three));
+        const uint2 r6 = *reinterpret_cast<const uint2 *>(s_bytes + rec_addr<2>(hi, three));
+        const uint2 r7 = *reinterpret_cast<const uint2 *>(s_bytes + rec_addr<3>(hi, three));
+        cand8r(x, r0, r1, r2, r3, r4, r5, r6, r7, g.neg2, m0, m1, m2);
+    };
+    // decision from the three smallest keys: `nearest`, and whether the outcome depends on the order in which scipy reports
+    // equidistant entries (then the colour's tie code is needed)
+    auto decide = [&](const uint32_t x, const LeanThr &th, const int m0, const int m1, const int m2, bool &nearest) -> bool {
+        const int a0 = m0 >> kLocalBits, a1 = m1 >> kLocalBits, a2 = m2 >> kLocalBits;
+        if (MODE == 0) {
+            nearest = true;
+            return a0 == a1;
+        }
+        const int xx = (int)__builtin_amdgcn_udot4(x, x, 0u, false);
+        const uint32_t d0 = (uint32_t)(a0 + xx), d1 = (uint32_t)(a1 + xx);
+        bool eq;
+        nearest = lean_decide<MODE>(d0, d0 + d1, th, thr.sh, eq);
+        if (eq)  // the literal float64 chain decides
+            nearest = ordered_use_nearest_call((double)d0, (double)d1,
+                                               MODE == 1 ? __fmul_rn((float)th.mt, 1.0f / (float)(1u << thr.sh)) : th.t);
+        // second and third equidistant: only the SECOND entry's identity is open, and it is written only when !nearest
+        return (a0 == a1) | ((a1 == a2) & !nearest);
+    };
+    // the colour written for tie code `code` (0 when no tie matters); codes no pair expresses: exception list or fix-up pass
+    auto pick = [&](const uint32_t x, const int m0, const int m1, const int m2, const bool nearest, const uint32_t code, bool &slow) -> uint32_t {
+        uint32_t ic;
+        if (MODE == 0) ic = code;
+        else ic = (kPickTable >> (2u * (2u * code + (nearest ? 0u : 1u)))) & 3u;
+        int sel = ic == 0u ? m0 : (ic == 1u ? m1 : m2);
+        uint32_t c = *reinterpret_cast<const uint32_t *>(s_bytes + rec_addr<0>((uint32_t)sel, three));
+        if (code > (MODE == 0 ? 2u : 5u)) {
+            uint32_t pair, single;
+            if (find_exception(pal, x, pair, single)) c = pal.out_rgb[MODE == 0 ? single : (nearest ? (pair & 0xffffu) : (pair >> 16))];
+            else slow = true;
+        }
+        return c;
+    };
+    auto code_word = [&](const uint32_t xa) -> uint32_t { return MODE == 0 ? pal.code1[xa >> 4] : pal.code2[xa >> 3]; };
+    auto code_in = [&](const uint32_t w, const uint32_t x) -> uint32_t {
+        return MODE == 0 ? ((w >> ((x & 15u) * 2)) & 3u) : ((w >> ((x & 7u) * 4)) & 15u);
+    };
+    // a pixel on its own (row-straddling groups, the partial last group): position and threshold from the pixel index
+    auto single_pixel = [&](const uint32_t p) {
+        const uint8_t *b = in + (size_t)p * 3;
+        const uint32_t x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+        LeanThr th;
+        th.mt = 0;
+        th.t = 0.0f;
+        if (MODE != 0) {
+            uint32_t py, px;
+            locate(g, p, py, px);
+            if (MODE == 3) {
+                th.t = ign_threshold(g.x0 + (int)px, g.y0 + (int)py, sx, sy, sc);
+            } else {
+                uint32_t row, col;
+                thr_pos(thr, (uint32_t)g.y0 + py, (uint32_t)g.x0 + px, row, col);
+                if (MODE == 1) th.mt = smem[thr_at + row * thr.tw_pad + col];
+                else th.t = thr.fpad[row * thr.tw_pad + col];
+            }
+        }
+        uint32_t lo, hi;
+        bool stuck;
+        find_block(x, lo, hi, stuck);
+        bool slow = stuck;
+        uint32_t c = 0;
+        if (!stuck) {
+            int m0, m1, m2;
+            keys_of(x, lo, hi, m0, m1, m2);
+            bool nearest;
+            const bool need = decide(x, th, m0, m1, m2, nearest);
+            const uint32_t code = need ? code_in(code_word(x), x) : 0u;
+            c = pick(x, m0, m1, m2, nearest, code, slow);
+        }
+        uint8_t *o = out + (size_t)p * 3;
+        o[0] = (uint8_t)c;
+        o[1] = (uint8_t)(c >> 8);
+        o[2] = (uint8_t)(c >> 16);
+        if (slow) flag_slow_pixel(p, flags, g);
+    };
+
+    uint32_t tile = blockIdx.x;
+    uint32_t fy = 0, fx = 0;
+    uint3 wn = make_uint3(0u, 0u, 0u);
+    if (tile < n_tiles) {
+        const uint32_t gidx0 = tile * kCellBlock + threadIdx.x;
+        if (gidx0 < n_full) wn = in3[gidx0];
+        if (gidx0 * 4u < g.n_px) locate(g, gidx0 * 4u, fy, fx);
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t gidx = tile * kCellBlock + threadIdx.x;
+        const uint3 wc = wn;
+        const uint32_t cy = fy, cx = fx;
+        {
+            const uint32_t next = tile + gridDim.x;
+            const uint32_t gn = next * kCellBlock + threadIdx.x;
+            if (next < n_tiles && gn < n_full) wn = in3[gn];  // prefetch the next tile
+            fx += g.adv_x;
+            fy += g.adv_y;
+            if (fx >= g.w) {
+                fx -= g.w;
+                ++fy;
+            }
+            if (fy >= g.h) fy -= g.h;
+        }
+        if (lane < 4u) flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
+        if (gidx < n_full && !((MODE != 0) && (cx + 3u >= g.w))) {
+            uint32_t xq[4];
+            xq[0] = wc.x & 0xffffffu;
+            xq[1] = __builtin_amdgcn_perm(wc.y, wc.x, 0x0c050403u);
+            xq[2] = __builtin_amdgcn_perm(wc.z, wc.y, 0x0c040302u);
+            xq[3] = wc.z >> 8;
+            LeanThr th[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                th[q].mt = 0;
+                th[q].t = 0.0f;
+            }
+            if (MODE == 1 || MODE == 2) {
+                uint32_t row, col;
+                thr_pos(thr, (uint32_t)g.y0 + cy, (uint32_t)g.x0 + cx, row, col);
+                const uint32_t at = row * (uint32_t)thr.tw_pad + col;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (MODE == 1) th[q].mt = smem[thr_at + at + q];
+                    else th[q].t = thr.fpad[at + q];
+                }
+            } else if (MODE == 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) th[q].t = ign_threshold(g.x0 + (int)cx + q, g.y0 + (int)cy, sx, sy, sc);
+            }
+            uint32_t lo[4], hi[4];
+            bool stuck[4], nearest[4], need[4];
+            int m0[4], m1[4], m2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) find_block(xq[q], lo[q], hi[q], stuck[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // (a marker block's bytes name records too: the keys of a stuck pixel are computed and not used)
+                keys_of(xq[q], lo[q], hi[q], m0[q], m1[q], m2[q]);
+                need[q] = decide(xq[q], th[q], m0[q], m1[q], m2[q], nearest[q]) & !stuck[q];
+            }
+            // the tie codes of the four pixels: requested together (one round trip), only when some lane needs one at all
+            uint32_t code[4] = {0u, 0u, 0u, 0u};
+            if (__ballot(need[0] | need[1] | need[2] | need[3]) != 0ull) {
+                uint32_t w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = code_word(need[q] ? xq[q] : 0u);  // (lanes that need none read word 0: one line)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) code[q] = need[q] ? code_in(w[q], xq[q]) : 0u;
+            }
+            uint32_t col[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bool slow = stuck[q];
+                col[q] = pick(xq[q], m0[q], m1[q], m2[q], nearest[q], code[q], slow);
+                if (slow) flag_slow_pixel(gidx * 4u + (uint32_t)q, flags, g);
+            }
+            uint3 wo;
+            wo.x = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);
+            wo.y = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);
+            wo.z = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);
+            out3[gidx] = wo;
+        } else {
+            // a group that runs over the end of its row (its pixels' threshold positions differ) or the partial last group
+#pragma unroll 1
+            for (uint32_t q = 0; q < 4u; ++q)
+                if (gidx * 4u + q < g.n_px) single_pixel(gidx * 4u + q);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ordered_fast_kernel: the lean kernel's successor for uncrowded integer palettes (plain cells).
 //
 // What bounds these kernels is the number of vector instructions per pixel: profiles/microbench/valu_rate*.txt
@@ -2198,6 +2520,8 @@ int num_cus()
     return cached;
 }
 
+static inline bool env_set(const char *name) { return exp_env(name) != nullptr; }
+
 template <int MODE>
 int launch_cell(uint32_t grid, size_t lds, hipStream_t s, const uint8_t *in, uint8_t *out, unsigned long long *flags,
                 const Geo &g, const PalDev &pal, const ThrDev &thr, float sx, float sy, float sc, uint32_t n_tiles)
@@ -2298,7 +2622,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             n_words = n_tiles * (kCellBlock / 64) * 4;
             const size_t lds = sizeof(uint32_t) * ((size_t)pal.tab_words + 256);  // launch_cell (plain table) only
             // 4-entry blocks on plain cells that leave half of LDS free: two workgroups per CU (DP_LEAN_NO_HALF=1: one)
-            const bool half = lean_ok && small && !warp && !getenv("DP_LEAN_NO_HALF") &&
+            const bool half = lean_ok && small && !warp && !exp_env("DP_LEAN_NO_HALF") &&
                               lean_tab_bytes + (mode == DP_MODE_MATRIX && int_lean ? (size_t)thr.th_h * thr.tw_pad * 4 : 0) <= (size_t)kLeanHalfTabBytes;
             const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus() * (half ? 2u : 1u));
             {
@@ -2345,11 +2669,11 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             // 0.45 ms against 0.50 ms of the lean kernel; with a matrix the per-slot class branches cost more than the
             // shorter candidate network saves (0.66 against 0.55 ms), so the matrix / IGN modes stay on the lean kernel
             // unless DP_FAST_ALL is set (experiments).
-            const bool fast_mode = mode == DP_MODE_NEAREST || getenv("DP_FAST_ALL") != nullptr;
+            const bool fast_mode = mode == DP_MODE_NEAREST || exp_env("DP_FAST_ALL") != nullptr;
             const bool fast_ok = fast_mode && geo_ok && !warp && !adapt && perm != nullptr && fast_fixed <= sizeof(uint32_t) * kLeanLdsWords &&
                                  (mode == DP_MODE_NEAREST || mode == DP_MODE_IGN ||
                                   (mode == DP_MODE_MATRIX && (int_fast || thr.fpad != nullptr)));
-            const int dbg = getenv("DP_FAST_DBG") ? atoi(getenv("DP_FAST_DBG")) : 0;  // (measurement switch)
+            const int dbg = exp_env("DP_FAST_DBG") ? atoi(exp_env("DP_FAST_DBG")) : 0;  // (measurement switch)
 #define DP_FAST(M)                                                                                                        \
     do {                                                                                                                 \
         if (dbg == 1 && !small) hipLaunchKernelGGL((ordered_fast_kernel<M, 8, 1>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, sx, sy, ign_scale, n_tiles); \
@@ -2358,7 +2682,52 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
         else if (small) hipLaunchKernelGGL((ordered_fast_kernel<M, 4>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, sx, sy, ign_scale, n_tiles); \
         else hipLaunchKernelGGL((ordered_fast_kernel<M, 8>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal4, thr, sx, sy, ign_scale, n_tiles); \
     } while (0)
-            if (fast_ok && mode == DP_MODE_NEAREST) {
+            // crowded palettes: the compact kernel (the whole octree in LDS, every pixel resolved in place), two workgroups
+            // per CU when table + colours + maps + thresholds fit 80 KB
+            const size_t comp_base = pal.comp_tab ? (size_t)kCompactTabAt + 4 * (size_t)pal.comp_words : 0;
+            // (integer thresholds go to LDS behind the table; a table too large for that -- blue noise -- is read as float32 from L1)
+            const bool int_comp = mode == DP_MODE_MATRIX && thr.mpad != nullptr &&
+                                  comp_base + (size_t)thr.th_h * thr.tw_pad * 4 <= sizeof(uint32_t) * kLeanLdsWords;
+            const size_t comp_bytes = comp_base + (int_comp ? (size_t)thr.th_h * thr.tw_pad * 4 : 0);
+            const bool comp_ok = pal.comp_tab != nullptr && geo_ok && adapt && comp_bytes <= sizeof(uint32_t) * kLeanLdsWords &&
+                                 (mode == DP_MODE_NEAREST || mode == DP_MODE_IGN || (mode == DP_MODE_MATRIX && (int_comp || thr.fpad != nullptr))) &&
+                                 !env_set("DP_NO_COMPACT_KERNEL");
+            const bool comp_half = comp_ok && comp_bytes <= sizeof(uint32_t) * kCompactHalfWords && !env_set("DP_COMPACT_NO_HALF");
+            const uint32_t pgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus() * (comp_half ? 2u : 1u));
+            if (comp_ok) {
+                const uint64_t adv = ((uint64_t)pgrid * kCellBlock * 4u) % (uint64_t)hw;
+                g.adv_y = (uint32_t)(adv / (uint64_t)w);
+                g.adv_x = (uint32_t)(adv % (uint64_t)w);
+            }
+#define DP_COMP_K(M, WP, HF)                                                                                             \
+    hipLaunchKernelGGL((ordered_compact_kernel<M, WP, HF>), dim3(pgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr, sx, sy, \
+                       ign_scale, n_tiles)
+#define DP_COMP(M)                                                                                                        \
+    do {                                                                                                                 \
+        if (pal.comp_warp && comp_half) DP_COMP_K(M, true, true);                                                        \
+        else if (pal.comp_warp) DP_COMP_K(M, true, false);                                                               \
+        else if (comp_half) DP_COMP_K(M, false, true);                                                                   \
+        else DP_COMP_K(M, false, false);                                                                                 \
+    } while (0)
+            if (comp_ok && mode == DP_MODE_NEAREST) {
+                DP_COMP(0);
+                rc = DP_OK;
+                fix_mode = 0;
+            } else if (comp_ok && mode == DP_MODE_IGN) {
+                DP_COMP(3);
+                rc = DP_OK;
+                fix_mode = 3;
+            } else if (comp_ok && mode == DP_MODE_MATRIX && int_comp) {
+                DP_COMP(1);
+                rc = DP_OK;
+                fix_mode = 2;
+            } else if (comp_ok && mode == DP_MODE_MATRIX) {
+                DP_COMP(2);
+                rc = DP_OK;
+                fix_mode = 2;
+#undef DP_COMP
+#undef DP_COMP_K
+            } else if (fast_ok && mode == DP_MODE_NEAREST) {
                 DP_FAST(0);
                 rc = DP_OK;
                 fix_mode = 0;

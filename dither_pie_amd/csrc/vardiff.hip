@@ -874,7 +874,7 @@ static int64_t variance_gate_chunk(int64_t n_frames, int h, int w)
 {
     const int64_t per_frame = (int64_t)h * w * (int64_t)sizeof(float) * 2;
     int64_t budget = (int64_t)1 << 30;
-    if (const char *e = getenv("DP_GATE_CHUNK_BYTES")) budget = std::max<int64_t>(1, atoll(e));  // tests: force several chunks
+    if (const char *e = exp_env("DP_GATE_CHUNK_BYTES")) budget = std::max<int64_t>(1, atoll(e));  // tests: force several chunks
     int64_t c = per_frame > 0 ? budget / per_frame : n_frames;
     c = c < 1 ? 1 : c;
     return c < n_frames ? c : (n_frames < 1 ? 1 : n_frames);
@@ -893,7 +893,7 @@ int launch_variance_gate(const uint8_t *in, uint8_t *gate, int64_t n_frames, int
         set_error("dp_variance_gate_u8: h > 65535 not supported");
         return DP_EUNSUPPORTED;
     }
-    if (radius <= kGateMaxR && !getenv("DP_GATE_TWO_PASS")) {
+    if (radius <= kGateMaxR && !exp_env("DP_GATE_TWO_PASS")) {
         for (int64_t f0 = 0; f0 < n_frames; f0 += 65535) {
             const int64_t nf = std::min<int64_t>(65535, n_frames - f0);
             const dim3 grid((w + kGateTW - 1) / kGateTW, (h + kGateTH - 1) / kGateTH, (unsigned)nf);
@@ -947,7 +947,7 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
         int G = 1, cus = 0, dev_id = 0;
         if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
         uint32_t *gprog = nullptr;
-        if (n_frames * 2 <= cus && n_bands >= 4 && w >= 64 && !getenv("DP_ED_ONE_WG")) {
+        if (n_frames * 2 <= cus && n_bands >= 4 && w >= 64 && !exp_env("DP_ED_ONE_WG")) {
             const int nwt = n_bands < 2 * kVWaves ? n_bands : 2 * kVWaves;
             while (G * 2 <= 16 && n_frames * (G * 2) <= cus && G * 2 <= nwt) G *= 2;
             if (G > 1) {
@@ -957,7 +957,7 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
                 DP_HIP(hipMemsetAsync(gprog, 0, (size_t)n_frames * kVProgWords * sizeof(uint32_t), s));
             }
         }
-        const int test_giveup = getenv("DP_ED_TEST_GIVEUP") ? 1 : 0;
+        const int test_giveup = exp_env("DP_ED_TEST_GIVEUP") ? 1 : 0;
         const int nw1 = n_bands < kVWaves ? n_bands : kVWaves;
         // (behind a G > 1 launch: the repair launch for frames whose workgroups gave up waiting for each other)
 #define DP_VARW(C, M)                                                                                                     \

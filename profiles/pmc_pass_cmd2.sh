@@ -1,0 +1,12 @@
+#!/bin/bash
+# Like pmc_pass_cmd.sh plus a third pass for the vector-memory path (TA busy, VMEM instruction counts, L2 hits/misses) and a
+# fourth for HBM bytes.  usage: profiles/pmc_pass_cmd2.sh <outdir> <program> [args...]   (the program itself, no wrappers)
+set -u
+OUT=$1; shift
+export TMPDIR=/tmp
+mkdir -p "$OUT"
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT/p1" -- "$@" > "$OUT/p1.log" 2>&1 || exit 11
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$OUT/p2" -- "$@" > "$OUT/p2.log" 2>&1 || exit 12
+rocprofv3 --pmc TA_BUSY_avr TA_TA_BUSY_sum TCC_HIT_sum TCC_MISS_sum SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM --output-format csv -d "$OUT/p3" -- "$@" > "$OUT/p3.log" 2>&1 || echo "p3 failed (counter names?)"
+rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d "$OUT/p4" -- "$@" > "$OUT/p4.log" 2>&1 || exit 14
+echo pmc_done

@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# the tests force tables / kernels / schedules through the DP_* switches, which only libditherpie_hip_exp.so reads
+# (dither_pie_amd/_lib.py); test_release_library_* run the product library in a subprocess
+os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
