@@ -229,6 +229,26 @@ def main():
             dt = float(t.item())
         return dt
 
+    def kernel_ms(fn, reps=3):
+        """mean duration of the main kernel of one call of fn (HIP events recorded by the library on the launch stream:
+        dp_profile_*; the fix-up pass / repair launch separately) -> (main ms, second-pass ms) per call"""
+        fn()
+        torch.cuda.synchronize()
+        backend.profile_enable(True)
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        m, f2, n = backend.profile_read()
+        backend.profile_enable(False)
+        return m / reps, f2 / reps
+
+    def leg(kernel, ms, alg_bytes, **more):
+        """one structured bench leg: the kernel that dominates it, its duration per call and its algorithmic bytes against the
+        HBM roofline (6 B per dithered pixel, 3 B per pixel of a Lloyd pass)"""
+        gbs = alg_bytes / (ms * 1e-3) / 1e9
+        return {"kernel": kernel, "kernel_ms": round(ms, 4), "algorithmic_bytes": int(alg_bytes), "achieved_gbs": round(gbs, 1),
+                "frac": round(gbs / HBM_PEAK_GBS, 4), **more}
+
     # ---------------- headline: C2 --------------------------------------------------------------
     pal256 = palr(256)
     # (a video keeps its palette for every frame: the search accelerator is prepared up front, outside the timed region;
@@ -318,7 +338,12 @@ def main():
     lo, hi = rank * total // world, (rank + 1) * total // world
     d5 = ImageDitherer(16, DitherMode.BAYER, ColorReducer.generate_uniform_palette(16), False, {"size": "4x4"}).prepare()
     chunk = 100
-    f5 = make_frames(torch, min(chunk, max(1, hi - lo)), 1080, 1920, dev)
+    # the frames resident in HBM: rnd(1080, 1920, seed) of SURVEY 8(d) for the first `chunk` frames of this rank's block
+    # (seeds lo .. lo + chunk - 1, numpy legacy RNG on the host, ~3 s), re-used for every further block of `chunk` frames
+    n5f = min(chunk, max(1, hi - lo))
+    f5 = torch.empty((n5f, 1080, 1920, 3), dtype=torch.uint8, device=dev)
+    for i in range(n5f):
+        f5[i].copy_(torch.from_numpy(np.random.RandomState(lo + i).randint(0, 256, (1080, 1920, 3), dtype=np.uint8)))
     o5 = torch.empty_like(f5)
 
     def video_pass():
@@ -330,10 +355,15 @@ def main():
 
     n5 = 10  # passes between the two barriers: at 8 ranks a pass is ~0.5 ms, the same order as an RCCL barrier
     t5 = timed(video_pass, n5, 2)
+    k5_ms, _ = kernel_ms(lambda: d5.apply_dithering_frames(f5, out=o5))
     result["c5_video"] = {"metric": "1080p frames/s, Bayer 4x4 + 16 uniform colours, 1000 frames", "scaling": "strong",
                           "frames_total": total, "n_gpus": world, "frames_per_s": round(total * n5 / t5, 1), "passes": n5,
                           "frames_this_rank": hi - lo,
-                          "note": "contiguous blocks of 1000/N frames per rank, frames resident in HBM, no collective"}
+                          **leg("ordered_lean_kernel<1,4,HALF> (one launch per block of 100 frames)", k5_ms, BYTES_PER_PX * n5f * 1080 * 1920,
+                                frames_per_launch=n5f),
+                          "note": "contiguous blocks of 1000/N frames per rank, no collective; frames resident in HBM: "
+                                  f"rnd(1080,1920,seed) of SURVEY 8(d) with seeds {lo}..{lo + n5f - 1} (numpy legacy RNG), the same "
+                                  f"{n5f} frames re-used for every block of {chunk} of this rank's {hi - lo} frames"}
     del f5, o5
 
     # ---------------- secondary lines (same process, after the headline) -------------------------
@@ -378,8 +408,11 @@ def main():
         ti = timed(lambda: dmc.apply_dithering_frames(fi, out=out), 3, 1) / 3
         extra["c2_image_like_median_cut256_mpixel_per_s"] = round(world * px_per_step / ti / 1e6, 1)
         extra["c2_image_like_note"] = ("smooth frames with grain + the 256-colour median-cut palette of that content: the palette "
-                                       "crowds a few cells of the colour cube (table over warped cells, adaptive kernel, deep split "
-                                       "nodes in global memory)")
+                                       "crowds a few cells of the colour cube (one-byte-per-entry table over warped cells, the whole "
+                                       "octree in LDS, every pixel resolved in place: ordered_compact_kernel)")
+        kmc_ms, kmc_fix = kernel_ms(lambda: dmc.apply_dithering_frames(fi, out=out))
+        result["c2_crowded"] = leg("ordered_compact_kernel<1,WARP,HALF>", kmc_ms, BYTES_PER_PX * px_per_step, fixup_ms=round(kmc_fix, 4),
+                                   workload="C2-shaped: image-like frames + their own median-cut 256 palette, Bayer 8x8")
         # the same content with the reference's default palette size: 16 colours by median cut
         pal_mc16 = _CR.reduce_colors(Image.fromarray(img, "RGB"), 16)
         dmc16 = ImageDitherer(16, DitherMode.BAYER, pal_mc16, False, {"size": "8x8"}).prepare()
@@ -392,6 +425,20 @@ def main():
         dgam.apply_dithering_frames(frames, out=out)
         tgm = timed(lambda: dgam.apply_dithering_frames(frames, out=out), 3, 1) / 3
         extra["c2_use_gamma_mpixel_per_s"] = round(world * px_per_step / tgm / 1e6, 1)
+        kg_ms, kg_fix = kernel_ms(lambda: dgam.apply_dithering_frames(frames, out=out))
+        result["c2_use_gamma"] = leg("ordered_lean_float_kernel<2>", kg_ms, BYTES_PER_PX * px_per_step, fixup_ms=round(kg_fix, 4),
+                                     workload="C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in)")
+        # what the unchanged CLI / GUI sees per image: apply_dithering(PIL) on one 4K image, host -> device -> host included
+        pil_img = Image.fromarray(frames[0].cpu().numpy(), "RGB")
+        dith.apply_dithering(pil_img)
+        pil_ts = []
+        for _ in range(10):
+            t_p = time.perf_counter()
+            dith.apply_dithering(pil_img)
+            pil_ts.append((time.perf_counter() - t_p) * 1e3)
+        extra["pil_4k_ms"] = round(sorted(pil_ts)[len(pil_ts) // 2], 2)
+        extra["pil_4k_note"] = ("ImageDitherer.apply_dithering(PIL image) on one 3840x2160 image, median of 10: PIL -> pinned host "
+                                "buffer -> HBM -> kernel -> pinned host buffer -> PIL (PCIe both ways; the kernel share is ~0.02 ms)")
         del out
         from dither_pie_amd.dithering_lib import ColorReducer
         # C3: Floyd-Steinberg, 16 colours, 4K, a batch of frames (one wave per frame)
@@ -402,6 +449,10 @@ def main():
         o3 = torch.empty_like(f3)
         t3 = timed(lambda: d3.apply_dithering_frames(f3, out=o3), 2, 1) / 2
         extra["c3_fs_k16_4k_mpixel_per_s"] = round(world * nf3 * H4K * W4K / t3 / 1e6, 2)
+        k3_ms, k3_rep = kernel_ms(lambda: d3.apply_dithering_frames(f3, out=o3), 2)
+        result["c3"] = leg("ed_wavefront_kernel (one workgroup of 16 waves per frame)", k3_ms, BYTES_PER_PX * nf3 * H4K * W4K,
+                           frames_in_flight=nf3, bound="dependency chain of the raster scan (W + skew*H steps per frame), not HBM",
+                           workload="C3: Floyd-Steinberg, 16 uniform colours, 3840x2160")
         # the C3 batch as SURVEY 8(d) words it (the 24 frames of C2), and one frame: few frames in flight, each frame's
         # bands spread over several workgroups
         o24 = o3[:args.frames]
@@ -446,6 +497,10 @@ def main():
         _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False)
         tp4 = timed(lambda: _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False), 10, 2) / 10
         extra["c4_kmeans_pass_ms"] = round(tp4 * 1e3, 4)
+        k4_ms, _ = kernel_ms(lambda: _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False), 5)
+        result["c4_kmeans_pass"] = leg("kmeans_cells_kernel<false,2> (+ its candidate-list build in front)", k4_ms, 3 * (bpx.numel() // 3),
+                                       pass_ms_with_memset_and_list_build=round(tp4 * 1e3, 4), iterations_of_the_fit=int(iters4),
+                                       workload=f"C4: one Lloyd pass over this rank's band of the 7680x4320 image, K=32 ({world} band(s))")
         extra["c4_kmeans_pass_hbm_gbs"] = round(bpx.numel() / tp4 / 1e9, 1)
         extra["c4_note"] = (f"7680x4320 in {world} row band(s), Lloyd over all pixels ({iters4} iterations, one int64 "
                             "all-reduce each), blue-noise(64,42) dither of the band with global coordinates")

@@ -2689,7 +2689,7 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             const bool int_comp = mode == DP_MODE_MATRIX && thr.mpad != nullptr &&
                                   comp_base + (size_t)thr.th_h * thr.tw_pad * 4 <= sizeof(uint32_t) * kLeanLdsWords;
             const size_t comp_bytes = comp_base + (int_comp ? (size_t)thr.th_h * thr.tw_pad * 4 : 0);
-            const bool comp_ok = pal.comp_tab != nullptr && geo_ok && adapt && comp_bytes <= sizeof(uint32_t) * kLeanLdsWords &&
+            const bool comp_ok = pal.comp_tab != nullptr && geo_ok && (adapt || env_set("DP_FORCE_COMPACT")) && comp_bytes <= sizeof(uint32_t) * kLeanLdsWords &&
                                  (mode == DP_MODE_NEAREST || mode == DP_MODE_IGN || (mode == DP_MODE_MATRIX && (int_comp || thr.fpad != nullptr))) &&
                                  !env_set("DP_NO_COMPACT_KERNEL");
             const bool comp_half = comp_ok && comp_bytes <= sizeof(uint32_t) * kCompactHalfWords && !env_set("DP_COMPACT_NO_HALF");

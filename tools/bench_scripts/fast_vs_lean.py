@@ -1,5 +1,6 @@
 """C2-shaped timing of the ordered kernels (24 x 4K noise frames, 256 random colours) through the library's own HIP events:
 the fast kernel (and its measurement variants DP_FAST_DBG=1..3) against the lean kernel, interleaved in one process."""
+import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
 from dither_pie_amd import backend as be

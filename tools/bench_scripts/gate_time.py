@@ -1,4 +1,5 @@
 """Adaptive-variance diffuser at 4K, 256 frames: the variance gate and the diffusion timed separately (events)."""
+import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import os, sys; sys.path.insert(0, '.')
 import torch
 from dither_pie_amd import backend as be

@@ -1,4 +1,5 @@
 """4-entry tables: one 160 KB workgroup per CU (DP_LEAN_NO_HALF=1) against two 80 KB workgroups.  Same process, same box."""
+import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import sys, os; sys.path.insert(0, '.')
 import numpy as np, torch
 from dither_pie_amd.dithering_lib import ImageDitherer, DitherMode, ColorReducer

@@ -1,6 +1,7 @@
 """Lloyd pass over the C4 image (33 M pixels), event-timed: full scan (DP_KMEANS_CELLS=0) vs per-cell candidate lists;
 totals compared.  Also a smooth image-like input and centres that are real k-means centres of the data.
 usage: kmeans_cells_time.py [K ...]"""
+import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import sys, os; sys.path.insert(0, '.')
 import numpy as np, torch
 from dither_pie_amd import backend as be

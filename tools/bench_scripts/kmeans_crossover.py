@@ -1,5 +1,6 @@
 """Where the candidate-list Lloyd pass overtakes the full scan: event-timed passes (incl. memset and list build) over
 n pixels of uniform noise, both paths forced.  usage: kmeans_crossover.py"""
+import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import sys, os; sys.path.insert(0, '.')
 import numpy as np, torch
 from dither_pie_amd import backend as be

@@ -1,5 +1,6 @@
 """Lloyd pass over the C4 image (33 M pixels), event-timed, VALU kernel vs matrix-core kernel; totals compared.
 usage: kmeans_time.py [K ...]"""
+import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import sys, os; sys.path.insert(0, '.')
 import numpy as np, torch
 from dither_pie_amd import backend as be

@@ -1,5 +1,6 @@
 """Which cell table serves image-derived palettes best: times the image-like frames with DP_FORCE_TABLE = u4/u8/w4/w8
 (experiment behind the accelerator's choice of table; prints the accelerator's own estimates next to the timings)."""
+import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import os, sys, time; sys.path.insert(0,'.')
 import numpy as np, torch
 from PIL import Image
