@@ -323,3 +323,23 @@ def test_pipe_path_follows_rotation_metadata(tmp_path, monkeypatch, rotation, sw
     assert vp._stream_through_pipes("in.mp4", str(out_path), None, None, 64, 2, None, info, run=lambda x: x.clone()) == n
     size, body = out_path.read_bytes().split(b"\n", 1)
     assert size == f"{w}x{h}".encode() and body == frames.tobytes()
+
+
+def test_release_library_reads_no_environment():
+    """csrc/Makefile builds the sources twice: libditherpie_hip.so (the product) must not import getenv nor carry the name of
+    any DP_* experiment switch; libditherpie_hip_exp.so (-DDP_EXPERIMENTS: what this test session loads, conftest.py sets
+    DITHER_PIE_EXPERIMENTS=1) has them compiled in.  Both export the whole C ABI."""
+    import subprocess
+    from dither_pie_amd import _lib
+    here = os.path.dirname(_lib.__file__)
+    rel, exp = os.path.join(here, "libditherpie_hip.so"), os.path.join(here, "libditherpie_hip_exp.so")
+    assert os.path.exists(rel) and os.path.exists(exp)
+    assert _lib.EXPERIMENTS and _lib.LIB_PATH == exp
+    sym = {p: subprocess.run(["nm", "-D", p], capture_output=True, text=True, check=True).stdout for p in (rel, exp)}
+    assert "getenv" not in sym[rel] and "getenv" in sym[exp]
+    names = {p: set(re.findall(rb"DP_[A-Z0-9_]{3,}", open(p, "rb").read())) for p in (rel, exp)}
+    assert not (names[rel] - {b"DP_MODE_MATRIX"}), names[rel]   # (DP_MODE_MATRIX: an error message of the C ABI, not a switch)
+    assert {b"DP_KMEANS_CELLS", b"DP_FORCE_TABLE", b"DP_NO_COMPACT_KERNEL"} <= names[exp]
+    for p in (rel, exp):
+        for fn in _lib.EXPORTS:
+            assert re.search(rf"\bT {fn}\b", sym[p]), (p, fn)

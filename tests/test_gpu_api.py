@@ -303,3 +303,41 @@ def test_distinct_colours_on_device_match_numpy():
         _, first = np.unique(packed, return_index=True)
         assert np.array_equal(got, arr[np.sort(first)])
     assert torch.cuda.is_available()
+
+
+@pytest.mark.gpu
+def test_release_library_on_the_gpu(orc, tmp_path):
+    """The product library (libditherpie_hip.so, no experiment switches) in a process of its own, as a user's process loads
+    it: DP_* variables in the environment change nothing, the C2-shaped, the crowded-palette and the diffusion results equal
+    the oracle's."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from dither_pie_amd import _lib
+assert not _lib.EXPERIMENTS and _lib.LIB_PATH.endswith('libditherpie_hip.so')
+from dither_pie_amd.dithering_lib import ImageDitherer, DitherMode, ColorReducer
+from oracle import oracle as orc
+from PIL import Image
+arr = orc.rnd(270, 481, 5)
+pal = orc.palr(256)
+d = ImageDitherer(256, DitherMode.BAYER, pal, False, {'size': '8x8'}).prepare()
+out = d.apply_dithering_frames(torch.from_numpy(arr).cuda()).cpu().numpy()
+assert np.array_equal(out, orc.apply_dithering(arr, pal, 'bayer', {'size': '8x8'}))
+img = orc.imgl(240, 320, 6, 'smooth')
+mc = ColorReducer.reduce_colors(Image.fromarray(img), 256)
+d = ImageDitherer(256, DitherMode.BAYER, mc, False, {'size': '8x8'}).prepare()
+out = d.apply_dithering_frames(torch.from_numpy(img).cuda()).cpu().numpy()
+assert np.array_equal(out, orc.apply_dithering(img, mc, 'bayer', {'size': '8x8'}))
+u16 = orc.generate_uniform_palette(16)
+d = ImageDitherer(16, DitherMode.ERROR_DIFFUSION, u16, False, {'variant': 'floyd_steinberg'})
+out = d.apply_dithering_frames(torch.from_numpy(arr[:64, :96].copy()).cuda()).cpu().numpy()
+assert np.array_equal(out, orc.apply_dithering(arr[:64, :96].copy(), u16, 'error_diffusion', {'variant': 'floyd_steinberg', 'serpentine': 'false'}))
+print('release ok')
+""" % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "DITHER_PIE_EXPERIMENTS"}
+    env.update(DP_NO_COMPACT_KERNEL="1", DP_KMEANS_CELLS="0", DP_FORCE_TABLE="u8", DP_ED_TEST_GIVEUP="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "release ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
