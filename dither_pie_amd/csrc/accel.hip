@@ -680,7 +680,7 @@ int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_o
     dev.comp_tab = nullptr;
     dev.comp_words = dev.comp_warp = 0;
     {
-        const bool from_warp = wbw == 8 && dev.warp_adapt != 0;
+        const bool from_warp = wbw == 8 && (dev.warp_adapt != 0 || exp_env("DP_FORCE_COMPACT"));
         const bool from_plain = wbw == 0 && (dev.adapt != 0 || exp_env("DP_FORCE_COMPACT")) && have8 && !st.too_big;
         const std::vector<uint32_t> &src = from_warp ? wtab : tab;
         if (K <= 256 && (from_warp || from_plain) && src.size() / 4 <= (size_t)kCompactMaxWords && !exp_env("DP_NO_COMPACT")) {

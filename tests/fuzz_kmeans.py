@@ -1,6 +1,7 @@
 """Soak of the candidate-list Lloyd pass (dp_kmeans_step_u8 with DP_KMEANS_CELLS=1) against the oracle's float64 labelling:
 the case generator of tests/test_gpu_fullsize.py::test_kmeans_cell_list_fuzz over many seeds (run on the GPU box).
 usage: fuzz_kmeans.py <first seed> <seeds>"""
+import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
 from oracle import oracle as orc
@@ -36,8 +37,10 @@ def run(seed0, seeds):
                 centers = px[rs.randint(0, n, K)].astype(np.float64) + rs.choice([0.0, 0.5, 0.25])
             else:
                 centers = 5.0 + rs.rand(K, 3) * 20.0
-            s_ref, n_ref, _ = orc.kmeans_step(px, centers)
-            s, cnt, _q = be.kmeans_step(torch.from_numpy(px).cuda(), torch.from_numpy(centers))
+            # half of the cases with sklearn's tie rule (mean_dev: labels of equidistant pixels from sklearn's float64 expression)
+            mean = orc.data_mean(px) if rs.rand() < 0.5 else None
+            s_ref, n_ref, _ = orc.kmeans_step(px, centers, mean)
+            s, cnt, _q = be.kmeans_step(torch.from_numpy(px).cuda(), torch.from_numpy(centers), None if mean is None else torch.from_numpy(mean))
             cases += 1
             if not (np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(cnt.cpu().numpy(), n_ref)):
                 bad += 1

@@ -1,4 +1,5 @@
 """Randomised cross-check of the ordered / error-diffusion paths against the CPU oracle (run on the GPU box)."""
+import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
 from oracle import oracle as orc
@@ -53,6 +54,9 @@ def run(seed, N):
           mid = ((pa[pick] + pa[(pick + 1) % len(pal)]) // 2).astype(np.uint8)
           frames = np.where(rs.randint(0, 2, (nf, h, w, 1)) == 0, mid, frames)
       os.environ["DP_FORCE_TABLE"] = str(rs.choice(["", "", "u4", "u8", "w4", "w8"]))  # which cell table the accelerator uses
+      # ... and, one case in three, the compact kernel on whatever 8-entry table that leaves (crowded palettes take it anyway)
+      if rs.rand() < 0.33: os.environ["DP_FORCE_COMPACT"] = "1"
+      else: os.environ.pop("DP_FORCE_COMPACT", None)
       pal_f32, oc, lut = orc.prepare_palette(pal, gamma)
       P = be.Palette(pal_f32, oc, lut, accel=bool(rs.rand() < 0.8))
       x = torch.from_numpy(frames).cuda()
@@ -79,6 +83,7 @@ def run(seed, N):
               print("MISMATCH", it, mode, params, "K", K, "gamma", gamma, (nf, h, w), "y0x0", (y0, x0), "accel", P.accel_entries, int((out[i] != ref).any(-1).sum()), "px", flush=True)
               break
   os.environ.pop("DP_FORCE_TABLE", None)
+  os.environ.pop("DP_FORCE_COMPACT", None)
   print(f"fuzz: {N} cases, {bad} mismatching, {time.time()-t0:.1f} s")
   return bad
 

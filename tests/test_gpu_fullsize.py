@@ -490,8 +490,10 @@ def test_kmeans_cell_list_fuzz(be, orc, monkeypatch, seed):
             centers = px[rs.randint(0, n, K)].astype(np.float64) + rs.choice([0.0, 0.5, 0.25])
         else:
             centers = 5.0 + rs.rand(K, 3) * 20.0
-        s_ref, n_ref, _ = orc.kmeans_step(px, centers)
-        s, cnt, q = be.kmeans_step(torch.from_numpy(px).cuda(), torch.from_numpy(centers))
+        # half of the cases with sklearn's tie rule (mean_dev: labels of equidistant pixels from sklearn's float64 expression)
+        mean = orc.data_mean(px) if rs.rand() < 0.5 else None
+        s_ref, n_ref, _ = orc.kmeans_step(px, centers, mean)
+        s, cnt, q = be.kmeans_step(torch.from_numpy(px).cuda(), torch.from_numpy(centers), None if mean is None else torch.from_numpy(mean))
         assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(cnt.cpu().numpy(), n_ref), (seed, case, K, n, kind, ckind)
         x64 = px.astype(np.int64)
         assert int(q.sum().item()) == int((x64 * x64).sum())
