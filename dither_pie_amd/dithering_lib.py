@@ -95,6 +95,8 @@ class PaletteSource(Enum):
 
 
 _OUT_OF_SCOPE = {DitherMode.RIEMERSMA, DitherMode.WAVELET, DitherMode.HALFTONE}
+# per-pixel independent given global coordinates: these shard by row bands / tiles (sharding.dither_band); the diffusers do not
+ORDERED_MODES = {DitherMode.NONE, DitherMode.BAYER, DitherMode.BLUE_NOISE, DitherMode.INTERLEAVED_GRADIENT_NOISE, DitherMode.POLKA_DOT}
 
 
 # ------------------------------------------------------------------------------------- tap tables

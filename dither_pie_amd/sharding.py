@@ -103,7 +103,13 @@ def process_on_devices(frames_host, fn, devices=None, chunk: int = 32):
 
 def dither_band(ditherer, band, y_lo: int):
     """Dither a row band of a larger image; `y_lo` is the band's first row in the full image, so the
-    threshold tile / IGN field are addressed with global coordinates (ordered modes only)."""
+    threshold tile / IGN field are addressed with global coordinates.  Ordered modes only: an error-diffusion scan
+    carries its state across every band boundary (dithering_lib.py:680-687) and does not shard within one image."""
+    from .dithering_lib import ORDERED_MODES
+    mode = getattr(ditherer, "dither_mode", None)
+    if mode is not None and mode not in ORDERED_MODES:
+        raise ValueError(f"dither_band: mode {getattr(mode, 'value', mode)!r} does not shard "
+                         "within one image (error diffusion crosses every band boundary); ordered modes only")
     return ditherer.apply_dithering_frames(band, y0=y_lo, x0=0)
 
 

@@ -160,3 +160,12 @@ def test_frames_and_row_bands_two_ranks_equal_one_rank():
     for rank, _, video, _, whole in res:
         assert np.array_equal(video, ref_video), rank
         assert np.array_equal(whole, ref_img), rank
+
+
+def test_dither_band_is_for_ordered_modes_only():
+    """sharding.dither_band says so itself: an error-diffusion scan does not shard within one image."""
+    from dither_pie_amd import sharding
+    from dither_pie_amd.dithering_lib import DitherMode, ImageDitherer
+    d = ImageDitherer(16, DitherMode.ERROR_DIFFUSION, [(0, 0, 0), (255, 255, 255)], False, {})
+    with pytest.raises(ValueError, match="ordered modes only"):
+        sharding.dither_band(d, None, 10)
