@@ -65,6 +65,13 @@ struct Taps {
 //   dist = ((dr*dr + dg*dg) + db*db), every operation rounded to float32   (not the float64 KD-tree query), and
 // (2) an error is pushed as  work[ny, nx] = float32( float64(work[ny, nx]) + float64(err) * (float64(w_f32) / divisor) )
 //   -- the product and the sum in float64, one rounding on the store (not float32 product + float32 sum).
+// EXPERIMENTAL, UNPINNED.  An open question about numba's typing (round-2 advisor): in the reference `r` is assigned both a
+// float32 array element and the float64 literals 0.0 / 255.0; numba unifies a variable's types over all assignments, and
+// float32 with float64 unify to float64 -- then `dr`, `dist` and `err0 = r - chosen0` are float64 (float32-valued inputs, exact
+// differences), the scan no longer collapses near-equal candidates onto the lowest index and the error is not rounded to
+// float32 before the push.  This kernel and its restatement both implement the float32 scan / float32 error reading; a float64
+// error needs the clamped value and the chosen colour in the rings (6 floats per pixel instead of 3).  Which reading a real
+// numba run follows can only be settled by a fixture from a machine that has numba.
 // No fixtures pin this branch: numba is not installable in the build image (no network), so the restatement in
 // the CPU restatement (orc_error_diffusion_numba_u8) is checked against an independent numpy transcription only.
 __device__ __forceinline__ int nearest_numba_f32(const float4 *__restrict__ cand, const int K, const float o0, const float o1,

@@ -502,6 +502,8 @@ class InterleavedGradientNoiseDitherStrategy(BaseDitherStrategy):
 # imports): "python" -- the pure-Python loop (:655-690), what the reference runs in an environment without numba, pinned by
 # the golden fixtures -- or "numba" -- _error_diffusion_numba (:213-308: float32 linear-scan nearest with the lowest index
 # on ties, float64 products and sums with one rounding on the store), restated in the oracle but not pinned by fixtures.
+# EXPERIMENTAL: no numba in the build image; whether numba keeps the scan and the error in float32 (as implemented) or
+# unifies them to float64 is open (csrc/ediff.hip).
 ERROR_DIFFUSION_ARITHMETIC = os.environ.get("DITHER_PIE_ED_ARITHMETIC", "python")
 
 

@@ -650,6 +650,9 @@ int orc_error_diffusion_u8(const uint8_t *in, uint8_t *out, int h, int w, const 
 /*  float32; best_dist starts at 1e20);                                */
 /*  push: wgt = weights[k] / divisor is float64, err * wgt is float64, */
 /*  work[ny,nx] += ... adds in float64 and rounds to float32 on the    */
+/*  EXPERIMENTAL: whether numba types r / dist / err as float32 (this   */
+/*  restatement) or unifies them to float64 (r is also assigned the      */
+/*  float64 literals 0.0 / 255.0) is open; see ediff.hip.               */
 /*  store.  PARITY UNPINNED: numba cannot be installed in the build    */
 /*  image, so no reference output exists for this function.            */
 /* ------------------------------------------------------------------ */
