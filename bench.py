@@ -426,7 +426,7 @@ def main():
         tgm = timed(lambda: dgam.apply_dithering_frames(frames, out=out), 3, 1) / 3
         extra["c2_use_gamma_mpixel_per_s"] = round(world * px_per_step / tgm / 1e6, 1)
         kg_ms, kg_fix = kernel_ms(lambda: dgam.apply_dithering_frames(frames, out=out))
-        result["c2_use_gamma"] = leg("ordered_lean_float_kernel<2>", kg_ms, BYTES_PER_PX * px_per_step, fixup_ms=round(kg_fix, 4),
+        result["c2_use_gamma"] = leg("ordered_compact_float_kernel<2>", kg_ms, BYTES_PER_PX * px_per_step, fixup_ms=round(kg_fix, 4),
                                      workload="C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in)")
         # what the unchanged CLI / GUI sees per image: apply_dithering(PIL) on one 4K image, host -> device -> host included
         pil_img = Image.fromarray(frames[0].cpu().numpy(), "RGB")

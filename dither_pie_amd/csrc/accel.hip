@@ -772,8 +772,8 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
         coord4[j] = c[0] | (c[1] << 8) | (c[2] << 16);
         word[j] = (uint32_t)j * 16u;
     }
-    // layout: table[max] | reach[256]
-    const size_t bytes = sizeof(uint32_t) * kTabMaxWords + 256;
+    // layout: table[max] | reach[256] | compact table [kCompactMaxWords]
+    const size_t bytes = sizeof(uint32_t) * kTabMaxWords + 256 + sizeof(uint32_t) * kCompactMaxWords;
     uint8_t *blob = nullptr;
     uint32_t *d_masks = nullptr;
     DP_HIP(hipMalloc((void **)&blob, bytes));
@@ -825,6 +825,21 @@ int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host
     dev.n_split = st.n_split;
     dev.n_slow_blocks = st.n_slow;
     dev.max_cell = st.max_cnt;
+    // the same table with one byte per entry (the index of the candidate record) for ordered_compact_float_kernel
+    dev.comp_tab = nullptr;
+    dev.comp_words = dev.comp_warp = 0;
+    if (K <= 256 && tab.size() / 4 <= (size_t)kCompactMaxWords && !exp_env("DP_NO_COMPACT")) {
+        const std::vector<uint32_t> ct = compact_table(tab, word);  // (word[j] = 16 j: unique, so entry -> j)
+        uint32_t *d_comp = reinterpret_cast<uint32_t *>(d_reach + 256);
+        e = hipMemcpy(d_comp, ct.data(), sizeof(uint32_t) * ct.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(blob);
+            dev.ftab = nullptr;
+            return hip_fail(e, "float accelerator upload (compact table)");
+        }
+        dev.comp_tab = d_comp;
+        dev.comp_words = (int)ct.size();
+    }
     *blob_out = blob;
     *blob_bytes = bytes;
     return DP_OK;

@@ -2247,6 +2247,254 @@ __global__ __launch_bounds__(kCellBlock) void ordered_lean_float_kernel(const ui
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ordered_compact_float_kernel: float (gamma) palettes on the one-byte-per-entry table (round 3).
+// The float table of ordered_lean_float_kernel with every byte offset replaced by the record's index (accel.hip,
+// build_accel_float -> compact_table): 8 bytes per block, the 256 records {x, y, z, out_rgb} at LDS address 0 (4 KB), lut_in
+// behind them -- for an uncrowded 256-colour palette 38 KB in all.  Per pixel: three lut
+// reads, one ds_read_b64 (block), descent while it is a marker, eight record addresses by v_lshlrev_b32_sdwa and eight
+// ds_read_b128, the float32 keys (distance bits | position) and top-3 network of the lean float kernel with its
+// margins; the winners' records are found again through the block's index bytes (v_perm_b32 by position) instead of a
+// 28-instruction select chain over the eight offsets, and the float64 replay of the decision sits behind a wave-uniform
+// branch instead of being if-converted into every pixel's path; and a near tie of the float32 keys is no longer a case for
+// the fix-up pass: the same rare branch ranks the block's eight candidates in float64 (compact_float_rare), only exact
+// float64 ties remain flagged -- the fix-up pass of the 24-frame batch drops from 0.12 ms to 0.006.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kCfRecBytes = 256 * 16;
+constexpr uint32_t kCfLutAt = kCfRecBytes;
+constexpr uint32_t kCfTabAt = kCfLutAt + 256;
+
+// The rare pixels of ordered_compact_float_kernel, out of line so that their float64 arithmetic does not take registers
+// from the main loop (a call about once per 50 tiles).  what = 1: the float64 chain decides between the two winners
+// (win = i0 | i1 << 8); what = 2: neighbouring float32 keys were too close to rank -- the block's eight candidates again in
+// float64 exactly as scipy evaluates them (sq_dist3): distinct float64 distances order uniquely; an exact float64 tie for
+// first place, or for second when the second entry matters, depends on scipy's traversal order and goes to the fix-up pass
+// (bit 31 of the result).  rec: LDS address of the candidate records.  x: the pixel after lut_in.
+__device__ __noinline__ uint32_t compact_float_rare(const uint32_t what, const uint32_t x, const uint32_t blo, const uint32_t bhi,
+                                                    const uint32_t win, const float t, const int mode, const uint32_t rec)
+{
+    typedef const __attribute__((address_space(3))) float lds_f32_t;
+    auto record = [&](const uint32_t j, double p[3]) -> uint32_t {
+        lds_f32_t *r = (lds_f32_t *)(uintptr_t)(rec + (j << 4));
+        p[0] = (double)r[0];
+        p[1] = (double)r[1];
+        p[2] = (double)r[2];
+        return __float_as_uint(r[3]);
+    };
+    const double xr = (double)(x & 255u), xg = (double)((x >> 8) & 255u), xb = (double)(x >> 16);
+    uint32_t j0 = win & 255u, j1 = win >> 8;
+    bool tie = false;
+    if (what == 2u) {
+        double b0 = __longlong_as_double(0x7ff0000000000000LL), b1 = b0, b2 = b0;
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t jc = ((c < 4 ? blo : bhi) >> (8 * (c & 3))) & 255u;
+            double pc[3];
+            (void)record(jc, pc);
+            const double d = sq_dist3(pc, xr, xg, xb);
+            if (d < b0) {
+                b2 = b1;
+                b1 = b0;
+                j1 = j0;
+                b0 = d;
+                j0 = jc;
+            } else if (d < b1) {
+                b2 = b1;
+                b1 = d;
+                j1 = jc;
+            } else if (d < b2) {
+                b2 = d;
+            }
+        }
+        tie = (b0 == b1) || (mode != 0 && b1 == b2);
+    }
+    double p0[3], p1[3];
+    const uint32_t o0 = record(j0, p0), o1 = record(j1, p1);
+    bool use_nearest = true;
+    if (mode != 0) use_nearest = ordered_use_nearest(sq_dist3(p0, xr, xg, xb), sq_dist3(p1, xr, xg, xb), t);
+    return (use_nearest ? o0 : o1) | (tie ? 0x80000000u : 0u);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kCellBlock) void ordered_compact_float_kernel(const uint8_t *__restrict__ in,
+                                                                                         uint8_t *__restrict__ out,
+                                                                                         unsigned long long *__restrict__ flags,
+                                                                                         const Geo g, const PalDev pal, const ThrDev thr,
+                                                                                         const float sx, const float sy, const float sc,
+                                                                                         const uint32_t n_tiles)
+{
+    // (one workgroup per CU: with 64 registers per lane -- two workgroups -- the main loop spills and measured 10-50 % slower)
+    __shared__ __align__(16) uint32_t smem[kLeanLdsWords];
+    for (int i = threadIdx.x; i < pal.K; i += kCellBlock) *reinterpret_cast<float4 *>(&smem[4 * i]) = pal.fcand[i];
+    if (threadIdx.x < 256)
+        reinterpret_cast<uint8_t *>(smem)[kCfLutAt + threadIdx.x] = pal.lut_in ? pal.lut_in[threadIdx.x] : (uint8_t)threadIdx.x;
+    for (int i = threadIdx.x; i < pal.comp_words; i += kCellBlock) smem[kCfTabAt / 4 + i] = pal.comp_tab[i];
+    __syncthreads();
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(smem);
+    const uint8_t *s_lut = s_bytes + kCfLutAt;
+    const uint8_t *s_tab = s_bytes + kCfTabAt;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint3 *in3 = reinterpret_cast<const uint3 *>(in);
+    uint3 *out3 = reinterpret_cast<uint3 *>(out);
+    const uint32_t n_full = g.n_px >> 2;
+    uint32_t four;
+    asm volatile("v_mov_b32 %0, 4" : "=v"(four));
+
+    uint32_t tile = blockIdx.x;
+    uint32_t fy = 0, fx = 0;
+    uint3 wn = make_uint3(0u, 0u, 0u);
+    if (tile < n_tiles) {
+        const uint32_t gidx0 = tile * kCellBlock + threadIdx.x;
+        if (gidx0 < n_full) wn = in3[gidx0];
+        if (gidx0 * 4u < g.n_px) locate(g, gidx0 * 4u, fy, fx);
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t gidx = tile * kCellBlock + threadIdx.x;
+        const uint3 wc = wn;
+        {
+            const uint32_t next = tile + gridDim.x;
+            const uint32_t gn = next * kCellBlock + threadIdx.x;
+            if (next < n_tiles && gn < n_full) wn = in3[gn];  // prefetch the next tile
+        }
+        bool slow[4] = {false, false, false, false};
+        if (gidx < n_full) {
+            uint32_t xs[4];
+            xs[0] = wc.x & 0xffffffu;
+            xs[1] = __builtin_amdgcn_perm(wc.y, wc.x, 0x0c050403u);
+            xs[2] = __builtin_amdgcn_perm(wc.z, wc.y, 0x0c040302u);
+            xs[3] = wc.z >> 8;
+            float tq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (MODE == 2) {
+                uint32_t row, col;
+                thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
+                const uint32_t at = row * (uint32_t)thr.tw_pad + col;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tq[q] = thr.fpad[at + q];
+            } else if (MODE == 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tq[q] = ign_threshold(g.x0 + (int)fx + q, g.y0 + (int)fy, sx, sy, sc);
+            }
+            const bool straddle = (MODE != 0) && (fx + 3u >= g.w);
+            uint32_t col[4], blo[4], bhi[4], win[4];  // win: index bytes of the two winners (i0 | i1 << 8)
+            // what is left for the rare branch below: 1 = the float64 chain decides between the two winners,
+            // 2 = neighbouring float32 keys too close to rank: all eight candidates again in float64
+            uint32_t rare[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t r = s_lut[xs[q] & 255u], gg = s_lut[(xs[q] >> 8) & 255u], b = s_lut[xs[q] >> 16];
+                const uint32_t x = r | (gg << 8) | (b << 16);
+                const uint32_t t = x & 0xf0f0f0u, y = t | (t << 12);
+                uint2 blk = *reinterpret_cast<const uint2 *>(s_tab + ((y >> 13) & 0x7ff8u));
+                bool s = straddle;
+                for (int bit = 3; blk.y == 0xffffffffu; --bit) {
+                    if ((blk.x & 0x40000000u) || bit < 0) {
+                        s = true;  // a single colour with more than 8 candidates: fix-up pass
+                        blk = make_uint2(0u, 0u);  // any valid entries
+                        break;
+                    }
+                    const uint32_t sub8 = (__umul24((x >> bit) & 0x010101u, 0x40201u) >> 13) & 0x38u;
+                    blk = *reinterpret_cast<const uint2 *>(s_tab + ((blk.x & 0xffffffu) | sub8));
+                }
+                blo[q] = blk.x;
+                bhi[q] = blk.y;
+                const float4 c0 = *reinterpret_cast<const float4 *>(s_bytes + rec_addr<0>(blk.x, four));
+                const float4 c1 = *reinterpret_cast<const float4 *>(s_bytes + rec_addr<1>(blk.x, four));
+                const float4 c2 = *reinterpret_cast<const float4 *>(s_bytes + rec_addr<2>(blk.x, four));
+                const float4 c3 = *reinterpret_cast<const float4 *>(s_bytes + rec_addr<3>(blk.x, four));
+                const float4 c4 = *reinterpret_cast<const float4 *>(s_bytes + rec_addr<0>(blk.y, four));
+                const float4 c5 = *reinterpret_cast<const float4 *>(s_bytes + rec_addr<1>(blk.y, four));
+                const float4 c6 = *reinterpret_cast<const float4 *>(s_bytes + rec_addr<2>(blk.y, four));
+                const float4 c7 = *reinterpret_cast<const float4 *>(s_bytes + rec_addr<3>(blk.y, four));
+                const float fr = (float)r, fg = (float)gg, fb = (float)b;
+                int key[8];
+                auto keyof = [&](const float4 cc, const uint32_t c) -> int {
+                    const float dx = cc.x - fr, dy = cc.y - fg, dz = cc.z - fb;
+                    const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    return (int)((__float_as_uint(d) & ~7u) | c);
+                };
+                key[0] = keyof(c0, 0u);
+                key[1] = keyof(c1, 1u);
+                key[2] = keyof(c2, 2u);
+                key[3] = keyof(c3, 3u);
+                key[4] = keyof(c4, 4u);
+                key[5] = keyof(c5, 5u);
+                key[6] = keyof(c6, 6u);
+                key[7] = keyof(c7, 7u);
+                int m0 = min(min(key[0], key[1]), key[2]);
+                int m1 = med3_i32(key[0], key[1], key[2]);
+                int m2 = max(max(key[0], key[1]), key[2]);
+#pragma unroll
+                for (int c = 3; c < 8; ++c) {
+                    m2 = med3_i32(m1, m2, key[c]);
+                    m1 = med3_i32(m0, m1, key[c]);
+                    m0 = min(m0, key[c]);
+                }
+                bool close = (m1 - m0) <= kFloatKeyGap;
+                if (MODE != 0) close |= (m2 - m1) <= kFloatKeyGap;
+                // the winners' records: index byte number (key & 7) of the block
+                const uint32_t i0 = __builtin_amdgcn_perm(blk.y, blk.x, 0x0c0c0c00u | ((uint32_t)m0 & 7u));
+                const uint32_t i1 = __builtin_amdgcn_perm(blk.y, blk.x, 0x0c0c0c00u | ((uint32_t)m1 & 7u));
+                win[q] = i0 | (i1 << 8);
+                uint32_t cpick = *reinterpret_cast<const uint32_t *>(s_bytes + (i0 << 4) + 12);  // the winner's output colour
+                uint32_t what = (close && !s) ? 2u : 0u;
+                if (MODE != 0) {
+                    const uint32_t cnext = *reinterpret_cast<const uint32_t *>(s_bytes + (i1 << 4) + 12);
+                    // the decision s0/(s0+s1) <= t in float32 first (see ordered_lean_float_kernel): a gap of more than 2e-5
+                    // to the threshold settles it; closer pixels (about one in 10^4) replay the float64 chain below
+                    const float s0f = __uint_as_float((uint32_t)m0 & ~7u), s1f = __uint_as_float((uint32_t)m1 & ~7u);
+                    const float gap = __fdividef(s0f, s0f + s1f) - tq[q];
+                    if (what == 0u && !s && fabsf(gap) <= 2e-5f) what = 1u;
+                    if (!(gap <= 0.0f)) cpick = cnext;
+                }
+                rare[q] = what;
+                slow[q] = s;
+                col[q] = cpick;
+            }
+            if (__ballot((rare[0] | rare[1] | rare[2] | rare[3]) != 0u) != 0ull) {  // wave-uniform: about one tile in 50
+                const uint32_t rec = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) {
+                    // (dynamic indexing of the per-pixel registers would spill them: select by compare)
+                    const uint32_t what = q == 0 ? rare[0] : q == 1 ? rare[1] : q == 2 ? rare[2] : rare[3];
+                    if (what != 0u) {
+                        const uint32_t xv = q == 0 ? xs[0] : q == 1 ? xs[1] : q == 2 ? xs[2] : xs[3];
+                        const uint32_t x = (uint32_t)s_lut[xv & 255u] | ((uint32_t)s_lut[(xv >> 8) & 255u] << 8) | ((uint32_t)s_lut[xv >> 16] << 16);
+                        const uint32_t res = compact_float_rare(what, x, q == 0 ? blo[0] : q == 1 ? blo[1] : q == 2 ? blo[2] : blo[3],
+                                                                q == 0 ? bhi[0] : q == 1 ? bhi[1] : q == 2 ? bhi[2] : bhi[3],
+                                                                q == 0 ? win[0] : q == 1 ? win[1] : q == 2 ? win[2] : win[3],
+                                                                q == 0 ? tq[0] : q == 1 ? tq[1] : q == 2 ? tq[2] : tq[3], MODE, rec);
+                        const uint32_t c = res & 0xffffffu;
+                        const bool tie = (res >> 31) != 0u;
+                        if (q == 0) { col[0] = c; slow[0] |= tie; }
+                        else if (q == 1) { col[1] = c; slow[1] |= tie; }
+                        else if (q == 2) { col[2] = c; slow[2] |= tie; }
+                        else { col[3] = c; slow[3] |= tie; }
+                    }
+                }
+            }
+            uint3 wo;
+            wo.x = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);
+            wo.y = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);
+            wo.z = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);
+            out3[gidx] = wo;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) slow[q] = gidx * 4u + (uint32_t)q < g.n_px;  // the partial last group
+        }
+        if (__ballot(slow[0] | slow[1] | slow[2] | slow[3]) != 0ull)
+            store_flags(flags, g.dirty, gidx, slow);
+        else if (lane < 4u)
+            flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
+        fx += g.adv_x;
+        fy += g.adv_y;
+        if (fx >= g.w) {
+            fx -= g.w;
+            ++fy;
+        }
+        if (fy >= g.h) fy -= g.h;
+    }
+}
+
 // General palettes (non-integer: gamma on) -- float64 brute force with the reference's arithmetic.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void ordered_f64_kernel(const uint8_t *__restrict__ in,
@@ -2782,11 +3030,18 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
             // float (gamma) palettes with a cell table
             const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
             n_words = n_tiles * (kCellBlock / 64) * 4;
+            // the one-byte-per-entry table (K <= 256): records + lut + table in LDS
+            const size_t cf_bytes = pal.comp_tab ? (size_t)kCfTabAt + 4 * (size_t)pal.comp_words : 0;
+            const bool cf_ok = pal.comp_tab != nullptr && cf_bytes <= sizeof(uint32_t) * kLeanLdsWords && !env_set("DP_NO_COMPACT_KERNEL");
             const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus());
             const uint64_t adv = ((uint64_t)cgrid * kCellBlock * 4u) % (uint64_t)hw;
             g.adv_y = (uint32_t)(adv / (uint64_t)w);
             g.adv_x = (uint32_t)(adv % (uint64_t)w);
-#define DP_LEANF(M) hipLaunchKernelGGL(ordered_lean_float_kernel<M>, dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles)
+#define DP_LEANF(M)                                                                                                      \
+    do {                                                                                                                 \
+        if (cf_ok) hipLaunchKernelGGL((ordered_compact_float_kernel<M>), dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles); \
+        else hipLaunchKernelGGL(ordered_lean_float_kernel<M>, dim3(cgrid), dim3(kCellBlock), 0, s, in_c, out_c, fl, g, pal, thr, sx, sy, ign_scale, n_tiles); \
+    } while (0)
             if (mode == DP_MODE_NEAREST) {
                 DP_LEANF(0);
                 fix_mode = 0;
