@@ -2323,12 +2323,21 @@ __global__ __launch_bounds__(kCellBlock) void ordered_compact_float_kernel(const
                                                                                          const float sx, const float sy, const float sc,
                                                                                          const uint32_t n_tiles)
 {
-    // (one workgroup per CU: with 64 registers per lane -- two workgroups -- the main loop spills and measured 10-50 % slower)
+    // One workgroup per CU.  Two of 1024 lanes (64 registers per lane) spill in the main loop and measured 10-50 % slower; three
+    // of 512 lanes (80 registers, 6 waves per SIMD, no spills) measured the same as one of 1024: the kernel is bound by its
+    // instruction and LDS throughput, not by latency.
     __shared__ __align__(16) uint32_t smem[kLeanLdsWords];
     for (int i = threadIdx.x; i < pal.K; i += kCellBlock) *reinterpret_cast<float4 *>(&smem[4 * i]) = pal.fcand[i];
     if (threadIdx.x < 256)
         reinterpret_cast<uint8_t *>(smem)[kCfLutAt + threadIdx.x] = pal.lut_in ? pal.lut_in[threadIdx.x] : (uint8_t)threadIdx.x;
     for (int i = threadIdx.x; i < pal.comp_words; i += kCellBlock) smem[kCfTabAt / 4 + i] = pal.comp_tab[i];
+    // MODE 2: the padded float32 threshold table behind the cell table when it fits (every Bayer / blue-noise size does)
+    const uint32_t thr_at = kCfTabAt / 4 + (uint32_t)pal.comp_words;
+    const bool thr_lds = MODE == 2 && (size_t)thr_at + (size_t)thr.th_h * thr.tw_pad <= (size_t)kLeanLdsWords;
+    if (thr_lds) {
+        const int n = thr.th_h * thr.tw_pad;
+        for (int i = threadIdx.x; i < n; i += kCellBlock) smem[thr_at + i] = __float_as_uint(thr.fpad[i]);
+    }
     __syncthreads();
     const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(smem);
     const uint8_t *s_lut = s_bytes + kCfLutAt;
@@ -2369,7 +2378,7 @@ __global__ __launch_bounds__(kCellBlock) void ordered_compact_float_kernel(const
                 thr_pos(thr, (uint32_t)g.y0 + fy, (uint32_t)g.x0 + fx, row, col);
                 const uint32_t at = row * (uint32_t)thr.tw_pad + col;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) tq[q] = thr.fpad[at + q];
+                for (int q = 0; q < 4; ++q) tq[q] = thr_lds ? __uint_as_float(smem[thr_at + at + q]) : thr.fpad[at + q];
             } else if (MODE == 3) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) tq[q] = ign_threshold(g.x0 + (int)fx + q, g.y0 + (int)fy, sx, sy, sc);
@@ -2408,6 +2417,9 @@ __global__ __launch_bounds__(kCellBlock) void ordered_compact_float_kernel(const
                 const float fr = (float)r, fg = (float)gg, fb = (float)b;
                 int key[8];
                 auto keyof = [&](const float4 cc, const uint32_t c) -> int {
+                    // (naming the fourth word keeps the read a ds_read_b128: 4 LDS cycles per wave in groups of 16 lanes over 64
+                    // banks, where the ds_read_b96 the compiler would narrow it to takes 8 in groups of 8 over 32)
+                    asm volatile("" ::"v"(cc.w));
                     const float dx = cc.x - fr, dy = cc.y - fg, dz = cc.z - fb;
                     const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     return (int)((__float_as_uint(d) & ~7u) | c);
@@ -2442,8 +2454,10 @@ __global__ __launch_bounds__(kCellBlock) void ordered_compact_float_kernel(const
                     // the decision s0/(s0+s1) <= t in float32 first (see ordered_lean_float_kernel): a gap of more than 2e-5
                     // to the threshold settles it; closer pixels (about one in 10^4) replay the float64 chain below
                     const float s0f = __uint_as_float((uint32_t)m0 & ~7u), s1f = __uint_as_float((uint32_t)m1 & ~7u);
-                    const float gap = __fdividef(s0f, s0f + s1f) - tq[q];
-                    if (what == 0u && !s && fabsf(gap) <= 2e-5f) what = 1u;
+                    // s0/(s0+s1) - t without the division: (s0 - t S) / S, compared with a margin of 2e-5 S
+                    const float S = s0f + s1f;
+                    const float gap = fmaf(-tq[q], S, s0f);
+                    if (what == 0u && !s && fabsf(gap) <= 2e-5f * S) what = 1u;
                     if (!(gap <= 0.0f)) cpick = cnext;
                 }
                 rare[q] = what;
@@ -3028,11 +3042,11 @@ int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int
                    (size_t)pal.ftab_words * 4 + (size_t)pal.K * 16 + 256 <= sizeof(uint32_t) * kLeanLdsWords &&  // staged part
                    (mode != DP_MODE_MATRIX || thr.fpad != nullptr)) {
             // float (gamma) palettes with a cell table
-            const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
-            n_words = n_tiles * (kCellBlock / 64) * 4;
             // the one-byte-per-entry table (K <= 256): records + lut + table in LDS
             const size_t cf_bytes = pal.comp_tab ? (size_t)kCfTabAt + 4 * (size_t)pal.comp_words : 0;
             const bool cf_ok = pal.comp_tab != nullptr && cf_bytes <= sizeof(uint32_t) * kLeanLdsWords && !env_set("DP_NO_COMPACT_KERNEL");
+            const uint32_t n_tiles = (groups + kCellBlock - 1) / kCellBlock;
+            n_words = n_tiles * (kCellBlock / 64) * 4;
             const uint32_t cgrid = std::min<uint32_t>(n_tiles, (uint32_t)num_cus());
             const uint64_t adv = ((uint64_t)cgrid * kCellBlock * 4u) % (uint64_t)hw;
             g.adv_y = (uint32_t)(adv / (uint64_t)w);

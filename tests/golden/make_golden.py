@@ -145,6 +145,19 @@ CASES += [
     ("c3_ed_fs_U16_rnd4k", "error_diffusion", {"variant": "floyd_steinberg", "serpentine": "false"}, ("U", 16),
      ("rnd", 2160, 3840, 1234), False, False),
 ]
+# Round 3: the kernels for crowded palettes (ordered_compact_kernel) and for use_gamma (ordered_compact_float_kernel) at 1080p,
+# hashed by the reference: image-like content with its own median-cut 256 palette (the reference's default palette source),
+# all three ordered decision modes, and the float path on noise and on image-like content.
+CASES += [
+    ("r3_bayer8_mc256_smooth1080", "bayer", {"size": "8x8"}, ("mc", 256), ("imgl", 1080, 1920, 31, "smooth"), False, False),
+    ("r3_none_mc256_dark1080", "none", {}, ("mc", 256), ("imgl", 1080, 1920, 32, "dark"), False, False),
+    ("r3_ign_mc128_smooth1080", "IGN", {"scale": 1.5, "seed": 3}, ("mc", 128), ("imgl", 1080, 1920, 33, "smooth"), False, False),
+    ("r3_blue64_mc256_dark1080", "blue_noise", {"size": 64, "seed": 42}, ("mc", 256), ("imgl", 1080, 1920, 34, "dark"), False, False),
+    ("r3_bayer8_p256_gamma_rnd1080", "bayer", {"size": "8x8"}, ("palr", 256), ("rnd", 1080, 1920, 35), True, False),
+    ("r3_none_p256_gamma_rnd1080", "none", {}, ("palr", 256, 9), ("rnd", 1080, 1920, 36), True, False),
+    ("r3_ign_mc256_gamma_smooth1080", "IGN", {}, ("mc", 256), ("imgl", 1080, 1920, 37, "smooth"), True, False),
+    ("r3_bayer4_p64_gamma_grad1080", "bayer", {"size": "4x4"}, ("palr", 64), ("grad", 1080, 1920), True, False),
+]
 for v in ED_VARIANTS:
     for s in ("false", "true"):
         CASES.append((f"ed_{v}_{s}_U16_grad", "error_diffusion", {"variant": v, "serpentine": s},
