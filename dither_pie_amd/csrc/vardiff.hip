@@ -63,6 +63,7 @@ __device__ __forceinline__ int nearest_any(const PalDev &pal, const float4 *__re
     int i0 = 0;
     const int K = pal.K;
     auto visit = [&](const float4 c, const int j) {
+        keep_record_whole(c);  // (ds_read_b128 instead of the narrowed ds_read_b96: ed_nearest.hip.h)
         const float a = c.x - o0, b = c.y - o1, cc = c.z - o2;
         const float d = __fmaf_rn(a, a, __fmaf_rn(b, b, cc * cc));
         const bool lt0 = d < b0;
