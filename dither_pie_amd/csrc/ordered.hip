@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(kCellBlock, HALF ? 8 : 4) void ordered_compact_kern
         return MODE == 0 ? ((w >> ((x & 15u) * 2)) & 3u) : ((w >> ((x & 7u) * 4)) & 15u);
     };
     // a pixel on its own (row-straddling groups, the partial last group): position and threshold from the pixel index
-    auto single_pixel = [&](const uint32_t p) {
+    auto single_pixel = [&](const uint32_t p) -> bool {
         const uint8_t *b = in + (size_t)p * 3;
         const uint32_t x = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
         LeanThr th;
@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(kCellBlock, HALF ? 8 : 4) void ordered_compact_kern
         o[0] = (uint8_t)c;
         o[1] = (uint8_t)(c >> 8);
         o[2] = (uint8_t)(c >> 16);
-        if (slow) flag_slow_pixel(p, flags, g);
+        return slow;
     };
 
     uint32_t tile = blockIdx.x;
@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(kCellBlock, HALF ? 8 : 4) void ordered_compact_kern
             }
             if (fy >= g.h) fy -= g.h;
         }
-        if (lane < 4u) flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
+        bool slowq[4] = {false, false, false, false};  // pixels left to the fix-up pass (single colours with more than 8 candidates, codes no pair expresses)
         if (gidx < n_full && !((MODE != 0) && (cx + 3u >= g.w))) {
             uint32_t xq[4];
             xq[0] = wc.x & 0xffffffu;
@@ -1534,7 +1534,7 @@ __global__ __launch_bounds__(kCellBlock, HALF ? 8 : 4) void ordered_compact_kern
             for (int q = 0; q < 4; ++q) {
                 bool slow = stuck[q];
                 col[q] = pick(xq[q], m0[q], m1[q], m2[q], nearest[q], code[q], slow);
-                if (slow) flag_slow_pixel(gidx * 4u + (uint32_t)q, flags, g);
+                slowq[q] = slow;
             }
             uint3 wo;
             wo.x = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);
@@ -1544,9 +1544,21 @@ __global__ __launch_bounds__(kCellBlock, HALF ? 8 : 4) void ordered_compact_kern
         } else {
             // a group that runs over the end of its row (its pixels' threshold positions differ) or the partial last group
 #pragma unroll 1
-            for (uint32_t q = 0; q < 4u; ++q)
-                if (gidx * 4u + q < g.n_px) single_pixel(gidx * 4u + q);
+            for (uint32_t q = 0; q < 4u; ++q) {
+                if (gidx * 4u + q < g.n_px) {
+                    const bool sl = single_pixel(gidx * 4u + q);
+                    slowq[0] |= sl & (q == 0u);  // (no dynamic register indexing)
+                    slowq[1] |= sl & (q == 1u);
+                    slowq[2] |= sl & (q == 2u);
+                    slowq[3] |= sl & (q == 3u);
+                }
+            }
         }
+        // the wave tile's flag words: plain stores of the four ballots (usually zero), the tile queued for the fix-up pass if not
+        if (__ballot(slowq[0] | slowq[1] | slowq[2] | slowq[3]) != 0ull)
+            store_flags(flags, g.dirty, gidx, slowq);
+        else if (lane < 4u)
+            flags[(size_t)(gidx >> 6) * 4 + lane] = 0ull;
     }
 }
 
