@@ -64,6 +64,8 @@ _SIGS = {
     "dp_kmeans_update": (_i, [_vp, _vp, _vp, _vp, _i, C.c_double, _i, _vp]),
     "dp_kmeans_plusplus_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "dp_resize_nearest_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "dp_pyset_order_host": (_i, [_vp, _i64, _vp, C.POINTER(_i64)]),
+    "dp_median_cut_host": (_i, [_vp, _i64, _i, _vp, C.POINTER(_i)]),
     "dp_profile_enable": (_i, [_i]),
     "dp_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
 }

@@ -745,6 +745,37 @@ int dp_kmeans_plusplus_u8(const uint8_t *sample_dev, int n, int K, int first, co
     return launch_kmeans_pp(sample_dev, n, K, first, uniforms_dev, n_trials, ids_dev, centers_dev, (hipStream_t)stream);
 }
 
+int dp_pyset_order_host(const uint8_t *rgb_host, int64_t n, uint32_t *order_out, int64_t *n_distinct)
+{
+    if (!rgb_host || n < 0 || n > ((int64_t)1 << 31) - 2 || !order_out || !n_distinct) {
+        set_error("dp_pyset_order_host: bad argument");
+        return DP_EINVAL;
+    }
+    std::vector<uint32_t> order;
+    pyset_order(rgb_host, (size_t)n, order);
+    std::copy(order.begin(), order.end(), order_out);
+    *n_distinct = (int64_t)order.size();
+    return DP_OK;
+}
+
+int dp_median_cut_host(const uint8_t *rgb_host, int64_t n, int depth, int32_t *palette_out, int *n_out)
+{
+    if (!rgb_host || n < 0 || n > ((int64_t)1 << 31) - 2 || depth < 0 || depth > 10 || !palette_out || !n_out) {
+        set_error("dp_median_cut_host: bad argument");
+        return DP_EINVAL;
+    }
+    std::vector<uint32_t> order;
+    pyset_order(rgb_host, (size_t)n, order);
+    std::vector<uint8_t> colours(3 * order.size() + 3), scratch(3 * order.size() + 3);
+    for (size_t i = 0; i < order.size(); ++i)
+        for (int c = 0; c < 3; ++c) colours[3 * i + c] = rgb_host[3 * (size_t)order[i] + c];
+    std::vector<int32_t> out;
+    median_cut_rgb(colours.data(), scratch.data(), order.size(), depth, out);
+    std::copy(out.begin(), out.end(), palette_out);
+    *n_out = (int)(out.size() / 3);
+    return DP_OK;
+}
+
 int dp_resize_nearest_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, int oh,
                          int ow, void *stream)
 {

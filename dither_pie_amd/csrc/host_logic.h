@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <initializer_list>
 #include <limits>
 #include <numeric>
 #include <thread>
@@ -818,6 +819,150 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
             }
         });
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Median cut as the reference runs it (ColorReducer.reduce_colors, dithering_lib.py:1813-1843):
+//     median_cut(list(set(image.getdata())), depth)
+// The cut sorts stably, so the ITERATION ORDER OF THE PYTHON SET is observable in the palette.  That order is a pure
+// function of the insertion sequence: CPython's tuple hash (xxHash-style, Objects/tupleobject.c, 3.8+; small ints hash to
+// themselves) and the open-addressing table of Objects/setobject.c (linear probes of 9 + perturbed jumps, growth to
+// used*4 -- used*2 above 50 000 -- whenever fill*5 >= mask*3, re-insertion in slot order).  pyset_order() replays it and
+// returns the elements in the order `list(set(...))` yields them, without creating a Python object per colour (1.2 M
+// tuples of a 4K photograph: ~1 s of interpreter time).  The Python side checks the replay against the running
+// interpreter's own set once per process and keeps building real sets if they ever disagree.
+// ---------------------------------------------------------------------------------------------
+inline uint64_t py_tuple3_hash(const uint64_t a, const uint64_t b, const uint64_t c)
+{
+    constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
+    uint64_t acc = P5;
+    for (const uint64_t lane : {a, b, c}) {
+        acc += lane * P2;
+        acc = (acc << 31) | (acc >> 33);
+        acc *= P1;
+    }
+    acc += 3ULL ^ (P5 ^ 3527539ULL);
+    return acc == ~0ULL ? 1546275796ULL : acc;
+}
+
+// rgb: n colours (3 bytes each) in insertion order, duplicates allowed.  order: for every element of the resulting set, in
+// the set's iteration order, the index of its first occurrence in rgb.
+inline void pyset_order(const uint8_t *rgb, const size_t n, std::vector<uint32_t> &order)
+{
+    constexpr size_t kLinearProbes = 9;
+    constexpr int kPerturbShift = 5;
+    size_t mask = 7, fill = 0;
+    std::vector<uint64_t> th(8, 0);   // hash of the entry in a slot
+    std::vector<uint32_t> ti(8, 0);   // index of its colour + 1 (0 = unused slot)
+    auto same = [&](const uint32_t slot_idx, const size_t k) {
+        const uint8_t *p = rgb + 3 * (size_t)(slot_idx - 1), *q = rgb + 3 * k;
+        return p[0] == q[0] && p[1] == q[1] && p[2] == q[2];
+    };
+    auto insert_clean = [&](std::vector<uint64_t> &nh, std::vector<uint32_t> &ni, const size_t m, const uint64_t h, const uint32_t idx1) {
+        uint64_t perturb = h;
+        size_t i = (size_t)h & m;
+        for (;;) {
+            if (ni[i] == 0) {
+                nh[i] = h;
+                ni[i] = idx1;
+                return;
+            }
+            if (i + kLinearProbes <= m)
+                for (size_t j = 1; j <= kLinearProbes; ++j)
+                    if (ni[i + j] == 0) {
+                        nh[i + j] = h;
+                        ni[i + j] = idx1;
+                        return;
+                    }
+            perturb >>= kPerturbShift;
+            i = (i * 5 + 1 + (size_t)perturb) & m;
+        }
+    };
+    for (size_t k = 0; k < n; ++k) {
+        const uint64_t h = py_tuple3_hash(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]);
+        uint64_t perturb = h;
+        size_t i = (size_t)h & mask;
+        bool added = false;
+        for (bool done = false; !done;) {
+            size_t probes = i + kLinearProbes <= mask ? kLinearProbes : 0;
+            for (size_t j = i;; ++j) {
+                if (ti[j] == 0) {
+                    th[j] = h;
+                    ti[j] = (uint32_t)k + 1u;
+                    added = done = true;
+                    break;
+                }
+                if (th[j] == h && same(ti[j], k)) {
+                    done = true;  // already in the set
+                    break;
+                }
+                if (probes == 0) break;
+                --probes;
+            }
+            if (!done) {
+                perturb >>= kPerturbShift;
+                i = (i * 5 + 1 + (size_t)perturb) & mask;
+            }
+        }
+        if (added && ++fill * 5 >= mask * 3) {
+            const size_t minused = fill > 50000 ? fill * 2 : fill * 4;  // (no deletions: used == fill)
+            size_t newsize = 8;
+            while (newsize <= minused) newsize <<= 1;
+            std::vector<uint64_t> nh(newsize, 0);
+            std::vector<uint32_t> ni(newsize, 0);
+            for (size_t slot = 0; slot <= mask; ++slot)
+                if (ti[slot] != 0) insert_clean(nh, ni, newsize - 1, th[slot], ti[slot]);
+            th.swap(nh);
+            ti.swap(ni);
+            mask = newsize - 1;
+        }
+    }
+    order.clear();
+    order.reserve(fill);
+    for (size_t slot = 0; slot <= mask; ++slot)
+        if (ti[slot] != 0) order.push_back(ti[slot] - 1u);
+}
+
+// median_cut(colors, depth) of the reference (dithering_lib.py:1822-1833) on n colours in list order: the first widest
+// channel, a STABLE sort on it (a counting sort over the 256 values), split at n // 2, at depth 0 the per-channel mean
+// int(sum / n) (true division in float64, truncated); an empty bucket yields the single entry (0, 0, 0) at any depth.
+// rgb is permuted in place (scratch: n * 3 bytes); the palette entries are appended to out (3 ints each).
+inline void median_cut_rgb(uint8_t *rgb, uint8_t *scratch, const size_t n, const int depth, std::vector<int32_t> &out)
+{
+    if (n == 0) {
+        out.insert(out.end(), {0, 0, 0});
+        return;
+    }
+    if (depth == 0) {
+        uint64_t s[3] = {0, 0, 0};
+        for (size_t i = 0; i < n; ++i)
+            for (int c = 0; c < 3; ++c) s[c] += rgb[3 * i + c];
+        for (int c = 0; c < 3; ++c) out.push_back((int32_t)((double)s[c] / (double)n));
+        return;
+    }
+    int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const int v = rgb[3 * i + c];
+            lo[c] = v < lo[c] ? v : lo[c];
+            hi[c] = v > hi[c] ? v : hi[c];
+        }
+    int ch = 0;
+    for (int c = 1; c < 3; ++c)
+        if (hi[c] - lo[c] > hi[ch] - lo[ch]) ch = c;  // the first of equal spans
+    size_t start[257] = {0};
+    for (size_t i = 0; i < n; ++i) ++start[rgb[3 * i + ch] + 1];
+    for (int v = 0; v < 256; ++v) start[v + 1] += start[v];
+    for (size_t i = 0; i < n; ++i) {
+        const size_t at = start[rgb[3 * i + ch]]++;
+        scratch[3 * at] = rgb[3 * i];
+        scratch[3 * at + 1] = rgb[3 * i + 1];
+        scratch[3 * at + 2] = rgb[3 * i + 2];
+    }
+    std::copy(scratch, scratch + 3 * n, rgb);
+    const size_t half = n / 2;
+    median_cut_rgb(rgb, scratch, half, depth - 1, out);
+    median_cut_rgb(rgb + 3 * half, scratch + 3 * half, n - half, depth - 1, out);
 }
 
 }  // namespace dp

@@ -12,6 +12,9 @@
 //                                     accel_scan_kernel computes on the device), nearest sets, staging orders, wide
 //                                     lists, node reordering, warp maps; checks on sampled colours that the block a
 //                                     kernel would reach holds all of T(x)
+//   host_xxx mediancut <rgb.u8> <n> <depth>   the replay of CPython's set order + the counting-sort median cut; prints the
+//                                     palette and the first 2000 entries of the order (compared with the interpreter's own
+//                                     set and with the Python cut by the test)
 // Exit code 0 = all checks passed (and the sanitizer had nothing to say).
 #include <cstdio>
 #include <cstdlib>
@@ -299,12 +302,38 @@ static int run_accel(const std::vector<double> &pts, int K, int bw)
     return (bad || warp_bad) ? 1 : 0;
 }
 
+// ---- median cut (set-order replay + counting-sort cut) ----------------------------------------------------------------
+static int run_mediancut(const char *path, long n, int depth)
+{
+    std::vector<uint8_t> rgb((size_t)n * 3 + 1);
+    FILE *f = fopen(path, "rb");
+    if (!f || fread(rgb.data(), 3, (size_t)n, f) != (size_t)n) {
+        fprintf(stderr, "cannot read %ld colours from %s\n", n, path);
+        return 2;
+    }
+    fclose(f);
+    std::vector<uint32_t> order;
+    pyset_order(rgb.data(), (size_t)n, order);
+    std::vector<uint8_t> colours(3 * order.size() + 3), scratch(3 * order.size() + 3);
+    for (size_t i = 0; i < order.size(); ++i)
+        for (int c = 0; c < 3; ++c) colours[3 * i + c] = rgb[3 * (size_t)order[i] + c];
+    std::vector<int32_t> out;
+    median_cut_rgb(colours.data(), scratch.data(), order.size(), depth, out);
+    printf("distinct %zu\npalette", order.size());
+    for (int32_t v : out) printf(" %d", v);
+    printf("\norder");
+    for (size_t i = 0; i < order.size() && i < 2000; ++i) printf(" %u", order[i]);
+    printf("\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s kdtree|edtables|accel <pts.f64> <K> [bw]\n", argv[0]);
+        fprintf(stderr, "usage: %s kdtree|edtables|accel <pts.f64> <K> [bw]  |  mediancut <rgb.u8> <n> <depth>\n", argv[0]);
         return 2;
     }
+    if (std::string(argv[1]) == "mediancut") return run_mediancut(argv[2], atol(argv[3]), argc > 4 ? atoi(argv[4]) : 4);
     const int K = atoi(argv[3]);
     if (K < 1 || K > 1024) return 2;
     const std::vector<double> pts = read_pts(argv[2], K);

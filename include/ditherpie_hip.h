@@ -227,6 +227,18 @@ int dp_kmeans_update(const int64_t *totals_dev, double *centers_dev, int64_t *pr
 int dp_kmeans_plusplus_u8(const uint8_t *sample_dev, int n, int K, int first, const double *uniforms_dev, int n_trials,
                           int32_t *ids_dev, double *centers_dev, void *stream);
 
+/* Median cut of the reference (ColorReducer.reduce_colors, dithering_lib.py:1813-1843:
+ * `median_cut(list(set(image.getdata())), depth)`), host side, no GPU involved.
+ *   rgb_host     n colours, 3 bytes each, in order of insertion into the reference's set (duplicates allowed: the image's
+ *                pixels in raster order, or only its distinct colours in order of first occurrence -- same set)
+ *   depth        int(log2(num_colors)); the palette has at most 2^depth entries (an empty bucket yields one (0,0,0))
+ *   palette_out  room for 3 * 2^depth int32; *n_out receives the number of entries written
+ * The stable sort of the cut makes the iteration order of the Python set observable; the call replays CPython's set
+ * (tuple hash + open addressing + growth policy of CPython 3.8 ... 3.12) to obtain it.  dp_pyset_order_host alone returns that
+ * order (index of the first occurrence of every distinct colour, in the order `list(set(...))` yields them). */
+int dp_pyset_order_host(const uint8_t *rgb_host, int64_t n, uint32_t *order_out, int64_t *n_distinct);
+int dp_median_cut_host(const uint8_t *rgb_host, int64_t n, int depth, int32_t *palette_out, int *n_out);
+
 /* NEAREST resize of packed RGB frames (pixelize_regular / final upscale,
  * video_processor.py:563-577, 393-420), bit-identical to Pillow's Image.resize(..., NEAREST): source indices
  * come from Pillow's double-accumulated coordinate tables. */

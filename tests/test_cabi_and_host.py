@@ -343,3 +343,44 @@ def test_release_library_reads_no_environment():
     for p in (rel, exp):
         for fn in _lib.EXPORTS:
             assert re.search(rf"\bT {fn}\b", sym[p]), (p, fn)
+
+
+def test_native_median_cut_equals_the_python_path(kat):
+    """ColorReducer.reduce_colors through dp_median_cut_host (CPython's set order replayed natively + counting-sort cut)
+    against the same function with real Python sets and numpy sorts -- which the reference fixtures pin
+    (test_median_cut_matches_reference above) -- on random, smooth, few-colour and single-colour images, every depth."""
+    from PIL import Image
+    from dither_pie_amd.dithering_lib import ColorReducer
+    from oracle import oracle as orc
+    assert ColorReducer._pyset_replay_ok(), "the replay has to match this interpreter's sets (CPython 3.8 ... 3.12)"
+    rs = np.random.RandomState(4)
+    images = [orc.rnd(90, 120, 3), orc.imgl(120, 160, 5, "smooth"), orc.grad(64, 96), rs.randint(0, 3, (40, 40, 3)).astype(np.uint8),
+              np.full((8, 8, 3), 200, np.uint8), orc.rnd(300, 300, 8)]
+    try:
+        for img in images:
+            for n in (1, 2, 3, 16, 20, 256, 1024):
+                ColorReducer._replay_ok = True
+                a = ColorReducer.reduce_colors(Image.fromarray(img), n)
+                ColorReducer._replay_ok = False
+                b = ColorReducer.reduce_colors(Image.fromarray(img), n)
+                assert a == b, (img.shape, n)
+                assert all(isinstance(v, int) for c in a for v in c)
+    finally:
+        ColorReducer._replay_ok = None
+
+
+def test_pyset_order_replay(tmp_path):
+    """dp_pyset_order_host against this interpreter's own sets: sizes around every growth step of CPython's table (8 slots,
+    x4 growth below 50 000 entries, x2 above), with and without duplicates."""
+    from dither_pie_amd import _lib
+    L = _lib.load()
+    rs = np.random.RandomState(11)
+    for n, top in [(1, 256), (4, 256), (5, 256), (6, 4), (19, 256), (20, 256), (77, 256), (308, 256), (1229, 256), (4916, 256),
+                   (19661, 256), (52000, 256), (78644, 256), (150000, 256), (30000, 5)]:
+        arr = np.ascontiguousarray(rs.randint(0, top, (n, 3)).astype(np.uint8))
+        order = np.empty(n, np.uint32)
+        nd = C.c_int64(0)
+        assert L.dp_pyset_order_host(arr.ctypes.data, n, order.ctypes.data, C.byref(nd)) == 0
+        real = list(set(zip(arr[:, 0].tolist(), arr[:, 1].tolist(), arr[:, 2].tolist())))
+        assert nd.value == len(real)
+        assert [tuple(int(v) for v in c) for c in arr[order[:nd.value]]] == real, (n, top)

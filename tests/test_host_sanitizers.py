@@ -80,3 +80,31 @@ def test_accelerator_table_assembly_under_sanitizers(tools, gold, tmp_path, san)
     for pts, bw in cases:
         out = _run(tools[san], "accel", pts, tmp_path, bw)
         assert " bad=0 " in out and "warp_bad=0" in out, out
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_median_cut_replay_under_sanitizers(tools, tmp_path, san):
+    """pyset_order (the replay of CPython's set: hash, probing, growth) and median_cut_rgb (counting sorts, recursion on
+    raw pointers) under ASan / UBSan / TSan: the order equals this interpreter's `list(set(...))`, the palette equals the
+    Python cut -- 60 000 colours (past the change of growth policy), a handful of colours with depth 8 (empty buckets), one
+    colour, many duplicates."""
+    from dither_pie_amd.dithering_lib import ColorReducer
+    rs = np.random.RandomState(9)
+    cases = [(rs.randint(0, 256, (60000, 3)), 8), (rs.randint(0, 6, (5000, 3)), 8), (np.full((100, 3), 7), 3), (rs.randint(0, 256, (1, 3)), 0),
+             (rs.randint(100, 140, (30000, 3)), 5)]
+    if san == "tsan":
+        cases = cases[1:3]
+    for arr, depth in cases:
+        arr = np.ascontiguousarray(arr.astype(np.uint8))
+        f = tmp_path / "rgb.u8"
+        arr.tofile(f)
+        r = subprocess.run([tools[san], "mediancut", str(f), str(len(arr)), str(depth)], capture_output=True, text=True, env=ENV, timeout=600)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        lines = r.stdout.strip().split("\n")
+        real = list(set(zip(arr[:, 0].tolist(), arr[:, 1].tolist(), arr[:, 2].tolist())))
+        assert int(lines[0].split()[1]) == len(real)
+        order = np.array(lines[2].split()[1:], np.int64)
+        assert [tuple(int(v) for v in c) for c in arr[order]] == real[:len(order)]
+        pal = np.array(lines[1].split()[1:], np.int64).reshape(-1, 3)
+        ref = ColorReducer._median_cut_arrays(np.array(real, np.uint8).reshape(-1, 3), depth)
+        assert [tuple(c) for c in pal.tolist()] == [tuple(int(v) for v in c) for c in ref]
