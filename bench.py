@@ -413,6 +413,19 @@ def main():
         kmc_ms, kmc_fix = kernel_ms(lambda: dmc.apply_dithering_frames(fi, out=out))
         result["c2_crowded"] = leg("ordered_compact_kernel<1,WARP,HALF>", kmc_ms, BYTES_PER_PX * px_per_step, fixup_ms=round(kmc_fix, 4),
                                    workload="C2-shaped: image-like frames + their own median-cut 256 palette, Bayer 8x8")
+        # what the palette itself costs (the reference's default palette source, once per image / per video): median cut of a
+        # 4K image of that content, distinct colours found on the GPU, CPython's set order replayed natively
+        img4k = Image.fromarray(fi[0].cpu().numpy(), "RGB")
+        _CR.reduce_colors(img4k, 256)
+        mc_ts = []
+        for _ in range(3):
+            t_m = time.perf_counter()
+            _CR.reduce_colors(img4k, 256)
+            mc_ts.append((time.perf_counter() - t_m) * 1e3)
+        extra["median_cut256_4k_ms"] = round(sorted(mc_ts)[1], 1)
+        extra["median_cut_note"] = ("ColorReducer.reduce_colors(4K image, 256), median of 3: host side (dp_median_cut_host) after a GPU pass "
+                                    "for the distinct colours; the reference needs seconds for this step")
+        del img4k
         # the same content with the reference's default palette size: 16 colours by median cut
         pal_mc16 = _CR.reduce_colors(Image.fromarray(img, "RGB"), 16)
         dmc16 = ImageDitherer(16, DitherMode.BAYER, pal_mc16, False, {"size": "8x8"}).prepare()
