@@ -288,7 +288,7 @@ def main():
     # comes from the committed rocprofv3 --pmc pass of this same command (profiles/pmc_pass.sh)
     # (profiles/pmc_pass.sh); the file names the kernel sources it was taken with and is ignored when they have changed
     traffic, traffic_src, valu_per_launch = None, None, None
-    pmc_name = "r02_pmc_ordered.json"
+    pmc_name = "r03_pmc_ordered.json"
     pmc_file = os.path.join(ROOT, "profiles", pmc_name)
     if args.frames == 24 and os.path.exists(pmc_file):
         try:
