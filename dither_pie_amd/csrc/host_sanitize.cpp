@@ -293,13 +293,39 @@ static int run_accel(const std::vector<double> &pts, int K, int bw)
         for (int k = 0; k < bw; ++k) seen |= 1u << ((pw >> (fb * k)) & ((1u << fb) - 1));
         if (seen != (1u << bw) - 1u) ++bad;
     }
+    // the one-byte-per-entry copy (ordered_compact_kernel): same blocks, same positions, markers as byte offsets of the node
+    int compact_bad = 0;
+    if (bw == 8) {
+        const std::vector<uint32_t> ct = compact_table(tab, coord4);
+        compact_bad += ct.size() * 4 != tab.size();
+        for (size_t b = 0; b + 8 <= tab.size(); b += 8) {
+            const uint32_t lo = ct[b / 4], hi = ct[b / 4 + 1];
+            if (tab[b] >> 31) {
+                compact_bad += hi != 0xffffffffu;
+                if ((tab[b] >> 30) == 2u) {
+                    const uint32_t off = lo & 0xffffffu;  // bytes from the start of the compact table
+                    compact_bad += (lo >> 30) != 2u || off != (4096u + (tab[b] & 0xffffffu) * 8u) * 8u || off + 64u > ct.size() * 4u;
+                } else {
+                    compact_bad += lo != 0xC0000000u;
+                }
+                continue;
+            }
+            uint32_t prev = 0;
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t idx = ((i < 4 ? lo : hi) >> (8 * (i & 3))) & 255u;
+                compact_bad += idx >= (uint32_t)K || coord4[idx] != tab[b + i];
+                compact_bad += i > 0 && idx <= prev && coord4[idx] != coord4[prev];  // index order (equal colours: ascending too)
+                prev = idx;
+            }
+        }
+    }
     int warp_bad = 0;
     for (int c = 0; c < 3; ++c)
         for (int x = 1; x < 256; ++x) warp_bad += wm.lut[c][x] < wm.lut[c][x - 1];
-    printf("accel K=%d bw=%d words=%zu split=%d split_cells=%d slow=%d max_cnt=%d wide=%zu mass_in_split=%d/%zu checked=%ld bad=%ld warp_bad=%d\n",
+    printf("accel K=%d bw=%d words=%zu split=%d split_cells=%d slow=%d max_cnt=%d wide=%zu mass_in_split=%d/%zu checked=%ld bad=%ld warp_bad=%d compact_bad=%d\n",
            K, bw, tab.size(), st.n_split, st.n_split_cells, st.n_slow, st.max_cnt, wide.size() / kWideList, in_split, mp.size(),
-           checked, bad, warp_bad);
-    return (bad || warp_bad) ? 1 : 0;
+           checked, bad, warp_bad, compact_bad);
+    return (bad || warp_bad || compact_bad) ? 1 : 0;
 }
 
 // ---- median cut (set-order replay + counting-sort cut) ----------------------------------------------------------------

@@ -71,7 +71,7 @@ def test_diffusion_tables_under_sanitizers(tools, gold, tmp_path, san):
 
 @pytest.mark.parametrize("san", ["asan", "tsan"])
 def test_accelerator_table_assembly_under_sanitizers(tools, gold, tmp_path, san):
-    """assemble_table / crowded_nodes_first / make_warp / mass_points / entries_in_split_cells from brute-force
+    """assemble_table / crowded_nodes_first / make_warp / mass_points / entries_in_split_cells / compact_table from brute-force
     membership masks (the harness scans all 2^24 colours as accel_scan_kernel does): a random, a uniform-grid and a
     crowded palette, 8- and 4-entry blocks; every sampled colour finds all of T(x) in the block it reaches."""
     cases = [(gold["tree_p32_pts"], 8), (gold["tree_U16_pts"], 4), (_crowded(40, 3), 8)]
@@ -79,7 +79,7 @@ def test_accelerator_table_assembly_under_sanitizers(tools, gold, tmp_path, san)
         cases = cases[2:]
     for pts, bw in cases:
         out = _run(tools[san], "accel", pts, tmp_path, bw)
-        assert " bad=0 " in out and "warp_bad=0" in out, out
+        assert " bad=0 " in out and "warp_bad=0" in out and "compact_bad=0" in out, out
 
 
 @pytest.mark.parametrize("san", ["asan", "tsan"])
