@@ -13,11 +13,18 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # Two builds of the same sources (csrc/Makefile): libditherpie_hip.so -- the product, which reads no environment variable --
 # and libditherpie_hip_exp.so (-DDP_EXPERIMENTS), in which the DP_* switches that force a table / kernel / schedule are
-# compiled in.  DITHER_PIE_EXPERIMENTS=1 (set by tests/conftest.py and tools/bench_scripts) selects the latter.
+# compiled in.  The product library is what load() returns unless DITHER_PIE_EXPERIMENTS=1 is set (tools/bench_scripts) or
+# select(True) was called (the `switches` fixture of tests/conftest.py: only the tests that set a DP_* switch run on the
+# twin; every other test, golden and fuzzer runs on the library that ships).
 # DP_LIB_PATH: another build altogether (A/B measurements of kernel variants: tools/bench_scripts/ab_kernel.py)
+PRODUCT_PATH = os.path.join(_HERE, "libditherpie_hip.so")
+EXPERIMENTS_PATH = os.path.join(_HERE, "libditherpie_hip_exp.so")
 EXPERIMENTS = os.environ.get("DITHER_PIE_EXPERIMENTS", "") not in ("", "0")
-LIB_PATH = os.environ.get("DP_LIB_PATH") or os.path.join(_HERE, "libditherpie_hip_exp.so" if EXPERIMENTS else "libditherpie_hip.so")
+LIB_PATH = os.environ.get("DP_LIB_PATH") or (EXPERIMENTS_PATH if EXPERIMENTS else PRODUCT_PATH)
 CSRC = os.path.join(_HERE, "csrc")
+# the ABI revision this binding was written against (include/ditherpie_hip.h: DP_ABI_VERSION); load() refuses a library
+# that reports another one -- a stale build bound through DP_LIB_PATH would otherwise read K as a pointer
+ABI_VERSION = 101
 
 DP_OK, DP_EINVAL, DP_EUNSUPPORTED, DP_EHIP, DP_ENOMEM, DP_EWORKSPACE = range(6)
 DP_MAX_COLORS = 1024
@@ -34,6 +41,7 @@ class DitherPieError(RuntimeError):
 
 _lock = threading.Lock()
 _lib = None
+_loaded = {}   # path -> CDLL (both builds may be mapped in one process; their device records have the same layout)
 
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 _SIGS = {
@@ -95,13 +103,33 @@ def load():
                 import torch  # noqa: F401
             except ImportError:  # host-only use (dp_kdtree_build_host, symbol checks)
                 pass
-            L = C.CDLL(LIB_PATH)
-            for name, (res, args) in _SIGS.items():
-                fn = getattr(L, name)
-                fn.restype = res
-                fn.argtypes = args
+            L = _loaded.get(LIB_PATH)
+            if L is None:
+                L = C.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGS.items():
+                    fn = getattr(L, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                got = L.dp_version()
+                if got != ABI_VERSION:
+                    raise DitherPieError(-1, f"{LIB_PATH} reports ABI version {got}, this binding was written for "
+                                             f"{ABI_VERSION}: rebuild it with `make -C {CSRC}`")
+                _loaded[LIB_PATH] = L
             _lib = L
     return _lib
+
+
+def select(experiments):
+    """Make load() return the product library (False) or its -DDP_EXPERIMENTS twin (True) from now on; returns the previous
+    choice.  Device objects (palettes, thresholds) made through one library must not be handed to the other: callers drop
+    their caches (dithering_lib.drop_device_caches) around a switch.  Test infrastructure; the product never calls it."""
+    global _lib, EXPERIMENTS, LIB_PATH
+    with _lock:
+        prev = EXPERIMENTS
+        EXPERIMENTS = bool(experiments)
+        LIB_PATH = EXPERIMENTS_PATH if EXPERIMENTS else PRODUCT_PATH
+        _lib = None
+    return prev
 
 
 def check(rc):

@@ -244,7 +244,8 @@ def ordered(frames, pal: Palette, mode, thr: Thresholds | None = None, ign_scale
 def error_diffusion(frames, pal: Palette, taps, divisor, serpentine=False, out=None, arithmetic="python"):
     """taps: [(dx, dy, weight)] in the reference's list order.  arithmetic: "python" -- the reference's pure-Python
     branch (dithering_lib.py:655-690: KD-tree nearest, float32 products and sums) -- or "numba" -- its
-    _error_diffusion_numba branch (:213-308: float32 linear-scan nearest, float64 products and sums rounded on the store)."""
+    _error_diffusion_numba branch (:213-308, typed per numba's unification rule: float64 linear-scan nearest, float64 error,
+    float64 products and sums rounded on the store; parity-unpinned, fixtures pending)."""
     f = _frames(frames)
     n, h, w, _ = f.shape
     out = _check_out(out, f)

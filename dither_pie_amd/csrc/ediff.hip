@@ -61,28 +61,30 @@ struct Taps {
 
 // ---- the reference's OTHER error-diffusion arithmetic: _error_diffusion_numba (dithering_lib.py:213-308), which the
 // reference takes instead of the pure-Python loop when numba is installed (dispatch at :638-653).  Same scan, same taps,
-// different numbers: (1) the nearest entry is the FIRST minimum of a float32 linear scan
-//   dist = ((dr*dr + dg*dg) + db*db), every operation rounded to float32   (not the float64 KD-tree query), and
-// (2) an error is pushed as  work[ny, nx] = float32( float64(work[ny, nx]) + float64(err) * (float64(w_f32) / divisor) )
-//   -- the product and the sum in float64, one rounding on the store (not float32 product + float32 sum).
-// EXPERIMENTAL, UNPINNED.  An open question about numba's typing (round-2 advisor): in the reference `r` is assigned both a
-// float32 array element and the float64 literals 0.0 / 255.0; numba unifies a variable's types over all assignments, and
-// float32 with float64 unify to float64 -- then `dr`, `dist` and `err0 = r - chosen0` are float64 (float32-valued inputs, exact
-// differences), the scan no longer collapses near-equal candidates onto the lowest index and the error is not rounded to
-// float32 before the push.  This kernel and its restatement both implement the float32 scan / float32 error reading; a float64
-// error needs the clamped value and the chosen colour in the rings (6 floats per pixel instead of 3).  Which reading a real
-// numba run follows can only be settled by a fixture from a machine that has numba.
-// No fixtures pin this branch: numba is not installable in the build image (no network), so the restatement in
-// the CPU restatement (orc_error_diffusion_numba_u8) is checked against an independent numpy transcription only.
-__device__ __forceinline__ int nearest_numba_f32(const float4 *__restrict__ cand, const int K, const float o0, const float o1,
+// different numbers.  TYPED PER NUMBA'S UNIFICATION RULE (fixtures pending: numba is not installable in the build image,
+// so nothing the reference produced pins this branch; the CPU restatement orc_error_diffusion_numba_u8 is checked against
+// an independent numpy transcription only): a variable has one type, the unification of all assignments to it, and
+// `r = work_2d[y, x, 0]` (float32, :239) is re-assigned the float64 literals `0.0` / `255.0` (:242-245) -- so r, g, b are
+// float64, and with them
+// (1) the scan: dr = r - palette_arr[i, 0] (float64 - float32 = float64), dist = (dr*dr + dg*dg) + db*db in float64 with
+//     separately rounded products and sums (no fastmath, no contraction), strict `<` against best_dist = 1e20: the FIRST
+//     minimum of the float64 distances (not the KD-tree's traversal order, and not a float32 ranking, which collapses
+//     near-equal candidates onto the lowest index);
+// (2) the error: err0 = r - chosen0 stays float64 (it is NOT rounded to float32: |r - c| > |r| loses bits in float32);
+// (3) the push: work[ny, nx] = float32( float64(work[ny, nx]) + err0 * (float64(w_f32) / divisor) ), product and sum in
+//     float64, one rounding on the store.
+// The error rings of the NB kernel instances therefore hold doubles (6 words per pixel instead of 3).  Rounds 1-3
+// implemented a float32 scan and a float32 error; no numba release is known to type the function that way.
+__device__ __forceinline__ int nearest_numba_f64(const float4 *__restrict__ cand, const int K, const float o0, const float o1,
                                                  const float o2)
 {
-    float best = __int_as_float(0x7f800000);
+    const double r = (double)o0, g = (double)o1, b = (double)o2;
+    double best = 1e20;
     int j0 = 0;
     for (int j = 0; j < K; ++j) {
         const float4 c = cand[j];
-        const float dr = __fsub_rn(o0, c.x), dg = __fsub_rn(o1, c.y), db = __fsub_rn(o2, c.z);
-        const float dist = __fadd_rn(__fadd_rn(__fmul_rn(dr, dr), __fmul_rn(dg, dg)), __fmul_rn(db, db));
+        const double dr = __dsub_rn(r, (double)c.x), dg = __dsub_rn(g, (double)c.y), db = __dsub_rn(b, (double)c.z);
+        const double dist = __dadd_rn(__dadd_rn(__dmul_rn(dr, dr), __dmul_rn(dg, dg)), __dmul_rn(db, db));
         if (dist < best) {
             best = dist;
             j0 = j;
@@ -91,9 +93,18 @@ __device__ __forceinline__ int nearest_numba_f32(const float4 *__restrict__ cand
     return j0;
 }
 
-__device__ __forceinline__ float push_numba(const float acc, const float err, const double w)
+__device__ __forceinline__ float push_numba(const float acc, const double err, const double w)
 {
-    return (float)__dadd_rn((double)acc, __dmul_rn((double)err, w));
+    return (float)__dadd_rn((double)acc, __dmul_rn(err, w));
+}
+
+// the type an error is kept in: float32 (the pure-Python branch) or float64 (the numba branch)
+template <bool NB> struct ErrT { typedef float type; };
+template <> struct ErrT<true> { typedef double type; };
+template <bool NB> __device__ __forceinline__ typename ErrT<NB>::type err_of(const float o, const float c)
+{
+    if (NB) return (typename ErrT<NB>::type)__dsub_rn((double)o, (double)c);
+    return (typename ErrT<NB>::type)__fsub_rn(o, c);
 }
 
 // min(max(v, 0), 255) for every non-NaN v, in one instruction
@@ -162,9 +173,11 @@ template <int CAP, int NT, bool EXACT, int MAXW, bool NB = false>
 __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
-                                                                      float *__restrict__ bnd_all, const int G,
+                                                                      void *__restrict__ bnd_all_v, const int G,
                                                                       uint32_t *__restrict__ gprog_all, const int test_giveup)
 {
+    typedef typename ErrT<NB>::type E;  // an error: float, or double with the numba arithmetic
+    E *__restrict__ bnd_all = reinterpret_cast<E *>(bnd_all_v);
     // G == 1 with progress words given: the REPAIR launch that follows a G > 1 launch on the stream -- only the frames
     // whose give-up flag is set are done again, one workgroup per frame (the others return at once).
     if (G == 1 && gprog_all != nullptr &&
@@ -182,17 +195,17 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
     // writes) slot (t - skew*L - dx) & 7 of a row, so with the natural stride of 24 words the lanes L, L+8, L+16, ... --
     // eight of them -- meet in one LDS bank on every ring access (SQ_LDS_BANK_CONFLICT: 72 % of the LDS cycles, the LDS
     // pipe 80 % busy with 16 waves per CU); 27 makes the accesses conflict-free at skew 2 and two-way at skew 3.
-    __shared__ float s_ring[MAXW][64][kRingStride];
-    __shared__ float s_vring[MAXW][2][64][3];            // errors of the two rows above the band (64-column ring)
-    __shared__ float s_bout[MAXW][2][kPeriod][3];        // this period's errors of rows 62/63, flushed to global
+    __shared__ E s_ring[MAXW][64][kRingStride];
+    __shared__ E s_vring[MAXW][2][64][3];                // errors of the two rows above the band (64-column ring)
+    __shared__ E s_bout[MAXW][2][kPeriod][3];            // this period's errors of rows 62/63, flushed to global
     __shared__ uint8_t s_lut[256];
     __shared__ volatile uint32_t s_prog[MAXW];           // (band << 16) | (acknowledged column of row 63 + 1024)
     // {x, y, z, out_rgb bits} of the palette; palettes of 9..16 colours keep the candidate lists of the 16^3 cells
     // (4096 words) behind their 16 entries
     __shared__ float4 s_pal[DP_MAX_COLORS + 16];
     uint32_t *s_coarse = reinterpret_cast<uint32_t *>(s_pal + 16);
-    __shared__ float s_zero[4];                          // the "error" of pixels that do not exist
-    typedef const __attribute__((address_space(3))) float lds_float_t;
+    __shared__ E s_zero[4];                              // the "error" of pixels that do not exist
+    typedef const __attribute__((address_space(3))) E lds_float_t;
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
@@ -212,19 +225,19 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
         lists16 = s_lists16;
     }
     if (threadIdx.x < MAXW) s_prog[threadIdx.x] = 0;
-    if (threadIdx.x < 4) s_zero[threadIdx.x] = 0.0f;
+    if (threadIdx.x < 4) s_zero[threadIdx.x] = (E)0;
     const uint8_t *fin = in + f * (size_t)h * w * 3;
     uint8_t *fout = out + f * (size_t)h * w * 3;
     const long frame_bytes = (long)h * w * 3;
-    float *bnd = bnd_all + f * (size_t)4 * w * 3;  // [2 buffers][2 rows][w][3]
+    E *bnd = bnd_all + f * (size_t)4 * w * 3;  // [2 buffers][2 rows][w][3]
     const int skew = taps.skew;
     const int n_bands = (h + 63) / 64;
     __syncthreads();  // the only workgroup barrier: from here on waves only meet through s_prog
 
     for (int band = gw; band < n_bands; band += NWT) {
         const int r = band * 64 + L;
-        const float *bprev = bnd + (size_t)((band + 1) & 1) * 2 * w * 3;  // written by band-1
-        float *bnext = bnd + (size_t)(band & 1) * 2 * w * 3;
+        const E *bprev = bnd + (size_t)((band + 1) & 1) * 2 * w * 3;  // written by band-1
+        E *bnext = bnd + (size_t)(band & 1) * 2 * w * 3;
         const int rows_here = min(64, h - band * 64);
         const int steps = w + skew * (rows_here - 1);
         const int pw = (gw + NWT - 1) % NWT;  // wave that owns band-1
@@ -240,12 +253,12 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
         for (int k = 0; k < NT; ++k) {
             const int rel = L - taps.dy[k];
             const bool exists = (EXACT || k < taps.n) && r - taps.dy[k] >= 0;
-            const float *row = rel >= 0 ? &s_ring[wv][rel & 63][0] : &s_vring[wv][(rel + 2) & 1][0][0];
+            const E *row = rel >= 0 ? &s_ring[wv][rel & 63][0] : &s_vring[wv][(rel + 2) & 1][0][0];
             tbase[k] = exists ? (lds_float_t *)row : (lds_float_t *)s_zero;
             tmask[k] = exists ? (rel >= 0 ? (uint32_t)(kRing - 1) : 63u) : 0u;
         }
         uint32_t pix[12], cur[13], outb[13];  // 16 pixels in flight / being consumed / being produced (raw bytes)
-        float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;  // boundary errors in flight (one column per lane)
+        E pb0 = 0, pb1 = 0, pb2 = 0;  // boundary errors in flight (one column per lane)
         int pb_col = 0;
         bool pb_valid = false;
 #pragma unroll
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
             }
             // park the boundary errors fetched during the previous period
             if (pb_valid) {
-                float *dst = &s_vring[wv][L >> 5][pb_col & 63][0];
+                E *dst = &s_vring[wv][L >> 5][pb_col & 63][0];
                 dst[0] = pb0;
                 dst[1] = pb1;
                 dst[2] = pb2;
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                 // rows 62/63: this band's boundary errors of the same period go to the global row buffer
                 if (L >= 62 && row_ok && hi > lo) {
                     for (int i = lo - xs; i < hi - xs; ++i) {
-                        float *b = bnext + ((size_t)(L - 62) * w + (xs + i)) * 3;
+                        E *b = bnext + ((size_t)(L - 62) * w + (xs + i)) * 3;
                         if (G == 1) {
                             b[0] = s_bout[wv][L - 62][i][0];
                             b[1] = s_bout[wv][L - 62][i][1];
@@ -360,14 +373,14 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     if (col >= 0 && col < w) {
                         // lanes 0..31 -> row -2 (lane 62 of band-1), lanes 32..63 -> row -1 (lane 63); the buffer was
                         // written by another wave of this workgroup and is reused every 2 bands: bypass L1
-                        const float *b = bprev + ((size_t)(L >> 5) * w + col) * 3;
+                        const E *b = bprev + ((size_t)(L >> 5) * w + col) * 3;
                         pb0 = __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pb1 = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pb2 = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pb_col = col;
                         pb_valid = true;
                     } else if (col >= -2 && col < w + 2) {  // the two columns either side of the image: zero errors
-                        pb0 = pb1 = pb2 = 0.f;
+                        pb0 = pb1 = pb2 = (E)0;
                         pb_col = col;
                         pb_valid = true;
                     }
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                 const int t = t0 + i;
                 const int x = t - skew * L;
                 const bool act = row_ok && (uint32_t)x < (uint32_t)w;  // (0 <= t < steps follows for the rows of the band)
-                float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+                E e0 = 0, e1 = 0, e2 = 0;
                 uint32_t cbytes = 0;
                 if (act) {
                     // this step's pixel: bytes 3q..3q+2 of the round's twelve
@@ -413,25 +426,25 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                             lds_float_t *src = tbase[k] + ((x - taps.dx[k]) & (int)tmask[k]) * 3;
                             if (NB) {
                                 const double w64 = taps.wq64[k];
-                                a0 = push_numba(a0, src[0], w64);
-                                a1 = push_numba(a1, src[1], w64);
-                                a2 = push_numba(a2, src[2], w64);
+                                a0 = push_numba(a0, (double)src[0], w64);
+                                a1 = push_numba(a1, (double)src[1], w64);
+                                a2 = push_numba(a2, (double)src[2], w64);
                             } else {
                                 const float wq = taps.wq[k];
-                                a0 = __fadd_rn(a0, __fmul_rn(src[0], wq));
-                                a1 = __fadd_rn(a1, __fmul_rn(src[1], wq));
-                                a2 = __fadd_rn(a2, __fmul_rn(src[2], wq));
+                                a0 = __fadd_rn(a0, __fmul_rn((float)src[0], wq));
+                                a1 = __fadd_rn(a1, __fmul_rn((float)src[1], wq));
+                                a2 = __fadd_rn(a2, __fmul_rn((float)src[2], wq));
                             }
                         }
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-                    const int j = NB ? nearest_numba_f32(s_pal, pal.K, o0, o1, o2)
+                    const int j = NB ? nearest_numba_f64(s_pal, pal.K, o0, o1, o2)
                                      : (pal.ed_cells ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2, lists16)
                                                      : nearest_color<CAP>(pal, s_pal, o0, o1, o2));
                     const float4 pj = s_pal[j];
-                    e0 = __fsub_rn(o0, pj.x);
-                    e1 = __fsub_rn(o1, pj.y);
-                    e2 = __fsub_rn(o2, pj.z);
+                    e0 = err_of<NB>(o0, pj.x);
+                    e1 = err_of<NB>(o1, pj.y);
+                    e2 = err_of<NB>(o2, pj.z);
                     cbytes = __float_as_uint(pj.w);
                 }
                 cb[q] = cbytes;
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                 // columns -2, -1, w and w+1 are written too, with zero errors (e is 0 without a pixel): a tap that reaches
                 // past either end of a row reads them instead of testing its column
                 if (row_ok && x >= -2 && x < w + 2) {
-                    float *slot = &s_ring[wv][L][(x & (kRing - 1)) * 3];
+                    E *slot = &s_ring[wv][L][(x & (kRing - 1)) * 3];
                     slot[0] = e0;
                     slot[1] = e1;
                     slot[2] = e2;
@@ -482,8 +495,10 @@ template <int CAP, bool NB = false>
 __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                        const int64_t n_frames, const int h, const int w,
                                                        const PalDev pal, const Taps taps, const int serpentine,
-                                                       float *__restrict__ ring)
+                                                       void *__restrict__ ring_v)
 {
+    typedef typename ErrT<NB>::type E;
+    E *__restrict__ ring = reinterpret_cast<E *>(ring_v);
     const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (f >= n_frames) return;
     const uint8_t *fin = in + (size_t)f * h * w * 3;
@@ -507,27 +522,27 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
                 const int sdir = (serpentine && (sr & 1)) ? -1 : 1;
                 const int sxp = x - taps.dx[k] * sdir;
                 if (sxp < 0 || sxp >= w) continue;
-                const float *e = ring + (((size_t)(sr % 3) * w + sxp) * 3) * nf + f;
+                const E *e = ring + (((size_t)(sr % 3) * w + sxp) * 3) * nf + f;
                 if (NB) {
                     const double w64 = taps.wq64[k];
-                    a0 = push_numba(a0, e[0], w64);
-                    a1 = push_numba(a1, e[nf], w64);
-                    a2 = push_numba(a2, e[2 * nf], w64);
+                    a0 = push_numba(a0, (double)e[0], w64);
+                    a1 = push_numba(a1, (double)e[nf], w64);
+                    a2 = push_numba(a2, (double)e[2 * nf], w64);
                 } else {
                     const float wq = taps.wq[k];
-                    a0 = __fadd_rn(a0, __fmul_rn(e[0], wq));
-                    a1 = __fadd_rn(a1, __fmul_rn(e[nf], wq));
-                    a2 = __fadd_rn(a2, __fmul_rn(e[2 * nf], wq));
+                    a0 = __fadd_rn(a0, __fmul_rn((float)e[0], wq));
+                    a1 = __fadd_rn(a1, __fmul_rn((float)e[nf], wq));
+                    a2 = __fadd_rn(a2, __fmul_rn((float)e[2 * nf], wq));
                 }
             }
             const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
-            const int j = NB ? nearest_numba_f32(pal.fcand, pal.K, o0, o1, o2)
+            const int j = NB ? nearest_numba_f64(pal.fcand, pal.K, o0, o1, o2)
                              : (pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, nullptr, o0, o1, o2)
                                              : nearest_color<CAP>(pal, pal.fcand, o0, o1, o2));
-            float *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
-            e[0] = __fsub_rn(o0, (float)pal.pts[3 * j]);
-            e[nf] = __fsub_rn(o1, (float)pal.pts[3 * j + 1]);
-            e[2 * nf] = __fsub_rn(o2, (float)pal.pts[3 * j + 2]);
+            E *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
+            e[0] = err_of<NB>(o0, (float)pal.pts[3 * j]);
+            e[nf] = err_of<NB>(o1, (float)pal.pts[3 * j + 1]);
+            e[2 * nf] = err_of<NB>(o2, (float)pal.pts[3 * j + 2]);
             const uint32_t c = pal.out_rgb[j];
             uint8_t *o = fout + ((size_t)y * w + x) * 3;
             o[0] = (uint8_t)c;
@@ -719,10 +734,11 @@ __global__ __launch_bounds__(64) void ed_rowserial_kernel(const uint8_t *__restr
 size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w)
 {
     (void)h;
-    // wavefront: 4 boundary rows per frame; serial: 3 error rows per frame; 4 floats per column (the variable-weight
-    // diffusers of vardiff.hip carry an extra value per error)
+    // wavefront: 4 boundary rows per frame; serial: 3 error rows per frame; up to 6 words per column and row (the
+    // variable-weight diffusers of vardiff.hip carry an extra value per error: 4 floats; the numba arithmetic keeps its
+    // errors in float64: 3 doubles)
     // + 256 bytes per frame of progress words (few frames in flight: a frame's bands spread over workgroups)
-    return (size_t)n_frames * (size_t)w * 4 * sizeof(float) * 4 + 512 + (size_t)n_frames * 256;
+    return (size_t)n_frames * (size_t)w * 6 * sizeof(float) * 4 + 512 + (size_t)n_frames * 256;
 }
 
 int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
@@ -832,7 +848,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
         uint32_t *gprog = nullptr;
         {
-            const size_t prog_off = ((size_t)n_frames * (size_t)w * 48 + 255) & ~(size_t)255;
+            const size_t prog_off = ((size_t)n_frames * (size_t)w * (numba ? 96 : 48) + 255) & ~(size_t)255;
             const size_t prog_bytes = (size_t)n_frames * kEdProgWords * sizeof(uint32_t);
             if (n_frames * 2 <= cus && n_bands >= 4 && w >= 64 && prog_off + prog_bytes <= ws_bytes && !exp_env("DP_ED_ONE_WG")) {
                 const int nwt = n_bands < 32 ? n_bands : 32;
@@ -854,28 +870,32 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
     do {                                                                                                                 \
         if (nw <= 4)                                                                                                     \
             hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, 4>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, \
-                               pal, t, reinterpret_cast<float *>(ws), G, gprog, test_giveup);                            \
+                               pal, t, ws, G, gprog, test_giveup);                            \
         else                                                                                                             \
             hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in,  \
-                               out, h, w, pal, t, reinterpret_cast<float *>(ws), G, gprog, test_giveup);                 \
+                               out, h, w, pal, t, ws, G, gprog, test_giveup);                 \
         if (G > 1)                                                                                                       \
             hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out,  \
-                               h, w, pal, t, reinterpret_cast<float *>(ws), 1, gprog, 0);                                \
+                               h, w, pal, t, ws, 1, gprog, 0);                                \
     } while (0)
 #define DP_EDN(N, X)                                                                                                      \
     do {                                                                                                                 \
         if (pal.n_inner > kQueueSmall) DP_EDW(kQueueLarge, N, X); else DP_EDW(kQueueSmall, N, X);                         \
     } while (0)
-        if (numba) {  // one general instance per workgroup size (a full float32 palette scan per pixel, no candidate lists)
+        if (numba) {  // one general instance per workgroup size (a full float64 palette scan per pixel, no candidate lists);
+            // float64 error rings: 8 waves per workgroup fill LDS (158 KB)
+            constexpr int kNbWaves = 8;
+            if (nw > kNbWaves) nw = kNbWaves;  // (bands are dealt round-robin over whatever waves there are)
+            const int nwr = nw1 < kNbWaves ? nw1 : kNbWaves;
             if (nw <= 4)
                 hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, 4, true>), dim3((unsigned)(n_frames * G)), dim3(64 * nw),
-                                   0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws), G, gprog, test_giveup);
+                                   0, s, in, out, h, w, pal, t, ws, G, gprog, test_giveup);
             else
-                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, kMaxWaves, true>), dim3((unsigned)(n_frames * G)),
-                                   dim3(64 * nw), 0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws), G, gprog, test_giveup);
+                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, kNbWaves, true>), dim3((unsigned)(n_frames * G)),
+                                   dim3(64 * nw), 0, s, in, out, h, w, pal, t, ws, G, gprog, test_giveup);
             if (G > 1)
-                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, kMaxWaves, true>), dim3((unsigned)n_frames),
-                                   dim3(64 * nw1), 0, s, in, out, h, w, pal, t, reinterpret_cast<float *>(ws), 1, gprog, 0);
+                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, kNbWaves, true>), dim3((unsigned)n_frames),
+                                   dim3(64 * nwr), 0, s, in, out, h, w, pal, t, ws, 1, gprog, 0);
         } else
         switch (ntaps) {  // the tap counts of the reference's kernels get a test-free instance
         case 3: DP_EDN(3, true); break;
@@ -912,13 +932,13 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         const int64_t blocks = (n_frames + 63) / 64;
         if (numba)  // serpentine scan with the numba arithmetic: the frame-parallel kernel (lane = frame)
             hipLaunchKernelGGL((ed_serial_kernel<kQueueSmall, true>), dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h,
-                               w, pal, t, serpentine, reinterpret_cast<float *>(ws));
+                               w, pal, t, serpentine, ws);
         else if (pal.n_inner > kQueueSmall)
             hipLaunchKernelGGL(ed_serial_kernel<kQueueLarge>, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h,
-                               w, pal, t, serpentine, reinterpret_cast<float *>(ws));
+                               w, pal, t, serpentine, ws);
         else
             hipLaunchKernelGGL(ed_serial_kernel<kQueueSmall>, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h,
-                               w, pal, t, serpentine, reinterpret_cast<float *>(ws));
+                               w, pal, t, serpentine, ws);
     }
     prof_end(pm, s);
     DP_HIP(hipGetLastError());

@@ -74,7 +74,7 @@ using namespace dp;
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int dp_version(void) { return 100; }
+int dp_version(void) { return DP_ABI_VERSION; }
 
 const char *dp_last_error(void) { return g_err; }
 

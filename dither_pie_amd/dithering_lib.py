@@ -242,6 +242,15 @@ _PALETTES = _LRU(32)
 _THRESHOLDS = _LRU(32)
 
 
+def drop_device_caches():
+    """Forget every cached device palette / threshold matrix (they are re-created on demand)."""
+    with _PALETTES._lock:
+        _PALETTES.clear()
+    with _THRESHOLDS._lock:
+        _THRESHOLDS.clear()
+    OstromoukhovDitherStrategy._coef_cache.clear()
+
+
 def _device_index():
     import torch
     return torch.cuda.current_device() if torch.cuda.is_available() else -1
@@ -500,10 +509,10 @@ class InterleavedGradientNoiseDitherStrategy(BaseDitherStrategy):
 
 # Which of the reference's two error-diffusion arithmetics to reproduce (dithering_lib.py:638-653 picks by whether numba
 # imports): "python" -- the pure-Python loop (:655-690), what the reference runs in an environment without numba, pinned by
-# the golden fixtures -- or "numba" -- _error_diffusion_numba (:213-308: float32 linear-scan nearest with the lowest index
-# on ties, float64 products and sums with one rounding on the store), restated in the oracle but not pinned by fixtures.
-# EXPERIMENTAL: no numba in the build image; whether numba keeps the scan and the error in float32 (as implemented) or
-# unifies them to float64 is open (csrc/ediff.hip).
+# the golden fixtures -- or "numba" -- _error_diffusion_numba (:213-308), typed per numba's unification rule: r / g / b are
+# assigned a float32 element and float64 literals (:239-251), hence float64 -- a float64 linear scan with the first minimum
+# winning, a float64 error, float64 products and sums with one rounding on the store.  Restated in the oracle; fixtures
+# pending (no numba in the build image), so this branch is parity-unpinned.
 ERROR_DIFFUSION_ARITHMETIC = os.environ.get("DITHER_PIE_ED_ARITHMETIC", "python")
 
 

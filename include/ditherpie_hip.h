@@ -19,12 +19,15 @@
  *   - no mutable global state besides the thread-local error text and profiling marks.  One call is a SEQUENCE of
  *     launches that use the caller's workspace in stream order (flag bitmap, progress words): concurrent calls are fine
  *     on different streams with different workspaces; calls that share a workspace and stream must not be issued from
- *     two host threads at once (the Python layer serialises them per (device, stream)).  dp_palette_build_accel
- *     mutates the palette: finish it before another thread launches with that palette.
- *   - environment variables read by the library are experiment / test switches only (DP_DEBUG_ACCEL, DP_FORCE_TABLE,
- *     DP_NO_WARP, DP_NO_FAST, DP_FAST_ALL, DP_FAST_DBG, DP_ED_ONE_WG, DP_ED_WAVES, DP_ED_TEST_GIVEUP,
- *     DP_GATE_CHUNK_BYTES, DP_GATE_TWO_PASS, DP_KMEANS_MFMA, DP_KMEANS_NO_KEYS, DP_KMEANS_CELLS, DP_LEAN_NO_HALF; INTEGRATION.md lists what each does); production
- *     callers set none of them.
+ *     two host threads at once (the Python layer serialises them per (device, stream)).  Tables a palette acquires after
+ *     creation (dp_palette_build_accel, the candidate tables of the first diffusion call) are built into a private copy
+ *     of the palette's device record under a per-palette mutex and published with one assignment; every launch works on
+ *     a by-value snapshot of that record, so other threads may keep launching with the palette while it is being built --
+ *     they simply still run without the new table.
+ *   - the library reads NO environment variable (nm -D shows no getenv).  The experiment / test switches that force a
+ *     table, kernel or schedule exist only in the twin build libditherpie_hip_exp.so (-DDP_EXPERIMENTS, same sources);
+ *     INTEGRATION.md lists them.
+ *   - dp_version() returns DP_ABI_VERSION; a binding checks it at load time (a changed argument list bumps it).
  */
 #ifndef DITHERPIE_HIP_H
 #define DITHERPIE_HIP_H
@@ -44,6 +47,9 @@ extern "C" {
 #define DP_EWORKSPACE 5  /* workspace too small; see the *_workspace_bytes query */
 
 #define DP_MAX_COLORS 1024
+
+/* 100: rounds 1-2.  101: dp_kmeans_step_u8 takes mean_dev (round 3); dp_distinct_first_u8, dp_kmeans_hist_* (round 4). */
+#define DP_ABI_VERSION 101
 
 #define DP_MODE_NEAREST 0 /* NoDitherStrategy                     dithering_lib.py:333-341 */
 #define DP_MODE_MATRIX 1  /* MatrixDitherStrategy (Bayer, blue)   dithering_lib.py:346-378 */
@@ -138,11 +144,14 @@ int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_fra
                           void *stream);
 
 /* The same with the arithmetic of the reference's numba branch (_error_diffusion_numba, dithering_lib.py:213-308, taken
- * at :638-653 when numba is importable): nearest entry = first minimum of a float32 linear scan
- * ((dr*dr + dg*dg) + db*db), errors pushed as float32(float64(v) + float64(err) * (float64(weights[k]) / divisor)).
+ * at :638-653 when numba is importable), typed per numba's unification rule: `r` is assigned a float32 array element
+ * (:239) and the float64 literals 0.0 / 255.0 (:242-245), so r, g, b -- and everything computed from them -- are float64:
+ * nearest entry = first minimum of a float64 linear scan ((dr*dr + dg*dg) + db*db, strict <), err = float64(r) -
+ * float64(chosen) kept in float64, pushed as float32(float64(v) + err * (float64(weights[k]) / divisor)).
  *   weights  host array of ntaps float32 (the reference's np.float32 weight values), divisor as the reference passes it
- * Parity status: restated in the CPU oracle (orc_error_diffusion_numba_u8); NOT pinned by fixtures (numba cannot be
- * installed in the build image). */
+ * Parity status: restated in the CPU oracle (orc_error_diffusion_numba_u8) and in numpy; fixtures pending -- NOT pinned
+ * by reference output (numba cannot be installed in the build image).  (Rounds 1-3 implemented a float32 scan and a
+ * float32 error; ABI 101 carries the float64 reading.) */
 int dp_error_diffusion_numba_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
                                 const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *weights,
                                 double divisor, int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,

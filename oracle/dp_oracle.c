@@ -645,16 +645,25 @@ int orc_error_diffusion_u8(const uint8_t *in, uint8_t *out, int h, int w, const 
 /* error diffusion, the numba branch: _error_diffusion_numba,          */
 /* dithering_lib.py:213-308 (dispatch :638-653, arrays built :640-642) */
 /* work float32; palette float32; weights float32; divisor float64.    */
-/*  nearest: first minimum of  dist = (dr*dr + dg*dg) + db*db  with    */
-/*  every operation in float32 (numba keeps float32 x float32 in       */
-/*  float32; best_dist starts at 1e20);                                */
-/*  push: wgt = weights[k] / divisor is float64, err * wgt is float64, */
-/*  work[ny,nx] += ... adds in float64 and rounds to float32 on the    */
-/*  EXPERIMENTAL: whether numba types r / dist / err as float32 (this   */
-/*  restatement) or unifies them to float64 (r is also assigned the      */
-/*  float64 literals 0.0 / 255.0) is open; see ediff.hip.               */
-/*  store.  PARITY UNPINNED: numba cannot be installed in the build    */
-/*  image, so no reference output exists for this function.            */
+/* TYPED PER NUMBA'S UNIFICATION RULE (fixtures pending): a variable   */
+/* has ONE type, the unification of every assignment to it.            */
+/*   r = work_2d[y, x, 0]   float32      (:239)                        */
+/*   r = 0.0 / r = 255.0    float64      (:242-245)                    */
+/* => r, g, b are float64 (holding the float32 value or a clamp bound) */
+/* => dr = r - palette_arr[i, 0] is float64 (float64 - float32),       */
+/*    dist = (dr*dr + dg*dg) + db*db in float64, no contraction        */
+/*    (numba emits separate fmul / fadd without fastmath),             */
+/*    strict `dist < best_dist`, best_dist = 1e20: first minimum;      */
+/* => err0 = r - chosen0 is float64 (NOT rounded to float32);          */
+/*    wgt = weights[k] / divisor  float32 / float64 = float64;         */
+/*    work[ny, nx] += err0 * wgt: float64 product, float64 sum with    */
+/*    the float32 element, ONE rounding to float32 on the store.       */
+/* Rounds 1-3 read the scan and the error as float32; no numba release */
+/* is known to type them so, and that reading is gone.                 */
+/* PARITY UNPINNED: numba cannot be installed in the build image (no   */
+/* network), so no reference output exists for this function; it is    */
+/* checked against an independent numpy transcription of the same      */
+/* lines (oracle.py: error_diffusion_numba_numpy) only.                */
 /* ------------------------------------------------------------------ */
 int orc_error_diffusion_numba_u8(const uint8_t *in, uint8_t *out, int h, int w, const float *pal, int K,
                                  const uint8_t *out_colors, const uint8_t *lut_in, const int *dx, const int *dy,
@@ -675,28 +684,29 @@ int orc_error_diffusion_numba_u8(const uint8_t *in, uint8_t *out, int h, int w, 
         for (int step = 0; step < w; step++) {
             int x = rev ? (w - 1 - step) : step;
             float *p = W + ((size_t)y * w + x) * 3;
-            float v[3];
+            double v[3];  /* r, g, b: float64 by unification */
             for (int c = 0; c < 3; c++) {
-                float t = p[c];
-                v[c] = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+                double t = (double)p[c];
+                v[c] = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);
             }
             int best = 0;
             double best_dist = 1e20;
             for (int i = 0; i < K; i++) {
-                volatile float dr = v[0] - pal[i * 3 + 0], dg = v[1] - pal[i * 3 + 1], db = v[2] - pal[i * 3 + 2];
-                volatile float rr = dr * dr, gg = dg * dg, bb = db * db;  /* (volatile: no contraction into fma) */
-                volatile float s1 = rr + gg;
-                volatile float dist = s1 + bb;
-                if ((double)dist < best_dist) {
-                    best_dist = (double)dist;
+                volatile double dr = v[0] - (double)pal[i * 3 + 0], dg = v[1] - (double)pal[i * 3 + 1], db = v[2] - (double)pal[i * 3 + 2];
+                volatile double rr = dr * dr, gg = dg * dg, bb = db * db;  /* (volatile: no contraction into fma) */
+                volatile double s1 = rr + gg;
+                volatile double dist = s1 + bb;
+                if (dist < best_dist) {
+                    best_dist = dist;
                     best = i;
                 }
             }
             pick[(size_t)y * w + x] = best;
-            float err[3];
+            double err[3];
             for (int c = 0; c < 3; c++) {
+                volatile double e = v[c] - (double)pal[best * 3 + c];
                 p[c] = pal[best * 3 + c];
-                err[c] = v[c] - pal[best * 3 + c];
+                err[c] = e;
             }
             for (int k = 0; k < ntaps; k++) {
                 int nx = x + dx[k] * dir, ny = y + dy[k];
@@ -704,7 +714,7 @@ int orc_error_diffusion_numba_u8(const uint8_t *in, uint8_t *out, int h, int w, 
                     volatile double wgt = (double)weights[k] / divisor;
                     float *tp = W + ((size_t)ny * w + nx) * 3;
                     for (int c = 0; c < 3; c++) {
-                        volatile double prod = (double)err[c] * wgt;
+                        volatile double prod = err[c] * wgt;
                         volatile double sum = (double)tp[c] + prod;
                         tp[c] = (float)sum;
                     }

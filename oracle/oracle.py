@@ -302,9 +302,11 @@ def error_diffusion_u8(arr, pal_f32, out_colors, lut_in, variant="atkinson", ser
 
 
 def error_diffusion_numba_u8(arr, pal_f32, out_colors, lut_in, variant="atkinson", serpentine=False):
-    """The reference's numba branch (_error_diffusion_numba, dithering_lib.py:213-308) restated in C.  PARITY UNPINNED:
-    numba cannot be installed here, so nothing the reference produced pins it; tests/test_oracle_golden.py checks it
-    against an independent numpy transcription of the same lines."""
+    """The reference's numba branch (_error_diffusion_numba, dithering_lib.py:213-308) restated in C, typed per numba's
+    unification rule: r / g / b are assigned a float32 element AND float64 literals (:239-251), hence float64, and so are
+    the distances of the scan and the error that is pushed.  PARITY UNPINNED (fixtures pending): numba cannot be installed
+    here, so nothing the reference produced pins it; tests/test_oracle_golden.py checks it against an independent numpy
+    transcription of the same lines."""
     arr = np.ascontiguousarray(arr, dtype=np.uint8)
     h, w, _ = arr.shape
     out = np.empty_like(arr)
@@ -319,9 +321,12 @@ def error_diffusion_numba_u8(arr, pal_f32, out_colors, lut_in, variant="atkinson
     return out
 
 
-def error_diffusion_numba_numpy(arr, pal_f32, out_colors, lut_in, variant="atkinson", serpentine=False):
+def error_diffusion_numba_numpy(arr, pal_f32, out_colors, lut_in, variant="atkinson", serpentine=False, scan="float64"):
     """A second, independent statement of the same lines with numpy scalar types doing the arithmetic (np.float32 /
-    np.float64 objects: every operation rounds as the dtype says).  Slow: small images only."""
+    np.float64 objects: every operation rounds as the dtype says), each variable carrying the type numba's unification
+    gives it (module docstring of dp_oracle.c's restatement).  Slow: small images only.
+    scan="float32": the reading of rounds 1-3 (scan and error in float32), kept ONLY so that a test can show an input on
+    which the two readings choose differently; nothing else uses it."""
     arr = np.asarray(arr, np.uint8)
     h, w, _ = arr.shape
     taps, div = ed_kernel(variant)
@@ -330,23 +335,24 @@ def error_diffusion_numba_numpy(arr, pal_f32, out_colors, lut_in, variant="atkin
     weights = np.array([t[2] for t in taps], np.float32)
     divisor = float(div)
     pick = np.zeros((h, w), np.int64)
-    f0, f255 = np.float32(0.0), np.float32(255.0)
+    T = np.float64 if scan == "float64" else np.float32   # the type of r, g, b (and of everything computed from them)
+    f0, f255 = T(0.0), T(255.0)
     for y in range(h):
         rev = serpentine and (y % 2 == 1)
         xs = range(w - 1, -1, -1) if rev else range(w)
         xdir = -1 if rev else 1
         for x in xs:
-            r, g, b = (min(max(work[y, x, c], f0), f255) for c in range(3))
+            r, g, b = (min(max(T(work[y, x, c]), f0), f255) for c in range(3))
             best, best_dist = 0, 1e20
             for i in range(pal.shape[0]):
-                dr, dg, db = r - pal[i, 0], g - pal[i, 1], b - pal[i, 2]
-                dist = dr * dr + dg * dg + db * db  # np.float32 scalars: each product and sum rounded to float32
+                dr, dg, db = r - T(pal[i, 0]), g - T(pal[i, 1]), b - T(pal[i, 2])
+                dist = dr * dr + dg * dg + db * db  # numpy scalars of type T: each product and sum rounded to T
                 if float(dist) < best_dist:
                     best_dist, best = float(dist), i
             pick[y, x] = best
             c0, c1, c2 = pal[best]
             work[y, x] = (c0, c1, c2)
-            err = (r - c0, g - c1, b - c2)
+            err = (r - T(c0), g - T(c1), b - T(c2))
             for k, (tdx, tdy, _) in enumerate(taps):
                 nx, ny = x + tdx * xdir, y + tdy
                 if 0 <= nx < w and 0 <= ny < h:

@@ -5,9 +5,10 @@ import sys
 import numpy as np
 import pytest
 
-# the tests force tables / kernels / schedules through the DP_* switches, which only libditherpie_hip_exp.so reads
-# (dither_pie_amd/_lib.py); test_release_library_* run the product library in a subprocess
-os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")
+# The suite runs on the library that ships, libditherpie_hip.so.  Only the tests that force a table / kernel / schedule
+# through a DP_* switch take the `switches` fixture below, which maps the -DDP_EXPERIMENTS twin (the only build that reads
+# those variables) for the duration of that one test.
+os.environ.pop("DITHER_PIE_EXPERIMENTS", None)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -18,6 +19,52 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _drop_device_objects():
+    from dither_pie_amd import dithering_lib
+    dithering_lib.drop_device_caches()
+
+
+@pytest.fixture
+def switches(monkeypatch):
+    """monkeypatch, with load() returning libditherpie_hip_exp.so while the test runs (DP_* variables mean something
+    there only).  Cached palettes / thresholds are dropped on both sides of the switch: a device object stays with the
+    library that made it."""
+    from dither_pie_amd import _lib
+    _drop_device_objects()
+    prev = _lib.select(True)
+    assert _lib.load() is not None and _lib.LIB_PATH.endswith("libditherpie_hip_exp.so")
+    try:
+        yield monkeypatch
+    finally:
+        _drop_device_objects()
+        _lib.select(prev)
+
+
+PRODUCT_LIBRARY_TESTS = []   # node ids of the GPU tests that ran with the product library mapped (reported at the end)
+
+
+@pytest.fixture(autouse=True)
+def _which_library(request):
+    """Every GPU test that does not ask for `switches` must find the product library selected."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from dither_pie_amd import _lib
+    if "switches" in request.fixturenames:
+        yield
+        return
+    assert not _lib.EXPERIMENTS and _lib.LIB_PATH.endswith("libditherpie_hip.so"), _lib.LIB_PATH
+    yield
+    assert not _lib.EXPERIMENTS and _lib.LIB_PATH.endswith("libditherpie_hip.so"), "a test left the twin library selected"
+    PRODUCT_LIBRARY_TESTS.append(request.node.nodeid)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if PRODUCT_LIBRARY_TESTS:
+        terminalreporter.write_line(f"{len(PRODUCT_LIBRARY_TESTS)} GPU tests ran on libditherpie_hip.so (the product library); "
+                                    "the rest took the `switches` fixture (libditherpie_hip_exp.so)")
 
 
 @pytest.fixture(scope="session")

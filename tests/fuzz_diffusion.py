@@ -2,7 +2,6 @@
 against the oracle: palette sizes around every table boundary (2, 8, 9, 16, 17, 64, 256), random / uniform / clustered
 palettes, gamma on and off, shapes from 1x1 up to a few bands, batches.  run(seed, n) -> number of mismatches.
 Used by tests/test_gpu_kernels.py; `python tests/fuzz_diffusion.py [seed] [n]` runs it by hand on a GPU box."""
-import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import os
 import sys
 

@@ -1,7 +1,6 @@
 """Soak of the candidate-list Lloyd pass (dp_kmeans_step_u8 with DP_KMEANS_CELLS=1) against the oracle's float64 labelling:
 the case generator of tests/test_gpu_fullsize.py::test_kmeans_cell_list_fuzz over many seeds (run on the GPU box).
 usage: fuzz_kmeans.py <first seed> <seeds>"""
-import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
 from oracle import oracle as orc
@@ -52,4 +51,6 @@ def run(seed0, seeds):
 
 
 if __name__ == "__main__":
+    from dither_pie_amd import _lib
+    if not _lib.EXPERIMENTS: _lib.select(True)   # DP_KMEANS_CELLS is read by libditherpie_hip_exp.so only
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 10, int(sys.argv[2]) if len(sys.argv) > 2 else 50) else 0)

@@ -1,5 +1,4 @@
 """Randomised cross-check of the ordered / error-diffusion paths against the CPU oracle (run on the GPU box)."""
-import os; os.environ.setdefault("DITHER_PIE_EXPERIMENTS", "1")  # the DP_* switches live in libditherpie_hip_exp.so
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
 from oracle import oracle as orc
@@ -9,8 +8,10 @@ modes = ["none", "bayer", "blue_noise", "IGN", "polka_dot", "error_diffusion", "
 DIFFUSERS = ("error_diffusion", "perceptual", "hybrid", "adaptive_variance", "ostromoukhov")
 
 
-def run(seed, N):
-  """-> number of mismatching cases"""
+def run(seed, N, force=True):
+  """-> number of mismatching cases.  force: per case, force a cell table / the compact kernel through the DP_* switches --
+  they exist only in libditherpie_hip_exp.so (the caller selects it: _lib.select(True) / DITHER_PIE_EXPERIMENTS=1); with
+  force=False the library's own choices are what is tested (the product library)."""
   orc.build()
   rs = np.random.RandomState(seed)
   bad = 0
@@ -53,10 +54,13 @@ def run(seed, N):
           pick = rs.randint(0, len(pal), (nf, h, w))
           mid = ((pa[pick] + pa[(pick + 1) % len(pal)]) // 2).astype(np.uint8)
           frames = np.where(rs.randint(0, 2, (nf, h, w, 1)) == 0, mid, frames)
-      os.environ["DP_FORCE_TABLE"] = str(rs.choice(["", "", "u4", "u8", "w4", "w8"]))  # which cell table the accelerator uses
+      table = str(rs.choice(["", "", "u4", "u8", "w4", "w8"]))  # which cell table the accelerator uses
       # ... and, one case in three, the compact kernel on whatever 8-entry table that leaves (crowded palettes take it anyway)
-      if rs.rand() < 0.33: os.environ["DP_FORCE_COMPACT"] = "1"
-      else: os.environ.pop("DP_FORCE_COMPACT", None)
+      compact = rs.rand() < 0.33
+      if force:
+          os.environ["DP_FORCE_TABLE"] = table
+          if compact: os.environ["DP_FORCE_COMPACT"] = "1"
+          else: os.environ.pop("DP_FORCE_COMPACT", None)
       pal_f32, oc, lut = orc.prepare_palette(pal, gamma)
       P = be.Palette(pal_f32, oc, lut, accel=bool(rs.rand() < 0.8))
       x = torch.from_numpy(frames).cuda()
@@ -89,4 +93,6 @@ def run(seed, N):
 
 
 if __name__ == "__main__":
+    from dither_pie_amd import _lib
+    if not _lib.EXPERIMENTS: _lib.select(True)
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 300) else 0)

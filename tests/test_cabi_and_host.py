@@ -327,14 +327,15 @@ def test_pipe_path_follows_rotation_metadata(tmp_path, monkeypatch, rotation, sw
 
 def test_release_library_reads_no_environment():
     """csrc/Makefile builds the sources twice: libditherpie_hip.so (the product) must not import getenv nor carry the name of
-    any DP_* experiment switch; libditherpie_hip_exp.so (-DDP_EXPERIMENTS: what this test session loads, conftest.py sets
-    DITHER_PIE_EXPERIMENTS=1) has them compiled in.  Both export the whole C ABI."""
+    any DP_* experiment switch; libditherpie_hip_exp.so (-DDP_EXPERIMENTS: what the `switches` fixture of conftest.py maps for
+    the tests that force a table / kernel / schedule) has them compiled in.  Both export the whole C ABI, and the session
+    loads the product library."""
     import subprocess
     from dither_pie_amd import _lib
     here = os.path.dirname(_lib.__file__)
     rel, exp = os.path.join(here, "libditherpie_hip.so"), os.path.join(here, "libditherpie_hip_exp.so")
     assert os.path.exists(rel) and os.path.exists(exp)
-    assert _lib.EXPERIMENTS and _lib.LIB_PATH == exp
+    assert not _lib.EXPERIMENTS and _lib.LIB_PATH == rel
     sym = {p: subprocess.run(["nm", "-D", p], capture_output=True, text=True, check=True).stdout for p in (rel, exp)}
     assert "getenv" not in sym[rel] and "getenv" in sym[exp]
     names = {p: set(re.findall(rb"DP_[A-Z0-9_]{3,}", open(p, "rb").read())) for p in (rel, exp)}

@@ -341,3 +341,31 @@ print('release ok')
     env.update(DP_NO_COMPACT_KERNEL="1", DP_KMEANS_CELLS="0", DP_FORCE_TABLE="u8", DP_ED_TEST_GIVEUP="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "release ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal():
+    """bench.py's N > 1 path end to end, as the driver's SCALE run will start it, rehearsed on the one GPU of the box: the
+    parent starts two ranks through torch.distributed.run before it touches the GPU, both ranks use cuda:0, the collectives
+    run over gloo.  Exactly one JSON line on stdout, carrying the per-rank shares of C5 (500 of the 1000 frames) and C4 (two
+    row bands), the C2 known answer, and the rehearsal mark (the numbers of such a run mean nothing)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.pop("DITHER_PIE_EXPERIMENTS", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2",
+                        "--warmup", "1", "--frames", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_world_size"] == 2 and "rehearsal" in res
+    assert res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["parity_kat_4k"] is True
+    assert res["c5_video"]["frames_this_rank"] == 500 and res["c5_video"]["n_gpus"] == 2 and res["c5_video"]["scaling"] == "strong"
+    assert "2 band(s)" in res["c4_kmeans_pass"]["workload"]
+    assert "cpu_baseline" not in res
+    assert res["roofline"]["frac"] > 0 and res["value"] > 0

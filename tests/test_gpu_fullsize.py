@@ -47,7 +47,7 @@ def _need(name):
 
 
 # ------------------------------------------------------------------------------------------------ C3
-def test_c3_floyd_steinberg_4k_both_schedules(d, orc, monkeypatch):
+def test_c3_floyd_steinberg_4k_both_schedules(d, orc, switches):
     """rnd(2160,3840,1234), U16, Floyd-Steinberg: one frame (bands spread over workgroups), the same frame with one
     workgroup per frame, and a 24-frame batch, all against the reference's own hash of that frame."""
     import torch
@@ -58,9 +58,9 @@ def test_c3_floyd_steinberg_4k_both_schedules(d, orc, monkeypatch):
     it = d.ImageDitherer(len(pal), d.DitherMode.ERROR_DIFFUSION, pal, False, dict(case["params"]))
     x = torch.from_numpy(arr).cuda()
     assert H(it.apply_dithering_frames(x).cpu().numpy()) == case["h_out"]          # G > 1 schedule
-    monkeypatch.setenv("DP_ED_ONE_WG", "1")
+    switches.setenv("DP_ED_ONE_WG", "1")
     assert H(it.apply_dithering_frames(x).cpu().numpy()) == case["h_out"]          # one workgroup per frame
-    monkeypatch.delenv("DP_ED_ONE_WG")
+    switches.delenv("DP_ED_ONE_WG")
     # a batch of 24: frames 0, 7, 23 are the KAT frame, the others rnd(.., 1235 + i) against the oracle for two of them
     others = {3: orc.rnd(2160, 3840, 1238), 16: orc.rnd(2160, 3840, 1251)}
     batch = torch.empty((24, 2160, 3840, 3), dtype=torch.uint8, device="cuda")
@@ -79,14 +79,14 @@ def test_c3_floyd_steinberg_4k_both_schedules(d, orc, monkeypatch):
         assert np.array_equal(out[i].cpu().numpy(), ref), i
 
 
-def test_error_diffusion_gives_up_and_repairs(d, be, orc, monkeypatch):
+def test_error_diffusion_gives_up_and_repairs(d, be, orc, switches):
     """A workgroup of a multi-workgroup launch that gives up waiting sets a flag; the repair launch behind it redoes the
     frame.  DP_ED_TEST_GIVEUP makes every workgroup of the first launch give up before it writes anything."""
     import torch
     pal = orc.generate_uniform_palette(16)
     frames = np.stack([orc.rnd(300, 200, 40 + i) for i in range(3)])  # 5 bands each: spread over workgroups
     x = torch.from_numpy(frames).cuda()
-    monkeypatch.setenv("DP_ED_TEST_GIVEUP", "1")
+    switches.setenv("DP_ED_TEST_GIVEUP", "1")
     for mode, params in [("error_diffusion", {"variant": "floyd_steinberg", "serpentine": "false"}),
                          ("error_diffusion", {"variant": "jjn", "serpentine": "false"}),
                          ("perceptual", {}), ("hybrid", {}), ("ostromoukhov", {"serpentine": "false"})]:
@@ -144,7 +144,7 @@ def test_c4_kmeans_totals_over_all_8k_pixels(be, orc):
 
 
 @pytest.mark.parametrize("K", [1, 5, 32, 33, 100, 256])
-def test_kmeans_matrix_core_kernel_totals(be, orc, monkeypatch, K):
+def test_kmeans_matrix_core_kernel_totals(be, orc, switches, K):
     """The opt-in matrix-core Lloyd pass (kmeans_mfma_kernel, DP_KMEANS_MFMA=1; measured slower, kept as evidence):
     same integer totals as the oracle and as the product kernel, ragged pixel count, centres on and off the lattice."""
     import torch
@@ -155,9 +155,9 @@ def test_kmeans_matrix_core_kernel_totals(be, orc, monkeypatch, K):
     centers = rs.rand(K, 3) * 255.0
     centers[: K // 2] = np.round(centers[: K // 2])  # integer centres: exact ties between clusters do occur
     s_ref, n_ref, _ = orc.kmeans_step(flat, centers)
-    monkeypatch.setenv("DP_KMEANS_MFMA", "1")
+    switches.setenv("DP_KMEANS_MFMA", "1")
     s, n, q = be.kmeans_step(px, torch.from_numpy(centers))
-    monkeypatch.delenv("DP_KMEANS_MFMA")
+    switches.delenv("DP_KMEANS_MFMA")
     s2, n2, q2 = be.kmeans_step(px, torch.from_numpy(centers))
     assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(n.cpu().numpy(), n_ref)
     assert torch.equal(s, s2) and torch.equal(n, n2) and torch.equal(q, q2)
@@ -166,7 +166,7 @@ def test_kmeans_matrix_core_kernel_totals(be, orc, monkeypatch, K):
 @pytest.mark.parametrize("K,kind", [(1, "random"), (2, "lattice"), (5, "random"), (16, "clustered"), (32, "lattice"), (33, "data"),
                                     (64, "random"), (65, "lattice"), (100, "clustered"), (200, "data"), (255, "random"), (256, "data"),
                                     (256, "clustered"), (8, "duplicates"), (130, "duplicates")])
-def test_kmeans_cell_list_kernel_totals(be, orc, monkeypatch, K, kind):
+def test_kmeans_cell_list_kernel_totals(be, orc, switches, K, kind):
     """The Lloyd pass over per-cell candidate lists (kmeans_cells_kernel, what images above 2^19 pixels take; forced here
     with DP_KMEANS_CELLS=1): integer totals equal the oracle's and the full-scan kernel's -- ragged pixel count, an
     unaligned pixel pointer, centres on the integer lattice (exact ties between clusters), centres crowded into one
@@ -194,17 +194,17 @@ def test_kmeans_cell_list_kernel_totals(be, orc, monkeypatch, K, kind):
     for offset in (0, 1):  # 4-byte aligned, then not
         px = buf[offset:offset + len(flat) * 3].view(-1, 3)
         px.copy_(torch.from_numpy(np.ascontiguousarray(flat)))
-        monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+        switches.setenv("DP_KMEANS_CELLS", "1")
         s, n, q = be.kmeans_step(px, torch.from_numpy(centers))
-        monkeypatch.setenv("DP_KMEANS_CELLS", "0")
+        switches.setenv("DP_KMEANS_CELLS", "0")
         s2, n2, q2 = be.kmeans_step(px, torch.from_numpy(centers))
-        monkeypatch.delenv("DP_KMEANS_CELLS")
+        switches.delenv("DP_KMEANS_CELLS")
         assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(n.cpu().numpy(), n_ref), (K, kind, offset)
         assert torch.equal(s, s2) and torch.equal(n, n2) and torch.equal(q, q2), (K, kind, offset)
         tot = torch.zeros(5 * K, dtype=torch.int64, device="cuda")
-        monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+        switches.setenv("DP_KMEANS_CELLS", "1")
         be.kmeans_step_into(px, torch.from_numpy(centers).cuda(), tot, want_sq=False)  # the instance without squared norms
-        monkeypatch.delenv("DP_KMEANS_CELLS")
+        switches.delenv("DP_KMEANS_CELLS")
         assert np.array_equal(tot[:3 * K].cpu().numpy().reshape(K, 3), s_ref) and np.array_equal(tot[3 * K:4 * K].cpu().numpy(), n_ref)
 
 
@@ -256,7 +256,7 @@ def test_kmeans_plusplus_kernel_picks_sklearns_seeds(be, orc, gold, kat):
 
 
 @pytest.mark.parametrize("variant,K", [("scan", 16), ("scan", 300), ("cells", 16), ("cells", 100), ("mfma", 40)])
-def test_kmeans_pass_sklearn_tie_rule(be, orc, monkeypatch, variant, K):
+def test_kmeans_pass_sklearn_tie_rule(be, orc, switches, variant, K):
     """dp_kmeans_step_u8 with mean_dev: pixels equidistant from two centres get the label of sklearn's float64
     expression on mean-centred data (the oracle's orc_kmeans_step_sk, pinned by the kmx_* fixtures), in every kernel
     that has a float64 decision (full scan with and without keys, both candidate-list widths, the matrix-core kernel).
@@ -273,11 +273,11 @@ def test_kmeans_pass_sklearn_tie_rule(be, orc, monkeypatch, variant, K):
     assert not np.array_equal(n_ref, n_low), "the input has to tell the two tie rules apart"
     px = torch.from_numpy(flat).cuda()
     if variant == "cells":
-        monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+        switches.setenv("DP_KMEANS_CELLS", "1")
     elif variant == "mfma":
-        monkeypatch.setenv("DP_KMEANS_MFMA", "1")
+        switches.setenv("DP_KMEANS_MFMA", "1")
     else:
-        monkeypatch.setenv("DP_KMEANS_CELLS", "0")
+        switches.setenv("DP_KMEANS_CELLS", "0")
     s, n, q = be.kmeans_step(px, torch.from_numpy(centers), torch.from_numpy(mean))
     s0, n0, _ = be.kmeans_step(px, torch.from_numpy(centers))
     assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(n.cpu().numpy(), n_ref)
@@ -462,12 +462,12 @@ def test_two_threads_share_a_stream(d, orc):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_kmeans_cell_list_fuzz(be, orc, monkeypatch, seed):
+def test_kmeans_cell_list_fuzz(be, orc, switches, seed):
     """Random cluster counts (1..256), centre layouts, pixel counts and content through the candidate-list pass: the
     int64 totals equal the oracle's float64 labelling every time."""
     import torch
     rs = np.random.RandomState(1000 + seed)
-    monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+    switches.setenv("DP_KMEANS_CELLS", "1")
     for case in range(12):
         K = int(rs.choice([1, 2, 3, 7, 16, 31, 32, 64, 65, 129, 255, 256]))
         n = int(rs.choice([1, 3, 255, 257, 4096, 50001, 200003]))
@@ -499,11 +499,11 @@ def test_kmeans_cell_list_fuzz(be, orc, monkeypatch, seed):
         assert int(q.sum().item()) == int((x64 * x64).sum())
 
 
-def test_two_threads_share_a_stream_for_lloyd_passes(be, orc, monkeypatch):
+def test_two_threads_share_a_stream_for_lloyd_passes(be, orc, switches):
     """dp_kmeans_step_u8 with per-cell candidate lists keeps the lists in library-owned memory per (device, stream): two
     threads on the default stream with different centres (ctypes drops the GIL) must not see each other's lists."""
     import torch
-    monkeypatch.setenv("DP_KMEANS_CELLS", "1")
+    switches.setenv("DP_KMEANS_CELLS", "1")
     px_np = orc.rnd(600, 1000, 77).reshape(-1, 3)
     px = torch.from_numpy(px_np).cuda()
     sets = []

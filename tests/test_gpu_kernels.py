@@ -178,8 +178,8 @@ def test_error_diffusion_vs_oracle(be, orc, variant, serp):
 @pytest.mark.parametrize("variant", ["floyd_steinberg", "jjn", "atkinson", "sierra_lite", "burkes"])
 @pytest.mark.parametrize("serp", [False, True])
 def test_error_diffusion_numba_arithmetic_vs_oracle(be, orc, variant, serp):
-    """The reference's numba branch (dithering_lib.py:213-308: float32 linear-scan nearest, float64 pushes rounded on the
-    store) through dp_error_diffusion_numba_u8 against its C restatement -- several bands, several frames, a palette with
+    """The reference's numba branch (dithering_lib.py:213-308, typed per numba's unification rule: float64 linear-scan
+    nearest, float64 error, float64 pushes rounded on the store) through dp_error_diffusion_numba_u8 against its C restatement -- several bands, several frames, a palette with
     exact float32 ties (uniform) and one without, with and without the gamma table.  (That restatement is itself not
     pinned by reference output: numba is not installable here.)"""
     import torch
@@ -193,6 +193,31 @@ def test_error_diffusion_numba_arithmetic_vs_oracle(be, orc, variant, serp):
         for f in range(2):
             ref = orc.error_diffusion_numba_u8(frames[f], pal_f32, out_colors, lut_in, variant, serp)
             _assert_same(out[f], ref, f"numba arithmetic {variant} serp={serp} frame {f}")
+
+
+@pytest.mark.gpu
+def test_error_diffusion_numba_float64_reading(be, orc):
+    """The probe of tests/test_oracle_golden.py::test_numba_branch_follows_float64_unification on the device: the kernel
+    takes the entry that is nearer in float64 (numba unifies r to float64), not the one a float32 scan collapses onto; and a
+    strip with tiny values against far colours (float64 errors that float32 cannot hold) equals the restatement on both
+    kernels (wavefront / frame-parallel serpentine)."""
+    import torch
+    from test_oracle_golden import _numba_reading_probe
+    arr, pal_f32, out_colors = _numba_reading_probe()
+    P = be.Palette(pal_f32, out_colors, None)
+    taps, div = orc.ed_kernel("floyd_steinberg")
+    out = be.error_diffusion(torch.from_numpy(arr).cuda(), P, taps, div, False, arithmetic="numba").cpu().numpy()
+    assert out[0, 0].tolist() == [200, 210, 220]
+    assert orc.error_diffusion_numba_numpy(arr, pal_f32, out_colors, None, "floyd_steinberg", False, scan="float32")[0, 0].tolist() == [10, 20, 30]
+    pal2 = np.array([[255.0, 255.0, 255.0], [0.3, 0.3, 0.3], [17.7, 200.1, 3.3]], np.float32)
+    oc2 = np.array([[255, 255, 255], [0, 0, 0], [18, 200, 3]], np.uint8)
+    P2 = be.Palette(pal2, oc2, None)
+    taps, div = orc.ed_kernel("jjn")
+    for shape, seed in [((3, 40), 8), ((200, 333), 9), ((70, 1), 10)]:
+        strip = orc.rnd(shape[0], shape[1], seed)
+        for serp in (False, True):
+            out = be.error_diffusion(torch.from_numpy(strip).cuda(), P2, taps, div, serp, arithmetic="numba").cpu().numpy()
+            _assert_same(out, orc.error_diffusion_numba_u8(strip, pal2, oc2, None, "jjn", serp), f"numba float64 {shape} serp={serp}")
 
 
 def test_error_diffusion_numba_arithmetic_1080p_bands_over_workgroups(be, orc):
@@ -470,17 +495,31 @@ def test_serpentine_wide_rows_use_the_frame_parallel_kernel(be, orc):
         _assert_same(out, orc.apply_dithering(arr, pal, "error_diffusion", params, False), f"w={w}")
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed", [11, 12])
-def test_randomised_cases_against_oracle(be, orc, seed):
-    """150 random (mode, parameters, palette size, gamma, shape, tile origin, tie-rich content) cases per seed."""
+def _fuzz_ordered():
     import importlib.util
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_ordered.py")
     spec = importlib.util.spec_from_file_location("fuzz_ordered", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.run(seed, 150) == 0
+    return mod
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_randomised_cases_against_oracle(be, orc, switches, seed):
+    """150 random (mode, parameters, palette size, gamma, shape, tile origin, tie-rich content) cases per seed, each with a
+    forced cell table and, one in three, the compact kernel forced onto it (DP_* switches: the twin library)."""
+    assert _fuzz_ordered().run(seed, 150) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [13, 14, 15])
+def test_randomised_cases_against_oracle_product_library(be, orc, seed):
+    """The same generator on the library that ships: 150 cases per seed, tables / kernels chosen by the library itself."""
+    from dither_pie_amd import _lib
+    assert not _lib.EXPERIMENTS
+    assert _fuzz_ordered().run(seed, 150, force=False) == 0
 
 
 @pytest.mark.gpu
@@ -591,7 +630,7 @@ def _image_like(rs, h, w, kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("table", ["", "u4", "u8", "w4", "w8"])
 @pytest.mark.parametrize("kind,K", [("dark", 8), ("dark", 16), ("smooth", 64), ("dark", 256), ("smooth", 256)])
-def test_image_derived_palettes_every_cell_table(be, orc, monkeypatch, table, kind, K):
+def test_image_derived_palettes_every_cell_table(be, orc, switches, table, kind, K):
     """Palettes extracted from the image itself crowd a few cells of the plain 16^3 grid; the accelerator then builds its
     table over warped cells (per-channel maps staged in LDS).  Every table variant the accelerator can choose -- plain or
     warped cells, 4- or 8-entry blocks (DP_FORCE_TABLE; "" = its own choice) -- has to give the oracle's bytes, on the
@@ -599,7 +638,7 @@ def test_image_derived_palettes_every_cell_table(be, orc, monkeypatch, table, ki
     from PIL import Image
     from dither_pie_amd.dithering_lib import ColorReducer
     if table:
-        monkeypatch.setenv("DP_FORCE_TABLE", table)
+        switches.setenv("DP_FORCE_TABLE", table)
     rs = np.random.RandomState(K + len(kind))
     h, w = 120, 203
     arr = _image_like(rs, h, w, kind)
@@ -613,7 +652,7 @@ def test_image_derived_palettes_every_cell_table(be, orc, monkeypatch, table, ki
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant,K,gamma", [("floyd_steinberg", 16, False), ("jjn", 40, False), ("atkinson", 256, True)])
-def test_error_diffusion_frame_spread_over_workgroups(be, orc, monkeypatch, variant, K, gamma):
+def test_error_diffusion_frame_spread_over_workgroups(be, orc, switches, variant, K, gamma):
     """Few frames in flight and at least four 64-row bands: the bands of a frame are spread over several workgroups that
     meet through progress words in global memory (agent-scope stores for the boundary rows).  Same bytes as the oracle and
     as the one-workgroup-per-frame schedule (DP_ED_ONE_WG=1)."""
@@ -625,10 +664,10 @@ def test_error_diffusion_frame_spread_over_workgroups(be, orc, monkeypatch, vari
     ref = orc.apply_dithering(arr, pal, "error_diffusion", params, gamma)
     out = _run_case(be, orc, arr, pal, "error_diffusion", params, gamma)
     _assert_same(out, ref, f"spread {variant}")
-    monkeypatch.setenv("DP_ED_ONE_WG", "1")
+    switches.setenv("DP_ED_ONE_WG", "1")
     out1 = _run_case(be, orc, arr, pal, "error_diffusion", params, gamma)
     _assert_same(out1, ref, f"one workgroup {variant}")
-    monkeypatch.delenv("DP_ED_ONE_WG")
+    switches.delenv("DP_ED_ONE_WG")
     # a small batch: three different frames
     taps, div = orc.ed_kernel(variant)
     frames = np.stack([arr, orc.rnd(h, w, K + 6), orc.rnd(h, w, K + 7)])
@@ -642,7 +681,7 @@ def test_error_diffusion_frame_spread_over_workgroups(be, orc, monkeypatch, vari
 @pytest.mark.parametrize("mode,params", [("perceptual", {}), ("hybrid", {"lum_factor": 1.4, "col_factor": 0.3}),
                                          ("adaptive_variance", {"var_threshold": 200.0, "window_radius": 2}),
                                          ("ostromoukhov", {"serpentine": "false"})])
-def test_variable_diffusers_frame_spread_over_workgroups(be, orc, monkeypatch, mode, params):
+def test_variable_diffusers_frame_spread_over_workgroups(be, orc, switches, mode, params):
     """The four variable-weight diffusers with few frames in flight and five 64-row bands: a frame's bands run in several
     workgroups (progress words in global memory).  Same bytes as the oracle and as one workgroup per frame."""
     h, w = 290, 130
@@ -651,7 +690,7 @@ def test_variable_diffusers_frame_spread_over_workgroups(be, orc, monkeypatch, m
     for gamma in (False, True):
         ref = orc.apply_dithering(arr, pal, mode, params, gamma)
         _assert_same(_run_case(be, orc, arr, pal, mode, params, gamma), ref, f"spread {mode} gamma={gamma}")
-    monkeypatch.setenv("DP_ED_ONE_WG", "1")
+    switches.setenv("DP_ED_ONE_WG", "1")
     _assert_same(_run_case(be, orc, arr, pal, mode, params, False), orc.apply_dithering(arr, pal, mode, params, False), f"one workgroup {mode}")
 
 
@@ -680,11 +719,11 @@ def test_diffusers_exact_ties_at_integer_points(be, orc, K, seed):
 
 
 @pytest.mark.gpu
-def test_variance_gate_in_chunks_of_frames(be, orc, monkeypatch):
+def test_variance_gate_in_chunks_of_frames(be, orc, switches):
     """The gate pass keeps its two float planes for a chunk of frames only (a gigabyte at most); with a tiny budget a small
     batch already needs several chunks.  Every frame's gate has to equal the scipy restatement's."""
     import torch
-    monkeypatch.setenv("DP_GATE_CHUNK_BYTES", str(3 * 33 * 47 * 8 + 100))  # three frames per chunk
+    switches.setenv("DP_GATE_CHUNK_BYTES", str(3 * 33 * 47 * 8 + 100))  # three frames per chunk
     frames = np.stack([orc.rnd(33, 47, 50 + i) for i in range(8)])
     pal_f32, oc, lut = orc.prepare_palette(orc.palr(16), False)
     P = be.Palette(pal_f32, oc, lut)

@@ -265,3 +265,36 @@ def test_numba_branch_restatement_agrees_with_a_numpy_transcription(variant, ser
     a = orc.error_diffusion_numba_u8(arr, pal_f32, out_colors, lut_in, variant, serp)
     assert np.array_equal(a, orc.error_diffusion_numba_numpy(arr, pal_f32, out_colors, lut_in, variant, serp))
     assert not np.array_equal(a, orc.error_diffusion_u8(arr, pal_f32, out_colors, lut_in, variant, serp))
+
+
+def _numba_reading_probe():
+    """A 1 x 1 image and a two-colour float palette on which the float32 and the float64 reading of the numba branch choose
+    differently: the pixel (100, 50, 50) is at squared distance 256 from entry 1 = (116, 50, 50) and 256 + 2**-36 from entry
+    0 = (84, 50 + 2**-18, 50).  In float32 both distances round to 256 and the strict `<` keeps entry 0; in float64 -- what
+    numba's unification of r (float32 element, float64 literals: dithering_lib.py:239-251) gives -- entry 1 is strictly
+    nearer."""
+    pal_f32 = np.array([[84.0, 50.0 + 2.0 ** -18, 50.0], [116.0, 50.0, 50.0]], np.float32)
+    assert float(pal_f32[0, 1]) != 50.0
+    out_colors = np.array([[10, 20, 30], [200, 210, 220]], np.uint8)
+    arr = np.array([[[100, 50, 50]]], np.uint8)
+    return arr, pal_f32, out_colors
+
+
+def test_numba_branch_follows_float64_unification():
+    from oracle import oracle as orc
+    arr, pal_f32, out_colors = _numba_reading_probe()
+    a = orc.error_diffusion_numba_u8(arr, pal_f32, out_colors, None, "floyd_steinberg", False)
+    b = orc.error_diffusion_numba_numpy(arr, pal_f32, out_colors, None, "floyd_steinberg", False)
+    old = orc.error_diffusion_numba_numpy(arr, pal_f32, out_colors, None, "floyd_steinberg", False, scan="float32")
+    assert a[0, 0].tolist() == [200, 210, 220] and np.array_equal(a, b)   # float64: entry 1
+    assert old[0, 0].tolist() == [10, 20, 30]                             # the float32 reading of rounds 1-3: entry 0
+    # and the float64 error is not the float32 one: r = 0.3f, chosen 255 -> r - c needs more than 24 bits
+    r, c = np.float32(0.3), np.float32(255.0)
+    assert np.float64(r) - np.float64(c) != np.float64(np.float32(r - c))
+    # a 3 x 40 strip of that situation (tiny non-zero values against a far colour), both statements, both scans
+    pal2 = np.array([[255.0, 255.0, 255.0], [0.3, 0.3, 0.3], [17.7, 200.1, 3.3]], np.float32)
+    oc2 = np.array([[255, 255, 255], [0, 0, 0], [18, 200, 3]], np.uint8)
+    strip = orc.rnd(3, 40, 8)
+    for serp in (False, True):
+        a = orc.error_diffusion_numba_u8(strip, pal2, oc2, None, "jjn", serp)
+        assert np.array_equal(a, orc.error_diffusion_numba_numpy(strip, pal2, oc2, None, "jjn", serp))
