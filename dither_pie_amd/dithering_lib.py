@@ -789,10 +789,12 @@ class ColorReducer:
 
     @staticmethod
     def generate_kmeans_palette(img, num_colors: int, random_state=42) -> List[Tuple[int, int, int]]:
-        """k-means palette (dithering_lib.py:1845-1857).  The reference fits sklearn KMeans on an
-        UNSEEDED random sample of 10 000 pixels, so its result is not reproducible; here Lloyd runs on
-        the GPU over every pixel with exact integer sums, k-means++ seeded from `random_state`
-        (see dither_pie_amd/kmeans.py for the parity definition)."""
+        """k-means palette (dithering_lib.py:1845-1857).  Images of at most 10 000 pixels, where the reference is
+        deterministic: the reference's palette (sklearn's seeds, sklearn's labelling of equidistant pixels; 11 reference
+        fixtures) -- except that a cluster mean that is an exact integer comes out as that integer, where the reference
+        returns it or one less depending on its thread scheduling.  Larger images: the reference fits on an UNSEEDED random
+        sample of 10 000 pixels and is not reproducible; here Lloyd runs on the GPU over every pixel (over the colour
+        histogram) with exact integer sums, seeded from `random_state` (dither_pie_amd/kmeans.py: parity definition)."""
         from .kmeans import kmeans_palette_from_image
         return kmeans_palette_from_image(img, num_colors, random_state)
 

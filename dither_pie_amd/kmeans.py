@@ -16,8 +16,16 @@ Python's unseeded global RNG, so two runs of the reference disagree with each ot
     exchange is ONE all-reduce(sum) of 4K int64 (1 KB at K=32; 5K in the first iteration) over RCCL/xGMI;
   * the centre update and sklearn's stopping rules run on the device (dp_kmeans_update): iterations are launched
     back to back and the host looks at the status words once per 8 iterations.
-Parity target: from identical initial centres on identical pixels the centres equal sklearn's to 1e-6
-(tests/test_gpu_api.py), and the final inertia over the full image is <= the reference's.
+Parity, two regimes.  At most 10 000 pixels -- the reference is deterministic there, and the fit
+reproduces it: sklearn's k-means++ draws (first centre by choice(n, p=uniform)), sklearn's labelling of pixels that are
+exactly equidistant from two centres (the rounding of its float64 expression on mean-centred data, as the x86 / OpenBLAS
+configuration recorded in tests/golden/kat.json computes it), same iteration count, centres to 1e-9, the same palette on all
+11 reference fixtures.  One class of images has no single reference answer: where a cluster's exact mean is an integer
+(flat colours, K >= distinct colours) sklearn's chunked float64 sums land on the integer or 1 ulp below it depending on the
+order its threads finish, and `astype(int)` gives colour or colour - 1, differently from run to run (tests/golden kmf_*);
+the exact integer sums here always give the colour.  More than 10 000 pixels -- the reference samples with an unseeded RNG:
+the bar is SURVEY A.6's quality definition (inertia over the full image), and the result is byte-identical for any number
+of ranks.
 """
 from __future__ import annotations
 

@@ -197,9 +197,14 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
  *   mean_dev     3 float64 or NULL.  Given (the mean of ALL the fit's pixels, sum / n per channel), a pixel that is
  *                equidistant from two centres gets the label sklearn gives it: the argmin of sklearn's own float64
  *                expression |c'|^2 - 2 x'.c' on mean-centred data (KMeans.fit centres the data; rounding decides exact
- *                ties, reproducibly -- see label_f64 in kmeans.hip for the operation order).  With it a fit of <= 10 000
- *                pixels, where the reference is deterministic, reproduces the reference's centres to 1e-12 on every
- *                fixture incl. structured images (tests/golden kmx_*).  NULL: lowest index on exact ties.
+ *                ties, reproducibly -- see label_f64 in kmeans.hip for the operation order: it is the order of the x86
+ *                AVX-512 / FMA OpenBLAS + numpy configuration the fixtures were recorded on, tests/golden/kat.json
+ *                "kmeans_fixture_host"; sklearn on another BLAS may break exact ties differently).  With it a fit of
+ *                <= 10 000 pixels, where the reference is deterministic, reproduces the reference's centres to 1e-9 on
+ *                every fixture incl. structured images (tests/golden kmx_*); the truncated palette is the reference's
+ *                except where a cluster mean is an exact integer: sklearn's threaded float64 sums land on it or 1 ulp
+ *                below, so the reference returns colour or colour - 1 from run to run (tests/golden kmf_*), the exact
+ *                integer totals here always the colour.  NULL: lowest index on exact ties.
  *   sumsq_dev    may be NULL: the squared norms are then not accumulated -- their total is a constant of the data, only
  *                the first pass of a fit needs it. */
 int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, const double *mean_dev, int K,

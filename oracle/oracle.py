@@ -544,6 +544,13 @@ def kmeans_lloyd(px, init_centers, max_iter=300, tol=1e-4, sklearn_ties=True):
 
 
 # ----------------------------------------------------------------------------- inputs
+def few_colour_pixels(n, nc, seed):
+    """n pixels drawn from nc random colours (tests/golden/make_golden.py: KM_FEW) -> uint8 [n,3]"""
+    rs = np.random.RandomState(seed)
+    cols = rs.randint(0, 256, (nc, 3))
+    return cols[rs.randint(0, nc, n)].astype(np.uint8)
+
+
 def rnd(h, w, seed):
     return np.random.RandomState(seed).randint(0, 256, (h, w, 3), dtype=np.uint8)
 

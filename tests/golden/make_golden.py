@@ -216,6 +216,61 @@ def append_kmeans_extra(kat, npz):
         print("pixelized_example", small.size, H(np.array(out)), flush=True)
 
 
+# Few-colour images, where a cluster's exact mean is an integer (flat-colour / pixel-art images, single-colour clusters,
+# K >= distinct colours): sklearn accumulates mean-centred float64 members per thread chunk, adds the partial sums in the
+# order the threads finish, divides and adds the mean back -- the centre lands ON the integer or 1 ulp below it, so the
+# reference's `astype(int)` yields the colour or colour - 1, and which one differs from RUN TO RUN of the reference (round-3
+# advisor; measured here: 7 of 20 such images gave more than one palette in five runs).  Recorded: every distinct palette
+# seen in REPEATS runs of the reference, and the centres of the first run.
+#   (name, pixels n, distinct colours, K, data seed)
+KM_FEW = [("kmf_5col_k5", 1200, 5, 5, 1), ("kmf_8col_k8", 2932, 8, 8, 2), ("kmf_3col_k6", 800, 3, 6, 3),
+          ("kmf_6col_k4", 2500, 6, 4, 4), ("kmf_flat_k3", 400, 1, 3, 5)]
+KM_FEW_REPEATS = 8
+
+
+def few_colour_pixels(n, nc, seed):
+    rs = np.random.RandomState(seed)
+    cols = rs.randint(0, 256, (nc, 3))
+    return cols[rs.randint(0, nc, n)].astype(np.uint8)
+
+
+def record_kmeans_host(kat):
+    """Which BLAS / SIMD / thread configuration the k-means fixtures were recorded on (exact ties are decided by its
+    rounding order; the kmf_* palettes also by thread scheduling)."""
+    import threadpoolctl
+    info = threadpoolctl.threadpool_info()
+    blas = next((i for i in info if i.get("user_api") == "blas" and "numpy" in i.get("filepath", "")), {})
+    omp = next((i for i in info if i.get("user_api") == "openmp"), {})
+    simd = np.__config__.show(mode="dicts").get("SIMD Extensions", {}).get("found", [])
+    kat["versions"]["kmeans_fixture_host"] = {
+        "note": "the k-means fixtures (km*, kmx_*, kmf_*) depend on the host's BLAS / SIMD rounding order where two centres are "
+                "exactly equidistant (label_f64 in kmeans.hip restates THIS configuration) and, for kmf_*, on thread scheduling",
+        "blas": f"OpenBLAS {blas.get('version')} ({os.path.basename(os.path.dirname(blas.get('filepath', '')))}/libscipy_openblas64_), "
+                f"threading {blas.get('threading_layer')}, architecture {blas.get('architecture')} (AVX-512 dgemm micro-kernel, FMA)",
+        "numpy_simd_found": " ".join(simd), "openmp": f"libgomp (scikit_learn.libs), {omp.get('num_threads')} threads",
+        "cpus": os.cpu_count()}
+
+
+def append_kmeans_few(kat, npz):
+    import warnings
+    done = kat["misc"].setdefault("kmeans_few", {})
+    for nm, n, nc, K, seed in KM_FEW:
+        if nm in done:
+            continue
+        px = few_colour_pixels(n, nc, seed)
+        img = Image.fromarray(px.reshape(-1, 1, 3))   # an n x 1 image: <= 10 000 pixels, no sampling
+        pals = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")            # (sklearn warns when there are fewer distinct points than clusters)
+            for _ in range(KM_FEW_REPEATS):
+                pal = [[int(v) for v in c] for c in dl.ColorReducer.generate_kmeans_palette(img, K, random_state=42)]
+                if pal not in pals:
+                    pals.append(pal)
+        npz[f"{nm}_palettes"] = np.array(pals, np.int32)
+        done[nm] = dict(n=n, colours=nc, K=K, seed=seed, repeats=KM_FEW_REPEATS, distinct_reference_palettes=len(pals))
+        print(nm, "distinct palettes in", KM_FEW_REPEATS, "runs of the reference:", len(pals), flush=True)
+
+
 def append_new():
     """Adds the cases of CASES that kat.json does not hold yet (and their median-cut palettes) and the KM_EXTRA k-means
     fixtures without touching the rest."""
@@ -223,6 +278,9 @@ def append_new():
         kat = json.load(f)
     npz = dict(np.load(os.path.join(HERE, "small.npz")))
     append_kmeans_extra(kat, npz)
+    append_kmeans_few(kat, npz)
+    if "kmeans_fixture_host" not in kat["versions"]:
+        record_kmeans_host(kat)
     have = {c["name"] for c in kat["cases"]}
     for name, mode, params, pspec, ispec, gamma, keep in CASES:
         if name in have:

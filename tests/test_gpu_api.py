@@ -149,6 +149,20 @@ def test_generate_kmeans_palette_equals_reference_on_small_images(d, orc, gold, 
         assert abs(inertia - m["inertia"]) <= 1e-9 * m["inertia"], nm
 
 
+def test_generate_kmeans_palette_on_few_colour_images(d, orc, gold, kat):
+    """The product on the kmf_* fixtures (few colours: cluster means that are exact integers; the reference itself returns
+    colour or colour - 1 there, differently from run to run -- tests/test_oracle_golden.py::
+    test_kmeans_few_colour_images_integer_means): the oracle's palette exactly, hence 0 <= ours - reference <= 1 against every
+    palette the reference produced."""
+    for nm, m in sorted(kat["misc"]["kmeans_few"].items()):
+        px = orc.few_colour_pixels(m["n"], m["colours"], m["seed"])
+        pal = np.array(d.ColorReducer.generate_kmeans_palette(Image.fromarray(px.reshape(-1, 1, 3)), m["K"], random_state=42))
+        centers, _, _ = orc.kmeans_lloyd(px, orc.kmeans_plusplus(px, m["K"], np.random.RandomState(42)))
+        assert np.array_equal(pal, centers.astype(int)), nm
+        for ref in gold[f"{nm}_palettes"]:
+            assert (pal - ref).min() >= 0 and (pal - ref).max() <= 1, nm
+
+
 def test_pixelized_example_end_to_end(d, orc, kat, gold):
     """examples/image_pixelized.json as dither_cli.process_single_image runs it (dither_cli.py:516, 423, 546-566) - the
     reference's one shipped k-means configuration - on a synthetic 400x300 stand-in for the absent test_300.png: regular

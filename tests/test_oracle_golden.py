@@ -221,6 +221,26 @@ def test_kmeans_fit_reproduces_reference_palette(orc, gold, kat):
     assert n2 != m["n_iter"] or np.abs(c2 - gold[f"{nm}_centers"]).max() > 1e-3
 
 
+def test_kmeans_few_colour_images_integer_means(orc, gold, kat):
+    """Few-colour images (flat colours, K >= distinct colours, single-colour clusters): a cluster's exact mean is an
+    integer.  The oracle (exact int64 sums / n) returns that colour.  The reference does NOT have one answer there: sklearn
+    sums mean-centred float64 members per thread, adds the partial sums in the order the threads finish and adds the mean
+    back, landing on the integer or 1 ulp below it, and `astype(int)` (dithering_lib.py:1857) turns that into colour or
+    colour - 1 -- differently from run to run (the kmf_* fixtures hold every palette seen in 8 runs of the reference: up to
+    5 distinct ones).  What holds against every one of them: 0 <= ours - reference <= 1 per channel, and a difference only
+    where the exact mean is an integer."""
+    few = kat["misc"]["kmeans_few"]
+    assert len(few) == 5 and max(m["distinct_reference_palettes"] for m in few.values()) > 1
+    for nm, m in sorted(few.items()):
+        px = orc.few_colour_pixels(m["n"], m["colours"], m["seed"])
+        centers, _, _ = orc.kmeans_lloyd(px, orc.kmeans_plusplus(px, m["K"], np.random.RandomState(42)))
+        ours = centers.astype(int)
+        for ref in gold[f"{nm}_palettes"]:
+            diff = ours - ref
+            assert diff.min() >= 0 and diff.max() <= 1, nm
+            assert np.all(np.abs(centers - np.round(centers))[diff != 0] < 1e-9), nm
+
+
 def test_scipy_statement_agrees_with_golden_and_c_oracle(orc, gold):
     """three-way agreement: reference output (golden) == C restatement == scipy/numpy statement"""
     pytest.importorskip("scipy.spatial")
