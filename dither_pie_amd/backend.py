@@ -347,6 +347,54 @@ def kmeans_step_into(px, centers, totals, want_sq=True, mean=None):
                                             (base + 8 * 4 * K) if want_sq else None, _stream()))
 
 
+KMEANS_HIST_MAX_K = 256   # dp_kmeans_hist_step: one thread per centre in the list build
+
+
+class ColourHistogram:
+    """count[colour] of uint8 RGB pixels over all 2^24 colours, resident in HBM (dp_kmeans_hist_*): the pixels of a k-means
+    fit are read once into it, every Lloyd pass then runs over the histogram (same labels, same int64 totals)."""
+
+    def __init__(self, px=None, device=None):
+        require_gpu()
+        dev = px.device if px is not None else torch.device(device or "cuda")
+        self.buf = torch.empty(_lib.load().dp_kmeans_hist_bytes(), dtype=torch.uint8, device=dev)
+        self.n = 0
+        if px is not None:
+            self.add(px, accumulate=False)
+
+    def add(self, px, accumulate=True):
+        if not (px.is_cuda and px.dtype == torch.uint8 and px.shape[-1] == 3):
+            raise TypeError("px must be a CUDA uint8 tensor [...,3]")
+        if px.device != self.buf.device:
+            raise ValueError(f"histogram lives on {self.buf.device}, pixels on {px.device}")
+        px = px.contiguous()
+        n = px.numel() // 3
+        if (self.n if accumulate else 0) + n >= 1 << 32:
+            raise ValueError("a colour histogram holds fewer than 2^32 pixels")
+        with torch.cuda.device(px.device):
+            check(_lib.load().dp_kmeans_hist_build_u8(px.data_ptr(), n, self.buf.data_ptr(), 1 if accumulate else 0, _stream()))
+        self.n = (self.n if accumulate else 0) + n
+        return self
+
+    def step_into(self, centers, totals, want_sq=True, mean=None):
+        """One Lloyd pass over the histogram into the planar totals buffer (see kmeans_step_into)."""
+        K = centers.shape[0]
+        base = totals.data_ptr()
+        with torch.cuda.device(self.buf.device):
+            check(_lib.load().dp_kmeans_hist_step(self.buf.data_ptr(), centers.data_ptr(), mean.data_ptr() if mean is not None else None,
+                                                  K, base, base + 8 * 3 * K, (base + 8 * 4 * K) if want_sq else None, _stream()))
+
+    def step(self, centers, mean=None):
+        """-> (sums [K,3], counts [K], sumsq [K]) int64, as kmeans_step"""
+        centers = centers.to(device=self.buf.device, dtype=torch.float64).contiguous()
+        K = centers.shape[0]
+        totals = torch.empty(5 * K, dtype=torch.int64, device=self.buf.device)
+        if mean is not None:
+            mean = mean.to(device=self.buf.device, dtype=torch.float64).contiguous()
+        self.step_into(centers, totals, True, mean)
+        return totals[:3 * K].view(K, 3), totals[3 * K:4 * K], totals[4 * K:]
+
+
 def kmeans_update(totals, centers, prev, status, tol, max_iter):
     """The centre update of one Lloyd iteration on the device (dp_kmeans_update); everything stays in HBM."""
     with torch.cuda.device(centers.device):

@@ -724,6 +724,27 @@ int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_de
     return launch_kmeans_step(px_dev, n, centers_dev, mean_dev, K, sums_dev, counts_dev, sumsq_dev, (hipStream_t)stream);
 }
 
+size_t dp_kmeans_hist_bytes(void) { return kmeans_hist_bytes(); }
+
+int dp_kmeans_hist_build_u8(const uint8_t *px_dev, int64_t n, void *hist_dev, int accumulate, void *stream)
+{
+    if ((!px_dev && n > 0) || n < 0 || n > (int64_t)0xffffffffLL || !hist_dev || ((uintptr_t)hist_dev & 15)) {
+        set_error("dp_kmeans_hist_build_u8: bad argument (n must be below 2^32, hist_dev 16-byte aligned)");
+        return DP_EINVAL;
+    }
+    return launch_kmeans_hist_build(px_dev, n, hist_dev, accumulate ? 1 : 0, (hipStream_t)stream);
+}
+
+int dp_kmeans_hist_step(const void *hist_dev, const double *centers_dev, const double *mean_dev, int K, int64_t *sums_dev,
+                        int64_t *counts_dev, int64_t *sumsq_dev, void *stream)
+{
+    if (!hist_dev || !centers_dev || K < 1 || !sums_dev || !counts_dev) {
+        set_error("dp_kmeans_hist_step: bad argument");
+        return DP_EINVAL;
+    }
+    return launch_kmeans_hist_step(hist_dev, centers_dev, mean_dev, K, sums_dev, counts_dev, sumsq_dev, (hipStream_t)stream);
+}
+
 int dp_kmeans_update(const int64_t *totals_dev, double *centers_dev, int64_t *prev_dev, double *status_dev, int K,
                      double tol, int max_iter, void *stream)
 {

@@ -1,0 +1,494 @@
+// Lloyd passes over the COLOUR HISTOGRAM instead of the pixels (ColorReducer.generate_kmeans_palette,
+// dithering_lib.py:1845-1857 -> sklearn KMeans; the fit of SURVEY 8(e)'s k-means row).
+//
+// A pixel's label is a function of its colour, and the totals a pass produces are sums of count x colour -- so the pixels
+// are read ONCE (3 B/pixel) into count[colour] over all 2^24 colours, and every Lloyd pass then runs over that table:
+//   hist_build_kernel   pixels -> table.  A workgroup first merges its pixels in an LDS hash table (runs of one colour --
+//                       flat regions, letterbox bars, pixel art -- would otherwise serialise on one address: 376 ms for a
+//                       flat 8K frame with one global atomic per pixel, profiles/microbench/hist24_results.txt), then one
+//                       agent-scope no-return atomic per (window, distinct colour).  Bound by the rate of random global
+//                       atomics (27 G/s measured): 1.2 ms for 33 M noise pixels.
+//   hist_cells_kernel   per 16^3 cell the number of pixels in it: passes skip empty cells without reading them.
+//   hist_pass_kernel    one workgroup per cell.  The table is CELL-MAJOR (index = cell << 12 | r_lo << 8 | g_lo << 4 | b_lo),
+//                       so a workgroup reads its 16 KB contiguously, builds the cell's candidate list itself (the
+//                       centres that can be nearest somewhere in the cell: bound test + pairwise bisector test, as
+//                       kmeans_cells_build_kernel -- no separate list launch, no 4096-list table), and
+//                         * a cell with ONE candidate (most cells at 32 centres) needs no distance at all: its totals are
+//                           sum(count), sum(count * r), ... by separable sums;
+//                         * otherwise every colour of the cell is scored against the list: float32 scores with the biased
+//                           key trick of kmeans_step_kernel, ONE v_fma_f32 per (colour, candidate) because r is uniform
+//                           over a wave's register, g over a lane, and only b varies inside a lane's four counts; near
+//                           ties go to the same float64 decision as everywhere (label_f64 semantics, incl. sklearn's
+//                           rule for equidistant colours), over the list only: every centre that can attain the minimum
+//                           is on it.
+//                       Labels and int64 totals are those of the per-pixel kernels, bit for bit (tests compare both with
+//                       the oracle).  Bytes per pass: 16 KB per occupied cell (64 MB when every cell is occupied).
+// Counts are 32-bit: a histogram holds fewer than 2^32 pixels (per rank).
+#include <algorithm>
+
+#include "dp_internal.h"
+#include "wave_util.hip.h"
+#include "kmeans_label.hip.h"
+
+namespace dp {
+namespace {
+
+constexpr int kHistCells = 4096;
+constexpr size_t kHistTableBytes = (size_t)4 << 24;          // 2^24 x uint32
+constexpr size_t kHistInfoBytes = (size_t)4 * kHistCells;    // pixels per cell
+constexpr uint32_t kEmptyKey = 0xffffffffu;
+
+// r | g << 8 | b << 16  ->  r' << 20 | g' << 16 | b' << 12 | r_lo << 8 | g_lo << 4 | b_lo   (x' = x >> 4, x_lo = x & 15)
+__device__ __forceinline__ uint32_t colour_index(const uint32_t v)
+{
+    return ((v & 0xf0u) << 16) | ((v & 0xf000u) << 4) | ((v & 0xf00000u) >> 8) | ((v & 0xfu) << 8) | ((v & 0xf00u) >> 4) |
+           ((v & 0xf0000u) >> 16);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kHB = 256;         // threads of a build workgroup
+constexpr int kHSlots = 4096;    // LDS hash slots (32 KB)
+constexpr int kHMaxWindow = 16;  // batches of 1024 pixels merged in LDS before a flush, at most
+
+__global__ __launch_bounds__(kHB) void hist_build_kernel(const uint8_t *__restrict__ px, const int64_t n, uint32_t *__restrict__ table)
+{
+    __shared__ uint32_t s_key[kHSlots];
+    __shared__ uint32_t s_cnt[kHSlots];
+    __shared__ uint32_t s_occ;
+    for (int i = threadIdx.x; i < kHSlots; i += kHB) {
+        s_key[i] = kEmptyKey;
+        s_cnt[i] = 0u;
+    }
+    if (threadIdx.x == 0) s_occ = 0u;
+    __syncthreads();
+    const int64_t n_groups = (n + 3) / 4;
+    const bool aligned = ((uintptr_t)px & 3) == 0;
+    int window = 1, in_window = 0;
+
+    auto insert = [&](const uint32_t ci, const uint32_t cnt) {
+        uint32_t slot = (ci * 0x9E3779B1u) >> 20;  // 12 bits
+#pragma unroll 1
+        for (int probe = 0; probe < 8; ++probe) {
+            const uint32_t old = atomicCAS(&s_key[slot], kEmptyKey, ci);
+            if (old == kEmptyKey || old == ci) {
+                atomicAdd(&s_cnt[slot], cnt);
+                return;
+            }
+            slot = (slot + 1u) & (uint32_t)(kHSlots - 1);
+        }
+        // the table is crowded (a window of noise): straight to global memory
+        __hip_atomic_fetch_add(&table[ci], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // every occupied slot leaves the workgroup as one atomic; returns (to every thread) how many there were
+    auto flush = [&]() -> uint32_t {
+        __syncthreads();
+        uint32_t occ = 0;
+        for (int i = threadIdx.x; i < kHSlots; i += kHB) {
+            const uint32_t k = s_key[i];
+            if (k != kEmptyKey) {
+                __hip_atomic_fetch_add(&table[k], s_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_key[i] = kEmptyKey;
+                s_cnt[i] = 0u;
+                ++occ;
+            }
+        }
+        occ = wave_sum_to_lane63(occ);
+        if ((threadIdx.x & 63) == 63) atomicAdd(&s_occ, occ);
+        __syncthreads();
+        const uint32_t total = s_occ;
+        __syncthreads();
+        if (threadIdx.x == 0) s_occ = 0u;
+        return total;
+    };
+
+    for (int64_t g0 = (int64_t)blockIdx.x * kHB; g0 < n_groups; g0 += (int64_t)gridDim.x * kHB) {
+        const int64_t gi = g0 + threadIdx.x;
+        const int64_t p0 = gi * 4;
+        const int cnt = gi < n_groups ? (int)min<int64_t>(4, n - p0) : 0;
+        uint32_t c[4] = {0u, 0u, 0u, 0u};
+        if (aligned && cnt == 4) {
+            const uint3 w = reinterpret_cast<const uint3 *>(px)[gi];
+            c[0] = colour_index(w.x & 0xffffffu);
+            c[1] = colour_index(__builtin_amdgcn_perm(w.y, w.x, 0x0c050403u));
+            c[2] = colour_index(__builtin_amdgcn_perm(w.z, w.y, 0x0c040302u));
+            c[3] = colour_index(w.z >> 8);
+        } else {
+            for (int q = 0; q < cnt; ++q) {
+                const uint8_t *b = px + (p0 + q) * 3;
+                c[q] = colour_index((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16));
+            }
+        }
+        // a lane's equal neighbours first (runs of one colour)
+        uint32_t run = 1;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            if (q < cnt) {
+                if (c[q] == c[q - 1]) ++run;
+                else {
+                    insert(c[q - 1], run);
+                    run = 1;
+                }
+            }
+        }
+        if (cnt > 0) insert(c[cnt - 1], run);
+        if (++in_window >= window) {  // (block-uniform)
+            const uint32_t occ = flush();
+            in_window = 0;
+            // coherent content: few distinct colours per window -> merge more pixels before the next flush
+            if (occ < (uint32_t)kHSlots / 8 && window < kHMaxWindow) window *= 2;
+            else if (occ > (uint32_t)kHSlots / 3 && window > 1) window /= 2;
+        }
+    }
+    if (in_window) flush();
+}
+
+__global__ __launch_bounds__(256) void hist_cells_kernel(const uint32_t *__restrict__ table, uint32_t *__restrict__ cellinfo)
+{
+    __shared__ uint32_t s_part[4];
+    const uint4 *tb = reinterpret_cast<const uint4 *>(table) + (size_t)blockIdx.x * 1024;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 v = tb[i * 256 + threadIdx.x];
+        sum += v.x + v.y + v.z + v.w;
+    }
+    sum = wave_sum_to_lane63(sum);
+    if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) cellinfo[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// float64 decision among the LISTED centres (ascending centre index, so "first minimum" means what it means over all K):
+// same expressions as label_f64 (kmeans_label.hip.h); returns the winner's POSITION in the list.
+__device__ __forceinline__ int label_f64_list(const double *s_c64, const int *list, const int n, const double *mean, const uint32_t r,
+                                              const uint32_t g, const uint32_t b)
+{
+    double bd = __longlong_as_double(0x7ff0000000000000LL);
+    int pos = 0;
+    if (mean) {
+        const double y0 = __dsub_rn((double)r, mean[0]), y1 = __dsub_rn((double)g, mean[1]), y2 = __dsub_rn((double)b, mean[2]);
+        for (int i = 0; i < n; ++i) {
+            const double *c = s_c64 + 4 * list[i];
+            double acc = __dmul_rn(y0, c[0]);
+            acc = __fma_rn(y1, c[1], acc);
+            acc = __fma_rn(y2, c[2], acc);
+            const double v = __dsub_rn(c[3], __dmul_rn(2.0, acc));
+            if (v < bd) {
+                bd = v;
+                pos = i;
+            }
+        }
+    } else {
+        const double x0 = (double)r, x1 = (double)g, x2 = (double)b;
+        for (int i = 0; i < n; ++i) {
+            const double *c = s_c64 + 4 * list[i];
+            const double a = __dsub_rn(x0, c[0]), d = __dsub_rn(x1, c[1]), e = __dsub_rn(x2, c[2]);
+            const double dist = __dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(d, d)), __dmul_rn(e, e));
+            if (dist < bd) {
+                bd = dist;
+                pos = i;
+            }
+        }
+    }
+    return pos;
+}
+
+constexpr int kHistMaxK = 256;  // one thread per centre in the list build
+
+template <bool SQ>
+__global__ __launch_bounds__(256) void hist_pass_kernel(const uint32_t *__restrict__ table, const uint32_t *__restrict__ cellinfo,
+                                                        const double *__restrict__ centers, const double *__restrict__ mean,
+                                                        const int K, unsigned long long *__restrict__ sums,
+                                                        unsigned long long *__restrict__ counts,
+                                                        unsigned long long *__restrict__ sumsq)
+{
+    const int cell = blockIdx.x;
+    const uint32_t ncell = cellinfo[cell];
+    if (ncell == 0u) return;  // (workgroup-uniform)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    // this thread's 16 counts: rows r_lo = 4 wv + jj (a wave-uniform r per register), g_lo = lane >> 2, b_lo = 4 (lane & 3) + k
+    const uint4 *tb = reinterpret_cast<const uint4 *>(table) + (size_t)cell * 1024;
+    uint4 d[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) d[jj] = tb[(4 * wv + jj) * 64 + lane];
+
+    __shared__ float4 s_c[kHistMaxK];        // {x, y, z, |c|^2}: the list tests
+    __shared__ float4 s_sc[kHistMaxK];       // {-2x, -2y, -2z, |c|^2 + BIAS}: the scores
+    __shared__ double s_c64[4 * kHistMaxK];  // float64 records of the near-tie decision (stage_centre_f64)
+    __shared__ double s_mean[3];
+    __shared__ unsigned long long s_mask[4];
+    __shared__ float s_red[4];
+    __shared__ int s_surv[kHistMaxK];
+    __shared__ int s_list[kHistMaxK];
+    __shared__ uint32_t s_drop;
+    __shared__ unsigned long long s_tot[kHistMaxK * 5];  // per list position: n, sum r, sum g, sum b, sum |x|^2
+
+    const float lo0 = (float)((cell >> 8) << 4), lo1 = (float)(((cell >> 4) & 15) << 4), lo2 = (float)((cell & 15) << 4);
+    const float hi0 = lo0 + 15.f, hi1 = lo1 + 15.f, hi2 = lo2 + 15.f;
+    const float inf = __int_as_float(0x7f800000);
+    float far2 = inf, near2 = inf;
+    if (t < 3 && mean) s_mean[t] = mean[t];
+    if (t < K) {
+        const double c0 = centers[3 * t], c1 = centers[3 * t + 1], c2 = centers[3 * t + 2];
+        stage_centre_f64(s_c64 + 4 * t, c0, c1, c2, mean);
+        const float x = (float)c0, y = (float)c1, z = (float)c2;
+        s_c[t] = make_float4(x, y, z, x * x + y * y + z * z);
+        s_sc[t] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2),
+                              (float)(c0 * c0 + c1 * c1 + c2 * c2 + (double)kScoreBias));
+        const float f0 = fmaxf(fabsf(x - lo0), fabsf(x - hi0)), f1 = fmaxf(fabsf(y - lo1), fabsf(y - hi1)),
+                    f2 = fmaxf(fabsf(z - lo2), fabsf(z - hi2));
+        far2 = f0 * f0 + f1 * f1 + f2 * f2;
+        const float n0 = fmaxf(fmaxf(lo0 - x, x - hi0), 0.f), n1 = fmaxf(fmaxf(lo1 - y, y - hi1), 0.f),
+                    n2 = fmaxf(fmaxf(lo2 - z, z - hi2), 0.f);
+        near2 = n0 * n0 + n1 * n1 + n2 * n2;
+    }
+    if (t == 0) s_drop = 0u;
+    {
+        const float u = wave_min_to_all(far2);
+        if (lane == 0) s_red[wv] = u;
+    }
+    __syncthreads();
+    // a centre survives when its smallest distance to the box does not exceed the smallest "largest distance" (+ slack:
+    // float32 arithmetic on values below 4e5, errors far below 1.0)
+    const float U = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3])) + 1.0f;
+    const bool surv = t < K && near2 <= U;
+    const unsigned long long mine = __ballot(surv);
+    if (lane == 0) s_mask[wv] = mine;
+    __syncthreads();
+    int before = 0, cnt = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int pc = __popcll(s_mask[w]);
+        before += w < wv ? pc : 0;
+        cnt += pc;
+    }
+    if (surv) s_surv[before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u))] = t;
+    __syncthreads();
+    int n_list;
+    if (cnt <= 16) {
+        // pairwise: entry a leaves if a listed b is closer on the WHOLE box by more than the slack:
+        // max over the box of |x - c_b|^2 - |x - c_a|^2 = 2 x.(c_a - c_b) + |c_b|^2 - |c_a|^2  <  -1
+        const int a = t >> 4, b = t & 15;
+        if (a < cnt && b < cnt && a != b) {
+            const float4 ca = s_c[s_surv[a]], cb = s_c[s_surv[b]];
+            const float d0 = ca.x - cb.x, d1 = ca.y - cb.y, d2 = ca.z - cb.z;
+            const float m = 2.f * ((d0 > 0.f ? hi0 : lo0) * d0 + (d1 > 0.f ? hi1 : lo1) * d1 + (d2 > 0.f ? hi2 : lo2) * d2) + (cb.w - ca.w);
+            if (m < -1.0f) atomicOr(&s_drop, 1u << a);
+        }
+        __syncthreads();
+        const uint32_t keep = ~s_drop & ((1u << cnt) - 1u);
+        n_list = __popc(keep);
+        if (t < cnt && ((keep >> t) & 1u)) s_list[__popc(keep & ((1u << t) - 1u))] = s_surv[t];
+    } else {
+        n_list = cnt;
+        if (t < cnt) s_list[t] = s_surv[t];
+    }
+    for (int i = t; i < n_list * 5; i += 256) s_tot[i] = 0ull;
+    __syncthreads();
+
+    const uint32_t rbase = (uint32_t)((cell >> 8) << 4) + 4u * (uint32_t)wv;
+    const uint32_t g = (uint32_t)(((cell >> 4) & 15) << 4) + (uint32_t)(lane >> 2);
+    const uint32_t b0 = (uint32_t)((cell & 15) << 4) + 4u * (uint32_t)(lane & 3);
+    uint32_t cn[4][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        cn[jj][0] = d[jj].x;
+        cn[jj][1] = d[jj].y;
+        cn[jj][2] = d[jj].z;
+        cn[jj][3] = d[jj].w;
+    }
+    // a cell with fewer than 2^24 pixels: every weighted partial sum below fits 32 bits (count x 255)
+    const bool small = ncell < (1u << 24);
+    // adds the wave's totals of the counts m[][] (already masked by label) to list position `pos`
+    auto add_slot = [&](const int pos, const uint32_t(&m)[4][4]) {
+        uint32_t rows[4], cols[4] = {0u, 0u, 0u, 0u}, nl = 0u;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            rows[jj] = (m[jj][0] + m[jj][1]) + (m[jj][2] + m[jj][3]);
+            nl += rows[jj];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cols[k] += m[jj][k];
+        }
+        if (__ballot(nl != 0u) == 0ull) return;  // (wave-uniform)
+        unsigned long long *tot = s_tot + 5 * pos;
+        if (small) {
+            uint32_t rl = 0u, bl = 0u;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rl += rows[jj] * (rbase + (uint32_t)jj);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bl += cols[k] * (b0 + (uint32_t)k);
+            const uint32_t gl = nl * g;
+            const uint32_t N = wave_sum_to_lane63(nl), R = wave_sum_to_lane63(rl), G = wave_sum_to_lane63(gl), B = wave_sum_to_lane63(bl);
+            if (lane == 63) {
+                atomicAdd(&tot[0], (unsigned long long)N);
+                atomicAdd(&tot[1], (unsigned long long)R);
+                atomicAdd(&tot[2], (unsigned long long)G);
+                atomicAdd(&tot[3], (unsigned long long)B);
+            }
+        } else if (nl != 0u) {  // a giant cell (>= 16.7 M pixels of near-identical colour): 64-bit partials, lane by lane
+            unsigned long long rl = 0ull, bl = 0ull;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) rl += (unsigned long long)rows[jj] * (rbase + (uint32_t)jj);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bl += (unsigned long long)cols[k] * (b0 + (uint32_t)k);
+            atomicAdd(&tot[0], (unsigned long long)nl);
+            atomicAdd(&tot[1], rl);
+            atomicAdd(&tot[2], (unsigned long long)nl * g);
+            atomicAdd(&tot[3], bl);
+        }
+        if (SQ && nl != 0u) {  // (the first pass of a fit only)
+            unsigned long long q = (unsigned long long)nl * (g * g);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) q += (unsigned long long)rows[jj] * ((rbase + (uint32_t)jj) * (rbase + (uint32_t)jj));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q += (unsigned long long)cols[k] * ((b0 + (uint32_t)k) * (b0 + (uint32_t)k));
+            atomicAdd(&tot[4], q);
+        }
+    };
+
+    if (n_list == 1) {
+        add_slot(0, cn);
+    } else {
+        // scores: |c|^2 + BIAS - 2 c.x through three v_fma_f32, g first (per lane), then b (per lane and k), then r (a
+        // wave-uniform value per register): one fma per (colour, candidate).  Within 0.15 of the exact score like the
+        // per-pixel kernels' (same three roundings + the record's), keys 256 apart per ulp of 0.0625.
+        int k0[4][4], k1[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) k0[jj][k] = k1[jj][k] = 0x7fffffff;
+        const float fg = (float)g;
+        for (int i = 0; i < n_list; ++i) {
+            const float4 c = s_sc[s_list[i]];
+            const float gs = fmaf(c.y, fg, c.w);
+            float bk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bk[k] = fmaf(c.z, (float)(b0 + (uint32_t)k), gs);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float fr = (float)(rbase + (uint32_t)jj);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sc = fmaf(c.x, fr, bk[k]);
+                    const int key = (int)((__float_as_uint(sc) << 8) + (uint32_t)i);
+                    k1[jj][k] = med3_s32(k0[jj][k], k1[jj][k], key);
+                    k0[jj][k] = min(k0[jj][k], key);
+                }
+            }
+        }
+        int lab[4][4];
+        bool near = false;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lab[jj][k] = k0[jj][k] & 255;
+                near |= cn[jj][k] != 0u && (k1[jj][k] - k0[jj][k] <= (6 << 8) + 255);
+            }
+        if (__ballot(near) != 0ull) {  // (wave-uniform: the float64 code stays off the common path)
+            if (near) {
+                const double *mp = mean ? s_mean : nullptr;
+#pragma unroll 1
+                for (int e = 0; e < 16; ++e) {
+                    const int jj = e >> 2, k = e & 3;
+                    int kk0, kk1;
+                    uint32_t cc;
+                    // (dynamic indexing of the register arrays would spill: select)
+                    kk0 = kk1 = 0;
+                    cc = 0u;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            if (a == jj && b == k) {
+                                kk0 = k0[a][b];
+                                kk1 = k1[a][b];
+                                cc = cn[a][b];
+                            }
+                    if (cc != 0u && kk1 - kk0 <= (6 << 8) + 255) {
+                        const int p = label_f64_list(s_c64, s_list, n_list, mp, rbase + (uint32_t)jj, g, b0 + (uint32_t)k);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 4; ++b)
+                                if (a == jj && b == k) lab[a][b] = p;
+                    }
+                }
+            }
+        }
+        for (int i = 0; i < n_list; ++i) {
+            uint32_t m[4][4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[jj][k] = lab[jj][k] == i ? cn[jj][k] : 0u;
+            add_slot(i, m);
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < n_list * 5; i += 256) {
+        const int pos = i / 5, what = i - 5 * pos;
+        const unsigned long long v = s_tot[i];
+        if (v == 0ull || (what == 4 && !SQ)) continue;
+        const int j = s_list[pos];
+        if (what == 0) atomicAdd(&counts[j], v);
+        else if (what == 4) atomicAdd(&sumsq[j], v);
+        else atomicAdd(&sums[3 * j + (what - 1)], v);
+    }
+}
+
+}  // namespace
+
+size_t kmeans_hist_bytes() { return kHistTableBytes + kHistInfoBytes; }
+
+int launch_kmeans_hist_build(const uint8_t *px, int64_t n, void *hist, int accumulate, hipStream_t s)
+{
+    uint32_t *table = static_cast<uint32_t *>(hist);
+    uint32_t *cellinfo = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(hist) + kHistTableBytes);
+    if (!accumulate) DP_HIP(hipMemsetAsync(table, 0, kHistTableBytes, s));
+    ProfMark *pm = prof_begin(s);
+    if (n > 0) {
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        const int64_t groups = (n + 3) / 4;
+        const int64_t want = (groups + kHB - 1) / kHB;
+        const unsigned blocks = (unsigned)std::min<int64_t>(want, (int64_t)cus * 4);
+        hipLaunchKernelGGL(hist_build_kernel, dim3(blocks), dim3(kHB), 0, s, px, n, table);
+    }
+    prof_end(pm, s);
+    hipLaunchKernelGGL(hist_cells_kernel, dim3(kHistCells), dim3(256), 0, s, table, cellinfo);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
+int launch_kmeans_hist_step(const void *hist, const double *centers, const double *mean, int K, int64_t *sums, int64_t *counts,
+                            int64_t *sumsq, hipStream_t s)
+{
+    if (K > kHistMaxK) {
+        set_error("dp_kmeans_hist_step: more than %d clusters (use dp_kmeans_step_u8)", kHistMaxK);
+        return DP_EUNSUPPORTED;
+    }
+    if (counts == sums + 3 * (size_t)K && (sumsq == nullptr || sumsq == counts + K)) {
+        DP_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * (size_t)K * (sumsq ? 5 : 4), s));
+    } else {
+        DP_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * 3 * (size_t)K, s));
+        DP_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)K, s));
+        if (sumsq) DP_HIP(hipMemsetAsync(sumsq, 0, sizeof(int64_t) * (size_t)K, s));
+    }
+    const uint32_t *table = static_cast<const uint32_t *>(hist);
+    const uint32_t *cellinfo = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(hist) + kHistTableBytes);
+    ProfMark *pm = prof_begin(s);
+    if (sumsq)
+        hipLaunchKernelGGL(hist_pass_kernel<true>, dim3(kHistCells), dim3(256), 0, s, table, cellinfo, centers, mean, K,
+                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
+                           reinterpret_cast<unsigned long long *>(sumsq));
+    else
+        hipLaunchKernelGGL(hist_pass_kernel<false>, dim3(kHistCells), dim3(256), 0, s, table, cellinfo, centers, mean, K,
+                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr);
+    prof_end(pm, s);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
+}  // namespace dp

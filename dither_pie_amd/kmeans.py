@@ -116,8 +116,16 @@ def _check_centres_in_cube(c):
         raise ValueError(f"k-means centres must lie within [0, 255] per channel (got {lo}..{hi})")
 
 
-def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sklearn_ties=True):
+HIST_MIN_PIXELS = 1 << 19   # from here on a fit reads its pixels once into the colour histogram and iterates over that
+
+
+def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sklearn_ties=True, histogram=None):
     """Lloyd iterations over the uint8 pixels `px` ([...,3] tensor on the GPU).
+
+    histogram: None -- images of HIST_MIN_PIXELS and more (per rank) with K <= 256 are read ONCE into count[colour]
+    (backend.ColourHistogram, dp_kmeans_hist_*) and every pass runs over the histogram: a label is a function of the colour,
+    the totals are sums of count x colour, so labels and int64 totals are those of the passes over the pixels, bit for bit,
+    at 16 KB per occupied cell of the colour cube per pass instead of 3 B per pixel.  True / False force the choice.
 
     sklearn_ties: a pass "zero" (one centre: the totals of all pixels, all-reduced like any other pass) gives the data
     mean KMeans.fit subtracts, and every pass labels equidistant pixels as sklearn's float64 expression on the centred
@@ -147,17 +155,27 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sk
     totals = torch.zeros(5 * max(K, 1), dtype=torch.int64, device=dev)
     prev = torch.zeros(4 * K, dtype=torch.int64, device=dev)
     status = torch.zeros(8, dtype=torch.float64, device=dev)
+    if histogram is None:
+        histogram = flat.shape[0] >= HIST_MIN_PIXELS
+    if histogram and K <= backend.KMEANS_HIST_MAX_K and 0 < flat.shape[0] < (1 << 32):
+        hist = backend.ColourHistogram(flat)
+
+        def one_pass(c, tot, want_sq, mean):
+            hist.step_into(c, tot, want_sq, mean)
+    else:
+        def one_pass(c, tot, want_sq, mean):
+            backend.kmeans_step_into(flat, c, tot, want_sq=want_sq, mean=mean)
     mean = None
     if sklearn_ties:
         t0 = torch.zeros(4, dtype=torch.int64, device=dev)
-        backend.kmeans_step_into(flat, torch.zeros((1, 3), dtype=torch.float64, device=dev), t0, want_sq=False)
+        one_pass(torch.zeros((1, 3), dtype=torch.float64, device=dev), t0, False, None)
         _all_reduce_totals(t0, group)
         mean = (t0[:3].to(torch.float64) / t0[3].to(torch.float64)).contiguous()   # exact sums: sum / n rounded once
     launched = 0
     while True:
         for _ in range(CHECK_EVERY):
             first = launched == 0
-            backend.kmeans_step_into(flat, centers, totals, want_sq=first, mean=mean)
+            one_pass(centers, totals, first, mean)
             _all_reduce_totals(totals if first else totals[:4 * K], group)
             backend.kmeans_update(totals, centers, prev, status, tol, max_iter)
             launched += 1

@@ -209,6 +209,24 @@ int dp_variance_gate_u8(const uint8_t *in_dev, uint8_t *gate_dev, int64_t n_fram
  *                the first pass of a fit needs it. */
 int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_dev, const double *mean_dev, int K,
                       int64_t *sums_dev, int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
+/* The same pass over the COLOUR HISTOGRAM of the pixels instead of the pixels (kmeans_hist.hip).  A pixel's label depends on
+ * its colour only and the totals are sums of count x colour, so a fit reads its pixels ONCE (3 B/pixel) into count[colour]
+ * over all 2^24 colours and every Lloyd pass of dithering_lib.py:1854-1856 then costs 16 KB per occupied 16^3 cell of the
+ * colour cube (64 MB when every cell is occupied), whatever the number of pixels.  Same labels (float64 decision, mean_dev as
+ * above), same int64 totals as dp_kmeans_step_u8, bit for bit.
+ *   dp_kmeans_hist_bytes     size of the caller-owned histogram buffer (2^24 uint32 counts, cell-major, + 4096 cell totals)
+ *   dp_kmeans_hist_build_u8  adds n pixels to hist_dev (16-byte aligned); accumulate = 0 clears it first, 1 keeps what it
+ *                            holds (several buffers into one histogram).  Fewer than 2^32 pixels in total (32-bit counts).
+ *                            Pixels are merged per workgroup in an LDS hash table first, so runs of one colour cost one
+ *                            global atomic, not one per pixel.
+ *   dp_kmeans_hist_step      one pass; K <= 256 (DP_EUNSUPPORTED above: use dp_kmeans_step_u8); centers_dev inside the colour
+ *                            cube as for dp_kmeans_step_u8; outputs as there (sumsq_dev may be NULL).  Each workgroup builds
+ *                            its cell's candidate list from centers_dev itself: no scratch, no second launch.
+ * With ranks, each rank histograms its own pixels and the totals are all-reduced per pass exactly as before. */
+size_t dp_kmeans_hist_bytes(void);
+int dp_kmeans_hist_build_u8(const uint8_t *px_dev, int64_t n, void *hist_dev, int accumulate, void *stream);
+int dp_kmeans_hist_step(const void *hist_dev, const double *centers_dev, const double *mean_dev, int K, int64_t *sums_dev,
+                        int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
 /*
  * The centre update of one Lloyd iteration ON THE DEVICE, so that a host loop can launch iterations back to back
  * (pass, all-reduce of the totals across ranks, update) and look at the status only every few iterations -- sklearn's

@@ -141,6 +141,124 @@ def test_c4_kmeans_totals_over_all_8k_pixels(be, orc):
         acc_s += bs
         acc_n += bn
     assert torch.equal(acc_s, s) and torch.equal(acc_n, n)
+    # the same pass over the colour histogram of the 33 M pixels (built once; in 8 bands accumulated into one histogram too)
+    hist = be.ColourHistogram(px)
+    hs, hn, hq = hist.step(torch.from_numpy(centers))
+    assert torch.equal(hs, s) and torch.equal(hn, n) and torch.equal(hq, q)
+    hist8 = be.ColourHistogram(device=px.device)
+    for i, (lo, hi) in enumerate(sharding.row_bands(4320, 8)):
+        hist8.add(px[lo * 7680:hi * 7680], accumulate=i > 0)
+    assert hist8.n == px.shape[0] and torch.equal(hist8.buf, hist.buf)
+    mean = torch.from_numpy(orc.data_mean(arr.reshape(-1, 3)))
+    ms_ref, mn_ref, _ = orc.kmeans_step(arr.reshape(-1, 3), np.round(centers), orc.data_mean(arr.reshape(-1, 3)))
+    hs, hn, _ = hist8.step(torch.from_numpy(np.round(centers)), mean)
+    assert np.array_equal(hs.cpu().numpy(), ms_ref) and np.array_equal(hn.cpu().numpy(), mn_ref)
+
+
+def _hist_table_numpy(px):
+    """count[colour] in the histogram's cell-major order, from numpy"""
+    r, g, b = (px[:, i].astype(np.int64) for i in range(3))
+    idx = ((r >> 4) << 20) | ((g >> 4) << 16) | ((b >> 4) << 12) | ((r & 15) << 8) | ((g & 15) << 4) | (b & 15)
+    return np.bincount(idx, minlength=1 << 24).astype(np.uint32)
+
+
+@pytest.mark.parametrize("kind", ["noise", "image", "flat", "few", "runs"])
+def test_colour_histogram_counts(be, orc, kind):
+    """dp_kmeans_hist_build_u8: count[colour] over all 2^24 colours equals numpy's, and the per-cell totals behind it, for
+    noise (every pixel a new colour: the LDS merge table overflows into direct atomics), image-like content, one flat colour
+    (every pixel the same address), a handful of colours, and runs; ragged pixel counts, an unaligned buffer, accumulation."""
+    import torch
+    rs = np.random.RandomState(5)
+    n = 1_000_003
+    if kind == "noise":
+        px = rs.randint(0, 256, (n, 3)).astype(np.uint8)
+    elif kind == "image":
+        px = orc.imgl(700, 1000, 3, "smooth").reshape(-1, 3)
+    elif kind == "flat":
+        px = np.tile(np.array([[17, 99, 200]], np.uint8), (n, 1))
+    elif kind == "few":
+        px = rs.randint(0, 256, (6, 3)).astype(np.uint8)[rs.randint(0, 6, n)]
+    else:
+        px = np.repeat(rs.randint(0, 256, (n // 37 + 1, 3)).astype(np.uint8), 37, axis=0)[:n]
+    t = torch.from_numpy(np.ascontiguousarray(px)).cuda()
+    hist = be.ColourHistogram(t)
+    table = hist.buf[:1 << 26].view(torch.int32).cpu().numpy().view(np.uint32)
+    ref = _hist_table_numpy(px)
+    assert np.array_equal(table, ref)
+    cells = hist.buf[1 << 26:].view(torch.int32).cpu().numpy().view(np.uint32)
+    assert np.array_equal(cells, ref.reshape(4096, 4096).sum(1).astype(np.uint32))
+    # an unaligned view (byte offset 3), a ragged count, accumulated on top
+    raw = torch.empty(3 * px.shape[0] + 3, dtype=torch.uint8, device="cuda")
+    raw[3:] = t.reshape(-1)
+    part = raw[3:3 + 3 * 1001].view(-1, 3)
+    assert part.data_ptr() % 4 != 0
+    hist.add(part, accumulate=True)
+    table2 = hist.buf[:1 << 26].view(torch.int32).cpu().numpy().view(np.uint32)
+    assert np.array_equal(table2, ref + _hist_table_numpy(px[:1001]))
+    # nothing at all
+    empty = be.ColourHistogram(t[:0])
+    assert int(empty.buf.view(torch.int32).abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_kmeans_histogram_pass_fuzz(be, orc, seed):
+    """Random cluster counts (1..256), centre layouts (float, integer = tie-rich, data points, crowded), pixel counts and
+    content through the histogram pass: the int64 totals equal the oracle's float64 labelling every time, with and without
+    sklearn's rule for equidistant colours -- the generator of test_kmeans_cell_list_fuzz, on the product library."""
+    import torch
+    rs = np.random.RandomState(3000 + seed)
+    for case in range(12):
+        K = int(rs.choice([1, 2, 3, 7, 16, 31, 32, 64, 65, 129, 255, 256]))
+        n = int(rs.choice([1, 3, 255, 257, 4096, 50001, 200003]))
+        kind = rs.randint(0, 4)
+        if kind == 0:
+            px = rs.randint(0, 256, (n, 3)).astype(np.uint8)
+        elif kind == 1:
+            t = np.arange(n)
+            px = np.clip(np.stack([t * 255 // max(n - 1, 1), 255 - t * 255 // max(n - 1, 1), (t // 7) % 256], -1) + rs.randint(-2, 3, (n, 3)), 0, 255).astype(np.uint8)
+        elif kind == 2:
+            px = rs.randint(0, 256, (5, 3)).astype(np.uint8)[rs.randint(0, 5, n)]
+        else:
+            px = rs.randint(0, 40, (n, 3)).astype(np.uint8)
+        ckind = rs.randint(0, 4)
+        if ckind == 0:
+            centers = rs.rand(K, 3) * 255.0
+        elif ckind == 1:
+            centers = np.round(rs.rand(K, 3) * 255.0)
+        elif ckind == 2:
+            centers = px[rs.randint(0, n, K)].astype(np.float64) + rs.choice([0.0, 0.5, 0.25])
+        else:
+            centers = 5.0 + rs.rand(K, 3) * 20.0
+        mean = orc.data_mean(px) if rs.rand() < 0.5 else None
+        s_ref, n_ref, _ = orc.kmeans_step(px, centers, mean)
+        hist = be.ColourHistogram(torch.from_numpy(px).cuda())
+        s, cnt, q = hist.step(torch.from_numpy(centers), None if mean is None else torch.from_numpy(mean))
+        assert np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(cnt.cpu().numpy(), n_ref), (seed, case, K, n, kind, ckind)
+        x64 = px.astype(np.int64)
+        assert int(q.sum().item()) == int((x64 * x64).sum())
+
+
+def test_lloyd_over_the_histogram_equals_lloyd_over_the_pixels(be, orc, gold, kat):
+    """kmeans.lloyd with histogram=True against histogram=False on the reference's k-means fixtures (same seeds, sklearn's tie
+    rule): identical centres, inertia and iteration counts -- and therefore the reference's palettes; and on 2^20 pixels of
+    image-like content, where the histogram is what lloyd() takes by itself."""
+    import torch
+    from dither_pie_amd import kmeans
+    for nm, m in sorted(kat["misc"]["kmeans_extra"].items()):
+        arr = case_input(orc, m["input"])
+        px = torch.from_numpy(arr).cuda().reshape(-1, 3)
+        init = arr.reshape(-1, 3)[gold[f"{nm}_init_idx"]].astype(np.float64)
+        a = kmeans.lloyd(px, init, histogram=True)
+        b = kmeans.lloyd(px, init, histogram=False)
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2] == m["n_iter"], nm
+        assert np.abs(a[0] - gold[f"{nm}_centers"]).max() < 1e-9, nm
+    big = orc.imgl(1024, 1024, 9, "smooth")
+    px = torch.from_numpy(big).cuda().reshape(-1, 3)
+    init = orc.kmeans_plusplus(big.reshape(-1, 3)[::97], 24, np.random.RandomState(3))
+    assert px.shape[0] >= kmeans.HIST_MIN_PIXELS
+    a = kmeans.lloyd(px, init)                    # (the histogram by default)
+    b = kmeans.lloyd(px, init, histogram=False)
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
 
 
 @pytest.mark.parametrize("K", [1, 5, 32, 33, 100, 256])
