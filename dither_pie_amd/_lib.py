@@ -72,6 +72,7 @@ _SIGS = {
     "dp_kmeans_hist_bytes": (_sz, []),
     "dp_kmeans_hist_build_u8": (_i, [_vp, _i64, _vp, _i, _vp]),
     "dp_kmeans_hist_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "dp_kmeans_hist_iterate": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _vp]),
     "dp_kmeans_update": (_i, [_vp, _vp, _vp, _vp, _i, C.c_double, _i, _vp]),
     "dp_kmeans_plusplus_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "dp_resize_nearest_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),

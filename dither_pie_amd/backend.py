@@ -384,6 +384,14 @@ class ColourHistogram:
             check(_lib.load().dp_kmeans_hist_step(self.buf.data_ptr(), centers.data_ptr(), mean.data_ptr() if mean is not None else None,
                                                   K, base, base + 8 * 3 * K, (base + 8 * 4 * K) if want_sq else None, _stream()))
 
+    def iterate(self, centers, totals, prev, status, ticket, tol, max_iter, first, mean=None):
+        """One whole Lloyd iteration in one launch (dp_kmeans_hist_iterate: pass + centre update, single device).  `totals`
+        (int64 [5K]) and `ticket` (int32 [1]) zero before the first iteration."""
+        with torch.cuda.device(self.buf.device):
+            check(_lib.load().dp_kmeans_hist_iterate(self.buf.data_ptr(), centers.data_ptr(), mean.data_ptr() if mean is not None else None,
+                                                     centers.shape[0], totals.data_ptr(), prev.data_ptr(), status.data_ptr(),
+                                                     ticket.data_ptr(), float(tol), int(max_iter), 1 if first else 0, _stream()))
+
     def step(self, centers, mean=None):
         """-> (sums [K,3], counts [K], sumsq [K]) int64, as kmeans_step"""
         centers = centers.to(device=self.buf.device, dtype=torch.float64).contiguous()

@@ -205,6 +205,8 @@ size_t kmeans_hist_bytes();
 int launch_kmeans_hist_build(const uint8_t *px, int64_t n, void *hist, int accumulate, hipStream_t s);
 int launch_kmeans_hist_step(const void *hist, const double *centers, const double *mean, int K, int64_t *sums, int64_t *counts,
                             int64_t *sumsq, hipStream_t s);
+int launch_kmeans_hist_iterate(const void *hist, double *centers, const double *mean, int K, int64_t *totals, int64_t *prev,
+                               double *status, uint32_t *ticket, double tol, int max_iter, int first, hipStream_t s);
 int launch_kmeans_pp(const uint8_t *sample, int n, int K, int first, const double *uniforms, int n_trials, int *out_ids,
                      double *out_centers, hipStream_t s);
 int launch_kmeans_update(const int64_t *totals, double *centers, int64_t *prev, double *status, int K, double tol, int max_iter,

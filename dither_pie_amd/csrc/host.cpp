@@ -745,6 +745,18 @@ int dp_kmeans_hist_step(const void *hist_dev, const double *centers_dev, const d
     return launch_kmeans_hist_step(hist_dev, centers_dev, mean_dev, K, sums_dev, counts_dev, sumsq_dev, (hipStream_t)stream);
 }
 
+int dp_kmeans_hist_iterate(const void *hist_dev, double *centers_dev, const double *mean_dev, int K, int64_t *totals_dev,
+                           int64_t *prev_dev, double *status_dev, uint32_t *ticket_dev, double tol, int max_iter, int first,
+                           void *stream)
+{
+    if (!hist_dev || !centers_dev || !totals_dev || !prev_dev || !status_dev || !ticket_dev || K < 1 || max_iter < 1 || !(tol >= 0.0)) {
+        set_error("dp_kmeans_hist_iterate: bad argument");
+        return DP_EINVAL;
+    }
+    return launch_kmeans_hist_iterate(hist_dev, centers_dev, mean_dev, K, totals_dev, prev_dev, status_dev, ticket_dev, tol, max_iter,
+                                      first ? 1 : 0, (hipStream_t)stream);
+}
+
 int dp_kmeans_update(const int64_t *totals_dev, double *centers_dev, int64_t *prev_dev, double *status_dev, int K,
                      double tol, int max_iter, void *stream)
 {

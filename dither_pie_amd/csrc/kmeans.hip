@@ -836,101 +836,13 @@ __global__ __launch_bounds__(W == 2 ? 512 : 1024, W == 2 ? 6 : 4) void kmeans_ce
     flush();
 }
 
-// status words (float64) of the device-side Lloyd loop
-enum { kStDone = 0, kStIter = 1, kStInertia = 2, kStShift = 3, kStTolAbs = 4, kStQTotal = 5, kStWords = 8 };
-
-// One workgroup.  totals: 5K int64, planar as dp_kmeans_step_u8 writes them into one buffer: sums [K][3] | counts [K] |
-// squared norms [K] (the last part only has to be valid in the first iteration: its total is a constant of the data).  centers: K*3 float64, updated in place.  prev: [K][4]
-// int64 scratch (the previous iteration's sums and counts).  status: kStWords float64.
-//   done = 0 running; 1 assignments unchanged (centres kept: converged strictly); 2 shift <= tol or max_iter reached
-//   (centres updated; the inertia of these final centres needs one more pass, flagged by done = 2 -> 3 below)
-// An iteration that finds done != 0 on entry only refreshes the inertia once (done 2 -> 3) and changes nothing else.
+// One workgroup: the centre update of one Lloyd iteration (lloyd_update_block, kmeans_label.hip.h).
 __global__ __launch_bounds__(256) void kmeans_update_kernel(const long long *__restrict__ totals, double *__restrict__ centers,
                                                             long long *__restrict__ prev, double *__restrict__ status,
                                                             const int K, const double tol, const int max_iter)
 {
     __shared__ double s_red[256];
-    const int t = threadIdx.x;
-    const int done = (int)status[kStDone];
-    auto block_sum = [&](double v) -> double {
-        s_red[t] = v;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (t < off) s_red[t] = __dadd_rn(s_red[t], s_red[t + off]);
-            __syncthreads();
-        }
-        const double r = s_red[0];
-        __syncthreads();
-        return r;
-    };
-    // inertia of the CURRENT centres with these totals: sum_k (q_k - 2 c_k.s_k + n_k |c_k|^2), q summed separately
-    double part = 0.0, qpart = 0.0, npart = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int k = t; k < K; k += 256) {
-        const double a = (double)totals[3 * k], b = (double)totals[3 * k + 1], c = (double)totals[3 * k + 2],
-                     nn = (double)totals[3 * K + k];
-        const double c0 = centers[3 * k], c1 = centers[3 * k + 1], c2 = centers[3 * k + 2];
-        part += -2.0 * (c0 * a + c1 * b + c2 * c) + nn * (c0 * c0 + c1 * c1 + c2 * c2);
-        qpart += (double)totals[4 * K + k];
-        npart += nn;
-        s0 += a;
-        s1 += b;
-        s2 += c;
-    }
-    const double cross = block_sum(part);
-    if (done == 3 || done == 1) return;  // nothing left to do
-    const int iter = (int)status[kStIter] + (done == 0 ? 1 : 0);
-    double qtot = status[kStQTotal];
-    if (iter == 1 && done == 0) {
-        qtot = block_sum(qpart);
-        const double N = block_sum(npart), m0 = block_sum(s0) / N, m1 = block_sum(s1) / N, m2 = block_sum(s2) / N;
-        if (t == 0) {
-            status[kStQTotal] = qtot;
-            // sklearn: tol * mean of the per-channel variances
-            status[kStTolAbs] = tol * ((qtot / N - (m0 * m0 + m1 * m1 + m2 * m2)) / 3.0);
-        }
-    }
-    __syncthreads();
-    if (done == 2) {  // the extra pass after the last update: the inertia of the final centres
-        if (t == 0) {
-            status[kStInertia] = qtot + cross;
-            status[kStDone] = 3.0;
-        }
-        return;
-    }
-    // same assignments as in the previous iteration?  (sums and counts all equal)
-    double diff = 0.0, shift = 0.0;
-    for (int k = t; k < K; k += 256) {
-        for (int c = 0; c < 4; ++c) {
-            const long long cur = c < 3 ? totals[3 * k + c] : totals[3 * K + k];
-            if (iter > 1 && prev[4 * k + c] != cur) diff += 1.0;
-            if (iter == 1) diff += 1.0;
-        }
-        const double nn = (double)totals[3 * K + k];
-        if (nn > 0.0) {
-            for (int c = 0; c < 3; ++c) {
-                const double nw = (double)totals[3 * k + c] / nn, d = nw - centers[3 * k + c];
-                shift += d * d;
-            }
-        }
-    }
-    const double ndiff = block_sum(diff);
-    const double tshift = block_sum(shift);
-    const bool same = ndiff == 0.0;
-    const double tol_abs = status[kStTolAbs];
-    __syncthreads();
-    for (int k = t; k < K; k += 256) {
-        for (int c = 0; c < 4; ++c) prev[4 * k + c] = c < 3 ? totals[3 * k + c] : totals[3 * K + k];
-        const double nn = (double)totals[3 * K + k];
-        if (!same && nn > 0.0)
-            for (int c = 0; c < 3; ++c) centers[3 * k + c] = (double)totals[3 * k + c] / nn;
-    }
-    if (t == 0) {
-        status[kStIter] = (double)iter;
-        status[kStInertia] = qtot + cross;  // of the centres this pass was run with
-        status[kStShift] = tshift;
-        if (same) status[kStDone] = 1.0;
-        else if (tshift <= tol_abs || iter >= max_iter) status[kStDone] = 2.0;
-    }
+    lloyd_update_block<false>(totals, centers, prev, status, K, tol, max_iter, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -35,7 +35,7 @@ namespace {
 
 constexpr int kHistCells = 4096;
 constexpr size_t kHistTableBytes = (size_t)4 << 24;          // 2^24 x uint32
-constexpr size_t kHistInfoBytes = (size_t)4 * kHistCells;    // pixels per cell
+constexpr size_t kHistInfoBytes = (size_t)4 * (2 * kHistCells + 4);  // pixels per cell | number of occupied cells | their list
 constexpr uint32_t kEmptyKey = 0xffffffffu;
 
 // r | g << 8 | b << 16  ->  r' << 20 | g' << 16 | b' << 12 | r_lo << 8 | g_lo << 4 | b_lo   (x' = x >> 4, x_lo = x & 15)
@@ -194,247 +194,398 @@ __device__ __forceinline__ int label_f64_list(const double *s_c64, const int *li
     return pos;
 }
 
-constexpr int kHistMaxK = 256;  // one thread per centre in the list build
+constexpr int kHistMaxK = 256;
+constexpr int kPassWaves = 4;   // waves per workgroup; every wave works on cells of its own
+constexpr int kPassGrid = 1024; // workgroups (persistent: a wave takes every (4 * grid)-th occupied cell)
 
-template <bool SQ>
-__global__ __launch_bounds__(256) void hist_pass_kernel(const uint32_t *__restrict__ table, const uint32_t *__restrict__ cellinfo,
-                                                        const double *__restrict__ centers, const double *__restrict__ mean,
-                                                        const int K, unsigned long long *__restrict__ sums,
-                                                        unsigned long long *__restrict__ counts,
-                                                        unsigned long long *__restrict__ sumsq)
+// One block, after the build: the occupied cells in ascending order (info[4096] = how many, info[4097 ...] = which), so
+// that a pass hands its waves occupied cells only.
+__global__ __launch_bounds__(1024) void hist_occupied_kernel(uint32_t *__restrict__ info)
 {
-    const int cell = blockIdx.x;
-    const uint32_t ncell = cellinfo[cell];
-    if (ncell == 0u) return;  // (workgroup-uniform)
+    __shared__ uint32_t s_part[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    // this thread's 16 counts: rows r_lo = 4 wv + jj (a wave-uniform r per register), g_lo = lane >> 2, b_lo = 4 (lane & 3) + k
-    const uint4 *tb = reinterpret_cast<const uint4 *>(table) + (size_t)cell * 1024;
-    uint4 d[4];
+    uint32_t flag[4], mine = 0;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) d[jj] = tb[(4 * wv + jj) * 64 + lane];
+    for (int i = 0; i < 4; ++i) {
+        flag[i] = info[4 * t + i] != 0u ? 1u : 0u;
+        mine += flag[i];
+    }
+    // inclusive prefix over the wave (row_shr ladder of wave_sum_to_lane63 is an inclusive scan), then over the 16 waves
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_part[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        base += w < wv ? s_part[w] : 0u;
+        total += s_part[w];
+    }
+    uint32_t pos = base + incl - mine;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (flag[i]) info[kHistCells + 1 + pos++] = (uint32_t)(4 * t + i);
+    if (t == 0) info[kHistCells] = total;
+}
 
+// FUSE: a whole Lloyd iteration in this one launch (single rank: nothing to all-reduce between the pass and the update).  The
+// totals buffer is planar (sums | counts | squared norms, as dp_kmeans_update takes it) and ZERO on entry; every workgroup that
+// has work adds its totals, fences, and takes a ticket; the last one runs the centre update with sklearn's stopping rules
+// (lloyd_update_block, through atomic loads), then clears sums and counts and the ticket counter for the next iteration.
+// No workgroup ever waits for another.
+struct FuseArgs {
+    double *centers_rw;
+    long long *prev;
+    double *status;
+    uint32_t *ticket;
+    double tol;
+    int max_iter;
+};
+
+template <bool SQ, bool FUSE>
+__global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uint32_t *__restrict__ table, const uint32_t *__restrict__ info,
+                                                                    const double *__restrict__ centers, const double *__restrict__ mean,
+                                                                    const int K, unsigned long long *__restrict__ sums,
+                                                                    unsigned long long *__restrict__ counts,
+                                                                    unsigned long long *__restrict__ sumsq, const FuseArgs fuse)
+{
+    const uint32_t n_occ = info[kHistCells];
+    // Few occupied cells (image-like content): a cell is split over 2 or 4 waves (each takes 2 / 1 of the cell's four chunks
+    // and builds the list for itself), so that the chip still has a few thousand waves to hide latency with.
+    const int split = n_occ * 4u <= (uint32_t)(kPassGrid * kPassWaves) ? 4 : (n_occ * 2u <= (uint32_t)(kPassGrid * kPassWaves) ? 2 : 1);
+    const int chunks_per_unit = 4 / split;
+    const uint32_t n_units = n_occ * (uint32_t)split;
+    if ((uint32_t)blockIdx.x * kPassWaves >= n_units) return;  // (workgroup-uniform)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     __shared__ float4 s_c[kHistMaxK];        // {x, y, z, |c|^2}: the list tests
     __shared__ float4 s_sc[kHistMaxK];       // {-2x, -2y, -2z, |c|^2 + BIAS}: the scores
     __shared__ double s_c64[4 * kHistMaxK];  // float64 records of the near-tie decision (stage_centre_f64)
     __shared__ double s_mean[3];
-    __shared__ unsigned long long s_mask[4];
-    __shared__ float s_red[4];
-    __shared__ int s_surv[kHistMaxK];
-    __shared__ int s_list[kHistMaxK];
-    __shared__ uint32_t s_drop;
-    __shared__ unsigned long long s_tot[kHistMaxK * 5];  // per list position: n, sum r, sum g, sum b, sum |x|^2
-
-    const float lo0 = (float)((cell >> 8) << 4), lo1 = (float)(((cell >> 4) & 15) << 4), lo2 = (float)((cell & 15) << 4);
-    const float hi0 = lo0 + 15.f, hi1 = lo1 + 15.f, hi2 = lo2 + 15.f;
-    const float inf = __int_as_float(0x7f800000);
-    float far2 = inf, near2 = inf;
+    __shared__ int s_surv[kPassWaves][kHistMaxK];
+    __shared__ int s_list[kPassWaves][kHistMaxK];
+    __shared__ uint32_t s_drop[kPassWaves];
+    __shared__ unsigned long long s_tot[kHistMaxK * 5];  // per CENTRE: n, sum r, sum g, sum b, sum |x|^2 of this workgroup's cells
     if (t < 3 && mean) s_mean[t] = mean[t];
-    if (t < K) {
-        const double c0 = centers[3 * t], c1 = centers[3 * t + 1], c2 = centers[3 * t + 2];
-        stage_centre_f64(s_c64 + 4 * t, c0, c1, c2, mean);
+    for (int j = t; j < K; j += 64 * kPassWaves) {
+        const double c0 = centers[3 * j], c1 = centers[3 * j + 1], c2 = centers[3 * j + 2];
+        stage_centre_f64(s_c64 + 4 * j, c0, c1, c2, mean);
         const float x = (float)c0, y = (float)c1, z = (float)c2;
-        s_c[t] = make_float4(x, y, z, x * x + y * y + z * z);
-        s_sc[t] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2),
+        s_c[j] = make_float4(x, y, z, x * x + y * y + z * z);
+        s_sc[j] = make_float4((float)(-2.0 * c0), (float)(-2.0 * c1), (float)(-2.0 * c2),
                               (float)(c0 * c0 + c1 * c1 + c2 * c2 + (double)kScoreBias));
-        const float f0 = fmaxf(fabsf(x - lo0), fabsf(x - hi0)), f1 = fmaxf(fabsf(y - lo1), fabsf(y - hi1)),
-                    f2 = fmaxf(fabsf(z - lo2), fabsf(z - hi2));
-        far2 = f0 * f0 + f1 * f1 + f2 * f2;
-        const float n0 = fmaxf(fmaxf(lo0 - x, x - hi0), 0.f), n1 = fmaxf(fmaxf(lo1 - y, y - hi1), 0.f),
-                    n2 = fmaxf(fmaxf(lo2 - z, z - hi2), 0.f);
-        near2 = n0 * n0 + n1 * n1 + n2 * n2;
     }
-    if (t == 0) s_drop = 0u;
-    {
-        const float u = wave_min_to_all(far2);
-        if (lane == 0) s_red[wv] = u;
-    }
-    __syncthreads();
-    // a centre survives when its smallest distance to the box does not exceed the smallest "largest distance" (+ slack:
-    // float32 arithmetic on values below 4e5, errors far below 1.0)
-    const float U = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3])) + 1.0f;
-    const bool surv = t < K && near2 <= U;
-    const unsigned long long mine = __ballot(surv);
-    if (lane == 0) s_mask[wv] = mine;
-    __syncthreads();
-    int before = 0, cnt = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const int pc = __popcll(s_mask[w]);
-        before += w < wv ? pc : 0;
-        cnt += pc;
-    }
-    if (surv) s_surv[before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u))] = t;
-    __syncthreads();
-    int n_list;
-    if (cnt <= 16) {
-        // pairwise: entry a leaves if a listed b is closer on the WHOLE box by more than the slack:
-        // max over the box of |x - c_b|^2 - |x - c_a|^2 = 2 x.(c_a - c_b) + |c_b|^2 - |c_a|^2  <  -1
-        const int a = t >> 4, b = t & 15;
-        if (a < cnt && b < cnt && a != b) {
-            const float4 ca = s_c[s_surv[a]], cb = s_c[s_surv[b]];
-            const float d0 = ca.x - cb.x, d1 = ca.y - cb.y, d2 = ca.z - cb.z;
-            const float m = 2.f * ((d0 > 0.f ? hi0 : lo0) * d0 + (d1 > 0.f ? hi1 : lo1) * d1 + (d2 > 0.f ? hi2 : lo2) * d2) + (cb.w - ca.w);
-            if (m < -1.0f) atomicOr(&s_drop, 1u << a);
-        }
-        __syncthreads();
-        const uint32_t keep = ~s_drop & ((1u << cnt) - 1u);
-        n_list = __popc(keep);
-        if (t < cnt && ((keep >> t) & 1u)) s_list[__popc(keep & ((1u << t) - 1u))] = s_surv[t];
-    } else {
-        n_list = cnt;
-        if (t < cnt) s_list[t] = s_surv[t];
-    }
-    for (int i = t; i < n_list * 5; i += 256) s_tot[i] = 0ull;
-    __syncthreads();
+    for (int i = t; i < K * 5; i += 64 * kPassWaves) s_tot[i] = 0ull;
+    __syncthreads();  // from here on the waves go their own ways until the totals leave the workgroup
+    const float inf = __int_as_float(0x7f800000);
+    const int KM = (K + 63) >> 6;  // centres per lane in the list build
+    int *surv = s_surv[wv], *list = s_list[wv];
 
-    const uint32_t rbase = (uint32_t)((cell >> 8) << 4) + 4u * (uint32_t)wv;
-    const uint32_t g = (uint32_t)(((cell >> 4) & 15) << 4) + (uint32_t)(lane >> 2);
-    const uint32_t b0 = (uint32_t)((cell & 15) << 4) + 4u * (uint32_t)(lane & 3);
-    uint32_t cn[4][4];
+    for (uint32_t ui = (uint32_t)blockIdx.x * kPassWaves + (uint32_t)wv; ui < n_units; ui += (uint32_t)gridDim.x * kPassWaves) {
+        const uint32_t ci = split == 4 ? ui >> 2 : (split == 2 ? ui >> 1 : ui);
+        const int c_first = (int)(ui - ci * (uint32_t)split) * chunks_per_unit, c_end = c_first + chunks_per_unit;
+        const int cell = (int)info[kHistCells + 1 + ci];
+        const uint32_t ncell = info[cell];
+        // a lane's 64 counts, 16 at a time: chunk c = rows r_lo = 4c .. 4c+3 (a wave-uniform r per register), g_lo = lane >> 2,
+        // b_lo = 4 (lane & 3) + k.  The next chunk is in flight while this one is worked on.
+        const uint4 *tb = reinterpret_cast<const uint4 *>(table) + (size_t)cell * 1024 + lane;
+        uint4 d[4], dn[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        cn[jj][0] = d[jj].x;
-        cn[jj][1] = d[jj].y;
-        cn[jj][2] = d[jj].z;
-        cn[jj][3] = d[jj].w;
-    }
-    // a cell with fewer than 2^24 pixels: every weighted partial sum below fits 32 bits (count x 255)
-    const bool small = ncell < (1u << 24);
-    // adds the wave's totals of the counts m[][] (already masked by label) to list position `pos`
-    auto add_slot = [&](const int pos, const uint32_t(&m)[4][4]) {
-        uint32_t rows[4], cols[4] = {0u, 0u, 0u, 0u}, nl = 0u;
+        for (int jj = 0; jj < 4; ++jj) d[jj] = tb[(4 * c_first + jj) * 64];
+
+        // ---- the cell's candidate list (this wave only)
+        const float lo0 = (float)((cell >> 8) << 4), lo1 = (float)(((cell >> 4) & 15) << 4), lo2 = (float)((cell & 15) << 4);
+        const float hi0 = lo0 + 15.f, hi1 = lo1 + 15.f, hi2 = lo2 + 15.f;
+        float near2[4];
+        float far_min = inf;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            rows[jj] = (m[jj][0] + m[jj][1]) + (m[jj][2] + m[jj][3]);
-            nl += rows[jj];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cols[k] += m[jj][k];
-        }
-        if (__ballot(nl != 0u) == 0ull) return;  // (wave-uniform)
-        unsigned long long *tot = s_tot + 5 * pos;
-        if (small) {
-            uint32_t rl = 0u, bl = 0u;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) rl += rows[jj] * (rbase + (uint32_t)jj);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bl += cols[k] * (b0 + (uint32_t)k);
-            const uint32_t gl = nl * g;
-            const uint32_t N = wave_sum_to_lane63(nl), R = wave_sum_to_lane63(rl), G = wave_sum_to_lane63(gl), B = wave_sum_to_lane63(bl);
-            if (lane == 63) {
-                atomicAdd(&tot[0], (unsigned long long)N);
-                atomicAdd(&tot[1], (unsigned long long)R);
-                atomicAdd(&tot[2], (unsigned long long)G);
-                atomicAdd(&tot[3], (unsigned long long)B);
+        for (int m = 0; m < 4; ++m) {
+            near2[m] = inf;
+            const int j = lane + 64 * m;
+            if (m < KM && j < K) {
+                const float4 c = s_c[j];
+                const float f0 = fmaxf(fabsf(c.x - lo0), fabsf(c.x - hi0)), f1 = fmaxf(fabsf(c.y - lo1), fabsf(c.y - hi1)),
+                            f2 = fmaxf(fabsf(c.z - lo2), fabsf(c.z - hi2));
+                far_min = fminf(far_min, f0 * f0 + f1 * f1 + f2 * f2);
+                const float n0 = fmaxf(fmaxf(lo0 - c.x, c.x - hi0), 0.f), n1 = fmaxf(fmaxf(lo1 - c.y, c.y - hi1), 0.f),
+                            n2 = fmaxf(fmaxf(lo2 - c.z, c.z - hi2), 0.f);
+                near2[m] = n0 * n0 + n1 * n1 + n2 * n2;
             }
-        } else if (nl != 0u) {  // a giant cell (>= 16.7 M pixels of near-identical colour): 64-bit partials, lane by lane
-            unsigned long long rl = 0ull, bl = 0ull;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) rl += (unsigned long long)rows[jj] * (rbase + (uint32_t)jj);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bl += (unsigned long long)cols[k] * (b0 + (uint32_t)k);
-            atomicAdd(&tot[0], (unsigned long long)nl);
-            atomicAdd(&tot[1], rl);
-            atomicAdd(&tot[2], (unsigned long long)nl * g);
-            atomicAdd(&tot[3], bl);
         }
-        if (SQ && nl != 0u) {  // (the first pass of a fit only)
-            unsigned long long q = (unsigned long long)nl * (g * g);
+        // a centre survives when its smallest distance to the box does not exceed the smallest "largest distance" (+ slack:
+        // float32 arithmetic on values below 4e5, errors far below 1.0)
+        const float U = wave_min_to_all(far_min) + 1.0f;
+        int cnt = 0;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) q += (unsigned long long)rows[jj] * ((rbase + (uint32_t)jj) * (rbase + (uint32_t)jj));
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q += (unsigned long long)cols[k] * ((b0 + (uint32_t)k) * (b0 + (uint32_t)k));
-            atomicAdd(&tot[4], q);
+        for (int m = 0; m < 4; ++m) {
+            if (m < KM) {
+                const bool sv = near2[m] <= U;  // (inf for lanes without a centre)
+                const unsigned long long mk = __ballot(sv);
+                if (sv) surv[cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = lane + 64 * m;
+                cnt += __popcll(mk);
+            }
         }
-    };
-
-    if (n_list == 1) {
-        add_slot(0, cn);
-    } else {
-        // scores: |c|^2 + BIAS - 2 c.x through three v_fma_f32, g first (per lane), then b (per lane and k), then r (a
-        // wave-uniform value per register): one fma per (colour, candidate).  Within 0.15 of the exact score like the
-        // per-pixel kernels' (same three roundings + the record's), keys 256 apart per ulp of 0.0625.
-        int k0[4][4], k1[4][4];
+        int n_list;
+        if (cnt <= 16) {
+            // pairwise: entry a leaves if a listed b is closer on the WHOLE box by more than the slack:
+            // max over the box of |x - c_b|^2 - |x - c_a|^2 = 2 x.(c_a - c_b) + |c_b|^2 - |c_a|^2  <  -1
+            if (lane == 0) s_drop[wv] = 0u;
+            uint32_t dropbits = 0u;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) k0[jj][k] = k1[jj][k] = 0x7fffffff;
-        const float fg = (float)g;
-        for (int i = 0; i < n_list; ++i) {
-            const float4 c = s_sc[s_list[i]];
-            const float gs = fmaf(c.y, fg, c.w);
-            float bk[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bk[k] = fmaf(c.z, (float)(b0 + (uint32_t)k), gs);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const float fr = (float)(rbase + (uint32_t)jj);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float sc = fmaf(c.x, fr, bk[k]);
-                    const int key = (int)((__float_as_uint(sc) << 8) + (uint32_t)i);
-                    k1[jj][k] = med3_s32(k0[jj][k], k1[jj][k], key);
-                    k0[jj][k] = min(k0[jj][k], key);
+            for (int q = 0; q < 4; ++q) {
+                const int a = (lane >> 4) + 4 * q, b = lane & 15;
+                if (a < cnt && b < cnt && a != b) {
+                    const float4 ca = s_c[surv[a]], cb = s_c[surv[b]];
+                    const float d0 = ca.x - cb.x, d1 = ca.y - cb.y, d2 = ca.z - cb.z;
+                    const float mm = 2.f * ((d0 > 0.f ? hi0 : lo0) * d0 + (d1 > 0.f ? hi1 : lo1) * d1 + (d2 > 0.f ? hi2 : lo2) * d2) + (cb.w - ca.w);
+                    if (mm < -1.0f) dropbits |= 1u << a;
                 }
             }
+            if (dropbits) atomicOr(&s_drop[wv], dropbits);
+            const uint32_t keep = ~s_drop[wv] & ((1u << cnt) - 1u);
+            n_list = __popc(keep);
+            int sv = 0;
+            if (lane < cnt) sv = surv[lane];
+            if (lane < cnt && ((keep >> lane) & 1u)) list[__popc(keep & ((1u << lane) - 1u))] = sv;
+        } else {
+            n_list = cnt;
+            for (int i = lane; i < cnt; i += 64) list[i] = surv[i];
         }
-        int lab[4][4];
-        bool near = false;
+
+        const uint32_t g = (uint32_t)(((cell >> 4) & 15) << 4) + (uint32_t)(lane >> 2);
+        const uint32_t b0 = (uint32_t)((cell & 15) << 4) + 4u * (uint32_t)(lane & 3);
+        const float fg = (float)g;
+        // a cell with fewer than 2^24 pixels: every weighted partial sum below fits 32 bits (count x 255)
+        const bool small = ncell < (1u << 24);
+        // the wave's totals of the counts m[][] of chunk rows rbase .. rbase+3 (already masked by label) go to centre j
+        auto add_to = [&](const int j, const uint32_t(&m)[4][4], const uint32_t rbase) {
+            uint32_t rows[4], cols[4] = {0u, 0u, 0u, 0u}, nl = 0u;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < 4; ++jj) {
+                rows[jj] = (m[jj][0] + m[jj][1]) + (m[jj][2] + m[jj][3]);
+                nl += rows[jj];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                lab[jj][k] = k0[jj][k] & 255;
-                near |= cn[jj][k] != 0u && (k1[jj][k] - k0[jj][k] <= (6 << 8) + 255);
+                for (int k = 0; k < 4; ++k) cols[k] += m[jj][k];
             }
-        if (__ballot(near) != 0ull) {  // (wave-uniform: the float64 code stays off the common path)
-            if (near) {
-                const double *mp = mean ? s_mean : nullptr;
+            if (__ballot(nl != 0u) == 0ull) return;  // (wave-uniform)
+            unsigned long long *tot = s_tot + 5 * j;
+            if (small) {
+                uint32_t rl = 0u, bl = 0u;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) rl += rows[jj] * (rbase + (uint32_t)jj);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bl += cols[k] * (b0 + (uint32_t)k);
+                uint32_t N = nl, R = rl, G = nl * g, B = bl;
+                wave_sum4_to_lane63(N, R, G, B);
+                if (lane == 63) {
+                    atomicAdd(&tot[0], (unsigned long long)N);
+                    atomicAdd(&tot[1], (unsigned long long)R);
+                    atomicAdd(&tot[2], (unsigned long long)G);
+                    atomicAdd(&tot[3], (unsigned long long)B);
+                }
+            } else if (nl != 0u) {  // a giant cell (>= 16.7 M pixels of near-identical colour): 64-bit partials, lane by lane
+                unsigned long long rl = 0ull, bl = 0ull;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) rl += (unsigned long long)rows[jj] * (rbase + (uint32_t)jj);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bl += (unsigned long long)cols[k] * (b0 + (uint32_t)k);
+                atomicAdd(&tot[0], (unsigned long long)nl);
+                atomicAdd(&tot[1], rl);
+                atomicAdd(&tot[2], (unsigned long long)nl * g);
+                atomicAdd(&tot[3], bl);
+            }
+            if (SQ && nl != 0u) {  // (the first pass of a fit only)
+                unsigned long long q = (unsigned long long)nl * (g * g);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) q += (unsigned long long)rows[jj] * ((rbase + (uint32_t)jj) * (rbase + (uint32_t)jj));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q += (unsigned long long)cols[k] * ((b0 + (uint32_t)k) * (b0 + (uint32_t)k));
+                atomicAdd(&tot[4], q);
+            }
+        };
+
+        const uint32_t r0 = (uint32_t)((cell >> 8) << 4);
+        if (n_list == 1) {
+            // ONE candidate: no distance needed, and the four chunks are summed per lane before anything crosses lanes
+            uint32_t cols[4] = {0u, 0u, 0u, 0u};
+            unsigned long long one_r = 0ull, one_q = 0ull;  // count x r (and x r^2), weighted chunk by chunk
 #pragma unroll 1
-                for (int e = 0; e < 16; ++e) {
-                    const int jj = e >> 2, k = e & 3;
-                    int kk0, kk1;
-                    uint32_t cc;
-                    // (dynamic indexing of the register arrays would spill: select)
-                    kk0 = kk1 = 0;
-                    cc = 0u;
+            for (int c = c_first; c < c_end; ++c) {
+                if (c + 1 < c_end) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int jj = 0; jj < 4; ++jj) dn[jj] = tb[(4 * (c + 1) + jj) * 64];
+                }
 #pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            if (a == jj && b == k) {
-                                kk0 = k0[a][b];
-                                kk1 = k1[a][b];
-                                cc = cn[a][b];
-                            }
-                    if (cc != 0u && kk1 - kk0 <= (6 << 8) + 255) {
-                        const int p = label_f64_list(s_c64, s_list, n_list, mp, rbase + (uint32_t)jj, g, b0 + (uint32_t)k);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const uint32_t rr = r0 + (uint32_t)(4 * c + jj);
+                    const uint32_t row = (d[jj].x + d[jj].y) + (d[jj].z + d[jj].w);
+                    one_r += (unsigned long long)row * rr;
+                    if (SQ) one_q += (unsigned long long)row * (rr * rr);
+                    cols[0] += d[jj].x;
+                    cols[1] += d[jj].y;
+                    cols[2] += d[jj].z;
+                    cols[3] += d[jj].w;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) d[jj] = dn[jj];
+            }
+            const uint32_t nl = (cols[0] + cols[1]) + (cols[2] + cols[3]);
+            unsigned long long *tot = s_tot + 5 * list[0];
+            if (small) {
+                uint32_t bl = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bl += cols[k] * (b0 + (uint32_t)k);
+                uint32_t N = nl, R = (uint32_t)one_r, G = nl * g, B = bl;
+                wave_sum4_to_lane63(N, R, G, B);
+                if (lane == 63) {
+                    atomicAdd(&tot[0], (unsigned long long)N);
+                    atomicAdd(&tot[1], (unsigned long long)R);
+                    atomicAdd(&tot[2], (unsigned long long)G);
+                    atomicAdd(&tot[3], (unsigned long long)B);
+                }
+            } else if (nl != 0u) {
+                unsigned long long bl = 0ull;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bl += (unsigned long long)cols[k] * (b0 + (uint32_t)k);
+                atomicAdd(&tot[0], (unsigned long long)nl);
+                atomicAdd(&tot[1], one_r);
+                atomicAdd(&tot[2], (unsigned long long)nl * g);
+                atomicAdd(&tot[3], bl);
+            }
+            if (SQ && nl != 0u) {
+                unsigned long long q = one_q + (unsigned long long)nl * (g * g);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q += (unsigned long long)cols[k] * ((b0 + (uint32_t)k) * (b0 + (uint32_t)k));
+                atomicAdd(&tot[4], q);
+            }
+            continue;
+        }
+#pragma unroll 1
+        for (int c = c_first; c < c_end; ++c) {
+            if (c + 1 < c_end) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) dn[jj] = tb[(4 * (c + 1) + jj) * 64];
+            }
+            const uint32_t rbase = r0 + 4u * (uint32_t)c;
+            uint32_t cn[4][4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                cn[jj][0] = d[jj].x;
+                cn[jj][1] = d[jj].y;
+                cn[jj][2] = d[jj].z;
+                cn[jj][3] = d[jj].w;
+            }
+            // scores: |c|^2 + BIAS - 2 c.x through three v_fma_f32, g first (per lane), then b (per lane and k), then r (a
+            // wave-uniform value per register): one fma per (colour, candidate).  Within 0.15 of the exact score like the
+            // per-pixel kernels' (the same three roundings + the record's), keys 256 apart per ulp of 0.0625.
+            int k0[4][4], k1[4][4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) k0[jj][k] = k1[jj][k] = 0x7fffffff;
+            for (int i = 0; i < n_list; ++i) {
+                const float4 cc = s_sc[list[i]];
+                const float gs = fmaf(cc.y, fg, cc.w);
+                float bk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bk[k] = fmaf(cc.z, (float)(b0 + (uint32_t)k), gs);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float fr = (float)(rbase + (uint32_t)jj);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float sc = fmaf(cc.x, fr, bk[k]);
+                        const int key = (int)((__float_as_uint(sc) << 8) + (uint32_t)i);
+                        k1[jj][k] = med3_s32(k0[jj][k], k1[jj][k], key);
+                        k0[jj][k] = min(k0[jj][k], key);
+                    }
+                }
+            }
+            bool near = false;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) near |= cn[jj][k] != 0u && (k1[jj][k] - k0[jj][k] <= (6 << 8) + 255);
+            // from here on k0 holds the label (the winner's list position)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool nt = k1[jj][k] - k0[jj][k] <= (6 << 8) + 255;
+                    k0[jj][k] = (k0[jj][k] & 255) | (nt && cn[jj][k] != 0u ? 0x100 : 0);
+                }
+            if (__ballot(near) != 0ull) {  // (wave-uniform: the float64 code stays off the common path)
+                if (near) {
+                    const double *mp = mean ? s_mean : nullptr;
+#pragma unroll 1
+                    for (int e = 0; e < 16; ++e) {
+                        const int jj = e >> 2, k = e & 3;
+                        int kk = 0;
+                        // (dynamic indexing of the register arrays would spill: select)
 #pragma unroll
                         for (int a = 0; a < 4; ++a)
 #pragma unroll
                             for (int b = 0; b < 4; ++b)
-                                if (a == jj && b == k) lab[a][b] = p;
+                                if (a == jj && b == k) kk = k0[a][b];
+                        if (kk & 0x100) {
+                            const int p = label_f64_list(s_c64, list, n_list, mp, rbase + (uint32_t)jj, g, b0 + (uint32_t)k);
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                                for (int b = 0; b < 4; ++b)
+                                    if (a == jj && b == k) k0[a][b] = p;
+                        }
                     }
                 }
             }
-        }
-        for (int i = 0; i < n_list; ++i) {
-            uint32_t m[4][4];
+            for (int i = 0; i < n_list; ++i) {
+                uint32_t m[4][4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+                for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) m[jj][k] = lab[jj][k] == i ? cn[jj][k] : 0u;
-            add_slot(i, m);
+                    for (int k = 0; k < 4; ++k) m[jj][k] = (k0[jj][k] & 255) == i ? cn[jj][k] : 0u;
+                add_to(list[i], m, rbase);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) d[jj] = dn[jj];
         }
     }
     __syncthreads();
-    for (int i = t; i < n_list * 5; i += 256) {
-        const int pos = i / 5, what = i - 5 * pos;
+    for (int i = t; i < K * 5; i += 64 * kPassWaves) {
+        const int j = i / 5, what = i - 5 * j;
         const unsigned long long v = s_tot[i];
         if (v == 0ull || (what == 4 && !SQ)) continue;
-        const int j = s_list[pos];
         if (what == 0) atomicAdd(&counts[j], v);
         else if (what == 4) atomicAdd(&sumsq[j], v);
         else atomicAdd(&sums[3 * j + (what - 1)], v);
+    }
+    if (FUSE) {
+        __shared__ uint32_t s_ticket;
+        // Ordering without a fence: an agent-scope fence writes back and invalidates the whole L2 of this XCD (1024 workgroups
+        // doing that while the others stream the table: measured 2x slower than three separate launches).  The totals are
+        // atomics, performed at the device's coherence point; each thread waits until its own are acknowledged (vmcnt), the
+        // barrier collects the workgroup, and only then the ticket is taken -- so the workgroup that draws the last ticket
+        // finds every total performed, and reads them back with atomic loads (never through its L2).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const uint32_t n_active = min((uint32_t)gridDim.x, (n_units + kPassWaves - 1) / kPassWaves);
+        if (t == 0) s_ticket = __hip_atomic_fetch_add(fuse.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != n_active - 1u) return;  // (workgroup-uniform)
+        // the totals, written by every workgroup's atomics, come in through atomic loads -- all of them in flight together (a
+        // chain of dependent ones costs microseconds each) -- into LDS, where the update reads them like any other buffer
+        long long *s_totals = reinterpret_cast<long long *>(s_tot);   // 5K <= 1280 words: the accumulators are spent
+        double *s_red = s_c64;                                        // 256 doubles of scratch: so are the centre records
+        __syncthreads();
+        for (int i = t; i < 5 * K; i += 64 * kPassWaves)
+            s_totals[i] = (long long)__hip_atomic_load(sums + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        lloyd_update_block<false>(s_totals, fuse.centers_rw, fuse.prev, fuse.status, K, fuse.tol, fuse.max_iter, s_red);
+        __syncthreads();
+        for (int i = t; i < 4 * K; i += 64 * kPassWaves) sums[i] = 0ull;  // sums | counts (planar): the next iteration adds to zero
+        if (t == 0) __hip_atomic_store(fuse.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -458,6 +609,7 @@ int launch_kmeans_hist_build(const uint8_t *px, int64_t n, void *hist, int accum
     }
     prof_end(pm, s);
     hipLaunchKernelGGL(hist_cells_kernel, dim3(kHistCells), dim3(256), 0, s, table, cellinfo);
+    hipLaunchKernelGGL(hist_occupied_kernel, dim3(1), dim3(1024), 0, s, cellinfo);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }
@@ -479,13 +631,37 @@ int launch_kmeans_hist_step(const void *hist, const double *centers, const doubl
     const uint32_t *table = static_cast<const uint32_t *>(hist);
     const uint32_t *cellinfo = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(hist) + kHistTableBytes);
     ProfMark *pm = prof_begin(s);
+    const FuseArgs none{nullptr, nullptr, nullptr, nullptr, 0.0, 0};
     if (sumsq)
-        hipLaunchKernelGGL(hist_pass_kernel<true>, dim3(kHistCells), dim3(256), 0, s, table, cellinfo, centers, mean, K,
+        hipLaunchKernelGGL((hist_pass_kernel<true, false>), dim3(kPassGrid), dim3(64 * kPassWaves), 0, s, table, cellinfo, centers, mean, K,
                            reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
-                           reinterpret_cast<unsigned long long *>(sumsq));
+                           reinterpret_cast<unsigned long long *>(sumsq), none);
     else
-        hipLaunchKernelGGL(hist_pass_kernel<false>, dim3(kHistCells), dim3(256), 0, s, table, cellinfo, centers, mean, K,
-                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr);
+        hipLaunchKernelGGL((hist_pass_kernel<false, false>), dim3(kPassGrid), dim3(64 * kPassWaves), 0, s, table, cellinfo, centers, mean, K,
+                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr, none);
+    prof_end(pm, s);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
+int launch_kmeans_hist_iterate(const void *hist, double *centers, const double *mean, int K, int64_t *totals, int64_t *prev,
+                               double *status, uint32_t *ticket, double tol, int max_iter, int first, hipStream_t s)
+{
+    if (K > kHistMaxK) {
+        set_error("dp_kmeans_hist_iterate: more than %d clusters", kHistMaxK);
+        return DP_EUNSUPPORTED;
+    }
+    const uint32_t *table = static_cast<const uint32_t *>(hist);
+    const uint32_t *cellinfo = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(hist) + kHistTableBytes);
+    unsigned long long *sums = reinterpret_cast<unsigned long long *>(totals);
+    const FuseArgs fa{centers, reinterpret_cast<long long *>(prev), status, ticket, tol, max_iter};
+    ProfMark *pm = prof_begin(s);
+    if (first)
+        hipLaunchKernelGGL((hist_pass_kernel<true, true>), dim3(kPassGrid), dim3(64 * kPassWaves), 0, s, table, cellinfo, centers, mean, K,
+                           sums, sums + 3 * (size_t)K, sums + 4 * (size_t)K, fa);
+    else
+        hipLaunchKernelGGL((hist_pass_kernel<false, true>), dim3(kPassGrid), dim3(64 * kPassWaves), 0, s, table, cellinfo, centers, mean, K,
+                           sums, sums + 3 * (size_t)K, nullptr, fa);
     prof_end(pm, s);
     DP_HIP(hipGetLastError());
     return DP_OK;

@@ -52,6 +52,22 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
     return v;
 }
 
+// Four sums at once: the four ladders interleaved, so that each v_add_u32_dpp finds its source written three instructions
+// earlier and the wait states between a VALU write and a DPP read are filled with work instead of s_nop.  Lane 63 only.
+__device__ __forceinline__ void wave_sum4_to_lane63(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
+{
+#define DP_STEP4(ctrl)                                        \
+    "v_add_u32_dpp %0, %0, %0 " ctrl "\n\t"                   \
+    "v_add_u32_dpp %1, %1, %1 " ctrl "\n\t"                   \
+    "v_add_u32_dpp %2, %2, %2 " ctrl "\n\t"                   \
+    "v_add_u32_dpp %3, %3, %3 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t" DP_STEP4("row_shr:1 row_mask:0xf bank_mask:0xf") DP_STEP4("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     DP_STEP4("row_shr:4 row_mask:0xf bank_mask:0xf") DP_STEP4("row_shr:8 row_mask:0xf bank_mask:0xf")
+                         DP_STEP4("row_bcast:15 row_mask:0xa bank_mask:0xf") DP_STEP4("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef DP_STEP4
+}
+
 // Value of lane (lane ^ mask) -- the butterfly exchange of wave-wide reductions over pairs (value, position), for which
 // no fused DPP minimum exists; one ds_bpermute_b32 (LDS crossbar, no memory).
 __device__ __forceinline__ uint32_t lane_xor_u32(const uint32_t v, const int mask)

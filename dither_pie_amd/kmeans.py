@@ -119,13 +119,16 @@ def _check_centres_in_cube(c):
 HIST_MIN_PIXELS = 1 << 19   # from here on a fit reads its pixels once into the colour histogram and iterates over that
 
 
-def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sklearn_ties=True, histogram=None):
+def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sklearn_ties=True, histogram=None, fuse=None):
     """Lloyd iterations over the uint8 pixels `px` ([...,3] tensor on the GPU).
 
     histogram: None -- images of HIST_MIN_PIXELS and more (per rank) with K <= 256 are read ONCE into count[colour]
     (backend.ColourHistogram, dp_kmeans_hist_*) and every pass runs over the histogram: a label is a function of the colour,
     the totals are sums of count x colour, so labels and int64 totals are those of the passes over the pixels, bit for bit,
     at 16 KB per occupied cell of the colour cube per pass instead of 3 B per pixel.  True / False force the choice.
+    fuse: None -- with the histogram and no other rank to exchange totals with, an iteration is ONE launch
+    (dp_kmeans_hist_iterate: the pass, and the centre update by the workgroup that finishes last); False keeps the three
+    steps pass / all-reduce / update (what a sharded fit runs).
 
     sklearn_ties: a pass "zero" (one centre: the totals of all pixels, all-reduced like any other pass) gives the data
     mean KMeans.fit subtracts, and every pass labels equidistant pixels as sklearn's float64 expression on the centred
@@ -157,6 +160,7 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sk
     status = torch.zeros(8, dtype=torch.float64, device=dev)
     if histogram is None:
         histogram = flat.shape[0] >= HIST_MIN_PIXELS
+    hist = None
     if histogram and K <= backend.KMEANS_HIST_MAX_K and 0 < flat.shape[0] < (1 << 32):
         hist = backend.ColourHistogram(flat)
 
@@ -171,13 +175,20 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sk
         one_pass(torch.zeros((1, 3), dtype=torch.float64, device=dev), t0, False, None)
         _all_reduce_totals(t0, group)
         mean = (t0[:3].to(torch.float64) / t0[3].to(torch.float64)).contiguous()   # exact sums: sum / n rounded once
+    import torch.distributed as dist
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    fused = hist is not None and not sharded and fuse is not False   # one device: ONE launch per iteration (dp_kmeans_hist_iterate)
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev) if fused else None
     launched = 0
     while True:
         for _ in range(CHECK_EVERY):
             first = launched == 0
-            one_pass(centers, totals, first, mean)
-            _all_reduce_totals(totals if first else totals[:4 * K], group)
-            backend.kmeans_update(totals, centers, prev, status, tol, max_iter)
+            if fused:
+                hist.iterate(centers, totals, prev, status, ticket, tol, max_iter, first, mean)
+            else:
+                one_pass(centers, totals, first, mean)
+                _all_reduce_totals(totals if first else totals[:4 * K], group)
+                backend.kmeans_update(totals, centers, prev, status, tol, max_iter)
             launched += 1
         st = status.cpu()
         if int(st[0]) in (1, 3):

@@ -227,6 +227,18 @@ size_t dp_kmeans_hist_bytes(void);
 int dp_kmeans_hist_build_u8(const uint8_t *px_dev, int64_t n, void *hist_dev, int accumulate, void *stream);
 int dp_kmeans_hist_step(const void *hist_dev, const double *centers_dev, const double *mean_dev, int K, int64_t *sums_dev,
                         int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
+/* One WHOLE Lloyd iteration over the histogram in one launch, for a fit that lives on one device (nothing to all-reduce between
+ * the pass and the update): dp_kmeans_hist_step into totals_dev followed by dp_kmeans_update, the update run by whichever
+ * workgroup finishes the pass last (no workgroup waits for another).
+ *   totals_dev  5K int64, planar as dp_kmeans_update takes it, ALL ZERO before the first iteration; the call leaves the sums
+ *               and counts zero again for the next one
+ *   ticket_dev  one uint32, zero before the first iteration (left zero)
+ *   first       non-zero for the first iteration of a fit (it also accumulates the squared norms)
+ *   centers_dev / prev_dev / status_dev / tol / max_iter   as dp_kmeans_update
+ * An empty histogram (no pixels) leaves everything untouched. */
+int dp_kmeans_hist_iterate(const void *hist_dev, double *centers_dev, const double *mean_dev, int K, int64_t *totals_dev,
+                           int64_t *prev_dev, double *status_dev, uint32_t *ticket_dev, double tol, int max_iter, int first,
+                           void *stream);
 /*
  * The centre update of one Lloyd iteration ON THE DEVICE, so that a host loop can launch iterations back to back
  * (pass, all-reduce of the totals across ranks, update) and look at the status only every few iterations -- sklearn's

@@ -185,8 +185,11 @@ def test_colour_histogram_counts(be, orc, kind):
     table = hist.buf[:1 << 26].view(torch.int32).cpu().numpy().view(np.uint32)
     ref = _hist_table_numpy(px)
     assert np.array_equal(table, ref)
-    cells = hist.buf[1 << 26:].view(torch.int32).cpu().numpy().view(np.uint32)
-    assert np.array_equal(cells, ref.reshape(4096, 4096).sum(1).astype(np.uint32))
+    info = hist.buf[1 << 26:].view(torch.int32).cpu().numpy().view(np.uint32)   # pixels per cell | occupied cells: how many, which
+    per_cell = ref.reshape(4096, 4096).sum(1).astype(np.uint32)
+    assert np.array_equal(info[:4096], per_cell)
+    occupied = np.nonzero(per_cell)[0]
+    assert info[4096] == len(occupied) and np.array_equal(info[4097:4097 + len(occupied)], occupied)
     # an unaligned view (byte offset 3), a ragged count, accumulated on top
     raw = torch.empty(3 * px.shape[0] + 3, dtype=torch.uint8, device="cuda")
     raw[3:] = t.reshape(-1)
@@ -197,7 +200,7 @@ def test_colour_histogram_counts(be, orc, kind):
     assert np.array_equal(table2, ref + _hist_table_numpy(px[:1001]))
     # nothing at all
     empty = be.ColourHistogram(t[:0])
-    assert int(empty.buf.view(torch.int32).abs().sum().item()) == 0
+    assert int(empty.buf[:(1 << 26) + 4 * 4097].view(torch.int32).abs().sum().item()) == 0
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
@@ -248,9 +251,11 @@ def test_lloyd_over_the_histogram_equals_lloyd_over_the_pixels(be, orc, gold, ka
         arr = case_input(orc, m["input"])
         px = torch.from_numpy(arr).cuda().reshape(-1, 3)
         init = arr.reshape(-1, 3)[gold[f"{nm}_init_idx"]].astype(np.float64)
-        a = kmeans.lloyd(px, init, histogram=True)
+        a = kmeans.lloyd(px, init, histogram=True)                  # one launch per iteration (dp_kmeans_hist_iterate)
         b = kmeans.lloyd(px, init, histogram=False)
+        c = kmeans.lloyd(px, init, histogram=True, fuse=False)      # pass / update as separate launches (a sharded fit's steps)
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2] == m["n_iter"], nm
+        assert np.array_equal(a[0], c[0]) and a[1] == c[1] and a[2] == c[2], nm
         assert np.abs(a[0] - gold[f"{nm}_centers"]).max() < 1e-9, nm
     big = orc.imgl(1024, 1024, 9, "smooth")
     px = torch.from_numpy(big).cuda().reshape(-1, 3)
