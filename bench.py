@@ -486,37 +486,62 @@ def main():
         # bands over the ranks; the per-iteration exchange is one RCCL all-reduce of [32,5] int64
         from dither_pie_amd import kmeans, sharding
         del f3, o3
-        g4 = torch.Generator(device=dev)
-        g4.manual_seed(99)
         lo4, hi4 = sharding.shard_range(4320, rank, world)
-        img = torch.randint(0, 256, (4320, 7680, 3), dtype=torch.uint8, device=dev, generator=g4)
-        band = img[lo4:hi4].contiguous()
-        del img
+        # SURVEY 8(d)'s C4 image rnd(4320, 7680, 99) (numpy legacy RNG on the host, ~1 s), this rank's row band of it
+        band = torch.from_numpy(np.random.RandomState(99).randint(0, 256, (4320, 7680, 3), dtype=np.uint8)[lo4:hi4]).to(dev).contiguous()
 
-        def c4():
-            pal, _, _, iters = kmeans.fit_palette(band.reshape(-1, 3), 32, 42, n_total=4320 * 7680, offset=lo4 * 7680)
+        def c4(src=None):
+            src = band if src is None else src
+            pal, _, _, iters = kmeans.fit_palette(src.reshape(-1, 3), 32, 42, n_total=4320 * 7680, offset=lo4 * 7680)
             d4 = ImageDitherer(32, DitherMode.BLUE_NOISE, pal, False, {"size": 64, "seed": 42})
-            sharding.dither_band(d4, band, lo4)
+            sharding.dither_band(d4, src, lo4)
             return iters
 
         iters4 = c4()
         t4 = timed(c4, 1, 0)
         extra["c4_8k_kmeans32_plus_blue_noise_seconds"] = round(t4, 4)
-        # one Lloyd pass over this rank's band on its own (dp_kmeans_step_u8 with its memset)
+        # the same on image-like content (smooth gradients + grain): what a photograph looks like to the fit
+        yy4, xx4 = torch.meshgrid(torch.arange(lo4, hi4, device=dev), torch.arange(7680, device=dev), indexing="ij")
+        g4 = torch.Generator(device=dev)
+        g4.manual_seed(99)
+        smooth = torch.stack([(xx4 * 255 // 7679), (yy4 * 255 // 4319), ((xx4 + yy4) * 255 // (7679 + 4319))], -1).to(torch.int16)
+        smooth = (smooth + torch.randint(-6, 7, smooth.shape, device=dev, generator=g4).to(torch.int16)).clamp(0, 255).to(torch.uint8).contiguous()
+        del yy4, xx4
+        iters4s = c4(smooth)
+        t4s = timed(lambda: c4(smooth), 1, 0)
+        extra["c4_8k_image_like_kmeans32_plus_blue_noise_seconds"] = round(t4s, 4)
+        # the fit's two kernels, each against its own bytes: the histogram build reads the pixels once (3 B/px); a Lloyd
+        # iteration reads 16 KB per occupied 16^3 cell of the colour cube (64 MB when all 4096 are occupied), not the pixels
         from dither_pie_amd import backend as _be
         c4c = torch.from_numpy(np.random.RandomState(1).rand(32, 3) * 255.0).to(dev)
         tot4 = torch.zeros(160, dtype=torch.int64, device=dev)
         bpx = band.reshape(-1, 3)
+        n4 = bpx.numel() // 3
+        hist4 = _be.ColourHistogram(bpx)
+        kb_ms, _ = kernel_ms(lambda: hist4.add(bpx, accumulate=False), 3)
+        info4 = hist4.buf[1 << 26:].view(torch.int32)
+        occ4 = int(info4[4096].item())
+        result["c4_kmeans_histogram"] = leg("hist_build_kernel (pixels -> count[colour] over 2^24 colours, once per fit)", kb_ms, 3 * n4,
+                                            bound="rate of random global atomics (one per distinct colour per 1024-pixel window), not HBM",
+                                            workload=f"C4: the {n4} pixels of this rank's band of rnd(4320,7680,99) ({world} band(s))")
+        hist4.step_into(c4c, tot4, False)
+        kp_ms, _ = kernel_ms(lambda: hist4.step_into(c4c, tot4, False), 5)
+        tp4 = timed(lambda: hist4.step_into(c4c, tot4, False), 10, 2) / 10
+        result["c4_kmeans_pass"] = leg("hist_pass_kernel<false,false> (one Lloyd pass over the colour histogram, candidate lists built in-kernel)",
+                                       kp_ms, occ4 * 16384, occupied_cells=occ4, pass_ms_with_memset=round(tp4 * 1e3, 4),
+                                       iterations_of_the_fit=int(iters4),
+                                       workload=f"C4: one Lloyd pass, K=32, over the histogram of this rank's band of the 7680x4320 image ({world} band(s)); "
+                                                "algorithmic bytes = 16 KB per occupied cell")
+        # the pass over the PIXELS (what fits with more than 256 clusters, or fewer than 2^19 pixels, still run): 3 B/px
         _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False)
-        tp4 = timed(lambda: _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False), 10, 2) / 10
+        kx_ms, _ = kernel_ms(lambda: _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False), 5)
+        result["c4_kmeans_pixel_pass"] = leg("kmeans_cells_kernel<false,2> (its list build launch not included)", kx_ms, 3 * n4,
+                                             workload="the same pass over the pixels themselves (round 3's Lloyd pass)")
         extra["c4_kmeans_pass_ms"] = round(tp4 * 1e3, 4)
-        k4_ms, _ = kernel_ms(lambda: _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False), 5)
-        result["c4_kmeans_pass"] = leg("kmeans_cells_kernel<false,2> (+ its candidate-list build in front)", k4_ms, 3 * (bpx.numel() // 3),
-                                       pass_ms_with_memset_and_list_build=round(tp4 * 1e3, 4), iterations_of_the_fit=int(iters4),
-                                       workload=f"C4: one Lloyd pass over this rank's band of the 7680x4320 image, K=32 ({world} band(s))")
-        extra["c4_kmeans_pass_hbm_gbs"] = round(bpx.numel() / tp4 / 1e9, 1)
-        extra["c4_note"] = (f"7680x4320 in {world} row band(s), Lloyd over all pixels ({iters4} iterations, one int64 "
-                            "all-reduce each), blue-noise(64,42) dither of the band with global coordinates")
+        extra["c4_note"] = (f"rnd(4320,7680,99) in {world} row band(s); per rank: pixels -> colour histogram once, then Lloyd over the "
+                            f"histogram ({iters4} iterations on noise, {iters4s} on the image-like content; one launch per iteration on one "
+                            "rank, pass / int64 all-reduce / update when sharded), blue-noise(64,42) dither of the band with global coordinates")
+        del hist4, smooth
         result["extra"] = extra
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -250,12 +250,13 @@ __global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uin
                                                                     const double *__restrict__ centers, const double *__restrict__ mean,
                                                                     const int K, unsigned long long *__restrict__ sums,
                                                                     unsigned long long *__restrict__ counts,
-                                                                    unsigned long long *__restrict__ sumsq, const FuseArgs fuse)
+                                                                    unsigned long long *__restrict__ sumsq, const FuseArgs fuse, const int force_split)
 {
     const uint32_t n_occ = info[kHistCells];
     // Few occupied cells (image-like content): a cell is split over 2 or 4 waves (each takes 2 / 1 of the cell's four chunks
     // and builds the list for itself), so that the chip still has a few thousand waves to hide latency with.
-    const int split = n_occ * 4u <= (uint32_t)(kPassGrid * kPassWaves) ? 4 : (n_occ * 2u <= (uint32_t)(kPassGrid * kPassWaves) ? 2 : 1);
+    const int split_auto = n_occ * 4u <= (uint32_t)(kPassGrid * kPassWaves) ? 4 : (n_occ * 2u <= (uint32_t)(kPassGrid * kPassWaves) ? 2 : 1);
+    const int split = force_split ? force_split : split_auto;
     const int chunks_per_unit = 4 / split;
     const uint32_t n_units = n_occ * (uint32_t)split;
     if ((uint32_t)blockIdx.x * kPassWaves >= n_units) return;  // (workgroup-uniform)
@@ -632,13 +633,15 @@ int launch_kmeans_hist_step(const void *hist, const double *centers, const doubl
     const uint32_t *cellinfo = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(hist) + kHistTableBytes);
     ProfMark *pm = prof_begin(s);
     const FuseArgs none{nullptr, nullptr, nullptr, nullptr, 0.0, 0};
+    const char *fse = exp_env("DP_KMEANS_HIST_SPLIT");  // experiments: waves per cell (1, 2, 4)
+    const int fs = fse ? atoi(fse) : 0;
     if (sumsq)
         hipLaunchKernelGGL((hist_pass_kernel<true, false>), dim3(kPassGrid), dim3(64 * kPassWaves), 0, s, table, cellinfo, centers, mean, K,
                            reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts),
-                           reinterpret_cast<unsigned long long *>(sumsq), none);
+                           reinterpret_cast<unsigned long long *>(sumsq), none, fs);
     else
         hipLaunchKernelGGL((hist_pass_kernel<false, false>), dim3(kPassGrid), dim3(64 * kPassWaves), 0, s, table, cellinfo, centers, mean, K,
-                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr, none);
+                           reinterpret_cast<unsigned long long *>(sums), reinterpret_cast<unsigned long long *>(counts), nullptr, none, fs);
     prof_end(pm, s);
     DP_HIP(hipGetLastError());
     return DP_OK;
@@ -658,10 +661,10 @@ int launch_kmeans_hist_iterate(const void *hist, double *centers, const double *
     ProfMark *pm = prof_begin(s);
     if (first)
         hipLaunchKernelGGL((hist_pass_kernel<true, true>), dim3(kPassGrid), dim3(64 * kPassWaves), 0, s, table, cellinfo, centers, mean, K,
-                           sums, sums + 3 * (size_t)K, sums + 4 * (size_t)K, fa);
+                           sums, sums + 3 * (size_t)K, sums + 4 * (size_t)K, fa, 0);
     else
         hipLaunchKernelGGL((hist_pass_kernel<false, true>), dim3(kPassGrid), dim3(64 * kPassWaves), 0, s, table, cellinfo, centers, mean, K,
-                           sums, sums + 3 * (size_t)K, nullptr, fa);
+                           sums, sums + 3 * (size_t)K, nullptr, fa, 0);
     prof_end(pm, s);
     DP_HIP(hipGetLastError());
     return DP_OK;
