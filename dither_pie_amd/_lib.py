@@ -76,6 +76,8 @@ _SIGS = {
     "dp_kmeans_update": (_i, [_vp, _vp, _vp, _vp, _i, C.c_double, _i, _vp]),
     "dp_kmeans_plusplus_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "dp_resize_nearest_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "dp_distinct_first_workspace_bytes": (_sz, [_i64]),
+    "dp_distinct_first_u8": (_i, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "dp_pyset_order_host": (_i, [_vp, _i64, _vp, C.POINTER(_i64)]),
     "dp_median_cut_host": (_i, [_vp, _i64, _i, _vp, C.POINTER(_i)]),
     "dp_profile_enable": (_i, [_i]),

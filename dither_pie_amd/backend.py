@@ -347,6 +347,23 @@ def kmeans_step_into(px, centers, totals, want_sq=True, mean=None):
                                             (base + 8 * 4 * K) if want_sq else None, _stream()))
 
 
+def distinct_first(px):
+    """The distinct colours of the uint8 RGB pixels `px` (CUDA tensor [...,3]) in order of first occurrence
+    (dp_distinct_first_u8) -> uint8 tensor [n_distinct, 3] on the device.  One host synchronisation (the count)."""
+    if not (px.is_cuda and px.dtype == torch.uint8 and px.shape[-1] == 3):
+        raise TypeError("px must be a CUDA uint8 tensor [...,3]")
+    px = px.contiguous()
+    n = px.numel() // 3
+    out = torch.empty((n, 3), dtype=torch.uint8, device=px.device)
+    nd = torch.zeros(1, dtype=torch.int64, device=px.device)
+    L = _lib.load()
+    with torch.cuda.device(px.device):
+        with _Launch(px.device, L.dp_distinct_first_workspace_bytes(n)) as ws:
+            check(L.dp_distinct_first_u8(px.data_ptr(), n, out.data_ptr(), nd.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+            k = int(nd.item())   # (synchronises: the workspace may be handed to the next call after this)
+    return out[:k]
+
+
 KMEANS_HIST_MAX_K = 256   # dp_kmeans_hist_step: one thread per centre in the list build
 
 

@@ -778,6 +778,22 @@ int dp_kmeans_plusplus_u8(const uint8_t *sample_dev, int n, int K, int first, co
     return launch_kmeans_pp(sample_dev, n, K, first, uniforms_dev, n_trials, ids_dev, centers_dev, (hipStream_t)stream);
 }
 
+size_t dp_distinct_first_workspace_bytes(int64_t n) { return n < 0 ? 0 : distinct_first_ws_bytes(n); }
+
+int dp_distinct_first_u8(const uint8_t *px_dev, int64_t n, uint8_t *out_dev, int64_t *n_distinct_dev, void *workspace_dev,
+                         size_t workspace_bytes, void *stream)
+{
+    if ((!px_dev && n > 0) || n < 0 || n > (int64_t)0xfffffff0LL || (!out_dev && n > 0) || !n_distinct_dev) {
+        set_error("dp_distinct_first_u8: bad argument (n must be below 2^32 - 16)");
+        return DP_EINVAL;
+    }
+    if (n > 0 && (!workspace_dev || ((uintptr_t)workspace_dev & 15) || workspace_bytes < distinct_first_ws_bytes(n))) {
+        set_error("dp_distinct_first_u8: workspace too small or not 16-byte aligned (need %zu bytes)", distinct_first_ws_bytes(n));
+        return DP_EWORKSPACE;
+    }
+    return launch_distinct_first(px_dev, n, out_dev, reinterpret_cast<long long *>(n_distinct_dev), workspace_dev, (hipStream_t)stream);
+}
+
 int dp_pyset_order_host(const uint8_t *rgb_host, int64_t n, uint32_t *order_out, int64_t *n_distinct)
 {
     if (!rgb_host || n < 0 || n > ((int64_t)1 << 31) - 2 || !order_out || !n_distinct) {
@@ -799,11 +815,13 @@ int dp_median_cut_host(const uint8_t *rgb_host, int64_t n, int depth, int32_t *p
     }
     std::vector<uint32_t> order;
     pyset_order(rgb_host, (size_t)n, order);
-    std::vector<uint8_t> colours(3 * order.size() + 3), scratch(3 * order.size() + 3);
-    for (size_t i = 0; i < order.size(); ++i)
-        for (int c = 0; c < 3; ++c) colours[3 * i + c] = rgb_host[3 * (size_t)order[i] + c];
+    std::vector<uint32_t> colours(order.size() + 1), scratch(order.size() + 1);
+    for (size_t i = 0; i < order.size(); ++i) {
+        const uint8_t *c = rgb_host + 3 * (size_t)order[i];
+        colours[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+    }
     std::vector<int32_t> out;
-    median_cut_rgb(colours.data(), scratch.data(), order.size(), depth, out);
+    median_cut_u32(colours.data(), scratch.data(), order.size(), depth, out, (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
     std::copy(out.begin(), out.end(), palette_out);
     *n_out = (int)(out.size() / 3);
     return DP_OK;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <initializer_list>
 #include <limits>
 #include <numeric>
@@ -847,52 +848,99 @@ inline uint64_t py_tuple3_hash(const uint64_t a, const uint64_t b, const uint64_
 
 // rgb: n colours (3 bytes each) in insertion order, duplicates allowed.  order: for every element of the resulting set, in
 // the set's iteration order, the index of its first occurrence in rgb.
+// An 8-byte slot {low 32 bits of the hash, index + 1}: the home slot and the duplicate test need no more (tables have fewer than
+// 2^32 slots; equal low words are settled by comparing the colours), and the high bits only enter the perturbed jumps after nine
+// occupied neighbours, where the hash is simply recomputed from the colour.  Half the table (4 MB instead of 8 for 180 k
+// colours) is half the cache misses.  (Prefetching home slots ahead was measured on the bench box's EPYC 9575F and costs time:
+// 4.8 -> 6.1 ms, profiles/experiments/r04_pyset_prefetch_ab.txt.)
+struct PySetSlot {
+    uint32_t h;     // low word of the hash
+    uint32_t idx1;  // index of the colour + 1 (0 = unused slot)
+};
+
+// Two slot arrays per thread, kept from call to call (a 180 k-colour set walks through 8 MB of tables; fresh allocations cost
+// more in page faults than the insertions themselves).  A buffer is handed out zeroed over the slots the caller asks for:
+// only what an earlier table left dirty is cleared.
+struct PySetTables {
+    std::vector<PySetSlot> buf[2];
+    size_t dirty[2] = {0, 0};   // slots of each buffer that may be non-zero
+    PySetSlot *fresh(const int which, const size_t size)
+    {
+        if (buf[which].size() < size) {
+            buf[which].assign(size, PySetSlot{0, 0});
+        } else if (dirty[which]) {
+            std::memset(buf[which].data(), 0, std::min(dirty[which], buf[which].size()) * sizeof(PySetSlot));
+        }
+        dirty[which] = size;
+        return buf[which].data();
+    }
+    void trim()   // (a one-off giant image must not pin hundreds of megabytes for the life of the thread)
+    {
+        for (int w = 0; w < 2; ++w)
+            if (buf[w].size() > ((size_t)1 << 23)) {
+                std::vector<PySetSlot>().swap(buf[w]);
+                dirty[w] = 0;
+            }
+    }
+};
+
 inline void pyset_order(const uint8_t *rgb, const size_t n, std::vector<uint32_t> &order)
 {
     constexpr size_t kLinearProbes = 9;
     constexpr int kPerturbShift = 5;
+    order.clear();
+    static thread_local PySetTables tables;
     size_t mask = 7, fill = 0;
-    std::vector<uint64_t> th(8, 0);   // hash of the entry in a slot
-    std::vector<uint32_t> ti(8, 0);   // index of its colour + 1 (0 = unused slot)
+    int cur = 0;
+    PySetSlot *tab = tables.fresh(0, 8);
+    auto hash_of = [&](const size_t k) { return py_tuple3_hash(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]); };
     auto same = [&](const uint32_t slot_idx, const size_t k) {
         const uint8_t *p = rgb + 3 * (size_t)(slot_idx - 1), *q = rgb + 3 * k;
         return p[0] == q[0] && p[1] == q[1] && p[2] == q[2];
     };
-    auto insert_clean = [&](std::vector<uint64_t> &nh, std::vector<uint32_t> &ni, const size_t m, const uint64_t h, const uint32_t idx1) {
-        uint64_t perturb = h;
-        size_t i = (size_t)h & m;
+    // insertion of an element that is known to be absent (growth steps)
+    auto insert_clean = [&](PySetSlot *nt, const size_t m, const uint32_t hlo, const uint32_t idx1) {
+        size_t i = (size_t)hlo & m;
+        if (nt[i].idx1 == 0) {
+            nt[i] = PySetSlot{hlo, idx1};
+            return;
+        }
+        uint64_t perturb = 0;
+        bool have_hash = false;
         for (;;) {
-            if (ni[i] == 0) {
-                nh[i] = h;
-                ni[i] = idx1;
-                return;
-            }
             if (i + kLinearProbes <= m)
                 for (size_t j = 1; j <= kLinearProbes; ++j)
-                    if (ni[i + j] == 0) {
-                        nh[i + j] = h;
-                        ni[i + j] = idx1;
+                    if (nt[i + j].idx1 == 0) {
+                        nt[i + j] = PySetSlot{hlo, idx1};
                         return;
                     }
+            if (!have_hash) {
+                perturb = hash_of((size_t)idx1 - 1);
+                have_hash = true;
+            }
             perturb >>= kPerturbShift;
             i = (i * 5 + 1 + (size_t)perturb) & m;
+            if (nt[i].idx1 == 0) {
+                nt[i] = PySetSlot{hlo, idx1};
+                return;
+            }
         }
     };
     for (size_t k = 0; k < n; ++k) {
-        const uint64_t h = py_tuple3_hash(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2]);
+        const uint64_t h = hash_of(k);
+        const uint32_t hlo = (uint32_t)h;
         uint64_t perturb = h;
         size_t i = (size_t)h & mask;
         bool added = false;
         for (bool done = false; !done;) {
             size_t probes = i + kLinearProbes <= mask ? kLinearProbes : 0;
             for (size_t j = i;; ++j) {
-                if (ti[j] == 0) {
-                    th[j] = h;
-                    ti[j] = (uint32_t)k + 1u;
+                if (tab[j].idx1 == 0) {
+                    tab[j] = PySetSlot{hlo, (uint32_t)k + 1u};
                     added = done = true;
                     break;
                 }
-                if (th[j] == h && same(ti[j], k)) {
+                if (tab[j].h == hlo && same(tab[j].idx1, k)) {
                     done = true;  // already in the set
                     break;
                 }
@@ -908,61 +956,83 @@ inline void pyset_order(const uint8_t *rgb, const size_t n, std::vector<uint32_t
             const size_t minused = fill > 50000 ? fill * 2 : fill * 4;  // (no deletions: used == fill)
             size_t newsize = 8;
             while (newsize <= minused) newsize <<= 1;
-            std::vector<uint64_t> nh(newsize, 0);
-            std::vector<uint32_t> ni(newsize, 0);
-            for (size_t slot = 0; slot <= mask; ++slot)
-                if (ti[slot] != 0) insert_clean(nh, ni, newsize - 1, th[slot], ti[slot]);
-            th.swap(nh);
-            ti.swap(ni);
-            mask = newsize - 1;
+            PySetSlot *nt = tables.fresh(cur ^ 1, newsize);
+            const size_t m = newsize - 1;
+            for (size_t slot = 0; slot <= mask; ++slot)   // re-insertion in slot order (the old table is read sequentially)
+                if (tab[slot].idx1 != 0) insert_clean(nt, m, tab[slot].h, tab[slot].idx1);
+            tab = nt;
+            cur ^= 1;
+            mask = m;
         }
     }
-    order.clear();
     order.reserve(fill);
     for (size_t slot = 0; slot <= mask; ++slot)
-        if (ti[slot] != 0) order.push_back(ti[slot] - 1u);
+        if (tab[slot].idx1 != 0) order.push_back(tab[slot].idx1 - 1u);
+    tables.trim();
 }
 
 // median_cut(colors, depth) of the reference (dithering_lib.py:1822-1833) on n colours in list order: the first widest
 // channel, a STABLE sort on it (a counting sort over the 256 values), split at n // 2, at depth 0 the per-channel mean
 // int(sum / n) (true division in float64, truncated); an empty bucket yields the single entry (0, 0, 0) at any depth.
-// rgb is permuted in place (scratch: n * 3 bytes); the palette entries are appended to out (3 ints each).
-inline void median_cut_rgb(uint8_t *rgb, uint8_t *scratch, const size_t n, const int depth, std::vector<int32_t> &out)
+// The colours travel as packed words r | g << 8 | b << 16 between two buffers (cur -> other at every level: no copy back);
+// the palette entries are appended to out (3 ints each).
+// threads > 1: the two halves of a big bucket are cut concurrently (they work on disjoint parts of both buffers; the left
+// half's entries come first in the palette, as in the recursion).
+inline void median_cut_u32(uint32_t *cur, uint32_t *other, const size_t n, const int depth, std::vector<int32_t> &out, const int threads = 1)
 {
     if (n == 0) {
         out.insert(out.end(), {0, 0, 0});
         return;
     }
     if (depth == 0) {
-        uint64_t s[3] = {0, 0, 0};
-        for (size_t i = 0; i < n; ++i)
-            for (int c = 0; c < 3; ++c) s[c] += rgb[3 * i + c];
-        for (int c = 0; c < 3; ++c) out.push_back((int32_t)((double)s[c] / (double)n));
+        uint64_t s0 = 0, s1 = 0, s2 = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t v = cur[i];
+            s0 += v & 255u;
+            s1 += (v >> 8) & 255u;
+            s2 += v >> 16;
+        }
+        out.push_back((int32_t)((double)s0 / (double)n));
+        out.push_back((int32_t)((double)s1 / (double)n));
+        out.push_back((int32_t)((double)s2 / (double)n));
         return;
     }
-    int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
-    for (size_t i = 0; i < n; ++i)
-        for (int c = 0; c < 3; ++c) {
-            const int v = rgb[3 * i + c];
-            lo[c] = v < lo[c] ? v : lo[c];
-            hi[c] = v > hi[c] ? v : hi[c];
+    // per-channel minimum and maximum, all three at once on the packed word (byte-wise min / max: the compiler vectorises it)
+    uint8_t lo[4] = {255, 255, 255, 255}, hi[4] = {0, 0, 0, 0};
+    {
+        const uint8_t *bytes = reinterpret_cast<const uint8_t *>(cur);
+        uint8_t l0 = 255, l1 = 255, l2 = 255, h0 = 0, h1 = 0, h2 = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const uint8_t a = bytes[4 * i], b = bytes[4 * i + 1], c = bytes[4 * i + 2];
+            l0 = a < l0 ? a : l0;
+            h0 = a > h0 ? a : h0;
+            l1 = b < l1 ? b : l1;
+            h1 = b > h1 ? b : h1;
+            l2 = c < l2 ? c : l2;
+            h2 = c > h2 ? c : h2;
         }
+        lo[0] = l0; lo[1] = l1; lo[2] = l2;
+        hi[0] = h0; hi[1] = h1; hi[2] = h2;
+    }
     int ch = 0;
     for (int c = 1; c < 3; ++c)
         if (hi[c] - lo[c] > hi[ch] - lo[ch]) ch = c;  // the first of equal spans
+    const int sh = 8 * ch;
     size_t start[257] = {0};
-    for (size_t i = 0; i < n; ++i) ++start[rgb[3 * i + ch] + 1];
+    for (size_t i = 0; i < n; ++i) ++start[((cur[i] >> sh) & 255u) + 1];
     for (int v = 0; v < 256; ++v) start[v + 1] += start[v];
-    for (size_t i = 0; i < n; ++i) {
-        const size_t at = start[rgb[3 * i + ch]]++;
-        scratch[3 * at] = rgb[3 * i];
-        scratch[3 * at + 1] = rgb[3 * i + 1];
-        scratch[3 * at + 2] = rgb[3 * i + 2];
-    }
-    std::copy(scratch, scratch + 3 * n, rgb);
+    for (size_t i = 0; i < n; ++i) other[start[(cur[i] >> sh) & 255u]++] = cur[i];
     const size_t half = n / 2;
-    median_cut_rgb(rgb, scratch, half, depth - 1, out);
-    median_cut_rgb(rgb + 3 * half, scratch + 3 * half, n - half, depth - 1, out);
+    if (threads > 1 && n >= 16384) {
+        std::vector<int32_t> right;
+        std::thread t([&] { median_cut_u32(other + half, cur + half, n - half, depth - 1, right, threads / 2); });
+        median_cut_u32(other, cur, half, depth - 1, out, threads - threads / 2);
+        t.join();
+        out.insert(out.end(), right.begin(), right.end());
+        return;
+    }
+    median_cut_u32(other, cur, half, depth - 1, out, 1);
+    median_cut_u32(other + half, cur + half, n - half, depth - 1, out, 1);
 }
 
 }  // namespace dp

@@ -340,11 +340,13 @@ static int run_mediancut(const char *path, long n, int depth)
     fclose(f);
     std::vector<uint32_t> order;
     pyset_order(rgb.data(), (size_t)n, order);
-    std::vector<uint8_t> colours(3 * order.size() + 3), scratch(3 * order.size() + 3);
-    for (size_t i = 0; i < order.size(); ++i)
-        for (int c = 0; c < 3; ++c) colours[3 * i + c] = rgb[3 * (size_t)order[i] + c];
+    std::vector<uint32_t> colours(order.size() + 1), scratch(order.size() + 1);
+    for (size_t i = 0; i < order.size(); ++i) {
+        const uint8_t *c = rgb.data() + 3 * (size_t)order[i];
+        colours[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+    }
     std::vector<int32_t> out;
-    median_cut_rgb(colours.data(), scratch.data(), order.size(), depth, out);
+    median_cut_u32(colours.data(), scratch.data(), order.size(), depth, out, 8);
     printf("distinct %zu\npalette", order.size());
     for (int32_t v : out) printf(" %d", v);
     printf("\norder");

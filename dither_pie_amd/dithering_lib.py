@@ -711,8 +711,10 @@ class ColorReducer:
 
     @staticmethod
     def _distinct_in_order(arr: np.ndarray) -> np.ndarray:
-        """The distinct rows of an [n,3] uint8 array in order of first occurrence.  On the GPU when there is one (a
-        2^24-entry table of first positions, filled by a deterministic scatter-min), numpy otherwise."""
+        """The distinct rows of an [n,3] uint8 array in order of first occurrence.  Images of 100 000 pixels and more go
+        through the device (dp_distinct_first_u8: a 2^24-entry first-index table filled by atomic minima, the first
+        occurrences compacted in pixel order; pinned staging buffer up, only the distinct colours down); smaller ones are
+        host plumbing (numpy: the PCIe round trip would cost more than the work)."""
         n = len(arr)
         try:
             import torch
@@ -720,13 +722,11 @@ class ColorReducer:
         except ImportError:
             use_gpu = False
         if use_gpu:
-            t = torch.from_numpy(arr).cuda().to(torch.int64)
-            packed = (t[:, 0] << 16) | (t[:, 1] << 8) | t[:, 2]
-            first = torch.full((1 << 24,), n, dtype=torch.int64, device=packed.device)
-            first.scatter_reduce_(0, packed, torch.arange(n, dtype=torch.int64, device=packed.device), reduce="amin")
-            present = torch.nonzero(first < n).squeeze(1)
-            order = torch.argsort(first[present])
-            return arr[first[present][order].cpu().numpy()]
+            from . import backend
+            h_in, _ = _pinned_pair(3 * n)
+            np.copyto(h_in.numpy()[:3 * n].reshape(n, 3), arr)   # (arr may be a read-only view of PIL's bytes)
+            t = h_in[:3 * n].cuda(non_blocking=True).view(n, 3)
+            return backend.distinct_first(t).cpu().numpy()
         packed = (arr[:, 0].astype(np.uint32) << 16) | (arr[:, 1].astype(np.uint32) << 8) | arr[:, 2].astype(np.uint32)
         _, first = np.unique(packed, return_index=True)
         return arr[np.sort(first)]
@@ -770,9 +770,8 @@ class ColorReducer:
         dp_median_cut_host replays CPython's set to get its iteration order and cuts with counting sorts -- a 4K
         photograph with 1.2 M distinct colours: ~0.1 s instead of ~1.5 s with a real set and numpy sorts (reference: ~9 s).
         Should the replay not match this interpreter's sets (_pyset_replay_ok), the set is built by Python as before."""
-        image = image.convert("RGB")
-        arr = np.array(image, dtype=np.uint8).reshape(-1, 3)  # a writable copy: torch.from_numpy wants one
-        distinct = np.ascontiguousarray(ColorReducer._distinct_in_order(arr))
+        rgb = image if image.mode == "RGB" else image.convert("RGB")   # (no copy of an image that is RGB already)
+        distinct = np.ascontiguousarray(ColorReducer._distinct_in_order(np.asarray(rgb, dtype=np.uint8).reshape(-1, 3)))
         n = max(int(num_colors), 1)
         depth = int(math.log2(n)) if n > 1 else 0
         if depth <= 10 and ColorReducer._pyset_replay_ok():

@@ -271,6 +271,17 @@ int dp_kmeans_update(const int64_t *totals_dev, double *centers_dev, int64_t *pr
 int dp_kmeans_plusplus_u8(const uint8_t *sample_dev, int n, int K, int first, const double *uniforms_dev, int n_trials,
                           int32_t *ids_dev, double *centers_dev, void *stream);
 
+/* The distinct colours of n packed RGB pixels in order of FIRST OCCURRENCE, on the device: the device side of the reference's
+ * `set(image.getdata())` (ColorReducer.reduce_colors, dithering_lib.py:1835-1843 -- a set built from all pixels is the set
+ * built from the first occurrences in that order), so that only the distinct colours cross PCIe for dp_median_cut_host.
+ *   out_dev         room for 3 * n bytes; the first 3 * (*n_distinct_dev) are written
+ *   n_distinct_dev  one int64 on the device
+ *   workspace_dev   dp_distinct_first_workspace_bytes(n) bytes (a 2^24-entry first-index table + flag words), 16-byte aligned
+ * n < 2^32 - 16.  Four launches on `stream`, nothing read back. */
+size_t dp_distinct_first_workspace_bytes(int64_t n);
+int dp_distinct_first_u8(const uint8_t *px_dev, int64_t n, uint8_t *out_dev, int64_t *n_distinct_dev, void *workspace_dev,
+                         size_t workspace_bytes, void *stream);
+
 /* Median cut of the reference (ColorReducer.reduce_colors, dithering_lib.py:1813-1843:
  * `median_cut(list(set(image.getdata())), depth)`), host side, no GPU involved.
  *   rgb_host     n colours, 3 bytes each, in order of insertion into the reference's set (duplicates allowed: the image's

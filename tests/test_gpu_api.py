@@ -304,19 +304,47 @@ def test_video_pipes_survive_failing_frames_on_the_device_path(d, orc, tmp_path,
         assert np.array_equal(got[i], ref[i - 1] if i in bad else ref[i]), i
 
 
+def _first_occurrences(arr):
+    packed = (arr[:, 0].astype(np.uint32) << 16) | (arr[:, 1].astype(np.uint32) << 8) | arr[:, 2]
+    _, first = np.unique(packed, return_index=True)
+    return arr[np.sort(first)]
+
+
 def test_distinct_colours_on_device_match_numpy():
-    """ColorReducer._distinct_in_order takes the GPU route for big images; it has to give the first-occurrence order the
-    numpy route gives (the set built from it, and so the median cut, depends on that order)."""
+    """dp_distinct_first_u8 (the device side of the reference's set(image.getdata()), dithering_lib.py:1835-1843): the distinct
+    colours in order of first occurrence equal numpy's -- noise, few colours, runs, one flat colour, counts around the block
+    and window sizes of the kernels, one pixel, an unaligned buffer -- and ColorReducer._distinct_in_order takes that route for
+    big images (the set built from it, and so the median cut, depends on the order)."""
     import torch
+    from dither_pie_amd import backend as be
     from dither_pie_amd.dithering_lib import ColorReducer
     rs = np.random.RandomState(3)
     for n, top in ((150_000, 256), (400_000, 12), (120_001, 40)):
         arr = rs.randint(0, top, (n, 3)).astype(np.uint8)
-        got = ColorReducer._distinct_in_order(arr)
-        packed = (arr[:, 0].astype(np.uint32) << 16) | (arr[:, 1].astype(np.uint32) << 8) | arr[:, 2]
-        _, first = np.unique(packed, return_index=True)
-        assert np.array_equal(got, arr[np.sort(first)])
+        assert np.array_equal(ColorReducer._distinct_in_order(arr), _first_occurrences(arr))
+    cases = [rs.randint(0, 256, (n, 3)).astype(np.uint8) for n in (1, 3, 255, 256, 2047, 2048, 2049, 4097, 1_000_003)]
+    cases.append(np.tile(np.array([[9, 200, 31]], np.uint8), (300_000, 1)))                                   # flat
+    cases.append(np.repeat(rs.randint(0, 256, (9000, 3)).astype(np.uint8), 37, axis=0))                        # runs
+    cases.append(rs.randint(0, 256, (7, 3)).astype(np.uint8)[rs.randint(0, 7, 500_001)])                       # few colours
+    cases.append(orc_image_like(rs))
+    for arr in cases:
+        t = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+        assert np.array_equal(be.distinct_first(t).cpu().numpy(), _first_occurrences(arr)), len(arr)
+    arr = cases[8]
+    raw = torch.empty(3 * len(arr) + 3, dtype=torch.uint8, device="cuda")
+    raw[3:] = torch.from_numpy(arr).cuda().reshape(-1)
+    view = raw[3:].view(-1, 3)
+    assert view.data_ptr() % 4 != 0
+    assert np.array_equal(be.distinct_first(view).cpu().numpy(), _first_occurrences(arr))
+    assert be.distinct_first(torch.empty((0, 3), dtype=torch.uint8, device="cuda")).shape[0] == 0
     assert torch.cuda.is_available()
+
+
+def orc_image_like(rs):
+    yy, xx = np.mgrid[0:540, 0:960]
+    img = np.clip(np.stack([80 + 60 * np.sin(xx / 300.0) + 40 * (yy / 540.0), 110 + 50 * np.cos(yy / 200.0) + 20 * np.sin(xx / 97.0),
+                            160 + 70 * (yy / 540.0) + 10 * np.sin((xx + yy) / 50.0)], -1) + rs.normal(0, 3, (540, 960, 3)), 0, 255)
+    return img.astype(np.uint8).reshape(-1, 3)
 
 
 @pytest.mark.gpu
