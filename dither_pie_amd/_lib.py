@@ -70,7 +70,8 @@ _SIGS = {
     "dp_variance_gate_u8": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _i, _vp, _sz, _vp]),
     "dp_kmeans_step_u8": (_i, [_vp, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "dp_kmeans_hist_bytes": (_sz, []),
-    "dp_kmeans_hist_build_u8": (_i, [_vp, _i64, _vp, _i, _vp]),
+    "dp_kmeans_hist_workspace_bytes": (_sz, [_i64]),
+    "dp_kmeans_hist_build_u8": (_i, [_vp, _i64, _vp, _i, _vp, _sz, _vp]),
     "dp_kmeans_hist_step": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "dp_kmeans_hist_iterate": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _vp]),
     "dp_kmeans_update": (_i, [_vp, _vp, _vp, _vp, _i, C.c_double, _i, _vp]),

@@ -388,8 +388,10 @@ class ColourHistogram:
         n = px.numel() // 3
         if (self.n if accumulate else 0) + n >= 1 << 32:
             raise ValueError("a colour histogram holds fewer than 2^32 pixels")
-        with torch.cuda.device(px.device):
-            check(_lib.load().dp_kmeans_hist_build_u8(px.data_ptr(), n, self.buf.data_ptr(), 1 if accumulate else 0, _stream()))
+        L = _lib.load()
+        with torch.cuda.device(px.device), _Launch(px.device, L.dp_kmeans_hist_workspace_bytes(n)) as ws:
+            check(L.dp_kmeans_hist_build_u8(px.data_ptr(), n, self.buf.data_ptr(), 1 if accumulate else 0, ws.data_ptr(), ws.numel(),
+                                            _stream()))
         self.n = (self.n if accumulate else 0) + n
         return self
 

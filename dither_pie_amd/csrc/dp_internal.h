@@ -204,7 +204,8 @@ int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, cons
 size_t distinct_first_ws_bytes(int64_t n);
 int launch_distinct_first(const uint8_t *px, int64_t n, uint8_t *out, long long *n_distinct, void *ws, hipStream_t s);
 size_t kmeans_hist_bytes();
-int launch_kmeans_hist_build(const uint8_t *px, int64_t n, void *hist, int accumulate, hipStream_t s);
+size_t kmeans_hist_ws_bytes(int64_t n);
+int launch_kmeans_hist_build(const uint8_t *px, int64_t n, void *hist, int accumulate, void *ws, hipStream_t s);
 int launch_kmeans_hist_step(const void *hist, const double *centers, const double *mean, int K, int64_t *sums, int64_t *counts,
                             int64_t *sumsq, hipStream_t s);
 int launch_kmeans_hist_iterate(const void *hist, double *centers, const double *mean, int K, int64_t *totals, int64_t *prev,

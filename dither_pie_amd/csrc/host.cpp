@@ -726,13 +726,20 @@ int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_de
 
 size_t dp_kmeans_hist_bytes(void) { return kmeans_hist_bytes(); }
 
-int dp_kmeans_hist_build_u8(const uint8_t *px_dev, int64_t n, void *hist_dev, int accumulate, void *stream)
+size_t dp_kmeans_hist_workspace_bytes(int64_t n) { return n < 0 ? 0 : kmeans_hist_ws_bytes(n); }
+
+int dp_kmeans_hist_build_u8(const uint8_t *px_dev, int64_t n, void *hist_dev, int accumulate, void *workspace_dev,
+                            size_t workspace_bytes, void *stream)
 {
-    if ((!px_dev && n > 0) || n < 0 || n > (int64_t)0xffffffffLL || !hist_dev || ((uintptr_t)hist_dev & 15)) {
-        set_error("dp_kmeans_hist_build_u8: bad argument (n must be below 2^32, hist_dev 16-byte aligned)");
+    if ((!px_dev && n > 0) || n < 0 || n > (int64_t)0xfffffff0LL || !hist_dev || ((uintptr_t)hist_dev & 15)) {
+        set_error("dp_kmeans_hist_build_u8: bad argument (n must be below 2^32 - 16, hist_dev 16-byte aligned)");
         return DP_EINVAL;
     }
-    return launch_kmeans_hist_build(px_dev, n, hist_dev, accumulate ? 1 : 0, (hipStream_t)stream);
+    if (!workspace_dev || ((uintptr_t)workspace_dev & 15) || workspace_bytes < kmeans_hist_ws_bytes(n)) {
+        set_error("dp_kmeans_hist_build_u8: workspace too small or not 16-byte aligned (need %zu bytes)", kmeans_hist_ws_bytes(n));
+        return DP_EWORKSPACE;
+    }
+    return launch_kmeans_hist_build(px_dev, n, hist_dev, accumulate ? 1 : 0, workspace_dev, (hipStream_t)stream);
 }
 
 int dp_kmeans_hist_step(const void *hist_dev, const double *centers_dev, const double *mean_dev, int K, int64_t *sums_dev,

@@ -3,12 +3,10 @@
 //
 // A pixel's label is a function of its colour, and the totals a pass produces are sums of count x colour -- so the pixels
 // are read ONCE (3 B/pixel) into count[colour] over all 2^24 colours, and every Lloyd pass then runs over that table:
-//   hist_build_kernel   pixels -> table.  A workgroup first merges its pixels in an LDS hash table (runs of one colour --
-//                       flat regions, letterbox bars, pixel art -- would otherwise serialise on one address: 376 ms for a
-//                       flat 8K frame with one global atomic per pixel, profiles/microbench/hist24_results.txt), then one
-//                       agent-scope no-return atomic per (window, distinct colour).  Bound by the rate of random global
-//                       atomics (27 G/s measured): 1.2 ms for 33 M noise pixels.
-//   hist_cells_kernel   per 16^3 cell the number of pixels in it: passes skip empty cells without reading them.
+//   hist_count / plan / scatter / parts kernels   pixels -> table by PARTITION (below): the pixels are bucketed by their 16^3
+//                       cell (2 bytes per pixel), every bucket becomes its cell's 16 KB table slice through an LDS histogram.
+//                       0.4 ms for 33 M pixels where one global atomic per pixel takes 1.2 ms (and 376 ms on a flat frame).
+//                       The per-cell pixel counts fall out of the first step: passes skip empty cells without reading them.
 //   hist_pass_kernel    one workgroup per cell.  The table is CELL-MAJOR (index = cell << 12 | r_lo << 8 | g_lo << 4 | b_lo),
 //                       so a workgroup reads its 16 KB contiguously, builds the cell's candidate list itself (the
 //                       centres that can be nearest somewhere in the cell: bound test + pairwise bisector test, as
@@ -36,126 +34,220 @@ namespace {
 constexpr int kHistCells = 4096;
 constexpr size_t kHistTableBytes = (size_t)4 << 24;          // 2^24 x uint32
 constexpr size_t kHistInfoBytes = (size_t)4 * (2 * kHistCells + 4);  // pixels per cell | number of occupied cells | their list
-constexpr uint32_t kEmptyKey = 0xffffffffu;
-
-// r | g << 8 | b << 16  ->  r' << 20 | g' << 16 | b' << 12 | r_lo << 8 | g_lo << 4 | b_lo   (x' = x >> 4, x_lo = x & 15)
-__device__ __forceinline__ uint32_t colour_index(const uint32_t v)
-{
-    return ((v & 0xf0u) << 16) | ((v & 0xf000u) << 4) | ((v & 0xf00000u) >> 8) | ((v & 0xfu) << 8) | ((v & 0xf00u) >> 4) |
-           ((v & 0xf0000u) >> 16);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kHB = 256;         // threads of a build workgroup
-constexpr int kHSlots = 4096;    // LDS hash slots (32 KB)
-constexpr int kHMaxWindow = 16;  // batches of 1024 pixels merged in LDS before a flush, at most
+// Building count[colour] by PARTITION.  One global atomic per pixel into the 64 MB table runs at 27 G atomics/s whatever the
+// content (every one misses L2: a 128-byte line in and out per pixel, profiles/microbench/hist24_results.txt: 1.23 ms for the
+// 33 M pixels of the C4 image), and a flat image serialises on one address (376 ms).  Instead (microbenchmark:
+// profiles/microbench/hist24_partition.hip, 0.45 ms on noise):
+//   A  hist_count_kernel    per-workgroup LDS histogram of the 4096 CELL ids -> pixels per cell (the passes need that anyway)
+//   B  hist_plan_kernel     bucket bases (exclusive scan), the parts a cell's bucket is cut into (8192 entries each), their scan
+//   C  hist_scatter_kernel  every pixel's low 12 bits (r_lo, g_lo, b_lo) as a uint16 into its cell's bucket: the rank inside
+//                           the tile from an LDS atomic, one global cursor atomic per (tile, non-empty cell)
+//   D  hist_parts_kernel    one workgroup per part: LDS histogram of its bucket entries (LDS atomics), added to the cell's
+//                           16 KB slice of the table -- plain coalesced read-modify-write when the cell has one part, atomics of the
+//                           non-zero counts when several workgroups share the cell (image-like content: big cells)
+// The buckets (2 bytes per pixel) and the plan live in a caller-provided workspace.
+constexpr int kCountThreads = 1024;
+constexpr int kScatterThreads = 1024;
+constexpr int kTileGroups = kScatterThreads * 4;   // groups of 4 pixels per scatter tile (16 pixels per thread)
+constexpr uint32_t kPartEntries = 8192;
 
-__global__ __launch_bounds__(kHB) void hist_build_kernel(const uint8_t *__restrict__ px, const int64_t n, uint32_t *__restrict__ table)
+// the workspace: [0] cell counts of this build | [1] bucket bases | [2] cursors | [3] part bases (4097) ... | buckets
+constexpr size_t kPlanWords = 4 * 4096 + 64;
+
+__device__ __forceinline__ void split_colour(const uint32_t v, uint32_t &cell, uint32_t &lo)
 {
-    __shared__ uint32_t s_key[kHSlots];
-    __shared__ uint32_t s_cnt[kHSlots];
-    __shared__ uint32_t s_occ;
-    for (int i = threadIdx.x; i < kHSlots; i += kHB) {
-        s_key[i] = kEmptyKey;
-        s_cnt[i] = 0u;
+    cell = ((v & 0xf0u) << 4) | ((v & 0xf000u) >> 8) | ((v & 0xf00000u) >> 20);   // r' << 8 | g' << 4 | b'
+    lo = ((v & 0xfu) << 8) | ((v & 0xf00u) >> 4) | ((v & 0xf0000u) >> 16);        // r_lo << 8 | g_lo << 4 | b_lo
+}
+
+// the four pixels of group gi as r | g << 8 | b << 16; cnt = how many of them exist
+__device__ __forceinline__ void load_group(const uint8_t *__restrict__ px, const int64_t n, const int64_t gi, const bool aligned,
+                                           uint32_t (&v)[4], int &cnt)
+{
+    const int64_t p0 = gi * 4;
+    cnt = p0 < n ? (int)min<int64_t>(4, n - p0) : 0;
+    v[0] = v[1] = v[2] = v[3] = 0u;
+    if (aligned && cnt == 4) {
+        const uint3 w = reinterpret_cast<const uint3 *>(px)[gi];
+        v[0] = w.x & 0xffffffu;
+        v[1] = __builtin_amdgcn_perm(w.y, w.x, 0x0c050403u);
+        v[2] = __builtin_amdgcn_perm(w.z, w.y, 0x0c040302u);
+        v[3] = w.z >> 8;
+    } else {
+        for (int q = 0; q < cnt; ++q) {
+            const uint8_t *b = px + (p0 + q) * 3;
+            v[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+        }
     }
-    if (threadIdx.x == 0) s_occ = 0u;
+}
+
+__global__ __launch_bounds__(kCountThreads) void hist_count_kernel(const uint8_t *__restrict__ px, const int64_t n, uint32_t *__restrict__ cell_count)
+{
+    __shared__ uint32_t s_cnt[kHistCells];
+    for (int i = threadIdx.x; i < kHistCells; i += kCountThreads) s_cnt[i] = 0u;
     __syncthreads();
     const int64_t n_groups = (n + 3) / 4;
     const bool aligned = ((uintptr_t)px & 3) == 0;
-    int window = 1, in_window = 0;
-
-    auto insert = [&](const uint32_t ci, const uint32_t cnt) {
-        uint32_t slot = (ci * 0x9E3779B1u) >> 20;  // 12 bits
-#pragma unroll 1
-        for (int probe = 0; probe < 8; ++probe) {
-            const uint32_t old = atomicCAS(&s_key[slot], kEmptyKey, ci);
-            if (old == kEmptyKey || old == ci) {
-                atomicAdd(&s_cnt[slot], cnt);
-                return;
-            }
-            slot = (slot + 1u) & (uint32_t)(kHSlots - 1);
-        }
-        // the table is crowded (a window of noise): straight to global memory
-        __hip_atomic_fetch_add(&table[ci], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    // every occupied slot leaves the workgroup as one atomic; returns (to every thread) how many there were
-    auto flush = [&]() -> uint32_t {
-        __syncthreads();
-        uint32_t occ = 0;
-        for (int i = threadIdx.x; i < kHSlots; i += kHB) {
-            const uint32_t k = s_key[i];
-            if (k != kEmptyKey) {
-                __hip_atomic_fetch_add(&table[k], s_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_key[i] = kEmptyKey;
-                s_cnt[i] = 0u;
-                ++occ;
-            }
-        }
-        occ = wave_sum_to_lane63(occ);
-        if ((threadIdx.x & 63) == 63) atomicAdd(&s_occ, occ);
-        __syncthreads();
-        const uint32_t total = s_occ;
-        __syncthreads();
-        if (threadIdx.x == 0) s_occ = 0u;
-        return total;
-    };
-
-    for (int64_t g0 = (int64_t)blockIdx.x * kHB; g0 < n_groups; g0 += (int64_t)gridDim.x * kHB) {
-        const int64_t gi = g0 + threadIdx.x;
-        const int64_t p0 = gi * 4;
-        const int cnt = gi < n_groups ? (int)min<int64_t>(4, n - p0) : 0;
-        uint32_t c[4] = {0u, 0u, 0u, 0u};
-        if (aligned && cnt == 4) {
-            const uint3 w = reinterpret_cast<const uint3 *>(px)[gi];
-            c[0] = colour_index(w.x & 0xffffffu);
-            c[1] = colour_index(__builtin_amdgcn_perm(w.y, w.x, 0x0c050403u));
-            c[2] = colour_index(__builtin_amdgcn_perm(w.z, w.y, 0x0c040302u));
-            c[3] = colour_index(w.z >> 8);
-        } else {
-            for (int q = 0; q < cnt; ++q) {
-                const uint8_t *b = px + (p0 + q) * 3;
-                c[q] = colour_index((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16));
-            }
-        }
-        // a lane's equal neighbours first (runs of one colour)
+    for (int64_t gi = (int64_t)blockIdx.x * kCountThreads + threadIdx.x; gi < n_groups; gi += (int64_t)gridDim.x * kCountThreads) {
+        uint32_t v[4];
+        int cnt;
+        load_group(px, n, gi, aligned, v, cnt);
+        // a lane's run of one cell costs one LDS atomic (flat regions: every lane the same address)
+        uint32_t c[4], lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split_colour(v[q], c[q], lo);
         uint32_t run = 1;
 #pragma unroll
         for (int q = 1; q < 4; ++q) {
             if (q < cnt) {
                 if (c[q] == c[q - 1]) ++run;
                 else {
-                    insert(c[q - 1], run);
+                    atomicAdd(&s_cnt[c[q - 1]], run);
                     run = 1;
                 }
             }
         }
-        if (cnt > 0) insert(c[cnt - 1], run);
-        if (++in_window >= window) {  // (block-uniform)
-            const uint32_t occ = flush();
-            in_window = 0;
-            // coherent content: few distinct colours per window -> merge more pixels before the next flush
-            if (occ < (uint32_t)kHSlots / 8 && window < kHMaxWindow) window *= 2;
-            else if (occ > (uint32_t)kHSlots / 3 && window > 1) window /= 2;
-        }
+        if (cnt > 0) atomicAdd(&s_cnt[c[cnt - 1]], run);
     }
-    if (in_window) flush();
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHistCells; i += kCountThreads)
+        if (s_cnt[i]) atomicAdd(&cell_count[i], s_cnt[i]);
 }
 
-__global__ __launch_bounds__(256) void hist_cells_kernel(const uint32_t *__restrict__ table, uint32_t *__restrict__ cellinfo)
+// One workgroup of 1024 threads, four cells each: bucket bases and cursors (exclusive scan of the counts), part bases (exclusive
+// scan of ceil(count / kPartEntries)), the number of parts; and the passes' per-cell totals: info[cell] (+)= count.
+__global__ __launch_bounds__(1024) void hist_plan_kernel(uint32_t *__restrict__ plan, uint32_t *__restrict__ info, const int accumulate)
 {
-    __shared__ uint32_t s_part[4];
-    const uint4 *tb = reinterpret_cast<const uint4 *>(table) + (size_t)blockIdx.x * 1024;
-    uint32_t sum = 0;
+    __shared__ uint32_t s_a[16], s_b[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t cnt[4], parts[4], sum_c = 0, sum_p = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint4 v = tb[i * 256 + threadIdx.x];
-        sum += v.x + v.y + v.z + v.w;
+        cnt[i] = plan[4 * t + i];
+        parts[i] = (cnt[i] + kPartEntries - 1) / kPartEntries;
+        sum_c += cnt[i];
+        sum_p += parts[i];
+        info[4 * t + i] = (accumulate ? info[4 * t + i] : 0u) + cnt[i];
     }
-    sum = wave_sum_to_lane63(sum);
-    if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = sum;
+    uint32_t inc_c = sum_c, inc_p = sum_p;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t oc = (uint32_t)__shfl_up((int)inc_c, off), op = (uint32_t)__shfl_up((int)inc_p, off);
+        if (lane >= off) {
+            inc_c += oc;
+            inc_p += op;
+        }
+    }
+    if (lane == 63) {
+        s_a[wv] = inc_c;
+        s_b[wv] = inc_p;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) cellinfo[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    uint32_t base_c = 0, base_p = 0, total_p = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        base_c += w < wv ? s_a[w] : 0u;
+        base_p += w < wv ? s_b[w] : 0u;
+        total_p += s_b[w];
+    }
+    uint32_t at_c = base_c + inc_c - sum_c, at_p = base_p + inc_p - sum_p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        plan[4096 + 4 * t + i] = at_c;       // bucket base
+        plan[2 * 4096 + 4 * t + i] = at_c;   // cursor
+        plan[3 * 4096 + 4 * t + i] = at_p;   // first part of the cell
+        at_c += cnt[i];
+        at_p += parts[i];
+    }
+    if (t == 0) plan[4 * 4096] = total_p;    // part base of "cell 4096" = number of parts
+}
+
+__global__ __launch_bounds__(kScatterThreads) void hist_scatter_kernel(const uint8_t *__restrict__ px, const int64_t n, uint32_t *__restrict__ cursor,
+                                                                        uint16_t *__restrict__ buckets)
+{
+    __shared__ uint32_t s_cnt[kHistCells];   // per cell: this tile's count, then its base in the cell's bucket
+    const int64_t n_groups = (n + 3) / 4;
+    const bool aligned = ((uintptr_t)px & 3) == 0;
+    const int64_t tiles = (n_groups + kTileGroups - 1) / kTileGroups;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < kHistCells; i += kScatterThreads) s_cnt[i] = 0u;
+        __syncthreads();
+        uint32_t key[16];   // cell << 12 | lo
+        uint32_t rank[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t gi = tile * kTileGroups + (int64_t)j * kScatterThreads + threadIdx.x;
+            uint32_t v[4];
+            int cnt;
+            load_group(px, n, gi, aligned, v, cnt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t cell, lo;
+                split_colour(v[q], cell, lo);
+                key[4 * j + q] = (cell << 12) | lo;
+                rank[4 * j + q] = q < cnt ? atomicAdd(&s_cnt[cell], 1u) : 0xffffffffu;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < kHistCells; i += kScatterThreads) {
+            const uint32_t c = s_cnt[i];
+            if (c) s_cnt[i] = atomicAdd(&cursor[i], c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (rank[e] != 0xffffffffu) buckets[(size_t)s_cnt[key[e] >> 12] + rank[e]] = (uint16_t)(key[e] & 0xfffu);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void hist_parts_kernel(const uint16_t *__restrict__ buckets, const uint32_t *__restrict__ plan,
+                                                         uint32_t *__restrict__ table)
+{
+    __shared__ uint32_t s_h[4096];
+    __shared__ int s_cell;
+    const uint32_t n_parts = plan[4 * 4096];
+    for (uint32_t part = blockIdx.x; part < n_parts; part += gridDim.x) {   // (workgroup-uniform)
+        for (int i = threadIdx.x; i < 4096; i += 256) s_h[i] = 0u;
+        if (threadIdx.x == 0) {
+            // the cell this part belongs to: the last cell whose first part is <= part (cells without pixels have no parts)
+            const uint32_t *pb = plan + 3 * 4096;
+            int lo = 0, hi = 4096;   // pb[4096] = n_parts > part
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (pb[mid] <= part) lo = mid;
+                else hi = mid;
+            }
+            s_cell = lo;
+        }
+        __syncthreads();
+        const int cell = s_cell;
+        const uint32_t cnt = plan[cell], first = plan[3 * 4096 + cell];
+        const uint32_t parts = (cnt + kPartEntries - 1) / kPartEntries;
+        const uint32_t lo_e = (part - first) * kPartEntries, hi_e = min(cnt, lo_e + kPartEntries);
+        const uint16_t *b = buckets + (size_t)plan[4096 + cell];
+        for (uint32_t i = lo_e + threadIdx.x; i < hi_e; i += 256) atomicAdd(&s_h[b[i]], 1u);
+        __syncthreads();
+        uint32_t *slice = table + (size_t)cell * 4096;
+        if (parts == 1) {
+            uint4 *o = reinterpret_cast<uint4 *>(slice);
+            for (int i = threadIdx.x; i < 1024; i += 256) {
+                uint4 v = o[i];
+                v.x += s_h[4 * i];
+                v.y += s_h[4 * i + 1];
+                v.z += s_h[4 * i + 2];
+                v.w += s_h[4 * i + 3];
+                o[i] = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < 4096; i += 256) {
+                const uint32_t c = s_h[i];
+                if (c) __hip_atomic_fetch_add(&slice[i], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -594,23 +686,36 @@ __global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uin
 
 size_t kmeans_hist_bytes() { return kHistTableBytes + kHistInfoBytes; }
 
-int launch_kmeans_hist_build(const uint8_t *px, int64_t n, void *hist, int accumulate, hipStream_t s)
+size_t kmeans_hist_ws_bytes(int64_t n) { return kPlanWords * 4 + (((size_t)(n > 0 ? n : 0) * 2 + 255) & ~(size_t)255) + 256; }
+
+int launch_kmeans_hist_build(const uint8_t *px, int64_t n, void *hist, int accumulate, void *ws, hipStream_t s)
 {
     uint32_t *table = static_cast<uint32_t *>(hist);
-    uint32_t *cellinfo = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(hist) + kHistTableBytes);
+    uint32_t *info = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(hist) + kHistTableBytes);
+    uint32_t *plan = static_cast<uint32_t *>(ws);
+    uint16_t *buckets = reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(ws) + kPlanWords * 4);
     if (!accumulate) DP_HIP(hipMemsetAsync(table, 0, kHistTableBytes, s));
+    DP_HIP(hipMemsetAsync(plan, 0, 4096 * sizeof(uint32_t), s));
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int64_t groups = (n + 3) / 4;
     ProfMark *pm = prof_begin(s);
     if (n > 0) {
-        int cus = 0, dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        const int64_t groups = (n + 3) / 4;
-        const int64_t want = (groups + kHB - 1) / kHB;
-        const unsigned blocks = (unsigned)std::min<int64_t>(want, (int64_t)cus * 4);
-        hipLaunchKernelGGL(hist_build_kernel, dim3(blocks), dim3(kHB), 0, s, px, n, table);
+        const unsigned cblocks = (unsigned)std::min<int64_t>((groups + kCountThreads - 1) / kCountThreads, (int64_t)cus * 2);
+        hipLaunchKernelGGL(hist_count_kernel, dim3(cblocks), dim3(kCountThreads), 0, s, px, n, plan);
+    }
+    hipLaunchKernelGGL(hist_plan_kernel, dim3(1), dim3(1024), 0, s, plan, info, accumulate);
+    if (n > 0) {
+        const int64_t tiles = (groups + kTileGroups - 1) / kTileGroups;
+        const unsigned sblocks = (unsigned)std::min<int64_t>(tiles, (int64_t)cus * 4);
+        hipLaunchKernelGGL(hist_scatter_kernel, dim3(sblocks), dim3(kScatterThreads), 0, s, px, n, plan + 2 * 4096, buckets);
+        // (the number of parts is on the device: n / 8192 + 4096 at most; a persistent grid takes them in turn)
+        const int64_t max_parts = n / (int64_t)kPartEntries + 4096;
+        const unsigned pblocks = (unsigned)std::min<int64_t>(max_parts, (int64_t)cus * 16);
+        hipLaunchKernelGGL(hist_parts_kernel, dim3(pblocks), dim3(256), 0, s, buckets, plan, table);
     }
     prof_end(pm, s);
-    hipLaunchKernelGGL(hist_cells_kernel, dim3(kHistCells), dim3(256), 0, s, table, cellinfo);
-    hipLaunchKernelGGL(hist_occupied_kernel, dim3(1), dim3(1024), 0, s, cellinfo);
+    hipLaunchKernelGGL(hist_occupied_kernel, dim3(1), dim3(1024), 0, s, info);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }

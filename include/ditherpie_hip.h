@@ -217,14 +217,17 @@ int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_de
  *   dp_kmeans_hist_bytes     size of the caller-owned histogram buffer (2^24 uint32 counts, cell-major, + 4096 cell totals)
  *   dp_kmeans_hist_build_u8  adds n pixels to hist_dev (16-byte aligned); accumulate = 0 clears it first, 1 keeps what it
  *                            holds (several buffers into one histogram).  Fewer than 2^32 pixels in total (32-bit counts).
- *                            Pixels are merged per workgroup in an LDS hash table first, so runs of one colour cost one
- *                            global atomic, not one per pixel.
+ *                            By partition, not by one global atomic per pixel: the pixels are bucketed by their 16^3 cell
+ *                            (2 bytes per pixel in workspace_dev, dp_kmeans_hist_workspace_bytes(n), 16-byte aligned), and
+ *                            every bucket becomes its cell's table slice through an LDS histogram.
  *   dp_kmeans_hist_step      one pass; K <= 256 (DP_EUNSUPPORTED above: use dp_kmeans_step_u8); centers_dev inside the colour
  *                            cube as for dp_kmeans_step_u8; outputs as there (sumsq_dev may be NULL).  Each workgroup builds
  *                            its cell's candidate list from centers_dev itself: no scratch, no second launch.
  * With ranks, each rank histograms its own pixels and the totals are all-reduced per pass exactly as before. */
 size_t dp_kmeans_hist_bytes(void);
-int dp_kmeans_hist_build_u8(const uint8_t *px_dev, int64_t n, void *hist_dev, int accumulate, void *stream);
+size_t dp_kmeans_hist_workspace_bytes(int64_t n);
+int dp_kmeans_hist_build_u8(const uint8_t *px_dev, int64_t n, void *hist_dev, int accumulate, void *workspace_dev,
+                            size_t workspace_bytes, void *stream);
 int dp_kmeans_hist_step(const void *hist_dev, const double *centers_dev, const double *mean_dev, int K, int64_t *sums_dev,
                         int64_t *counts_dev, int64_t *sumsq_dev, void *stream);
 /* One WHOLE Lloyd iteration over the histogram in one launch, for a fit that lives on one device (nothing to all-reduce between
