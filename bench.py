@@ -521,8 +521,10 @@ def main():
         kb_ms, _ = kernel_ms(lambda: hist4.add(bpx, accumulate=False), 3)
         info4 = hist4.buf[1 << 26:].view(torch.int32)
         occ4 = int(info4[4096].item())
-        result["c4_kmeans_histogram"] = leg("hist_build_kernel (pixels -> count[colour] over 2^24 colours, once per fit)", kb_ms, 3 * n4,
-                                            bound="rate of random global atomics (one per distinct colour per 1024-pixel window), not HBM",
+        result["c4_kmeans_histogram"] = leg("hist_count / plan / scatter / parts kernels (pixels -> count[colour] over 2^24 colours by "
+                                            "partition, once per fit; kernel_ms = the four together)", kb_ms, 3 * n4,
+                                            bound="LDS atomics and scattered 2-byte stores of the partition (pixels read twice, 2 B/px of "
+                                                  "buckets written and read, 64 MB of table): not HBM",
                                             workload=f"C4: the {n4} pixels of this rank's band of rnd(4320,7680,99) ({world} band(s))")
         hist4.step_into(c4c, tot4, False)
         kp_ms, _ = kernel_ms(lambda: hist4.step_into(c4c, tot4, False), 5)

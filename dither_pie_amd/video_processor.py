@@ -223,6 +223,23 @@ class VideoProcessor:
 
     ATTEMPTS = 3  # the first try plus the reference's two retries (video_processor.py:325-336)
 
+    @staticmethod
+    def _device_is_gone(e: BaseException) -> bool:
+        """A failure of the DEVICE, not of a frame: the library's DP_EHIP / DP_ENOMEM, or a HIP / out-of-memory error out of
+        torch.  The reference's per-frame retry policy is about PNG and I/O failures; retrying on a faulted or exhausted GPU
+        only makes 3 x batch doomed launches and would fill the rest of the video with copies of the last good frame."""
+        from ._lib import DP_EHIP, DP_ENOMEM, DitherPieError
+        if isinstance(e, DitherPieError):
+            return e.code in (DP_EHIP, DP_ENOMEM)
+        try:
+            import torch
+            if isinstance(e, torch.cuda.OutOfMemoryError):
+                return True
+        except Exception:  # noqa: BLE001
+            pass
+        text = str(e)
+        return isinstance(e, RuntimeError) and any(k in text for k in ("HIP error", "CUDA error", "hipError", "out of memory"))
+
     def _batch_with_retries(self, host_frames, run):
         """The reference's failure policy for one batch (video_processor.py:304-346): the whole batch in one go; if that
         raises, every frame on its own, up to ATTEMPTS times; a frame that keeps failing is reported as None and the
@@ -231,6 +248,8 @@ class VideoProcessor:
         try:
             return run(host_frames), None
         except Exception as e:  # noqa: BLE001 - "a frame that errors must not abort the video"
+            if self._device_is_gone(e):
+                raise   # not a frame's fault: process_video_streaming reports failure instead of substituting frames
             print(f"Batch failed ({e}); retrying frame by frame", file=sys.stderr)
         outs = []
         for i in range(host_frames.shape[0]):
@@ -240,6 +259,8 @@ class VideoProcessor:
                     o = run(host_frames[i:i + 1])[0].cpu()
                     break
                 except Exception as e:  # noqa: BLE001
+                    if self._device_is_gone(e):
+                        raise
                     print(f"Error processing frame {i} of the batch (attempt {attempt + 1}): {e}", file=sys.stderr)
             outs.append(o)
         return None, outs

@@ -307,6 +307,35 @@ def test_pipe_path_fails_only_when_nothing_succeeds(tmp_path, monkeypatch):
         vp._stream_through_pipes("in.mp4", str(tmp_path / "o.bin"), None, None, 64, 2, None, vp.get_video_info("in.mp4"), run=run)
 
 
+def test_pipe_path_treats_a_dead_device_as_fatal(tmp_path, monkeypatch):
+    """The reference's retry-and-substitute policy (video_processor.py:325-336) is about frames that fail -- PNG and I/O
+    errors.  A failure of the DEVICE (the library's DP_EHIP / DP_ENOMEM, a HIP or out-of-memory error out of torch) is not a
+    frame's fault: no frame-by-frame retries (3 x batch doomed launches), no video whose tail is copies of the last good
+    frame reported as success -- the error leaves _stream_through_pipes, and process_video_streaming returns False."""
+    from dither_pie_amd import video_processor as v
+    from dither_pie_amd._lib import DP_EHIP, DP_EINVAL, DitherPieError
+    frames = np.zeros((9, 4, 4, 3), np.uint8)
+    for i in range(9):
+        frames[i] = i
+    _fake_ffmpeg_tools(tmp_path, monkeypatch, frames)
+    calls = []
+
+    def run(x):
+        calls.append(len(x))
+        if int(x[0, 0, 0, 0]) >= 4:          # the second batch: the GPU is gone
+            raise DitherPieError(DP_EHIP, "hipErrorIllegalAddress")
+        return 255 - x.clone()
+
+    vp = v.VideoProcessor()
+    with pytest.raises(DitherPieError):
+        vp._stream_through_pipes("in.mp4", str(tmp_path / "o.bin"), None, None, 64, 4, None, vp.get_video_info("in.mp4"), run=run)
+    assert calls == [4, 4]                    # the failing batch was tried once, no frame of it on its own
+    assert v.VideoProcessor._device_is_gone(RuntimeError("HIP error: an illegal memory access was encountered"))
+    assert v.VideoProcessor._device_is_gone(DitherPieError(4, "hipMalloc failed"))
+    assert not v.VideoProcessor._device_is_gone(DitherPieError(DP_EINVAL, "bad argument"))
+    assert not v.VideoProcessor._device_is_gone(ValueError("frames of one batch differ in size"))
+
+
 @pytest.mark.parametrize("rotation,swap", [(None, False), ("90", True), ("-90.000000", True), ("180", False), ("270", True)])
 def test_pipe_path_follows_rotation_metadata(tmp_path, monkeypatch, rotation, swap):
     """Phone footage: ffprobe reports the CODED size plus a rotate tag / display matrix; ffmpeg rotates while decoding
