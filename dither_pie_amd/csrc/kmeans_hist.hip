@@ -344,6 +344,11 @@ __global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uin
                                                                     unsigned long long *__restrict__ counts,
                                                                     unsigned long long *__restrict__ sumsq, const FuseArgs fuse, const int force_split)
 {
+    // a fused iteration launched past convergence (the host looks at the status every few iterations) has nothing to do
+    if (FUSE) {
+        const int done = (int)fuse.status[kStDone];
+        if (done == 1 || done == 3) return;   // (uniform over the grid: only the last workgroup of a launch writes the status)
+    }
     const uint32_t n_occ = info[kHistCells];
     // Few occupied cells (image-like content): a cell is split over 2 or 4 waves (each takes 2 / 1 of the cell's four chunks
     // and builds the list for itself), so that the chip still has a few thousand waves to hide latency with.
