@@ -119,13 +119,15 @@ def _check_centres_in_cube(c):
 HIST_MIN_PIXELS = 1 << 19   # from here on a fit reads its pixels once into the colour histogram and iterates over that
 
 
-def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sklearn_ties=True, histogram=None, fuse=None):
+def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sklearn_ties=True, histogram=None, fuse=None, hist=None):
     """Lloyd iterations over the uint8 pixels `px` ([...,3] tensor on the GPU).
 
     histogram: None -- images of HIST_MIN_PIXELS and more (per rank) with K <= 256 are read ONCE into count[colour]
     (backend.ColourHistogram, dp_kmeans_hist_*) and every pass runs over the histogram: a label is a function of the colour,
     the totals are sums of count x colour, so labels and int64 totals are those of the passes over the pixels, bit for bit,
     at 16 KB per occupied cell of the colour cube per pass instead of 3 B per pixel.  True / False force the choice.
+    hist: a backend.ColourHistogram of exactly these pixels that the caller has built already (fit_palette builds it on a second
+    stream while the seeding runs).
     fuse: None -- with the histogram and no other rank to exchange totals with, an iteration is ONE launch
     (dp_kmeans_hist_iterate: the pass, and the centre update by the workgroup that finishes last); False keeps the three
     steps pass / all-reduce / update (what a sharded fit runs).
@@ -159,9 +161,10 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sk
     prev = torch.zeros(4 * K, dtype=torch.int64, device=dev)
     status = torch.zeros(8, dtype=torch.float64, device=dev)
     if histogram is None:
-        histogram = flat.shape[0] >= HIST_MIN_PIXELS
-    hist = None
-    if histogram and K <= backend.KMEANS_HIST_MAX_K and 0 < flat.shape[0] < (1 << 32):
+        histogram = hist is not None or flat.shape[0] >= HIST_MIN_PIXELS
+    if hist is not None and (hist.n != flat.shape[0] or K > backend.KMEANS_HIST_MAX_K or histogram is False):
+        hist = None
+    if hist is None and histogram and K <= backend.KMEANS_HIST_MAX_K and 0 < flat.shape[0] < (1 << 32):
         hist = backend.ColourHistogram(flat)
 
         def one_pass(c, tot, want_sq, mean):
@@ -272,17 +275,45 @@ def seed_sample(px, n_total, offset, random_state, group=None, as_tensor=False):
     return buf.cpu().numpy().astype(np.uint8)
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One extra stream per device (kept: creating a stream per fit costs more than the overlap gains)."""
+    import torch
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def fit_palette(px, K, random_state=42, n_total=None, offset=0, group=None, max_iter=300, tol=1e-4):
     """px: uint8 CUDA tensor [...,3] holding this rank's band of the image.  -> (palette list, centers, inertia, n_iter)"""
     n_local = px.numel() // 3
     n_total = n_local if n_total is None else int(n_total)
+    hist = None
     if px.is_cuda:
+        import torch
+        from . import backend
+        flat = px.reshape(-1, 3)
+        if HIST_MIN_PIXELS <= n_local < (1 << 32) and K <= backend.KMEANS_HIST_MAX_K:
+            # the colour histogram does not depend on the seeds: it is built on a second stream while the sample is gathered and the
+            # k-means++ kernel (one workgroup) runs
+            cur = torch.cuda.current_stream(px.device)
+            side = _side_stream(px.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                hist = backend.ColourHistogram(flat if flat.is_contiguous() else flat.contiguous())
         sample = seed_sample(px, n_total, offset, random_state, group, as_tensor=True)
         init = kmeans_plusplus_device(sample, K, np.random.RandomState(random_state))
+        if hist is not None:
+            cur.wait_stream(side)
+            hist.buf.record_stream(cur)
     else:
         sample = seed_sample(px, n_total, offset, random_state, group)
         init = kmeans_plusplus(sample, K, np.random.RandomState(random_state))
-    centers, inertia, n_iter = lloyd(px, init, max_iter=max_iter, tol=tol, group=group)
+    centers, inertia, n_iter = lloyd(px, init, max_iter=max_iter, tol=tol, group=group, hist=hist)
     palette = [tuple(int(v) for v in c) for c in centers.astype(int)]
     return palette, centers, inertia, n_iter
 
