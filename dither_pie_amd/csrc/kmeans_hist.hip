@@ -290,8 +290,9 @@ constexpr int kHistMaxK = 256;
 constexpr int kPassWaves = 4;   // waves per workgroup; every wave works on cells of its own
 constexpr int kPassGrid = 1024; // workgroups (persistent: a wave takes every (4 * grid)-th occupied cell)
 
-// One block, after the build: the occupied cells in ascending order (info[4096] = how many, info[4097 ...] = which), so
-// that a pass hands its waves occupied cells only.
+// One block, after the build: the occupied cells in ascending order (info[4096] = how many, info[4097 ...] = which; bit 31 of an
+// entry: the cell holds 2^24 pixels or more -- its weighted sums need 64 bits), so that a pass hands its waves occupied cells only
+// and a wave learns everything about its cell from ONE word.
 __global__ __launch_bounds__(1024) void hist_occupied_kernel(uint32_t *__restrict__ info)
 {
     __shared__ uint32_t s_part[16];
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(1024) void hist_occupied_kernel(uint32_t *__restric
     uint32_t pos = base + incl - mine;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (flag[i]) info[kHistCells + 1 + pos++] = (uint32_t)(4 * t + i);
+        if (flag[i]) info[kHistCells + 1 + pos++] = (uint32_t)(4 * t + i) | (info[4 * t + i] >= (1u << 24) ? 0x80000000u : 0u);
     if (t == 0) info[kHistCells] = total;
 }
 
@@ -349,6 +350,11 @@ __global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uin
         const int done = (int)fuse.status[kStDone];
         if (done == 1 || done == 3) return;   // (uniform over the grid: only the last workgroup of a launch writes the status)
     }
+    // the wave's first list entry is read next to the number of occupied cells, not after it: which entry that is depends on the
+    // split (1, 2 or 4 waves per cell), so all three candidates are fetched (always inside the 4096-entry list; checked below)
+    const uint32_t ui0 = (uint32_t)blockIdx.x * kPassWaves + (uint32_t)(threadIdx.x >> 6);
+    const uint32_t spec1 = info[kHistCells + 1 + (ui0 & 4095u)], spec2 = info[kHistCells + 1 + ((ui0 >> 1) & 4095u)],
+                   spec4 = info[kHistCells + 1 + ((ui0 >> 2) & 4095u)];
     const uint32_t n_occ = info[kHistCells];
     // Few occupied cells (image-like content): a cell is split over 2 or 4 waves (each takes 2 / 1 of the cell's four chunks
     // and builds the list for itself), so that the chip still has a few thousand waves to hide latency with.
@@ -384,11 +390,13 @@ __global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uin
     for (uint32_t ui = (uint32_t)blockIdx.x * kPassWaves + (uint32_t)wv; ui < n_units; ui += (uint32_t)gridDim.x * kPassWaves) {
         const uint32_t ci = split == 4 ? ui >> 2 : (split == 2 ? ui >> 1 : ui);
         const int c_first = (int)(ui - ci * (uint32_t)split) * chunks_per_unit, c_end = c_first + chunks_per_unit;
-        const int cell = (int)info[kHistCells + 1 + ci];
-        const uint32_t ncell = info[cell];
+        const uint32_t entry = ui == ui0 ? (split == 4 ? spec4 : (split == 2 ? spec2 : spec1)) : info[kHistCells + 1 + ci];
+        const int cell = (int)(entry & 0xfffu);
         // a lane's 64 counts, 16 at a time: chunk c = rows r_lo = 4c .. 4c+3 (a wave-uniform r per register), g_lo = lane >> 2,
         // b_lo = 4 (lane & 3) + k.  The next chunk is in flight while this one is worked on.
         const uint4 *tb = reinterpret_cast<const uint4 *>(table) + (size_t)cell * 1024 + lane;
+        // (two chunks ahead was measured: the 16 more registers spill at 4 waves per SIMD -- 39 -> 47 us on noise -- and at 3 waves per
+        // SIMD without spills it is 45 us: the pass is not waiting on this chain, profiles/experiments/r04_kmeans_hist_split.txt)
         uint4 d[4], dn[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) d[jj] = tb[(4 * c_first + jj) * 64];
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uin
         const uint32_t b0 = (uint32_t)((cell & 15) << 4) + 4u * (uint32_t)(lane & 3);
         const float fg = (float)g;
         // a cell with fewer than 2^24 pixels: every weighted partial sum below fits 32 bits (count x 255)
-        const bool small = ncell < (1u << 24);
+        const bool small = (entry >> 31) == 0u;
         // the wave's totals of the counts m[][] of chunk rows rbase .. rbase+3 (already masked by label) go to centre j
         auto add_to = [&](const int j, const uint32_t(&m)[4][4], const uint32_t rbase) {
             uint32_t rows[4], cols[4] = {0u, 0u, 0u, 0u}, nl = 0u;

@@ -190,7 +190,8 @@ def test_colour_histogram_counts(be, orc, kind):
     per_cell = ref.reshape(4096, 4096).sum(1).astype(np.uint32)
     assert np.array_equal(info[:4096], per_cell)
     occupied = np.nonzero(per_cell)[0]
-    assert info[4096] == len(occupied) and np.array_equal(info[4097:4097 + len(occupied)], occupied)
+    assert info[4096] == len(occupied) and np.array_equal(info[4097:4097 + len(occupied)] & 0xfff, occupied)
+    assert not (info[4097:4097 + len(occupied)] >> 31).any()   # (bit 31: a cell of 2^24 pixels and more)
     # an unaligned view (byte offset 3), a ragged count, accumulated on top
     raw = torch.empty(3 * px.shape[0] + 3, dtype=torch.uint8, device="cuda")
     raw[3:] = t.reshape(-1)
