@@ -1,15 +1,19 @@
-"""Soak of the candidate-list Lloyd pass (dp_kmeans_step_u8 with DP_KMEANS_CELLS=1) against the oracle's float64 labelling:
-the case generator of tests/test_gpu_fullsize.py::test_kmeans_cell_list_fuzz over many seeds (run on the GPU box).
-usage: fuzz_kmeans.py <first seed> <seeds>"""
+"""Soak of the Lloyd passes against the oracle's float64 labelling: the case generator of
+tests/test_gpu_fullsize.py::test_kmeans_cell_list_fuzz over many seeds (run on the GPU box).
+usage: fuzz_kmeans.py <first seed> <seeds> [cells|hist]
+  cells (default): the candidate-list pass over the pixels (dp_kmeans_step_u8 with DP_KMEANS_CELLS=1; the experiment library)
+  hist:            the pass over the colour histogram (dp_kmeans_hist_build_u8 + dp_kmeans_hist_step; the product library) --
+                   the histogram is built by partition, every pass builds its candidate lists in-kernel"""
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
 from oracle import oracle as orc
 from dither_pie_amd import backend as be
 
 
-def run(seed0, seeds):
+def run(seed0, seeds, which="cells"):
     orc.build()
-    os.environ["DP_KMEANS_CELLS"] = "1"
+    if which == "cells":
+        os.environ["DP_KMEANS_CELLS"] = "1"
     bad = cases = 0
     t0 = time.time()
     for seed in range(seed0, seed0 + seeds):
@@ -39,18 +43,22 @@ def run(seed0, seeds):
             # half of the cases with sklearn's tie rule (mean_dev: labels of equidistant pixels from sklearn's float64 expression)
             mean = orc.data_mean(px) if rs.rand() < 0.5 else None
             s_ref, n_ref, _ = orc.kmeans_step(px, centers, mean)
-            s, cnt, _q = be.kmeans_step(torch.from_numpy(px).cuda(), torch.from_numpy(centers), None if mean is None else torch.from_numpy(mean))
+            if which == "hist":
+                s, cnt, _q = be.ColourHistogram(torch.from_numpy(px).cuda()).step(torch.from_numpy(centers), None if mean is None else torch.from_numpy(mean))
+            else:
+                s, cnt, _q = be.kmeans_step(torch.from_numpy(px).cuda(), torch.from_numpy(centers), None if mean is None else torch.from_numpy(mean))
             cases += 1
             if not (np.array_equal(s.cpu().numpy(), s_ref) and np.array_equal(cnt.cpu().numpy(), n_ref)):
                 bad += 1
                 print("MISMATCH", seed, case, K, n, kind, ckind, flush=True)
         if (seed - seed0) % 20 == 19:
             print(f"  {seed - seed0 + 1} seeds, {cases} cases, {bad} mismatching, {time.time() - t0:.0f} s", flush=True)
-    print(f"fuzz_kmeans: {cases} cases, {bad} mismatching, {time.time() - t0:.1f} s")
+    print(f"fuzz_kmeans ({which}): {cases} cases, {bad} mismatching, {time.time() - t0:.1f} s")
     return bad
 
 
 if __name__ == "__main__":
     from dither_pie_amd import _lib
-    if not _lib.EXPERIMENTS: _lib.select(True)   # DP_KMEANS_CELLS is read by libditherpie_hip_exp.so only
-    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 10, int(sys.argv[2]) if len(sys.argv) > 2 else 50) else 0)
+    which = sys.argv[3] if len(sys.argv) > 3 else "cells"
+    if which == "cells" and not _lib.EXPERIMENTS: _lib.select(True)   # DP_KMEANS_CELLS is read by libditherpie_hip_exp.so only
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 10, int(sys.argv[2]) if len(sys.argv) > 2 else 50, which) else 0)
