@@ -98,6 +98,24 @@ def main():
                 "derived": {"hbm_traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 3 * N8K,
                             "traffic_over_algorithmic": traffic / (3 * N8K)},
                 "kernel_sources_sha16": sha16(KMEANS_SRC)}
+    # r04_pmc_kmeans.json: the Lloyd pass before / after on one box -- over the pixels (round 3's kmeans_cells_kernel + its list build)
+    # against over the colour histogram (hist_pass_kernel), and what the histogram costs to build
+    kp = os.path.join(root, "pmc_kpix_summary.json")
+    if os.path.exists(kp) and "c4_kmeans_pass" in out["legs"]:
+        j = json.load(open(kp))["counters_mean_per_launch"]
+        before = {k: {"counters_mean_per_launch": c, "derived": derive(c, 3 * N8K if "cells_kernel" in k else None, N8K)}
+                  for k, c in j.items() if "kmeans_cells" in k}
+        km = {"workload": "K = 32 over the 33 M pixels of a 7680x4320 noise image (tools/bench_scripts/prof_kmeans.py / prof_kmeans_hist.py), same box, same session",
+              "before_pass_over_the_pixels": before,
+              "after_pass_over_the_histogram": out["legs"]["c4_kmeans_pass"],
+              "after_pass_over_the_histogram_image_like": out["legs"].get("c4_kmeans_pass_image_like"),
+              "histogram_build_once_per_fit": out["legs"].get("c4_kmeans_histogram"),
+              "histogram_build_once_per_fit_image_like": out["legs"].get("c4_kmeans_histogram_image_like"),
+              "note": out["note"], "kernel_sources_sha16": sha16(KMEANS_SRC)}
+        json.dump(km, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "r04_pmc_kmeans.json"), "w"), indent=1, sort_keys=True)
+        for k, v in before.items():
+            d = v["derived"]
+            print(f"before: {k[:60]:60s} VALU/px {d.get('valu_wave_instructions_per_unit', 0):.1f} traffic {d.get('hbm_traffic_bytes_per_launch', 0) / 1e6:.1f} MB")
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r04_pmc_legs.json")
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
     for leg, o in out["legs"].items():
