@@ -65,6 +65,7 @@ _SIGS = {
     "dp_error_diffusion_workspace_bytes": (_sz, [_i64, _i, _i]),
     "dp_error_diffusion_u8": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "dp_error_diffusion_numba_u8": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _vp, _sz, _vp]),
+    "dp_hybrid_numba_u8": (_i, [_vp, _vp, _i64, _i, _i, _vp, C.c_double, C.c_double, _vp, _sz, _vp]),
     "dp_variable_diffusion_u8": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _sz, _vp]),
     "dp_variance_gate_workspace_bytes": (_sz, [_i64, _i, _i]),
     "dp_variance_gate_u8": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _i, _vp, _sz, _vp]),

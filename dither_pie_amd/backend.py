@@ -270,6 +270,21 @@ def error_diffusion(frames, pal: Palette, taps, divisor, serpentine=False, out=N
     return out.view(frames.shape)
 
 
+def hybrid_numba(frames, pal: Palette, lum_factor=1.0, col_factor=0.2, out=None):
+    """HybridDitherStrategy as the reference's numba branch computes it (_hybrid_numba, dithering_lib.py:1396-1494: clamped
+    values, float64 linear-scan nearest, float64 luminance / colour split of the error, float64 pushes rounded on the store)."""
+    f = _frames(frames)
+    n, h, w, _ = f.shape
+    out = _check_out(out, f)
+    _check_palette_device(pal, f)
+    L = _lib.load()
+    ws_bytes = L.dp_error_diffusion_workspace_bytes(n, h, w)
+    with torch.cuda.device(f.device), _Launch(f.device, ws_bytes) as ws:
+        check(L.dp_hybrid_numba_u8(f.data_ptr(), out.data_ptr(), n, h, w, pal._h, float(lum_factor), float(col_factor),
+                                   ws.data_ptr(), ws.numel(), _stream()))
+    return out.view(frames.shape)
+
+
 DIFFUSER_PERCEPTUAL, DIFFUSER_HYBRID, DIFFUSER_ADAPTIVE_VARIANCE, DIFFUSER_OSTROMOUKHOV = 1, 2, 3, 4
 
 

@@ -197,7 +197,7 @@ int launch_blue_noise(int size, uint32_t seed, float *out_dev, void *scratch_dev
 size_t blue_noise_scratch_bytes(int size);
 int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal,
                            const int32_t *dx, const int32_t *dy, const float *wq, int ntaps, int serpentine,
-                           void *ws, size_t ws_bytes, hipStream_t s, const double *wq64 = nullptr);
+                           void *ws, size_t ws_bytes, hipStream_t s, const double *wq64 = nullptr, const double *hybrid = nullptr);
 size_t error_diffusion_ws_bytes(int64_t n_frames, int h, int w);
 int launch_kmeans_step(const uint8_t *px, int64_t n, const double *centers, const double *mean, int K, int64_t *sums, int64_t *counts,
                        int64_t *sumsq, hipStream_t s);

@@ -57,6 +57,10 @@ struct Taps {
     int dx[kMaxTaps], dy[kMaxTaps];
     float wq[kMaxTaps];
     double wq64[kMaxTaps];  // numba arithmetic: (double)float32(weight) / divisor
+    // numba arithmetic of the HYBRID diffuser (_hybrid_numba, dithering_lib.py:1396-1494): the error is split into its luminance
+    // part and the rest, scaled by lum_factor / col_factor, before it is pushed with the Floyd-Steinberg weights
+    int hybrid;
+    double hyb_lum, hyb_col;
 };
 
 // ---- the reference's OTHER error-diffusion arithmetic: _error_diffusion_numba (dithering_lib.py:213-308), which the
@@ -96,6 +100,18 @@ __device__ __forceinline__ int nearest_numba_f64(const float4 *__restrict__ cand
 __device__ __forceinline__ float push_numba(const float acc, const double err, const double w)
 {
     return (float)__dadd_rn((double)acc, __dmul_rn(err, w));
+}
+
+// _hybrid_numba's error transform (dithering_lib.py:1444-1451), every variable float64 (err0 = r - chosen0 with r unified to
+// float64; the literals and lum_factor / col_factor are float64), the operations in source order, no contraction:
+//   lum_err_val = (0.299 * err0 + 0.587 * err1) + 0.114 * err2;  lum_c = w_c * lum_err_val;  fe_c = lum_factor * lum_c + col_factor * (err_c - lum_c)
+__device__ __forceinline__ void hybrid_error_f64(double &e0, double &e1, double &e2, const double lf, const double cf)
+{
+    const double l = __dadd_rn(__dadd_rn(__dmul_rn(0.299, e0), __dmul_rn(0.587, e1)), __dmul_rn(0.114, e2));
+    const double l0 = __dmul_rn(0.299, l), l1 = __dmul_rn(0.587, l), l2 = __dmul_rn(0.114, l);
+    e0 = __dadd_rn(__dmul_rn(lf, l0), __dmul_rn(cf, __dsub_rn(e0, l0)));
+    e1 = __dadd_rn(__dmul_rn(lf, l1), __dmul_rn(cf, __dsub_rn(e1, l1)));
+    e2 = __dadd_rn(__dmul_rn(lf, l2), __dmul_rn(cf, __dsub_rn(e2, l2)));
 }
 
 // the type an error is kept in: float32 (the pure-Python branch) or float64 (the numba branch)
@@ -445,6 +461,13 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     e0 = err_of<NB>(o0, pj.x);
                     e1 = err_of<NB>(o1, pj.y);
                     e2 = err_of<NB>(o2, pj.z);
+                    if (NB && taps.hybrid) {
+                        double h0 = (double)e0, h1 = (double)e1, h2 = (double)e2;
+                        hybrid_error_f64(h0, h1, h2, taps.hyb_lum, taps.hyb_col);
+                        e0 = (E)h0;
+                        e1 = (E)h1;
+                        e2 = (E)h2;
+                    }
                     cbytes = __float_as_uint(pj.w);
                 }
                 cb[q] = cbytes;
@@ -540,9 +563,18 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
                              : (pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, nullptr, o0, o1, o2)
                                              : nearest_color<CAP>(pal, pal.fcand, o0, o1, o2));
             E *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
-            e[0] = err_of<NB>(o0, (float)pal.pts[3 * j]);
-            e[nf] = err_of<NB>(o1, (float)pal.pts[3 * j + 1]);
-            e[2 * nf] = err_of<NB>(o2, (float)pal.pts[3 * j + 2]);
+            E v0 = err_of<NB>(o0, (float)pal.pts[3 * j]), v1 = err_of<NB>(o1, (float)pal.pts[3 * j + 1]),
+              v2 = err_of<NB>(o2, (float)pal.pts[3 * j + 2]);
+            if (NB && taps.hybrid) {
+                double h0 = (double)v0, h1 = (double)v1, h2 = (double)v2;
+                hybrid_error_f64(h0, h1, h2, taps.hyb_lum, taps.hyb_col);
+                v0 = (E)h0;
+                v1 = (E)h1;
+                v2 = (E)h2;
+            }
+            e[0] = v0;
+            e[nf] = v1;
+            e[2 * nf] = v2;
             const uint32_t c = pal.out_rgb[j];
             uint8_t *o = fout + ((size_t)y * w + x) * 3;
             o[0] = (uint8_t)c;
@@ -791,12 +823,16 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
 
 int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal,
                            const int32_t *dx, const int32_t *dy, const float *wq, int ntaps, int serpentine,
-                           void *ws, size_t ws_bytes, hipStream_t s, const double *wq64)
+                           void *ws, size_t ws_bytes, hipStream_t s, const double *wq64, const double *hybrid)
 {
     // wq64 != nullptr: the numba arithmetic (see nearest_numba_f32) with these float64 tap weights
     const bool numba = wq64 != nullptr;
     Taps t;
     t.n = ntaps;
+    // hybrid != nullptr (with wq64): {lum_factor, col_factor} of _hybrid_numba
+    t.hybrid = (numba && hybrid) ? 1 : 0;
+    t.hyb_lum = hybrid ? hybrid[0] : 0.0;
+    t.hyb_col = hybrid ? hybrid[1] : 0.0;
     // reference visiting order of the source pixels: earlier rows first (dy descending), and inside a
     // source row in its scan order, which is dx descending for both scan directions
     int order[kMaxTaps];

@@ -608,7 +608,7 @@ size_t dp_error_diffusion_workspace_bytes(int64_t n_frames, int h, int w)
 static int error_diffusion_common(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
                                   const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *wq,
                                   const double *wq64, int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
-                                  void *stream);
+                                  void *stream, const double *hybrid = nullptr);
 
 int dp_error_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
                           const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *wq,
@@ -638,10 +638,23 @@ int dp_error_diffusion_numba_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t
                                   workspace_bytes, stream);
 }
 
+int dp_hybrid_numba_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, const dp_palette *pal,
+                       double lum_factor, double col_factor, void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    // _hybrid_numba's Floyd-Steinberg pushes (dithering_lib.py:1453-1468): (x+1, y) 7/16, (x-1, y+1) 3/16, (x, y+1) 5/16, (x+1, y+1) 1/16,
+    // the weights float64 constants
+    static const int32_t dx[4] = {1, -1, 0, 1}, dy[4] = {0, 1, 1, 1};
+    static const double wq64[4] = {7.0 / 16.0, 3.0 / 16.0, 5.0 / 16.0, 1.0 / 16.0};
+    static const float wq[4] = {7.0f / 16.0f, 3.0f / 16.0f, 5.0f / 16.0f, 1.0f / 16.0f};
+    const double hybrid[2] = {lum_factor, col_factor};
+    return error_diffusion_common(in_dev, out_dev, n_frames, h, w, pal, dx, dy, wq, wq64, 4, 0, workspace_dev, workspace_bytes, stream,
+                                  hybrid);
+}
+
 static int error_diffusion_common(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,
                                   const dp_palette *pal, const int32_t *dx, const int32_t *dy, const float *wq,
                                   const double *wq64, int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
-                                  void *stream)
+                                  void *stream, const double *hybrid)
 {
     if (n_frames == 0 && pal && h >= 1 && w >= 1) return DP_OK;  // nothing to do (pointers may be null)
     if (!in_dev || !out_dev || !pal || n_frames < 0 || h < 1 || w < 1 || ntaps < 0 || ntaps > 16 ||
@@ -666,7 +679,7 @@ static int error_diffusion_common(const uint8_t *in_dev, uint8_t *out_dev, int64
     const int rc_tab = ensure_ed_tables(pal);
     if (rc_tab != DP_OK) return rc_tab;
     return launch_error_diffusion(in_dev, out_dev, n_frames, h, w, snapshot(pal), dx, dy, wq, ntaps, serpentine,
-                                  workspace_dev, workspace_bytes, (hipStream_t)stream, wq64);
+                                  workspace_dev, workspace_bytes, (hipStream_t)stream, wq64, hybrid);
 }
 
 int dp_variable_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w,

@@ -576,8 +576,10 @@ class PerceptualDitherStrategy(_VariableDiffuser):
 
 
 class HybridDitherStrategy(_VariableDiffuser):
-    """Luminance part of the error diffused at lum_factor, colour part at col_factor (dithering_lib.py:1071-1155,
-    pure-Python branch)."""
+    """Luminance part of the error diffused at lum_factor, colour part at col_factor (dithering_lib.py:1071-1155).  By default
+    the pure-Python branch (:1127-1152), which is what runs without numba and is pinned by reference fixtures; with
+    ERROR_DIFFUSION_ARITHMETIC = "numba" the strategy's numba branch (_hybrid_numba, :1396-1494, dispatched at :1114-1125),
+    which clamps, scans the palette in float64 and keeps a float64 error -- typed per numba's unification rule, unpinned."""
 
     @staticmethod
     def get_parameter_info() -> Dict[str, Any]:
@@ -602,6 +604,8 @@ class HybridDitherStrategy(_VariableDiffuser):
 
     def _diffuse(self, frames, pal, out):
         from . import backend
+        if ERROR_DIFFUSION_ARITHMETIC == "numba":
+            return backend.hybrid_numba(frames, pal, self.lum_factor, self.col_factor, out=out)
         return backend.variable_diffusion(frames, pal, backend.DIFFUSER_HYBRID, self.lum_factor, self.col_factor, out=out)
 
 

@@ -157,6 +157,16 @@ int dp_error_diffusion_numba_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t
                                 double divisor, int ntaps, int serpentine, void *workspace_dev, size_t workspace_bytes,
                                 void *stream);
 
+/* HybridDitherStrategy's numba branch (_hybrid_numba, dithering_lib.py:1396-1494, taken at :1114-1125 when numba is importable):
+ * unlike the pure-Python branch of the same strategy (dp_variable_diffusion_u8, model 2) it CLAMPS the value to [0, 255] before
+ * the search, takes the first minimum of a float64 linear scan, and -- typed per numba's unification rule exactly as
+ * dp_error_diffusion_numba_u8 -- keeps the error in float64: err = r - chosen, lum_err_val = (0.299 err0 + 0.587 err1) + 0.114 err2,
+ * lum_c = w_c lum_err_val, fe_c = lum_factor lum_c + col_factor (err_c - lum_c), pushed with the Floyd-Steinberg weights as
+ * float32(float64(v) + fe_c * (7/16 | 3/16 | 5/16 | 1/16)).  Workspace: dp_error_diffusion_workspace_bytes.
+ * Parity status: restated in the CPU oracle (orc_hybrid_numba_u8) and in numpy; fixtures pending, NOT pinned (no numba here). */
+int dp_hybrid_numba_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_frames, int h, int w, const dp_palette *pal,
+                       double lum_factor, double col_factor, void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* variable-weight diffusers -------------------------------------------------------
  * Replaces the pure-Python branches of PerceptualDitherStrategy.dither (dithering_lib.py:1030-1066, model 1),
  * HybridDitherStrategy.dither (:1111-1155, model 2; p0 = lum_factor, p1 = col_factor),

@@ -26,6 +26,7 @@
  *   orc_blue_noise        generate_blue_noise              dithering_lib.py:381-399
  *                         (numpy legacy RandomState.shuffle = MT19937, restated)
  *   orc_error_diffusion_numba_u8  the same strategy's numba branch (:213-308) -- parity unpinned, see the function
+ *   orc_hybrid_numba_u8   HybridDitherStrategy's numba branch (_hybrid_numba, :1396-1494) -- parity unpinned, see the function
  *   orc_error_diffusion_u8 ErrorDiffusionDitherStrategy.dither, pure-Python
  *                         branch                           dithering_lib.py:655-690
  *   orc_kmeans_step       one Lloyd assignment + accumulation pass of
@@ -1063,4 +1064,100 @@ void orc_uniform_filter1d_f32(const float *in, float *out, int n_lines, int leng
         }
     }
     free(buf);
+}
+
+/* ------------------------------------------------------------------ */
+/* HybridDitherStrategy, the numba branch: _hybrid_numba,              */
+/* dithering_lib.py:1396-1494 (dispatch :1114-1125).                   */
+/* work float32; palette float32; lum_factor / col_factor float64.     */
+/* TYPED PER NUMBA'S UNIFICATION RULE (fixtures pending), exactly as   */
+/* orc_error_diffusion_numba_u8 above: r, g, b are assigned a float32  */
+/* element (:1408-1410) and float64 literals (:1411-1422) => float64;  */
+/* the scan, err = r - chosen, and everything computed from it are     */
+/* float64, every product and sum rounded on its own (no fastmath):    */
+/*   lum_err_val = (0.299*err0 + 0.587*err1) + 0.114*err2   (:1445)    */
+/*   lum_c = w_c * lum_err_val                              (:1446-48) */
+/*   fe_c = lum_factor*lum_c + col_factor*(err_c - lum_c)   (:1449-51) */
+/*   work[.., c] += fe_c * (7.0/16.0 | 3.0/16.0 | 5.0/16.0 | 1.0/16.0) */
+/*      -- float64 product, float64 sum with the float32 element, one  */
+/*      rounding to float32 on the store                  (:1453-1468) */
+/* Unlike the pure-Python branch of the same strategy (:1127-1152) the */
+/* value IS clamped to [0, 255] before the search (:1411-1422).        */
+/* PARITY UNPINNED: numba cannot be installed in the build image.      */
+/* ------------------------------------------------------------------ */
+int orc_hybrid_numba_u8(const uint8_t *in, uint8_t *out, int h, int w, const float *pal, int K, const uint8_t *out_colors,
+                        const uint8_t *lut_in, double lum_factor, double col_factor)
+{
+    float *W = (float *)malloc(sizeof(float) * 3 * (size_t)h * w);
+    int32_t *pick = (int32_t *)malloc(sizeof(int32_t) * (size_t)h * w);
+    if (!W || !pick || K < 1) {
+        free(W);
+        free(pick);
+        return -1;
+    }
+    for (size_t i = 0; i < (size_t)h * w * 3; i++)
+        W[i] = (float)(lut_in ? lut_in[in[i]] : in[i]);
+    static const int tdx[4] = {1, -1, 0, 1}, tdy[4] = {0, 1, 1, 1};
+    const double tw[4] = {7.0 / 16.0, 3.0 / 16.0, 5.0 / 16.0, 1.0 / 16.0};
+    static const double lw[3] = {0.299, 0.587, 0.114};
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            float *p = W + ((size_t)y * w + x) * 3;
+            double v[3];
+            for (int c = 0; c < 3; c++) {
+                double t = (double)p[c];
+                v[c] = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);
+            }
+            int best = 0;
+            double best_dist = 1e20;
+            for (int i = 0; i < K; i++) {
+                volatile double dr = v[0] - (double)pal[i * 3 + 0], dg = v[1] - (double)pal[i * 3 + 1], db = v[2] - (double)pal[i * 3 + 2];
+                volatile double rr = dr * dr, gg = dg * dg, bb = db * db;
+                volatile double s1 = rr + gg;
+                volatile double dist = s1 + bb;
+                if (dist < best_dist) {
+                    best_dist = dist;
+                    best = i;
+                }
+            }
+            pick[(size_t)y * w + x] = best;
+            double err[3];
+            for (int c = 0; c < 3; c++) {
+                volatile double e = v[c] - (double)pal[best * 3 + c];
+                p[c] = pal[best * 3 + c];
+                err[c] = e;
+            }
+            volatile double a0 = lw[0] * err[0], a1 = lw[1] * err[1], a2 = lw[2] * err[2];
+            volatile double a01 = a0 + a1;
+            volatile double lum = a01 + a2;
+            double fe[3];
+            for (int c = 0; c < 3; c++) {
+                volatile double lc = lw[c] * lum;
+                volatile double rest = err[c] - lc;
+                volatile double t1 = lum_factor * lc, t2 = col_factor * rest;
+                volatile double f = t1 + t2;
+                fe[c] = f;
+            }
+            for (int k = 0; k < 4; k++) {
+                int nx = x + tdx[k], ny = y + tdy[k];
+                if (nx >= 0 && nx < w && ny >= 0 && ny < h) {
+                    float *tp = W + ((size_t)ny * w + nx) * 3;
+                    for (int c = 0; c < 3; c++) {
+                        volatile double prod = fe[c] * tw[k];
+                        volatile double sum = (double)tp[c] + prod;
+                        tp[c] = (float)sum;
+                    }
+                }
+            }
+        }
+    }
+    for (size_t i = 0; i < (size_t)h * w; i++) {
+        int j = pick[i];
+        out[i * 3 + 0] = out_colors[j * 3 + 0];
+        out[i * 3 + 1] = out_colors[j * 3 + 1];
+        out[i * 3 + 2] = out_colors[j * 3 + 2];
+    }
+    free(W);
+    free(pick);
+    return 0;
 }

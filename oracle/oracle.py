@@ -58,6 +58,8 @@ def lib():
         L.orc_error_diffusion_numba_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_double, C.c_int, C.c_int]
+        L.orc_hybrid_numba_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_double, C.c_double]
         L.orc_blue_noise.argtypes = [C.c_int, C.c_uint32, C.c_void_p]
         L.orc_var_diffusion_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
@@ -359,6 +361,53 @@ def error_diffusion_numba_numpy(arr, pal_f32, out_colors, lut_in, variant="atkin
                     wgt = np.float64(weights[k]) / np.float64(divisor)
                     for c in range(3):
                         work[ny, nx, c] = np.float32(np.float64(work[ny, nx, c]) + np.float64(err[c]) * wgt)
+    return np.asarray(out_colors, np.uint8)[pick]
+
+
+def hybrid_numba_u8(arr, pal_f32, out_colors, lut_in, lum_factor=1.0, col_factor=0.2):
+    """HybridDitherStrategy's numba branch (_hybrid_numba, dithering_lib.py:1396-1494) restated in C, typed per numba's
+    unification rule (float64 r / g / b, float64 scan, float64 error and luminance split).  PARITY UNPINNED, fixtures pending."""
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    h, w, _ = arr.shape
+    out = np.empty_like(arr)
+    rc = lib().orc_hybrid_numba_u8(_p(arr), _p(out), h, w, _p(pal_f32), pal_f32.shape[0], _p(out_colors), _p(lut_in),
+                                   float(lum_factor), float(col_factor))
+    if rc != 0:
+        raise ValueError("oracle hybrid_numba_u8 failed")
+    return out
+
+
+def hybrid_numba_numpy(arr, pal_f32, out_colors, lut_in, lum_factor=1.0, col_factor=0.2):
+    """A second, independent statement of the same lines with numpy scalars doing the arithmetic (every variable np.float64,
+    the work array np.float32).  Slow: small images only."""
+    arr = np.asarray(arr, np.uint8)
+    h, w, _ = arr.shape
+    work = (lut_in[arr] if lut_in is not None else arr).astype(np.float32)
+    pal = np.asarray(pal_f32, np.float32)
+    lf, cf = np.float64(lum_factor), np.float64(col_factor)
+    F = np.float64
+    pick = np.zeros((h, w), np.int64)
+    for y in range(h):
+        for x in range(w):
+            r, g, b = (min(max(F(work[y, x, c]), F(0.0)), F(255.0)) for c in range(3))
+            best, best_dist = 0, 1e20
+            for i in range(pal.shape[0]):
+                dr, dg, db = r - F(pal[i, 0]), g - F(pal[i, 1]), b - F(pal[i, 2])
+                dist = dr * dr + dg * dg + db * db
+                if float(dist) < best_dist:
+                    best_dist, best = float(dist), i
+            pick[y, x] = best
+            c0, c1, c2 = pal[best]
+            work[y, x] = (c0, c1, c2)
+            err0, err1, err2 = r - F(c0), g - F(c1), b - F(c2)
+            lum_err_val = F(0.299) * err0 + F(0.587) * err1 + F(0.114) * err2
+            lum = (F(0.299) * lum_err_val, F(0.587) * lum_err_val, F(0.114) * lum_err_val)
+            fe = tuple(lf * lc + cf * (e - lc) for lc, e in zip(lum, (err0, err1, err2)))
+            for dx, dy, wgt in ((1, 0, 7.0 / 16.0), (-1, 1, 3.0 / 16.0), (0, 1, 5.0 / 16.0), (1, 1, 1.0 / 16.0)):
+                nx, ny = x + dx, y + dy
+                if 0 <= nx < w and 0 <= ny < h:
+                    for c in range(3):
+                        work[ny, nx, c] = np.float32(F(work[ny, nx, c]) + fe[c] * F(wgt))
     return np.asarray(out_colors, np.uint8)[pick]
 
 

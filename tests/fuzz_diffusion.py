@@ -1,4 +1,5 @@
-"""Random error-diffusion cases (all eight tap sets, both scans, both arithmetics, the four variable-coefficient diffusers)
+"""Random error-diffusion cases (all eight tap sets, both scans, both arithmetics, the four variable-coefficient diffusers and
+the hybrid diffuser's numba branch)
 against the oracle: palette sizes around every table boundary (2, 8, 9, 16, 17, 64, 256), random / uniform / clustered
 palettes, gamma on and off, shapes from 1x1 up to a few bands, batches.  run(seed, n) -> number of mismatches.
 Used by tests/test_gpu_kernels.py; `python tests/fuzz_diffusion.py [seed] [n]` runs it by hand on a GPU box."""
@@ -67,10 +68,16 @@ def run(seed, n, verbose=False):
             mode = VAR_MODES[int(rs.randint(0, 4))]
             params = {"serpentine": "true"} if (mode == "ostromoukhov" and rs.randint(0, 2)) else {}
             from dither_pie_amd.dithering_lib import DitherMode, ImageDitherer
-            d = ImageDitherer(K, DitherMode(mode), pal, gamma, params)
-            out = d.apply_dithering_frames(t).cpu().numpy()
-            ref = np.stack([orc.apply_dithering(f, pal, mode, params, gamma) for f in frames])
-            what = f"{mode} {params}"
+            if mode == "hybrid" and rs.randint(0, 2):   # the hybrid diffuser's own numba branch (_hybrid_numba)
+                lf, cf = float(rs.choice([1.0, 1.4, 0.3])), float(rs.choice([0.2, 0.0, 1.0]))
+                out = be.hybrid_numba(t, P, lf, cf).cpu().numpy()
+                ref = np.stack([orc.hybrid_numba_u8(f, pal_f32, out_colors, lut_in, lf, cf) for f in frames])
+                what = f"hybrid numba {lf} {cf}"
+            else:
+                d = ImageDitherer(K, DitherMode(mode), pal, gamma, params)
+                out = d.apply_dithering_frames(t).cpu().numpy()
+                ref = np.stack([orc.apply_dithering(f, pal, mode, params, gamma) for f in frames])
+                what = f"{mode} {params}"
         if not np.array_equal(out, ref):
             bad += 1
             print(f"MISMATCH seed={seed} case={case}: {what} K={K} {nf}x{h}x{w} gamma={gamma}: "

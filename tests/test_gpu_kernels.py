@@ -220,6 +220,41 @@ def test_error_diffusion_numba_float64_reading(be, orc):
             _assert_same(out, orc.error_diffusion_numba_u8(strip, pal2, oc2, None, "jjn", serp), f"numba float64 {shape} serp={serp}")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("lum_factor,col_factor", [(1.0, 0.2), (1.4, 0.0), (0.3, 1.0)])
+def test_hybrid_numba_arithmetic_vs_oracle(be, orc, lum_factor, col_factor):
+    """HybridDitherStrategy's numba branch (_hybrid_numba, dithering_lib.py:1396-1494) through dp_hybrid_numba_u8 against its C
+    restatement: several bands, frames in a batch, with and without the gamma table, one 1080p frame spread over workgroups; and
+    through the strategy with ERROR_DIFFUSION_ARITHMETIC = "numba" (default: the pure-Python branch, pinned by fixtures).
+    Unpinned like the other numba branch: numba is not installable here."""
+    import torch
+    from dither_pie_amd import dithering_lib as dl
+    for arr, pal, gamma in [(orc.rnd(150, 97, 4), orc.palr(16, 3), False), (orc.grad(131, 200), orc.generate_uniform_palette(16), False),
+                            (orc.rnd(70, 40, 5), orc.palr(40, 9), True), (orc.rnd(9, 5, 6), orc.palr(2, 1), False)]:
+        pal_f32, out_colors, lut_in = orc.prepare_palette(pal, gamma)
+        P = be.Palette(pal_f32, out_colors, lut_in)
+        frames = np.stack([arr, arr[::-1].copy()])
+        out = be.hybrid_numba(torch.from_numpy(frames).cuda(), P, lum_factor, col_factor).cpu().numpy()
+        for f in range(2):
+            _assert_same(out[f], orc.hybrid_numba_u8(frames[f], pal_f32, out_colors, lut_in, lum_factor, col_factor), f"hybrid numba frame {f}")
+    arr = orc.rnd(1080, 1920, 12)
+    pal = orc.generate_uniform_palette(16)
+    pal_f32, out_colors, lut_in = orc.prepare_palette(pal, False)
+    ref = orc.hybrid_numba_u8(arr, pal_f32, out_colors, lut_in, lum_factor, col_factor)
+    old = dl.ERROR_DIFFUSION_ARITHMETIC
+    dl.ERROR_DIFFUSION_ARITHMETIC = "numba"
+    try:
+        d = dl.ImageDitherer(16, dl.DitherMode.HYBRID, pal, False, {"lum_factor": lum_factor, "col_factor": col_factor})
+        out = d.apply_dithering_frames(torch.from_numpy(arr).cuda()).cpu().numpy()
+    finally:
+        dl.ERROR_DIFFUSION_ARITHMETIC = old
+    _assert_same(out, ref, "hybrid numba, 1080p")
+    d = dl.ImageDitherer(16, dl.DitherMode.HYBRID, pal, False, {"lum_factor": lum_factor, "col_factor": col_factor})
+    py = d.apply_dithering_frames(torch.from_numpy(arr).cuda()).cpu().numpy()
+    _assert_same(py, orc.apply_dithering(arr, pal, "hybrid", {"lum_factor": lum_factor, "col_factor": col_factor}), "hybrid python, 1080p")
+    assert not np.array_equal(py, out)
+
+
 def test_error_diffusion_numba_arithmetic_1080p_bands_over_workgroups(be, orc):
     """One 1080p frame (17 bands spread over workgroups, the few-frames schedule) and the strategy-level switch."""
     import torch

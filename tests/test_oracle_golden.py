@@ -318,3 +318,20 @@ def test_numba_branch_follows_float64_unification():
     for serp in (False, True):
         a = orc.error_diffusion_numba_u8(strip, pal2, oc2, None, "jjn", serp)
         assert np.array_equal(a, orc.error_diffusion_numba_numpy(strip, pal2, oc2, None, "jjn", serp))
+
+
+@pytest.mark.parametrize("lum_factor,col_factor", [(1.0, 0.2), (1.4, 0.0), (0.3, 1.0)])
+def test_hybrid_numba_branch_restatement_agrees_with_a_numpy_transcription(lum_factor, col_factor):
+    """HybridDitherStrategy has a numba branch of its own (_hybrid_numba, dithering_lib.py:1396-1494, taken at :1114-1125 when
+    numba imports): clamped values, float64 scan, float64 luminance / colour split.  It cannot be run here either; its C
+    restatement is checked against an independent numpy transcription of the same lines (np.float64 scalars, float32 work
+    array), and it is a different function from the strategy's pure-Python branch (which does not clamp and asks the KD-tree)."""
+    from oracle import oracle as orc
+    differs = 0
+    for arr, pal, gamma in [(orc.rnd(13, 17, 3), orc.generate_uniform_palette(16), False), (orc.grad(9, 21), orc.palr(9, 5), True),
+                            (orc.rnd(11, 8, 4), orc.palr(5, 2), False)]:
+        pal_f32, out_colors, lut_in = orc.prepare_palette(pal, gamma)
+        a = orc.hybrid_numba_u8(arr, pal_f32, out_colors, lut_in, lum_factor, col_factor)
+        assert np.array_equal(a, orc.hybrid_numba_numpy(arr, pal_f32, out_colors, lut_in, lum_factor, col_factor))
+        differs += int((a != orc.var_diffusion_u8(arr, pal_f32, out_colors, lut_in, 2, lum_factor, col_factor)).any())
+    assert differs > 0
