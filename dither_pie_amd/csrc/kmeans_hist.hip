@@ -7,8 +7,9 @@
 //                       cell (2 bytes per pixel), every bucket becomes its cell's 16 KB table slice through an LDS histogram.
 //                       0.4 ms for 33 M pixels where one global atomic per pixel takes 1.2 ms (and 376 ms on a flat frame).
 //                       The per-cell pixel counts fall out of the first step: passes skip empty cells without reading them.
-//   hist_pass_kernel    one workgroup per cell.  The table is CELL-MAJOR (index = cell << 12 | r_lo << 8 | g_lo << 4 | b_lo),
-//                       so a workgroup reads its 16 KB contiguously, builds the cell's candidate list itself (the
+//   hist_pass_kernel    a persistent grid of independent waves over the OCCUPIED cells (a cell is cut over 2 or 4 waves when few
+//                       are occupied).  The table is CELL-MAJOR (index = cell << 12 | r_lo << 8 | g_lo << 4 | b_lo), so a wave
+//                       reads its cell's 16 KB contiguously, 4 KB at a time; it builds the cell's candidate list itself (the
 //                       centres that can be nearest somewhere in the cell: bound test + pairwise bisector test, as
 //                       kmeans_cells_build_kernel -- no separate list launch, no 4096-list table), and
 //                         * a cell with ONE candidate (most cells at 32 centres) needs no distance at all: its totals are
@@ -21,6 +22,8 @@
 //                           is on it.
 //                       Labels and int64 totals are those of the per-pixel kernels, bit for bit (tests compare both with
 //                       the oracle).  Bytes per pass: 16 KB per occupied cell (64 MB when every cell is occupied).
+//                       FUSE instances (dp_kmeans_hist_iterate): the workgroup that finishes last also runs the centre update,
+//                       so that a Lloyd iteration on one device is ONE launch.
 // Counts are 32-bit: a histogram holds fewer than 2^32 pixels (per rank).
 #include <algorithm>
 
