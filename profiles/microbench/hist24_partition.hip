@@ -82,6 +82,35 @@ __global__ __launch_bounds__(TB) void scatter_kernel(const uint32_t *__restrict_
     }
 }
 
+// variant 2: big tiles (tile_groups groups of 4 pixels per workgroup), two passes over the tile's pixels (the second one hits L2):
+// count per cell -> one cursor atomic per (tile, cell) -> rank by a second LDS counter + store.  Runs of tile/4096 entries per cell.
+__global__ __launch_bounds__(TB) void scatter2_kernel(const uint32_t *__restrict__ px, const size_t n_groups, const size_t tile_groups,
+                                                      uint32_t *__restrict__ cursor, uint16_t *__restrict__ buckets)
+{
+    __shared__ uint32_t s_cnt[4096];
+    __shared__ uint32_t s_base[4096];
+    const size_t tiles = (n_groups + tile_groups - 1) / tile_groups;
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < 4096; i += TB) s_cnt[i] = 0;
+        __syncthreads();
+        const size_t g0 = tile * tile_groups, g1 = g0 + tile_groups < n_groups ? g0 + tile_groups : n_groups;
+        for (size_t gi = g0 + threadIdx.x; gi < g1; gi += TB) {
+            uint32_t v[4]; load4(px, gi, v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { uint32_t c, lo; split(v[q], c, lo); atomicAdd(&s_cnt[c], 1u); }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4096; i += TB) { const uint32_t c = s_cnt[i]; s_base[i] = c ? atomicAdd(&cursor[i], c) : 0u; s_cnt[i] = 0; }
+        __syncthreads();
+        for (size_t gi = g0 + threadIdx.x; gi < g1; gi += TB) {
+            uint32_t v[4]; load4(px, gi, v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { uint32_t c, lo; split(v[q], c, lo); const uint32_t r = atomicAdd(&s_cnt[c], 1u); buckets[s_base[c] + r] = (uint16_t)lo; }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void cell_hist_kernel(const uint16_t *__restrict__ buckets, const uint32_t *__restrict__ base,
                                                         const uint32_t *__restrict__ cell_count, uint32_t *__restrict__ table)
 {
@@ -129,14 +158,16 @@ int main()
         CK(hipMemcpy(d, h.data(), n * 3, hipMemcpyHostToDevice));
         const uint32_t *px = reinterpret_cast<const uint32_t *>(d);
         if (content != 2) { CK(hipMemset(ref, 0, (size_t)1 << 26)); hist_atomic<<<2048, 256>>>(px, n / 4, ref); CK(hipDeviceSynchronize()); }
-        for (int rep = 0; rep < 3; ++rep) {
+        for (int variant = 0; variant < 4; ++variant)
+        for (int rep = 0; rep < 2; ++rep) {
             CK(hipMemsetAsync(cell_count, 0, 16384));
             CK(hipEventRecord(e[0]));
             count_kernel<<<512, TB>>>(px, n / 4, cell_count);
             CK(hipEventRecord(e[1]));
             scan_kernel<<<1, 1024>>>(cell_count, base, cursor);
             CK(hipEventRecord(e[2]));
-            scatter_kernel<<<1024, TB>>>(px, n / 4, cursor, buckets);
+            if (variant == 0) scatter_kernel<<<1024, TB>>>(px, n / 4, cursor, buckets);
+            else scatter2_kernel<<<512, TB>>>(px, n / 4, (size_t)(variant == 1 ? 32768 : (variant == 2 ? 16384 : 65536)), cursor, buckets);
             CK(hipEventRecord(e[3]));
             cell_hist_kernel<<<4096, 256>>>(buckets, base, cell_count, table);
             CK(hipEventRecord(e[4]));
@@ -144,7 +175,7 @@ int main()
             float a, b, c, dd, all;
             CK(hipEventElapsedTime(&a, e[0], e[1])); CK(hipEventElapsedTime(&b, e[1], e[2])); CK(hipEventElapsedTime(&c, e[2], e[3]));
             CK(hipEventElapsedTime(&dd, e[3], e[4])); CK(hipEventElapsedTime(&all, e[0], e[4]));
-            printf("%-13s count %.3f  scan %.3f  scatter %.3f  cell histograms %.3f  = %.3f ms\n", names[content], a, b, c, dd, all);
+            printf("%-13s scatter variant %d: count %.3f  scan %.3f  scatter %.3f  cell histograms %.3f  = %.3f ms\n", names[content], variant, a, b, c, dd, all);
         }
         if (content != 2) {
             std::vector<uint32_t> t1((size_t)1 << 24), t2((size_t)1 << 24);
