@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kPpThreads) void kmeans_pp_kernel(const uint8_t *__
                                                                 double *__restrict__ out_centers)
 {
     __shared__ uint32_t s_pt[kPpMaxN];
-    __shared__ unsigned long long s_scan[kPpThreads];
+    __shared__ unsigned long long s_scan[kPpThreads / 64];  // the waves' totals
     __shared__ unsigned long long s_red[kPpMaxTrials][kPpThreads / 64];
     __shared__ int s_pick[kPpMaxTrials];
     __shared__ int s_best;
@@ -892,21 +892,29 @@ __global__ __launch_bounds__(kPpThreads) void kmeans_pp_kernel(const uint8_t *__
         out_centers[2] = (double)(c0 >> 16);
     }
     for (int c = 1; c < K; ++c) {
-        // inclusive prefix sums over the threads' own totals (Hillis-Steele in LDS)
+        // inclusive prefix sums over the threads' own totals
         unsigned long long mine = 0;
 #pragma unroll
         for (int e = 0; e < kPpPer; ++e) mine += closest[e];
-        s_scan[t] = mine;
+        // (inside a wave by shuffles, across the 16 waves through LDS: two barriers instead of the twenty of a Hillis-Steele scan
+        // over all 1024 threads -- this kernel is one workgroup working through K dependent centres, every barrier is on its path)
+        unsigned long long wincl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(wincl, off);
+            if ((t & 63) >= off) wincl += o;
+        }
+        if ((t & 63) == 63) s_scan[t >> 6] = wincl;
         if (t < kPpMaxTrials) s_pick[t] = n - 1;  // np.clip(picks, None, n - 1): a value above the total
         __syncthreads();
-        for (int off = 1; off < kPpThreads; off <<= 1) {
-            const unsigned long long add = t >= off ? s_scan[t - off] : 0ull;
-            __syncthreads();
-            s_scan[t] += add;
-            __syncthreads();
+        unsigned long long before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kPpThreads / 64; ++w) {
+            const unsigned long long v = s_scan[w];
+            before += w < (t >> 6) ? v : 0ull;
+            total += v;
         }
-        const unsigned long long incl = s_scan[t], excl = incl - mine;
-        const double pot = (double)s_scan[kPpThreads - 1];
+        const unsigned long long incl = before + wincl, excl = incl - mine;
+        const double pot = (double)total;
         // the trials' picks: the first point whose inclusive prefix sum is >= value lies in exactly one thread's range
         for (int q = 0; q < n_trials; ++q) {
             const double rv = __dmul_rn(uniforms[(size_t)(c - 1) * n_trials + q], pot);

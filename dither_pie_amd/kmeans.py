@@ -106,7 +106,8 @@ def _all_reduce_totals(totals, group):
     return totals
 
 
-CHECK_EVERY = 8  # iterations launched back to back between two looks at the status words
+CHECK_EVERY = 8         # iterations launched back to back between two looks at the status words
+CHECK_EVERY_FUSED = 16  # ... when an iteration is one launch that returns at once after convergence (dp_kmeans_hist_iterate)
 
 
 def _check_centres_in_cube(c):
@@ -183,8 +184,9 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sk
     fused = hist is not None and not sharded and fuse is not False   # one device: ONE launch per iteration (dp_kmeans_hist_iterate)
     ticket = torch.zeros(1, dtype=torch.int32, device=dev) if fused else None
     launched = 0
+    every = CHECK_EVERY_FUSED if fused else CHECK_EVERY
     while True:
-        for _ in range(CHECK_EVERY):
+        for _ in range(every):
             first = launched == 0
             if fused:
                 hist.iterate(centers, totals, prev, status, ticket, tol, max_iter, first, mean)
@@ -196,7 +198,7 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sk
         st = status.cpu()
         if int(st[0]) in (1, 3):
             break
-        if launched > max_iter + CHECK_EVERY + 2:  # cannot happen (the update kernel stops at max_iter)
+        if launched > max_iter + every + 2:  # cannot happen (the update kernel stops at max_iter)
             raise RuntimeError("k-means did not terminate")
     return centers.cpu().numpy(), float(st[2]), int(st[1])
 
