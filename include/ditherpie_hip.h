@@ -48,7 +48,8 @@ extern "C" {
 
 #define DP_MAX_COLORS 1024
 
-/* 100: rounds 1-2.  101: dp_kmeans_step_u8 takes mean_dev (round 3); dp_distinct_first_u8, dp_kmeans_hist_* (round 4). */
+/* 100: rounds 1-2.  101: dp_kmeans_step_u8 takes mean_dev (round 3); round 4: dp_distinct_first_u8, dp_kmeans_hist_*,
+ * dp_hybrid_numba_u8, dp_error_diffusion_numba_u8 computes the float64 reading of the numba branch. */
 #define DP_ABI_VERSION 101
 
 #define DP_MODE_NEAREST 0 /* NoDitherStrategy                     dithering_lib.py:333-341 */
