@@ -167,7 +167,7 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sk
         hist = None
     if hist is None and histogram and K <= backend.KMEANS_HIST_MAX_K and 0 < flat.shape[0] < (1 << 32):
         hist = backend.ColourHistogram(flat)
-
+    if hist is not None:
         def one_pass(c, tot, want_sq, mean):
             hist.step_into(c, tot, want_sq, mean)
     else:
