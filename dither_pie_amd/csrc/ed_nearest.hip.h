@@ -31,6 +31,21 @@ __device__ __forceinline__ int ed_key16(const float4 c, const float o0, const fl
     return (int)((__float_as_uint(d) & ~15u) | tag);
 }
 
+// The same key from a candidate's EXPANDED record {-2x, -2y, -2z, |c|^2 + 2^18} (ediff.hip, palettes of up to 16 colours):
+// |c - o|^2 - |o|^2 + 2^18 in three fused multiply-adds, four instructions per candidate with the tag instead of seven.  The
+// term |o|^2 is common to all candidates and the bias keeps the value inside [2^16, 2^19) for points of the cube -- positive,
+// so the bit patterns order like the values, and with an ulp of at most 2^-5: one rounding of the fourth word (float
+// palettes; integer ones are exact), one per multiply-add and up to 8 ulp from the tag bits are below 0.32 in absolute
+// terms per key (ed_expanded_margin).
+__device__ __forceinline__ int ed_key_expanded(const float4 x, const float o0, const float o1, const float o2, const uint32_t tag)
+{
+    keep_record_whole(x);
+    const float d = __fmaf_rn(x.x, o0, __fmaf_rn(x.y, o1, __fmaf_rn(x.z, o2, x.w)));
+    return (int)((__float_as_uint(d) & ~7u) | tag);
+}
+constexpr float kEdExpandedBias = 262144.0f;
+constexpr float kEdExpandedMargin = 0.75f;  // > 2 * 0.32: a second key this far above the first proves the float64 order
+
 __device__ __forceinline__ int ed_med3(const int a, const int b, const int c)
 {
     int r;
@@ -139,10 +154,12 @@ __device__ __forceinline__ int nearest_color(const PalDev &pal, const float4 *__
 // every step of the dependency chain would pay).
 // `lists16` (wavefront kernel on the few-frames schedule, palettes of 17..256 colours; else nullptr): an LDS copy of the
 // lists of the 16x16x16 cells in the format of the 8x8x8 table (count byte 255: more than 15 entries, use that table).
-template <int CAP>
+// `expanded` (with `coarse`, EXPANDED instances): the candidates' expanded records for ed_key_expanded.
+template <int CAP, bool EXPANDED = false>
 __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const float4 *__restrict__ cand,
                                                    const uint32_t *__restrict__ coarse, const float o0, const float o1,
-                                                   const float o2, const uint4 *__restrict__ lists16 = nullptr)
+                                                   const float o2, const uint4 *__restrict__ lists16 = nullptr,
+                                                   const float4 *__restrict__ expanded = nullptr)
 {
     float b0 = __int_as_float(0x7f800000), b1 = b0;
     int i0 = 0;
@@ -162,13 +179,33 @@ __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const floa
         const int n = (int)(e & 15u);
         if (n <= 7) {
             const int j1 = (e >> 4) & 15, j2 = (e >> 8) & 15, j3 = (e >> 12) & 15, j4 = (e >> 16) & 15;
+            if (EXPANDED) {
+                const float4 x1 = expanded[j1], x2 = expanded[j2], x3 = expanded[j3], x4 = expanded[j4];
+                int k1 = ed_key_expanded(x1, o0, o1, o2, 1u), k2 = ed_key_expanded(x2, o0, o1, o2, 2u),
+                    k3 = ed_key_expanded(x3, o0, o1, o2, 3u), k4 = ed_key_expanded(x4, o0, o1, o2, 4u);
+                int m0 = min(min(k1, k2), k3), m1 = ed_med3(k1, k2, k3);
+                m1 = ed_med3(m0, m1, k4);
+                m0 = min(m0, k4);
+                if (n > 4) {
+                    const float4 x5 = expanded[(e >> 20) & 15], x6 = expanded[(e >> 24) & 15], x7 = expanded[(e >> 28) & 15];
+                    const int k5 = ed_key_expanded(x5, o0, o1, o2, 5u), k6 = ed_key_expanded(x6, o0, o1, o2, 6u),
+                              k7 = ed_key_expanded(x7, o0, o1, o2, 7u);
+                    m1 = ed_med3(m0, m1, k5);
+                    m0 = min(m0, k5);
+                    m1 = ed_med3(m0, m1, k6);
+                    m0 = min(m0, k6);
+                    m1 = ed_med3(m0, m1, k7);
+                    m0 = min(m0, k7);
+                }
+                if (__int_as_float(m1 & ~7) - __int_as_float(m0 & ~7) > kEdExpandedMargin) return (int)((e >> (4 * (m0 & 7))) & 15u);
+            }
             const float4 c1 = cand[j1], c2 = cand[j2], c3 = cand[j3], c4 = cand[j4];
             // First a scan without bookkeeping: key = float32 distance bits (non-negative floats order as integers) with
             // the list position in the low 3 bits, the two smallest keys from a min3/med3 network -- 8 instructions per
             // position instead of 16.  Unused positions hold an entry that is not on the list (ediff.hip, build_ed_cells).
             // The masked bits cost up to 7 ulp (8.4e-7 relative) on top of the 2e-6 margin of the float32 evaluation: a
             // second key more than 3e-6 above the first proves the float64 order; otherwise the scan below decides as before.
-            {
+            if (!EXPANDED) {
                 int k1 = ed_key(c1, o0, o1, o2, 1u), k2 = ed_key(c2, o0, o1, o2, 2u), k3 = ed_key(c3, o0, o1, o2, 3u),
                     k4 = ed_key(c4, o0, o1, o2, 4u);
                 int m0 = min(min(k1, k2), k3), m1 = ed_med3(k1, k2, k3);

@@ -234,6 +234,13 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
     if (pal.ed_coarse)
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_coarse[i] = pal.ed_coarse[i];
     const uint32_t *coarse = pal.ed_coarse ? s_coarse : nullptr;
+    // ... and their expanded records for the key scan (ed_nearest.hip.h, ed_key_expanded): |c|^2 rounded once, from float64
+    __shared__ float4 s_expanded[16];
+    if (pal.ed_coarse && threadIdx.x < 16) {
+        const float4 c = threadIdx.x < (unsigned)pal.K ? pal.fcand[threadIdx.x] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const double n2 = (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z + (double)kEdExpandedBias;
+        s_expanded[threadIdx.x] = make_float4(-2.0f * c.x, -2.0f * c.y, -2.0f * c.z, (float)n2);
+    }
     __shared__ uint4 s_lists16[MAXW <= 4 ? 4096 : 1];
     const uint4 *lists16 = nullptr;
     if (MAXW <= 4 && pal.ed_lists16) {
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
                     const int j = NB ? nearest_numba_f64(s_pal, pal.K, o0, o1, o2)
-                                     : (pal.ed_cells ? nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2, lists16)
+                                     : (pal.ed_cells ? nearest_color_cells<CAP, true>(pal, s_pal, coarse, o0, o1, o2, lists16, s_expanded)
                                                      : nearest_color<CAP>(pal, s_pal, o0, o1, o2));
                     const float4 pj = s_pal[j];
                     e0 = err_of<NB>(o0, pj.x);

@@ -1,6 +1,6 @@
 """use_gamma with a palette extracted from the content (median cut of the linearised image, as apply_dithering does with
 palette=None): ordered_compact_float_kernel against ordered_lean_float_kernel (DP_NO_COMPACT_KERNEL=1), 24 4K frames.
-usage: gamma_crowded.py"""
+usage: gamma_crowded.py [SWITCH]   (another DP_* switch for the second leg, e.g. DP_NO_ROTATED_RECORDS)"""
 import os, sys; sys.path.insert(0, '.')
 os.environ["DITHER_PIE_EXPERIMENTS"] = "1"
 import numpy as np, torch
@@ -31,7 +31,7 @@ for kind in ("smooth", "dark"):
         pal = ColorReducer.reduce_colors(Image.fromarray(_tables.LUT_IN[a], "RGB"), K)   # dithering_lib.py:1960-1966
         d = ImageDitherer(K, DitherMode.BAYER, pal, True, {"size": "8x8"}).prepare()
         res = []
-        for i, env in enumerate(({}, {"DP_NO_COMPACT_KERNEL": "1"})):
+        for i, env in enumerate(({}, {(sys.argv[1] if len(sys.argv) > 1 else "DP_NO_COMPACT_KERNEL"): "1"})):
             for k, v in env.items(): os.environ[k] = v
             res.append(timeit(lambda: d.apply_dithering_frames(f, out=outs[i])))
             for k in env: del os.environ[k]
