@@ -1359,17 +1359,14 @@ __global__ __launch_bounds__(kCellBlock, HALF ? 8 : 4) void ordered_compact_kern
         if (WARP) xc = (uint32_t)s_lut[x & 255u] | ((uint32_t)s_lut[256u + ((x >> 8) & 255u)] << 8) | ((uint32_t)s_lut[512u + (x >> 16)] << 16);
         const uint32_t t = xc & 0xf0f0f0u, y = t | (t << 12);
         uint2 b = *reinterpret_cast<const uint2 *>(s_tab + ((y >> 13) & 0x7ff8u));  // slot (r' | b'<<4 | g'<<8) x 8 bytes
-        stuck = false;
-        for (int bit = 3; b.y == 0xffffffffu; --bit) {
-            if ((b.x & 0x40000000u) || bit < 0) {
-                stuck = true;
-                break;
-            }
+        // (one exit condition: a loop with a break inside costs ~20 scalar instructions of mask bookkeeping per round)
+        for (int bit = 3; bit >= 0 && b.y == 0xffffffffu && !(b.x & 0x40000000u); --bit) {
             // child number r<<2 | g<<1 | b from bit `bit` of the three coordinates, times 8 bytes: the three bits land on
             // bits 18, 17, 16 of the product (no carries: all partial products are distinct powers of two)
             const uint32_t sub8 = (__umul24((xc >> bit) & 0x010101u, 0x40201u) >> 13) & 0x38u;
             b = *reinterpret_cast<const uint2 *>(s_tab + ((b.x & 0xffffffu) | sub8));
         }
+        stuck = b.y == 0xffffffffu;  // still a marker: a single colour with more than 8 candidates (or a table deeper than its colours)
         lo = b.x;
         hi = b.y;
     };
@@ -2407,14 +2404,13 @@ __global__ __launch_bounds__(kCellBlock) void ordered_compact_float_kernel(const
                 const uint32_t t = x & 0xf0f0f0u, y = t | (t << 12);
                 uint2 blk = *reinterpret_cast<const uint2 *>(s_tab + ((y >> 13) & 0x7ff8u));
                 bool s = straddle;
-                for (int bit = 3; blk.y == 0xffffffffu; --bit) {
-                    if ((blk.x & 0x40000000u) || bit < 0) {
-                        s = true;  // a single colour with more than 8 candidates: fix-up pass
-                        blk = make_uint2(0u, 0u);  // any valid entries
-                        break;
-                    }
+                for (int bit = 3; bit >= 0 && blk.y == 0xffffffffu && !(blk.x & 0x40000000u); --bit) {  // (one exit condition: see ordered_compact_kernel)
                     const uint32_t sub8 = (__umul24((x >> bit) & 0x010101u, 0x40201u) >> 13) & 0x38u;
                     blk = *reinterpret_cast<const uint2 *>(s_tab + ((blk.x & 0xffffffu) | sub8));
+                }
+                if (blk.y == 0xffffffffu) {  // still a marker: a single colour with more than 8 candidates -- fix-up pass
+                    s = true;
+                    blk = make_uint2(0u, 0u);  // any valid entries
                 }
                 blo[q] = blk.x;
                 bhi[q] = blk.y;

@@ -1,6 +1,7 @@
 """Crowded palettes (median cut / k-means of the content itself), 24 4K frames: the compact kernel (default) against the
 adaptive lean kernel (DP_NO_COMPACT_KERNEL=1) and against one workgroup per CU (DP_COMPACT_NO_HALF=1), same process, same
-box; outputs compared byte for byte.  usage: crowded_ab.py [K ...]"""
+box; outputs compared byte for byte.  usage: crowded_ab.py [K ...] [DP_SWITCH]   (a DP_* switch replaces the third leg, e.g.
+DP_COMPACT_NO_CLASSES: every slot through the decision arithmetic)"""
 import os, sys; sys.path.insert(0, '.')
 os.environ["DITHER_PIE_EXPERIMENTS"] = "1"
 import numpy as np, torch
@@ -21,7 +22,8 @@ def timeit(fn, n=5):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return min(ts)
-Ks = [int(v) for v in sys.argv[1:]] or [256, 64]
+Ks = [int(v) for v in sys.argv[1:] if v.isdigit()] or [256, 64]
+THIRD = ([v for v in sys.argv[1:] if v.startswith("DP_")] or ["DP_COMPACT_NO_HALF"])[0]
 for kind in ("smooth", "dark"):
     a = img(kind)
     f = torch.from_numpy(a).cuda().repeat(4, 4, 1).unsqueeze(0).repeat(24, 1, 1, 1).contiguous()
@@ -32,10 +34,10 @@ for kind in ("smooth", "dark"):
             for mode, params in ((DitherMode.BAYER, {"size": "8x8"}), (DitherMode.NONE, {})):
                 d = ImageDitherer(K, mode, pal, False, params).prepare()
                 res = []
-                for i, env in enumerate(({}, {"DP_NO_COMPACT_KERNEL": "1"}, {"DP_COMPACT_NO_HALF": "1"})):
+                for i, env in enumerate(({}, {"DP_NO_COMPACT_KERNEL": "1"}, {THIRD: "1"})):
                     for k, v in env.items(): os.environ[k] = v
                     res.append(timeit(lambda: d.apply_dithering_frames(f, out=outs[i])))
                     for k in env: del os.environ[k]
                 same = torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
                 print(f"{kind:7s} K={K:3d} {src:10s} {mode.value:6s}: compact {res[0]:6.3f} ms ({24*2160*3840/res[0]/1e6:6.1f} Gpx/s) | lean adaptive {res[1]:6.3f} ms | "
-                      f"compact, one workgroup per CU {res[2]:6.3f} ms | identical bytes: {same}", flush=True)
+                      f"compact, {THIRD}=1 {res[2]:6.3f} ms | identical bytes: {same}", flush=True)
