@@ -2,7 +2,7 @@
 the hybrid diffuser's numba branch)
 against the oracle: palette sizes around every table boundary (2, 8, 9, 16, 17, 64, 256), random / uniform / clustered
 palettes, gamma on and off, shapes from 1x1 up to a few bands, batches.  run(seed, n) -> number of mismatches.
-Used by tests/test_gpu_kernels.py; `python tests/fuzz_diffusion.py [seed] [n]` runs it by hand on a GPU box."""
+Used by tests/test_gpu_kernels.py; `python tests/fuzz_diffusion.py [seed] [n] [K,K,...]` runs it by hand on a GPU box."""
 import os
 import sys
 
@@ -37,14 +37,14 @@ def _image(rs, h, w, kind, pal):
     return ((pa[i] + pa[j]) // 2).astype(np.uint8)
 
 
-def run(seed, n, verbose=False):
+def run(seed, n, verbose=False, ks=None):
     import torch
     from dither_pie_amd import backend as be
     from oracle import oracle as orc
     rs = np.random.RandomState(seed)
     bad = 0
     for case in range(n):
-        K = int(rs.choice([2, 5, 8, 9, 12, 16, 17, 40, 64, 256]))
+        K = int(rs.choice(ks if ks else [2, 5, 8, 9, 12, 16, 17, 40, 64, 256]))
         pal = _palette(rs, orc, K, int(rs.randint(0, 3)))
         h = int(rs.choice([1, 2, 3, 17, 63, 64, 65, 130, 200]))
         w = int(rs.choice([1, 2, 3, 7, 8, 9, 31, 64, 97, 160, 333]))
@@ -90,4 +90,6 @@ def run(seed, n, verbose=False):
 if __name__ == "__main__":
     s = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    print("mismatches:", run(s, n, verbose=len(sys.argv) > 3))
+    # a third argument "K,K,...": palette sizes to draw from (e.g. 9,12,16: the expanded-key scan of ed_nearest.hip.h); anything else: verbose
+    ks = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 and sys.argv[3][0].isdigit() else None
+    print("mismatches:", run(s, n, verbose=len(sys.argv) > 3 and ks is None, ks=ks))
