@@ -414,3 +414,34 @@ def test_pyset_order_replay(tmp_path):
         real = list(set(zip(arr[:, 0].tolist(), arr[:, 1].tolist(), arr[:, 2].tolist())))
         assert nd.value == len(real)
         assert [tuple(int(v) for v in c) for c in arr[order[:nd.value]]] == real, (n, top)
+
+
+def test_expanded_key_error_bound():
+    """The candidate scan of error diffusion for palettes of up to 16 colours ranks by |c|^2 + 2^18 - 2 c.o in three float32
+    multiply-adds (ed_nearest.hip.h: ed_key_expanded) and accepts the winner when the second key is more than 0.75 above the
+    first.  The claim behind that margin, checked here on the float32 arithmetic itself: for points of the cube the value stays
+    inside [2^16, 2^19) (positive: bit patterns order like values) and is within 0.32 of the exact one, tag bits included --
+    so a computed gap above 0.75 proves the float64 order."""
+    rs = np.random.RandomState(5)
+
+    def fma32(a, b, c):  # float32 fused multiply-add: the product of two float32 values is exact in float64
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+    worst = 0.0
+    for trial in range(24):
+        if trial % 2 == 0:
+            pal = rs.randint(0, 256, (16, 3)).astype(np.float32)
+        else:  # gamma palettes: float32 values anywhere in [0, 255]
+            pal = (255.0 * (rs.rand(16, 3) ** 2.2)).astype(np.float32)
+        o = np.clip(rs.uniform(-20.0, 275.0, (20000, 3)), 0.0, 255.0).astype(np.float32)  # clamped, as the diffusers' points are
+        if trial % 3 == 0:
+            o = np.round(o)  # integer points: the tie-rich case
+        w = ((pal.astype(np.float64) ** 2).sum(1) + 262144.0).astype(np.float32)
+        neg2 = (-2.0 * pal).astype(np.float32)
+        for j in range(16):
+            key = fma32(neg2[j, 0][None], o[:, 0], fma32(neg2[j, 1][None], o[:, 1], fma32(neg2[j, 2][None], o[:, 2], w[j][None])))
+            assert key.min() >= 65536.0 and key.max() < 524288.0
+            tagged = ((key.view(np.uint32) & ~np.uint32(7)) | np.uint32(7)).view(np.float32)  # the largest tag
+            exact = ((pal[j].astype(np.float64)[None] - o.astype(np.float64)) ** 2).sum(1) - (o.astype(np.float64) ** 2).sum(1) + 262144.0
+            worst = max(worst, float(np.abs(key.astype(np.float64) - exact).max()), float(np.abs(tagged.astype(np.float64) - exact).max()))
+    assert worst < 0.32, worst
