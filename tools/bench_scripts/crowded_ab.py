@@ -1,7 +1,7 @@
 """Crowded palettes (median cut / k-means of the content itself), 24 4K frames: the compact kernel (default) against the
 adaptive lean kernel (DP_NO_COMPACT_KERNEL=1) and against one workgroup per CU (DP_COMPACT_NO_HALF=1), same process, same
-box; outputs compared byte for byte.  usage: crowded_ab.py [K ...] [DP_SWITCH]   (a DP_* switch replaces the third leg, e.g.
-DP_COMPACT_NO_CLASSES: every slot through the decision arithmetic)"""
+box; outputs compared byte for byte.  usage: crowded_ab.py [K ...] [DP_SWITCH]   (a DP_* switch of the experiments library replaces the
+third leg: how the variants of profiles/experiments/r04_compact_kernel_trials.md were measured)"""
 import os, sys; sys.path.insert(0, '.')
 os.environ["DITHER_PIE_EXPERIMENTS"] = "1"
 import numpy as np, torch

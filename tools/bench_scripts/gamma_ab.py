@@ -1,7 +1,7 @@
 """use_gamma (float palettes), 24 4K frames: ordered_compact_float_kernel (default) against ordered_lean_float_kernel
 (DP_NO_COMPACT_KERNEL=1); whole call (main kernel + fix-up pass), same
 process, outputs compared byte for byte.  usage: gamma_ab.py [SWITCH]   (another DP_* switch to set for the second
-leg instead, e.g. DP_NO_ROTATED_RECORDS: the compact float kernel with and without the sixteen record copies)"""
+leg instead: how profiles/experiments/r04_rotated_records.md was measured, with a switch that variant carried)"""
 import os, sys; sys.path.insert(0, '.')
 os.environ["DITHER_PIE_EXPERIMENTS"] = "1"
 import numpy as np, torch

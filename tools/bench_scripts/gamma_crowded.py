@@ -1,6 +1,6 @@
 """use_gamma with a palette extracted from the content (median cut of the linearised image, as apply_dithering does with
 palette=None): ordered_compact_float_kernel against ordered_lean_float_kernel (DP_NO_COMPACT_KERNEL=1), 24 4K frames.
-usage: gamma_crowded.py [SWITCH]   (another DP_* switch for the second leg, e.g. DP_NO_ROTATED_RECORDS)"""
+usage: gamma_crowded.py [SWITCH]   (another DP_* switch of the experiments library for the second leg)"""
 import os, sys; sys.path.insert(0, '.')
 os.environ["DITHER_PIE_EXPERIMENTS"] = "1"
 import numpy as np, torch
