@@ -443,6 +443,25 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     // fully unrolled with constant indices: the tap parameters stay in scalar registers instead of
                     // being re-read from the kernel arguments at every step
                     // no column test: the rings hold zero errors for the two columns either side of the image (below)
+                    if (!NB && EXACT) {
+                        // the reads of every tap first, then the sums in the reference's order: written as one loop the compiler
+                        // waits for each tap's two reads before it issues the next tap's (eight LDS round trips in a row per step)
+                        float v0[NT], v1[NT], v2[NT];
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) {
+                            lds_float_t *src = tbase[k] + ((x - taps.dx[k]) & (int)tmask[k]) * 3;
+                            v0[k] = (float)src[0];
+                            v1[k] = (float)src[1];
+                            v2[k] = (float)src[2];
+                        }
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) {
+                            const float wq = taps.wq[k];
+                            a0 = __fadd_rn(a0, __fmul_rn(v0[k], wq));
+                            a1 = __fadd_rn(a1, __fmul_rn(v1[k], wq));
+                            a2 = __fadd_rn(a2, __fmul_rn(v2[k], wq));
+                        }
+                    } else {
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
                         if (EXACT || k < taps.n) {
@@ -459,6 +478,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                                 a2 = __fadd_rn(a2, __fmul_rn((float)src[2], wq));
                             }
                         }
+                    }
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
                     const int j = NB ? nearest_numba_f64(s_pal, pal.K, o0, o1, o2)

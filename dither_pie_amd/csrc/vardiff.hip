@@ -629,22 +629,35 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     const float g0 = (float)s_lut[pxv & 255u], g1 = (float)s_lut[(pxv >> 8) & 255u],
                                 g2 = (float)s_lut[(pxv >> 16) & 255u];
                     float a0 = g0, a1 = g1, a2 = g2;
+                    // the reads of every tap first (and, Ostromoukhov, the coefficient reads that depend on them), then the sums in
+                    // the reference's order: written as one loop the compiler waits for each tap's read before it issues the next
+                    // tap's -- one LDS round trip after the other on the step's critical path (ediff.hip, round 4)
+                    float s0[4], s1[4], s2[4], s3[4], wt[4];
 #pragma unroll
                     for (int k = 0; k < ntaps; ++k) {
                         lds_float_t *src = tb[k] + ((x - kDx[k]) & (int)tm[k]) * 4;
-                        const float sa = src[3];
-                        float wk;
+                        s0[k] = src[0];
+                        s1[k] = src[1];
+                        s2[k] = src[2];
+                        s3[k] = src[3];
+                    }
+#pragma unroll
+                    for (int k = 0; k < ntaps; ++k) {
+                        const float sa = s3[k];
                         if (model == 1)
-                            wk = __fmul_rn(kW[k], sa);
+                            wt[k] = __fmul_rn(kW[k], sa);
                         else if (model == 3)
-                            wk = sa == 0.0f ? 0.0f : kW[k];  // a closed gate: the source adds +-0, which changes nothing (a is never -0)
+                            wt[k] = sa == 0.0f ? 0.0f : kW[k];  // a closed gate: the source adds +-0, which changes nothing (a is never -0)
                         else if (model == 4)
-                            wk = vp.coef[3 * (int)sa + kCol[k]];
+                            wt[k] = vp.coef[3 * (int)sa + kCol[k]];
                         else
-                            wk = kW[k];
-                        a0 = __fadd_rn(a0, __fmul_rn(src[0], wk));
-                        a1 = __fadd_rn(a1, __fmul_rn(src[1], wk));
-                        a2 = __fadd_rn(a2, __fmul_rn(src[2], wk));
+                            wt[k] = kW[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < ntaps; ++k) {
+                        a0 = __fadd_rn(a0, __fmul_rn(s0[k], wt[k]));
+                        a1 = __fadd_rn(a1, __fmul_rn(s1[k], wt[k]));
+                        a2 = __fadd_rn(a2, __fmul_rn(s2[k], wt[k]));
                     }
                     float o0 = a0, o1 = a1, o2 = a2;
                     if (model == 4) {

@@ -1,5 +1,5 @@
 """One 4K frame (and 24, and 256) through error diffusion, timed with events over several repetitions.
-usage: ed_single.py [variant] [K] [reps]"""
+usage: ed_single.py [variant | perceptual | hybrid | adaptive_variance | ostromoukhov] [K] [reps]"""
 import sys; sys.path.insert(0, '.')
 import torch, numpy as np
 from dither_pie_amd.dithering_lib import ImageDitherer, DitherMode, ColorReducer
@@ -10,7 +10,10 @@ pal = ColorReducer.generate_uniform_palette(K) if K <= 64 else [tuple(int(v) for
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 nmax = 256
 f = torch.randint(0, 256, (nmax, 2160, 3840, 3), dtype=torch.uint8, device='cuda', generator=g); o = torch.empty_like(f)
-d = ImageDitherer(K, DitherMode.ERROR_DIFFUSION, pal, False, {"variant": variant, "serpentine": "false"})
+if variant in ("perceptual", "hybrid", "adaptive_variance", "ostromoukhov"):
+    d = ImageDitherer(K, DitherMode(variant), pal, False, {})
+else:
+    d = ImageDitherer(K, DitherMode.ERROR_DIFFUSION, pal, False, {"variant": variant, "serpentine": "false"})
 for nf in (1, 24, nmax):
     d.apply_dithering_frames(f[:nf], out=o[:nf]); torch.cuda.synchronize()
     ts = []
