@@ -521,6 +521,15 @@ def main():
         extra["c3_fs_k16_4k_one_frame_ms"] = round(t1f * 1e3, 2)
         extra["c3_note"] = (f"{nf3} frames in flight per GPU (one workgroup of 16 waves per frame), "
                             "bit-exact float32 error accumulation")
+        # a batch larger than the device (what a video is): one persistent workgroup per CU whose waves run on into the next
+        # frame's bands, so that the tail of a frame (34 bands over 16 waves: the third round has two waves busy) is not idle
+        nf3l = 3 * nf3
+        f3l = f3.repeat(3, 1, 1, 1)
+        o3l = torch.empty_like(f3l)
+        t3l = timed(lambda: d3.apply_dithering_frames(f3l, out=o3l), 2, 1) / 2
+        extra["c3_fs_k16_4k_long_batch_mpixel_per_s"] = round(world * nf3l * H4K * W4K / t3l / 1e6, 2)
+        extra["c3_long_batch_note"] = (f"{nf3l} frames per GPU in one call: persistent workgroups, three frames each")
+        del f3l, o3l
         # the same frame with 256 (random) colours: candidate lists instead of a 16-entry table
         pal3b = [tuple(int(v) for v in c) for c in np.random.RandomState(7).randint(0, 256, (256, 3))]
         d3b = ImageDitherer(256, DitherMode.ERROR_DIFFUSION, pal3b, False, {"variant": "floyd_steinberg", "serpentine": "false"})

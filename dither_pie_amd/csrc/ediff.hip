@@ -190,7 +190,8 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
                                                                       void *__restrict__ bnd_all_v, const int G,
-                                                                      uint32_t *__restrict__ gprog_all, const int test_giveup)
+                                                                      uint32_t *__restrict__ gprog_all, const int test_giveup,
+                                                                      const uint32_t n_frames)
 {
     typedef typename ErrT<NB>::type E;  // an error: float, or double with the numba arithmetic
     E *__restrict__ bnd_all = reinterpret_cast<E *>(bnd_all_v);
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
     __shared__ E s_vring[MAXW][2][64][3];                // errors of the two rows above the band (64-column ring)
     __shared__ E s_bout[MAXW][2][kPeriod][3];            // this period's errors of rows 62/63, flushed to global
     __shared__ uint8_t s_lut[256];
-    __shared__ volatile uint32_t s_prog[MAXW];           // (band << 16) | (acknowledged column of row 63 + 1024)
+    __shared__ volatile uint32_t s_prog[MAXW];           // (running band number << 16) | (acknowledged column of row 63 + 1024)
     // {x, y, z, out_rgb bits} of the palette; palettes of 9..16 colours keep the candidate lists of the 16^3 cells
     // (4096 words) behind their 16 entries
     __shared__ float4 s_pal[DP_MAX_COLORS + 16];
@@ -225,10 +226,14 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
-    const size_t f = blockIdx.x / (unsigned)G;
+    // PERSISTENT (plain one-workgroup launches, G == 1 without progress words in global memory): the workgroup does the frames
+    // blockIdx.x, blockIdx.x + gridDim.x, ... and its waves take the bands of ALL of them round-robin by a running band number
+    // -- a wave that has finished its last band of one frame starts on the next frame (whose first band waits for nobody)
+    // instead of idling through the tail: 34 bands of a 4K frame over 16 waves are two full rounds and one with two waves busy.
+    const bool persist = G == 1 && gprog_all == nullptr;
+    const size_t f0 = blockIdx.x / (unsigned)G;
     const int NWT = NW * G;                                // waves working on this frame
     const int gw = (int)(blockIdx.x % (unsigned)G) * NW + wv;  // this wave's number among them
-    uint32_t *gprog = gprog_all + f * (size_t)kEdProgWords;   // [NWT] progress words + [kEdProgWords-1] give-up flag
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
     for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
     if (pal.ed_coarse)
@@ -249,15 +254,21 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
     }
     if (threadIdx.x < MAXW) s_prog[threadIdx.x] = 0;
     if (threadIdx.x < 4) s_zero[threadIdx.x] = (E)0;
-    const uint8_t *fin = in + f * (size_t)h * w * 3;
-    uint8_t *fout = out + f * (size_t)h * w * 3;
     const long frame_bytes = (long)h * w * 3;
-    E *bnd = bnd_all + f * (size_t)4 * w * 3;  // [2 buffers][2 rows][w][3]
     const int skew = taps.skew;
     const int n_bands = (h + 63) / 64;
+    const int n_mine = persist ? (int)((n_frames - (uint32_t)f0 + gridDim.x - 1u) / gridDim.x) : 1;  // frames of this workgroup
+    const int n_gbands = n_mine * n_bands;  // (< 65536: the launcher sizes the grid for it)
     __syncthreads();  // the only workgroup barrier: from here on waves only meet through s_prog
 
-    for (int band = gw; band < n_bands; band += NWT) {
+    // gb: running band number over this workgroup's frames (= the band, with one frame); the progress words carry it
+    for (int gb = gw; gb < n_gbands; gb += NWT) {
+        const int fi = gb / n_bands, band = gb - fi * n_bands;
+        const size_t f = f0 + (size_t)fi * gridDim.x;
+        const uint8_t *fin = in + f * (size_t)h * w * 3;
+        uint8_t *fout = out + f * (size_t)h * w * 3;
+        E *bnd = bnd_all + f * (size_t)4 * w * 3;  // [2 buffers][2 rows][w][3]
+        uint32_t *gprog = gprog_all + f * (size_t)kEdProgWords;   // [NWT] progress words + [kEdProgWords-1] give-up flag
         const int r = band * 64 + L;
         const E *bprev = bnd + (size_t)((band + 1) & 1) * 2 * w * 3;  // written by band-1
         E *bnext = bnd + (size_t)(band & 1) * 2 * w * 3;
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                 // boundary columns produced in steps < t0 - kPeriod are acknowledged
                 int ack = t0 - kPeriod - 63 * skew + 1024;
                 ack = ack < 0 ? 0 : ack;
-                const uint32_t word = ((uint32_t)band << 16) | (uint32_t)ack;
+                const uint32_t word = ((uint32_t)gb << 16) | (uint32_t)ack;
                 if (G == 1) s_prog[wv] = word;
                 else __hip_atomic_store(&gprog[gw], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     const uint32_t want = (uint32_t)(need + 1024);
                     for (uint32_t spins = 0;; ++spins) {
                         const uint32_t v = G == 1 ? s_prog[pw] : __hip_atomic_load(&gprog[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((int)(v >> 16) > band - 1 || ((int)(v >> 16) == band - 1 && (v & 0xffffu) >= want)) break;
+                        if ((int)(v >> 16) > gb - 1 || ((int)(v >> 16) == gb - 1 && (v & 0xffffu) >= want)) break;
                         __builtin_amdgcn_s_sleep(4);
                         // across workgroups the producer is another workgroup of the grid: never wait for it forever
                         // (a give-up flag stays in the workspace; the launch ends instead of hanging)
@@ -534,8 +545,8 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
         // band finished: once its boundary stores are acknowledged the next band may read any column
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (L == 0) {
-            if (G == 1) s_prog[wv] = ((uint32_t)(band + 1) << 16);
-            else __hip_atomic_store(&gprog[gw], (uint32_t)(band + 1) << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (G == 1) s_prog[wv] = ((uint32_t)(gb + 1) << 16);
+            else __hip_atomic_store(&gprog[gw], (uint32_t)(gb + 1) << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -929,17 +940,32 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         // over partly written frames.
         const int test_giveup = exp_env("DP_ED_TEST_GIVEUP") ? 1 : 0;
         const int nw1 = n_bands < kMaxWaves ? n_bands : kMaxWaves;
+        // More frames than CUs, one workgroup per frame and CU (more than 4 waves: the instances that fill a CU's LDS): a
+        // PERSISTENT grid of one workgroup per CU, each doing every grid-th frame with its waves running on into the next frame
+        // (ed_wavefront_kernel) -- the tail of a frame, when most of its bands are done, overlaps the head of the next.
+        // The running band number has 16 bits in the progress words: enough workgroups that none counts past them.
+        int64_t pgrid = n_frames * G;
+        if (G == 1 && nw > 4 && cus > 0 && n_frames > cus && !exp_env("DP_ED_NO_PERSIST")) {
+            pgrid = cus;
+            const int64_t need = (n_frames * n_bands + 59999) / 60000;
+            if (pgrid < need) pgrid = need;
+        }
+        if (const char *e = exp_env("DP_ED_GRID")) {  // experiments / tests: any grid (several frames per workgroup on small batches)
+            const int64_t v = atoll(e);
+            if (G == 1 && v >= 1 && v <= n_frames && (n_frames + v - 1) / v * n_bands < 60000) pgrid = v;
+        }
+        const uint32_t nfr = (uint32_t)n_frames;
 #define DP_EDW(C, N, X)                                                                                                   \
     do {                                                                                                                 \
         if (nw <= 4)                                                                                                     \
-            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, 4>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, \
-                               pal, t, ws, G, gprog, test_giveup);                            \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, 4>), dim3((unsigned)pgrid), dim3(64 * nw), 0, s, in, out, h, w, \
+                               pal, t, ws, G, gprog, test_giveup, nfr);                            \
         else                                                                                                             \
-            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in,  \
-                               out, h, w, pal, t, ws, G, gprog, test_giveup);                 \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves>), dim3((unsigned)pgrid), dim3(64 * nw), 0, s, in,  \
+                               out, h, w, pal, t, ws, G, gprog, test_giveup, nfr);                 \
         if (G > 1)                                                                                                       \
             hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out,  \
-                               h, w, pal, t, ws, 1, gprog, 0);                                \
+                               h, w, pal, t, ws, 1, gprog, 0, nfr);                                \
     } while (0)
 #define DP_EDN(N, X)                                                                                                      \
     do {                                                                                                                 \
@@ -951,14 +977,14 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
             if (nw > kNbWaves) nw = kNbWaves;  // (bands are dealt round-robin over whatever waves there are)
             const int nwr = nw1 < kNbWaves ? nw1 : kNbWaves;
             if (nw <= 4)
-                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, 4, true>), dim3((unsigned)(n_frames * G)), dim3(64 * nw),
-                                   0, s, in, out, h, w, pal, t, ws, G, gprog, test_giveup);
+                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, 4, true>), dim3((unsigned)pgrid), dim3(64 * nw),
+                                   0, s, in, out, h, w, pal, t, ws, G, gprog, test_giveup, nfr);
             else
-                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, kNbWaves, true>), dim3((unsigned)(n_frames * G)),
-                                   dim3(64 * nw), 0, s, in, out, h, w, pal, t, ws, G, gprog, test_giveup);
+                hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, kNbWaves, true>), dim3((unsigned)pgrid),
+                                   dim3(64 * nw), 0, s, in, out, h, w, pal, t, ws, G, gprog, test_giveup, nfr);
             if (G > 1)
                 hipLaunchKernelGGL((ed_wavefront_kernel<kQueueSmall, kMaxTaps, false, kNbWaves, true>), dim3((unsigned)n_frames),
-                                   dim3(64 * nwr), 0, s, in, out, h, w, pal, t, ws, 1, gprog, 0);
+                                   dim3(64 * nwr), 0, s, in, out, h, w, pal, t, ws, 1, gprog, 0, nfr);
         } else
         switch (ntaps) {  // the tap counts of the reference's kernels get a test-free instance
         case 3: DP_EDN(3, true); break;

@@ -382,7 +382,8 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                                                                      uint8_t *__restrict__ out, const int h, const int w,
                                                                      const PalDev pal, const VarParams vp,
                                                                      float *__restrict__ bnd_all, const int G,
-                                                                     uint32_t *__restrict__ gprog_all, const int test_giveup)
+                                                                     uint32_t *__restrict__ gprog_all, const int test_giveup,
+                                                                     const uint32_t n_frames)
 {
     // G == 1 with progress words given: the repair launch behind a G > 1 launch (see ed_wavefront_kernel) -- only frames
     // whose give-up flag is set are done again
@@ -409,10 +410,12 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     const int L = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int NW = blockDim.x >> 6;
-    const size_t f = blockIdx.x / (unsigned)G;
+    // PERSISTENT (plain one-workgroup launches): the workgroup does every gridDim.x-th frame, its waves taking the bands of all of
+    // them round-robin by a running band number (ediff.hip, ed_wavefront_kernel)
+    const bool persist = G == 1 && gprog_all == nullptr;
+    const size_t f0 = blockIdx.x / (unsigned)G;
     const int NWT = NW * G;
     const int gw = (int)(blockIdx.x % (unsigned)G) * NW + wv;
-    uint32_t *gprog = gprog_all + f * (size_t)kVProgWords;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
     for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
     // (model 4 clamps its values: the plain table; the others look their unclamped values up in the extended one)
@@ -422,19 +425,24 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
     const uint32_t *coarse = coarse_src ? s_coarse : nullptr;
     if (threadIdx.x < kVWaves) s_prog[threadIdx.x] = 0;
     if (threadIdx.x < 4) s_zero4[threadIdx.x] = threadIdx.x == 3 ? 1.0f : 0.0f;
-    const uint8_t *fin = in + f * (size_t)h * w * 3;
-    uint8_t *fout = out + f * (size_t)h * w * 3;
-    const uint8_t *fgate = vp.gate ? vp.gate + f * (size_t)h * w : nullptr;
     const long frame_bytes = (long)h * w * 3;
     const long gate_bytes = (long)h * w;
-    float *bnd = bnd_all + f * (size_t)4 * w * 4;  // [2 buffers][2 rows][w][4]
     constexpr int model = MODEL;
     constexpr int ntaps = model == 4 ? 3 : 4;
     constexpr int skew = 2;
     const int n_bands = (h + 63) / 64;
+    const int n_mine = persist ? (int)((n_frames - (uint32_t)f0 + gridDim.x - 1u) / gridDim.x) : 1;  // frames of this workgroup
+    const int n_gbands = n_mine * n_bands;  // (< 65536: the launcher sizes the grid for it)
     __syncthreads();
 
-    for (int band = gw; band < n_bands; band += NWT) {
+    for (int gb = gw; gb < n_gbands; gb += NWT) {  // gb: running band number over this workgroup's frames
+        const int fi = gb / n_bands, band = gb - fi * n_bands;
+        const size_t f = f0 + (size_t)fi * gridDim.x;
+        const uint8_t *fin = in + f * (size_t)h * w * 3;
+        uint8_t *fout = out + f * (size_t)h * w * 3;
+        const uint8_t *fgate = vp.gate ? vp.gate + f * (size_t)h * w : nullptr;
+        float *bnd = bnd_all + f * (size_t)4 * w * 4;  // [2 buffers][2 rows][w][4]
+        uint32_t *gprog = gprog_all + f * (size_t)kVProgWords;
         const int r = band * 64 + L;
         const float *bprev = bnd + (size_t)((band + 1) & 1) * 2 * w * 4;
         float *bnext = bnd + (size_t)(band & 1) * 2 * w * 4;
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
             if (L == 0) {
                 int ack = t0 - kVPeriod - 63 * skew + 1024;
                 ack = ack < 0 ? 0 : ack;
-                const uint32_t word = ((uint32_t)band << 16) | (uint32_t)ack;
+                const uint32_t word = ((uint32_t)gb << 16) | (uint32_t)ack;
                 if (G == 1) s_prog[wv] = word;
                 else __hip_atomic_store(&gprog[gw], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -583,7 +591,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     const uint32_t want = (uint32_t)(need + 1024);
                     for (uint32_t spins = 0;; ++spins) {
                         const uint32_t v = G == 1 ? s_prog[pw] : __hip_atomic_load(&gprog[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((int)(v >> 16) > band - 1 || ((int)(v >> 16) == band - 1 && (v & 0xffffu) >= want)) break;
+                        if ((int)(v >> 16) > gb - 1 || ((int)(v >> 16) == gb - 1 && (v & 0xffffu) >= want)) break;
                         __builtin_amdgcn_s_sleep(4);
                         // another workgroup produces this: never wait forever (a give-up flag stays in the workspace)
                         if (G != 1 && (spins > (1u << 24) || (spins % 1024u == 1023u &&
@@ -730,8 +738,8 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (L == 0) {
-            if (G == 1) s_prog[wv] = ((uint32_t)(band + 1) << 16);
-            else __hip_atomic_store(&gprog[gw], (uint32_t)(band + 1) << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (G == 1) s_prog[wv] = ((uint32_t)(gb + 1) << 16);
+            else __hip_atomic_store(&gprog[gw], (uint32_t)(gb + 1) << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -974,13 +982,25 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
         const int test_giveup = exp_env("DP_ED_TEST_GIVEUP") ? 1 : 0;
         const int nw1 = n_bands < kVWaves ? n_bands : kVWaves;
         // (behind a G > 1 launch: the repair launch for frames whose workgroups gave up waiting for each other)
+        // batches larger than the device: one persistent workgroup per CU (launch_error_diffusion, ediff.hip)
+        int64_t pgrid = n_frames * G;
+        if (G == 1 && nw > 4 && cus > 0 && n_frames > cus && !exp_env("DP_ED_NO_PERSIST")) {
+            pgrid = cus;
+            const int64_t need = (n_frames * n_bands + 59999) / 60000;
+            if (pgrid < need) pgrid = need;
+        }
+        if (const char *e = exp_env("DP_ED_GRID")) {
+            const int64_t v = atoll(e);
+            if (G == 1 && v >= 1 && v <= n_frames && (n_frames + v - 1) / v * n_bands < 60000) pgrid = v;
+        }
+        const uint32_t nfr = (uint32_t)n_frames;
 #define DP_VARW(C, M)                                                                                                     \
     do {                                                                                                                 \
-        hipLaunchKernelGGL((var_wavefront_kernel<C, M>), dim3((unsigned)(n_frames * G)), dim3(64 * nw), 0, s, in, out, h, w, pal, vp, \
-                           reinterpret_cast<float *>(ws), G, gprog, test_giveup);                                        \
+        hipLaunchKernelGGL((var_wavefront_kernel<C, M>), dim3((unsigned)pgrid), dim3(64 * nw), 0, s, in, out, h, w, pal, vp, \
+                           reinterpret_cast<float *>(ws), G, gprog, test_giveup, nfr);                                   \
         if (G > 1)                                                                                                       \
             hipLaunchKernelGGL((var_wavefront_kernel<C, M>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out, h, w, pal, vp, \
-                               reinterpret_cast<float *>(ws), 1, gprog, 0);                                              \
+                               reinterpret_cast<float *>(ws), 1, gprog, 0, nfr);                                         \
     } while (0)
 #define DP_VARW_M(C)                   \
     do {                               \

@@ -55,6 +55,12 @@ def run(seed, n, verbose=False, ks=None):
         P = be.Palette(pal_f32, out_colors, lut_in)
         t = torch.from_numpy(frames).cuda()
         which = int(rs.randint(0, 4))
+        # several frames per workgroup (the persistent grid of batches larger than the device; libditherpie_hip_exp.so reads the switch)
+        grid = int(rs.randint(1, nf + 1)) if nf > 1 and rs.randint(0, 2) else 0
+        if grid:
+            os.environ["DP_ED_GRID"] = str(grid)
+        else:
+            os.environ.pop("DP_ED_GRID", None)
         if which < 3:
             variant = VARIANTS[int(rs.randint(0, len(VARIANTS)))]
             serp = bool(rs.randint(0, 2))
@@ -78,9 +84,10 @@ def run(seed, n, verbose=False, ks=None):
                 out = d.apply_dithering_frames(t).cpu().numpy()
                 ref = np.stack([orc.apply_dithering(f, pal, mode, params, gamma) for f in frames])
                 what = f"{mode} {params}"
+        os.environ.pop("DP_ED_GRID", None)
         if not np.array_equal(out, ref):
             bad += 1
-            print(f"MISMATCH seed={seed} case={case}: {what} K={K} {nf}x{h}x{w} gamma={gamma}: "
+            print(f"MISMATCH seed={seed} case={case}: {what} K={K} {nf}x{h}x{w} gamma={gamma} grid={grid}: "
                   f"{int((out != ref).any(-1).sum())} pixels", flush=True)
         elif verbose:
             print(f"ok {case}: {what} K={K} {nf}x{h}x{w} gamma={gamma}", flush=True)

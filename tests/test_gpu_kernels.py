@@ -713,6 +713,49 @@ def test_error_diffusion_frame_spread_over_workgroups(be, orc, switches, variant
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant,K,gamma,grid", [("floyd_steinberg", 16, False, 2), ("atkinson", 12, True, 3), ("jjn", 40, False, 1),
+                                                  ("sierra_lite", 256, False, 4)])
+def test_error_diffusion_persistent_workgroups(be, orc, switches, variant, K, gamma, grid):
+    """More frames than workgroups (DP_ED_GRID forces what a batch larger than the number of CUs gets): a workgroup does every
+    grid-th frame and its waves run on into the next frame's bands by a running band number -- frames of 6 and of 5 bands (the
+    running number then changes which wave owns which band from frame to frame), the last band partial.  Same bytes as the
+    oracle for every frame, and as one workgroup per frame."""
+    import torch
+    taps, div = orc.ed_kernel(variant)
+    pal = orc.generate_uniform_palette(K) if K <= 16 else orc.palr(K, seed=K)
+    params = {"variant": variant, "serpentine": "false"}
+    for h, w, n in ((333, 90, 7), (290, 61, 9)):
+        frames = np.stack([orc.rnd(h, w, 100 * K + i) for i in range(n)])
+        P = be.Palette(*orc.prepare_palette(pal, gamma), accel=True)
+        t = torch.from_numpy(frames).cuda()
+        switches.setenv("DP_ED_ONE_WG", "1")  # (few frames: keep one workgroup per frame, the schedule a large batch has)
+        one = be.error_diffusion(t, P, taps, div, False).cpu().numpy()
+        switches.setenv("DP_ED_GRID", str(grid))
+        got = be.error_diffusion(t, P, taps, div, False).cpu().numpy()
+        switches.delenv("DP_ED_GRID")
+        for i in range(n):
+            ref = orc.apply_dithering(frames[i], pal, "error_diffusion", params, gamma)
+            _assert_same(got[i], ref, f"persistent grid {grid}, {variant}, frame {i} of {n} ({h}x{w})")
+            _assert_same(one[i], ref, f"one workgroup per frame, {variant}, frame {i}")
+
+
+@pytest.mark.gpu
+def test_error_diffusion_more_frames_than_compute_units(be, orc):
+    """The product library on a batch larger than the device has CUs (what a video is): the persistent grid it chooses by
+    itself.  330 small frames of six bands; every frame against the oracle."""
+    import torch
+    n, h, w = 330, 340, 24
+    frames = np.stack([orc.rnd(h, w, 9000 + i) for i in range(n)])
+    pal = orc.generate_uniform_palette(16)
+    taps, div = orc.ed_kernel("floyd_steinberg")
+    P = be.Palette(*orc.prepare_palette(pal, False), accel=True)
+    got = be.error_diffusion(torch.from_numpy(frames).cuda(), P, taps, div, False).cpu().numpy()
+    params = {"variant": "floyd_steinberg", "serpentine": "false"}
+    for i in range(n):
+        _assert_same(got[i], orc.apply_dithering(frames[i], pal, "error_diffusion", params, False), f"frame {i} of {n}")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,params", [("perceptual", {}), ("hybrid", {"lum_factor": 1.4, "col_factor": 0.3}),
                                          ("adaptive_variance", {"var_threshold": 200.0, "window_radius": 2}),
                                          ("ostromoukhov", {"serpentine": "false"})])
@@ -727,6 +770,27 @@ def test_variable_diffusers_frame_spread_over_workgroups(be, orc, switches, mode
         _assert_same(_run_case(be, orc, arr, pal, mode, params, gamma), ref, f"spread {mode} gamma={gamma}")
     switches.setenv("DP_ED_ONE_WG", "1")
     _assert_same(_run_case(be, orc, arr, pal, mode, params, False), orc.apply_dithering(arr, pal, mode, params, False), f"one workgroup {mode}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,params", [("perceptual", {}), ("hybrid", {"lum_factor": 1.4, "col_factor": 0.3}),
+                                         ("adaptive_variance", {"var_threshold": 200.0, "window_radius": 2}),
+                                         ("ostromoukhov", {"serpentine": "false"})])
+def test_variable_diffusers_persistent_workgroups(be, orc, switches, mode, params):
+    """The variable-weight diffusers with several frames per workgroup (DP_ED_GRID: what a batch larger than the number of CUs
+    gets): waves run on into the next frame's bands by a running band number.  Every frame against the oracle."""
+    import torch
+    from dither_pie_amd.dithering_lib import DitherMode, ImageDitherer
+    h, w, n = 290, 70, 7  # five bands, the last one partial
+    frames = np.stack([orc.rnd(h, w, 700 + i) for i in range(n)])
+    pal = orc.palr(16, 8)
+    switches.setenv("DP_ED_ONE_WG", "1")
+    for grid in (1, 3):
+        switches.setenv("DP_ED_GRID", str(grid))
+        d = ImageDitherer(16, DitherMode(mode), pal, False, params)
+        got = d.apply_dithering_frames(torch.from_numpy(frames).cuda()).cpu().numpy()
+        for i in range(n):
+            _assert_same(got[i], orc.apply_dithering(frames[i], pal, mode, params, False), f"{mode} grid {grid} frame {i}")
 
 
 @pytest.mark.gpu
