@@ -1,5 +1,5 @@
 """One 4K frame (and 24, and 256) through error diffusion, timed with events over several repetitions.
-usage: ed_single.py [variant | perceptual | hybrid | adaptive_variance | ostromoukhov] [K] [reps] [nmax=256]
+usage: ed_single.py [variant | perceptual | hybrid | adaptive_variance | ostromoukhov] [K] [reps] [nmax=256] [H=2160] [W=3840]
 (nmax: the largest batch; above the number of CUs the diffusion kernel runs its persistent grid)"""
 import sys; sys.path.insert(0, '.')
 import torch, numpy as np
@@ -10,7 +10,9 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 pal = ColorReducer.generate_uniform_palette(K) if K <= 64 else [tuple(int(v) for v in c) for c in np.random.RandomState(7).randint(0, 256, (K, 3))]
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 nmax = int(sys.argv[4]) if len(sys.argv) > 4 else 256
-f = torch.randint(0, 256, (nmax, 2160, 3840, 3), dtype=torch.uint8, device='cuda', generator=g); o = torch.empty_like(f)
+H = int(sys.argv[5]) if len(sys.argv) > 5 else 2160
+W = int(sys.argv[6]) if len(sys.argv) > 6 else 3840
+f = torch.randint(0, 256, (nmax, H, W, 3), dtype=torch.uint8, device='cuda', generator=g); o = torch.empty_like(f)
 if variant in ("perceptual", "hybrid", "adaptive_variance", "ostromoukhov"):
     d = ImageDitherer(K, DitherMode(variant), pal, False, {})
 else:
@@ -22,4 +24,4 @@ for nf in sorted({1, 24, min(256, nmax), nmax}):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); d.apply_dithering_frames(f[:nf], out=o[:nf]); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    print(f"{variant} K={K} frames={nf}: min {min(ts):.2f} ms  median {sorted(ts)[len(ts)//2]:.2f} ms  {nf*2160*3840/min(ts)/1e6:.1f} Gpx/s", flush=True)
+    print(f"{variant} K={K} frames={nf}: min {min(ts):.2f} ms  median {sorted(ts)[len(ts)//2]:.2f} ms  {nf*H*W/min(ts)/1e6:.1f} Gpx/s", flush=True)
