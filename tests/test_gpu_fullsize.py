@@ -79,6 +79,35 @@ def test_c3_floyd_steinberg_4k_both_schedules(d, orc, switches):
         assert np.array_equal(out[i].cpu().numpy(), ref), i
 
 
+def test_c3_long_batch_of_4k_frames_on_persistent_workgroups(d, orc):
+    """A batch larger than the device has CUs (300 4K frames, the product library): persistent workgroups, their waves running
+    on from one frame into the next.  The reference's C3 frame sits at positions 0, 1, 255, 256 (first / second frame of a
+    workgroup), 299 and must hash as the reference hashed it; a frame of another content (oracle) at 257."""
+    import torch
+    case = _need("c3_ed_fs_U16_rnd4k")
+    arr = case_input(orc, case["input"])
+    pal = case_palette(orc, case["palette"])
+    it = d.ImageDitherer(len(pal), d.DitherMode.ERROR_DIFFUSION, pal, False, dict(case["params"]))
+    n = 300
+    batch = torch.empty((n, 2160, 3840, 3), dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    batch.copy_(torch.randint(0, 256, batch.shape, dtype=torch.uint8, device="cuda", generator=g))
+    x = torch.from_numpy(arr).cuda()
+    kat_at = (0, 1, 255, 256, 299)
+    for i in kat_at:
+        batch[i].copy_(x)
+    other = orc.rnd(2160, 3840, 1260)
+    batch[257].copy_(torch.from_numpy(other))
+    out = it.apply_dithering_frames(batch)
+    for i in kat_at:
+        assert H(out[i].cpu().numpy()) == case["h_out"], i
+    assert np.array_equal(out[257].cpu().numpy(), orc.apply_dithering(other, pal, "error_diffusion", case["params"]))
+    # ... and every other frame equals what the same frame gives in a small batch (the few-frames schedule)
+    for i in (2, 128, 258, 298):
+        assert torch.equal(out[i], it.apply_dithering_frames(batch[i:i + 1])[0]), i
+
+
 def test_error_diffusion_gives_up_and_repairs(d, be, orc, switches):
     """A workgroup of a multi-workgroup launch that gives up waiting sets a flag; the repair launch behind it redoes the
     frame.  DP_ED_TEST_GIVEUP makes every workgroup of the first launch give up before it writes anything."""
