@@ -945,7 +945,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         // (ed_wavefront_kernel) -- the tail of a frame, when most of its bands are done, overlaps the head of the next.
         // The running band number has 16 bits in the progress words: enough workgroups that none counts past them.
         int64_t pgrid = n_frames * G;
-        if (G == 1 && nw > 4 && cus > 0 && n_frames > cus && !exp_env("DP_ED_NO_PERSIST")) {
+        if (G == 1 && nw > 4 && cus > 0 && n_frames > cus && n_bands <= 4096 && !exp_env("DP_ED_NO_PERSIST")) {
             pgrid = cus;
             const int64_t need = (n_frames * n_bands + 59999) / 60000;
             if (pgrid < need) pgrid = need;

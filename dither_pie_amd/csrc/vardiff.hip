@@ -984,7 +984,7 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
         // (behind a G > 1 launch: the repair launch for frames whose workgroups gave up waiting for each other)
         // batches larger than the device: one persistent workgroup per CU (launch_error_diffusion, ediff.hip)
         int64_t pgrid = n_frames * G;
-        if (G == 1 && nw > 4 && cus > 0 && n_frames > cus && !exp_env("DP_ED_NO_PERSIST")) {
+        if (G == 1 && nw > 4 && cus > 0 && n_frames > cus && n_bands <= 4096 && !exp_env("DP_ED_NO_PERSIST")) {
             pgrid = cus;
             const int64_t need = (n_frames * n_bands + 59999) / 60000;
             if (pgrid < need) pgrid = need;
