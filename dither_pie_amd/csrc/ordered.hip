@@ -928,9 +928,12 @@ __device__ __forceinline__ uint32_t lean_pixel_full(const uint32_t entry, const 
 // pixels tend to sit in split cells -- the plain instantiation keeps its scalar registers for the lean loop
 // HALF (4-entry blocks on plain cells, not adaptive): the workgroup declares 80 KB of LDS instead of all 160 -- the
 // 64 KB table, thresholds and queue fit -- so that two workgroups share a CU (8 waves per SIMD; these instances need fewer
-// than 64 VGPRs) and a wave's LDS waits are covered twice as often.
+// than 64 VGPRs) and a wave's LDS waits are covered twice as often.  The launch bounds must SAY 8 waves per SIMD: without the
+// hint the compiler used 106 scalar registers, and at 112 allocated per wave a SIMD's 800 hold only seven waves -- the second
+// workgroup never fitted (rounds 2-3 ran this instance at one workgroup per CU without knowing; with 78 SGPRs C5's launch
+// goes from 0.477 to 0.441 ms, same process, tools/bench_scripts/ab_libs.py bayer4:16:100).
 template <int MODE, int BW, bool ADAPT, bool WARP, bool HALF = false>
-__global__ __launch_bounds__(kCellBlock) void ordered_lean_kernel(const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(kCellBlock, HALF ? 8 : 4) void ordered_lean_kernel(const uint8_t *__restrict__ in,
                                                                   uint8_t *__restrict__ out,
                                                                   unsigned long long *__restrict__ flags,
                                                                   const Geo g, const PalDev pal, const ThrDev thr,
