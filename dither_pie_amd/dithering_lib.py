@@ -925,5 +925,8 @@ class ImageDitherer:
         dev_out = self.apply_dithering_frames(dev_in)
         pin_out.view(h, w, 3).copy_(dev_out, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        # the returned image owns its pixels (the staging buffer is overwritten by the next call)
-        return Image.frombuffer("RGB", (w, h), pin_out.numpy(), "raw", "RGB", 0, 1).copy()
+        # The returned image owns its pixels (the staging buffer is overwritten by the next call): PIL stores 'RGB' as four bytes
+        # per pixel, so building it from packed bytes always unpacks into storage of its own -- only the four-byte modes can be
+        # mapped onto a buffer (tests/test_cabi_and_host.py checks that).  fromarray, not frombuffer(...).copy(): the copy of
+        # the 33 MB it has just written costs more than the unpacking (GPU-box host: 2.5 ms against 17.6, tools/bench_scripts/pil_probe.py).
+        return Image.fromarray(pin_out.numpy().reshape(h, w, 3), "RGB")

@@ -445,3 +445,14 @@ def test_expanded_key_error_bound():
             exact = ((pal[j].astype(np.float64)[None] - o.astype(np.float64)) ** 2).sum(1) - (o.astype(np.float64) ** 2).sum(1) + 262144.0
             worst = max(worst, float(np.abs(key.astype(np.float64) - exact).max()), float(np.abs(tagged.astype(np.float64) - exact).max()))
     assert worst < 0.32, worst
+
+
+def test_pil_image_from_the_staging_buffer_owns_its_pixels():
+    """apply_dithering hands out Image.fromarray(staging buffer) and then reuses that buffer: the image must not be a view of it
+    (PIL keeps 'RGB' as four bytes per pixel, packed bytes are always unpacked into storage of the image's own)."""
+    from PIL import Image
+    buf = np.random.RandomState(3).randint(0, 256, 37 * 53 * 3, dtype=np.uint8)
+    want = buf.copy().reshape(37, 53, 3)
+    img = Image.fromarray(buf.reshape(37, 53, 3), "RGB")
+    buf[:] = 0
+    assert np.array_equal(np.asarray(img), want)
