@@ -177,10 +177,17 @@ def _check_out(out, f):
 # kernel) use it in stream order, so two host threads on the SAME stream must not interleave their sequences (ctypes
 # drops the GIL): workspace acquisition + launches run under the lock of that (device, stream).  Different streams
 # have different workspaces and run concurrently.
-_WS_KEEP = 8                 # (device, stream) scratch buffers kept; the least recently used one is dropped beyond that
+_WS_KEEP_MIN = 8             # (device, stream) scratch buffers kept at least; see _ws_keep()
 _WS_SHRINK = 8               # a buffer more than this many times larger than a request is replaced by a smaller one
-_ws_cache = OrderedDict()    # key -> [tensor, lock]
+_ws_cache = OrderedDict()    # key -> [tensor, lock, users]: users = launches inside or waiting for the entry
 _ws_guard = threading.Lock()
+
+
+def _ws_keep():
+    """How many (device, stream) scratch buffers are kept before the least recently used idle one is dropped: every device
+    with its default stream, its worker stream (sharding.process_on_devices) and its pipe stream (video_processor), plus
+    slack -- 8 GPUs in one process are 24 live keys, and a fixed 8 evicted and re-allocated one per batch."""
+    return max(_WS_KEEP_MIN, 3 * torch.cuda.device_count() + 4)
 
 
 class _Launch:
@@ -194,13 +201,16 @@ class _Launch:
         with _ws_guard:
             ent = _ws_cache.get(self.key)
             if ent is None:
-                ent = _ws_cache[self.key] = [None, threading.RLock()]
+                ent = _ws_cache[self.key] = [None, threading.RLock(), 0]
+            ent[2] += 1
             _ws_cache.move_to_end(self.key)
-            while len(_ws_cache) > _WS_KEEP:
-                k = next(iter(_ws_cache))
-                if k == self.key:
-                    break
-                del _ws_cache[k]  # (a thread still inside that entry keeps its own references)
+            if len(_ws_cache) > _ws_keep():
+                # least recently used first; an entry somebody is inside of (or queued for) is never dropped: its lock is
+                # what serialises that stream's launch sequences, a fresh entry for the same key would hand out a second one
+                for k in [k for k, e in _ws_cache.items() if e[2] == 0]:
+                    if len(_ws_cache) <= _ws_keep():
+                        break
+                    del _ws_cache[k]
         self.ent = ent
         ent[1].acquire()
         try:
@@ -209,18 +219,23 @@ class _Launch:
                 t = ent[0] = torch.empty(max(self.nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
         except BaseException:   # out of memory on a grow: __exit__ will not run, the stream's lock must not stay held
             ent[1].release()
+            with _ws_guard:
+                ent[2] -= 1
             raise
         return t
 
     def __exit__(self, *exc):
         self.ent[1].release()
+        with _ws_guard:
+            self.ent[2] -= 1
         return False
 
 
 def release_workspaces():
-    """Drop every cached scratch buffer (they are re-created on demand)."""
+    """Drop every cached scratch buffer nobody is using (they are re-created on demand)."""
     with _ws_guard:
-        _ws_cache.clear()
+        for k in [k for k, e in _ws_cache.items() if e[2] == 0]:
+            del _ws_cache[k]
 
 
 def ordered(frames, pal: Palette, mode, thr: Thresholds | None = None, ign_scale=1.0, ign_seed=0, y0=0, x0=0,

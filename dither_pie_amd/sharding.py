@@ -58,13 +58,26 @@ def visible_devices():
     return list(range(torch.cuda.device_count()))
 
 
-def process_on_devices(frames_host, fn, devices=None, chunk: int = 32):
+_dev_streams = {}   # (device index, slot) -> torch.cuda.Stream: worker streams are made once per process, not per call
+
+
+def _worker_stream(dev_index: int, slot: int):
+    import torch
+    key = (dev_index, slot)
+    st = _dev_streams.get(key)
+    if st is None:
+        st = _dev_streams[key] = torch.cuda.Stream(torch.device("cuda", dev_index))
+    return st
+
+
+def process_on_devices(frames_host, fn, devices=None, chunk: int = 32, out=None):
     """In-process data parallelism over the GPUs of the node -- what the reference's multiprocessing.Pool over frames
     (video_processor.py:304-346) becomes here: the frames [N,H,W,3] (host uint8 tensor, ideally pinned) are cut into one
     contiguous block per device; one worker thread per device copies its block up in chunks on a stream of its own,
     runs `fn(frames_on_device) -> frames_on_device` and copies the result back.  Returns the host tensor
     [N,H',W',3].  Frames are independent: no exchange between devices.  `devices` may name a device more than once
-    (two streams on one GPU)."""
+    (two streams on one GPU).  `out`: a host tensor [N,H',W',3] (pinned, kept by the caller between calls) the workers
+    write into; without it ONE pinned result tensor is allocated per call, by the first worker that knows H' x W'."""
     import threading
     import torch
     devices = visible_devices() if devices is None else list(devices)
@@ -72,21 +85,29 @@ def process_on_devices(frames_host, fn, devices=None, chunk: int = 32):
         raise RuntimeError("no HIP device visible: the MI355X backend has no CPU fallback")
     n = int(frames_host.shape[0])
     blocks = [shard_range(n, i, len(devices)) for i in range(len(devices))]
-    outs, errors = [None] * len(devices), []
+    errors = []
+    res = {"out": out}
+    res_mu = threading.Lock()
+
+    def result_for(y):
+        with res_mu:
+            o = res["out"]
+            if o is None:
+                o = res["out"] = torch.empty((n,) + tuple(y.shape[1:]), dtype=y.dtype, pin_memory=True)
+            elif tuple(o.shape) != (n,) + tuple(y.shape[1:]) or o.dtype != y.dtype:
+                raise ValueError(f"out is {tuple(o.shape)} {o.dtype}, the result {(n,) + tuple(y.shape[1:])} {y.dtype}")
+            return o
 
     def work(i, dev_index, lo, hi):
         try:
             dev = torch.device("cuda", dev_index)
-            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):
-                parts = []
+            st = _worker_stream(dev_index, i)
+            with torch.cuda.device(dev), torch.cuda.stream(st):
                 for a in range(lo, hi, chunk):
                     b = min(hi, a + chunk)
                     y = fn(frames_host[a:b].to(dev, non_blocking=True))
-                    host = torch.empty(tuple(y.shape), dtype=y.dtype, pin_memory=True)
-                    host.copy_(y, non_blocking=True)
-                    parts.append(host)
-                torch.cuda.current_stream().synchronize()
-                outs[i] = parts
+                    result_for(y)[a:b].copy_(y, non_blocking=True)
+                st.synchronize()
         except Exception as e:  # noqa: BLE001 - reported to the caller below
             errors.append(e)
 
@@ -97,8 +118,9 @@ def process_on_devices(frames_host, fn, devices=None, chunk: int = 32):
         t.join()
     if errors:
         raise errors[0]
-    flat = [p for parts in outs if parts for p in parts]
-    return torch.cat(flat, dim=0) if flat else torch.empty((0,) + tuple(frames_host.shape[1:]), dtype=torch.uint8)
+    if res["out"] is None:
+        return torch.empty((0,) + tuple(frames_host.shape[1:]), dtype=torch.uint8)
+    return res["out"]
 
 
 def dither_band(ditherer, band, y_lo: int):

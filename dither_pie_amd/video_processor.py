@@ -70,6 +70,16 @@ def _final_size(w: int, h: int, multiplier: int) -> Tuple[int, int]:
     return nw + (nw % 2), nh + (nh % 2)
 
 
+def output_size(h: int, w: int, pixelize_method: Optional[str] = None, max_size: int = 64,
+                final_resize_multiplier: Optional[int] = None) -> Tuple[int, int]:
+    """(H', W') of process_frames() for frames of h x w: the geometry of video_processor.py:423-475 without running it."""
+    if pixelize_method in (PixelizeMethod.REGULAR.value, "regular"):
+        w, h = _even_dimensions(w, h, max_size)
+    if final_resize_multiplier:
+        w, h = _final_size(w, h, final_resize_multiplier)
+    return h, w
+
+
 def _apply_final_resize_to_frame(image: Image.Image, multiplier: int) -> Image.Image:
     """video_processor.py:393-420"""
     import torch
@@ -240,11 +250,15 @@ class VideoProcessor:
         text = str(e)
         return isinstance(e, RuntimeError) and any(k in text for k in ("HIP error", "CUDA error", "hipError", "out of memory"))
 
-    def _batch_with_retries(self, host_frames, run):
+    def _batch_with_retries(self, host_frames, run, to_host=None):
         """The reference's failure policy for one batch (video_processor.py:304-346): the whole batch in one go; if that
         raises, every frame on its own, up to ATTEMPTS times; a frame that keeps failing is reported as None and the
-        caller substitutes a neighbour.  run(frames [k,H,W,3]) -> [k,H',W',3].
+        caller substitutes a neighbour.  run(frames [k,H,W,3]) -> [k,H',W',3]; to_host(frame tensor) -> host tensor (the
+        default is .cpu() on the current stream; a caller whose run() works on a stream of its own passes its own).
         -> (out tensor [n,...] or None, per-frame list or None): exactly one of the two is set."""
+        if to_host is None:
+            def to_host(t):
+                return t.cpu()
         try:
             return run(host_frames), None
         except Exception as e:  # noqa: BLE001 - "a frame that errors must not abort the video"
@@ -256,7 +270,7 @@ class VideoProcessor:
             o = None
             for attempt in range(self.ATTEMPTS):
                 try:
-                    o = run(host_frames[i:i + 1])[0].cpu()
+                    o = to_host(run(host_frames[i:i + 1])[0])
                     break
                 except Exception as e:  # noqa: BLE001
                     if self._device_is_gone(e):
@@ -282,13 +296,43 @@ class VideoProcessor:
             print(f"Warning: Could not probe rotation: {e}", file=sys.stderr)
         return 0
 
+    PIPE_SLOTS = 3            # rotating pinned batch slots of the overlapped pipe path (reader / GPU / writer each hold one)
+    PIPE_BYTES = 1 << 20      # requested pipe capacity (F_SETPIPE_SZ; the kernel default is 64 KiB = one syscall per 64 KiB)
+
+    @staticmethod
+    def _widen_pipe(fileobj):
+        """Best effort: a 1 MiB pipe instead of 64 KiB, so that a 6 MB frame is ~6 reads / writes instead of ~95."""
+        try:
+            import fcntl
+            fcntl.fcntl(fileobj.fileno(), getattr(fcntl, "F_SETPIPE_SZ", 1031), VideoProcessor.PIPE_BYTES)
+        except Exception:  # noqa: BLE001 - not Linux, or above /proc/sys/fs/pipe-max-size
+            pass
+
+    @staticmethod
+    def _write_all(f, buf):
+        """The whole buffer into an unbuffered pipe (a raw write may be partial when a signal arrives)."""
+        mv = memoryview(buf).cast("B")
+        while len(mv):
+            n = f.write(mv)
+            mv = mv[len(mv) if n is None else n:]
+
     def _stream_through_pipes(self, input_path, output_path, ditherer, method, max_size, batch_size,
-                              final_resize_multiplier, info, run=None) -> int:
+                              final_resize_multiplier, info, run=None, overlap=True) -> int:
         """decode -> GPU -> encode through two ffmpeg rawvideo pipes; returns the number of frames written.
         Failure policy as in the reference: a batch that fails is retried frame by frame, a frame that still fails is
         replaced by the nearest good output frame (the previous one first, video_processor.py:53-96) and the video goes
         on; the call fails only when ffmpeg does or when no frame at all could be processed.  `run` (tests): the batch
-        function, default process_frames on the configured devices."""
+        function, default process_frames on the configured devices.
+
+        overlap=True (the default): the three stages run CONCURRENTLY on PIPE_SLOTS rotating pinned batch slots -- a reader
+        thread fills a slot from the decoder pipe, this thread submits it to the GPU on a stream of its own (H2D,
+        process_frames, D2H into the slot's pinned output buffer, one event; it never waits for the device), a writer
+        thread waits for the event, applies the substitution policy in frame order and feeds the encoder pipe -- so a
+        video costs max(decode, GPU, encode) per batch instead of their sum (the reference overlaps nothing either: it
+        extracts every PNG, then processes, then encodes, video_processor.py:204-217, 304-346, 361-382).
+        overlap=False: the serial loop of rounds 2-4 (read -> H2D -> kernels -> D2H -> write per batch), kept as the
+        byte-for-byte A/B partner of the overlapped path.  Both fill self.last_pipe_stats."""
+        import time
         import torch
         w, h, fps = int(info["width"]), int(info["height"]), info["fps"]
         if self._probe_rotation(input_path) in (90, 270):
@@ -297,106 +341,293 @@ class VideoProcessor:
         total_hint = info.get("frame_count") or 0
         devs = self._devices() if run is None else [None]
         batch_size = batch_size * len(devs)  # one batch per device in flight
-        if run is None:
-            def run(x):
+        product_run = run is None
+        pin = torch.cuda.is_available()
+        out_geom = None   # (H', W') of the product path: known up front, so that the output slots are allocated once
+        gpu_stream = None  # overlap, one device: the stream this call's H2D / kernels / D2H are queued on
+        target = {"out": None}   # several devices: the pinned host tensor the workers write the current batch into
+        if product_run:
+            out_geom = output_size(h, w, method, max_size, final_resize_multiplier)
+            if overlap and len(devs) == 1 and pin:
+                with torch.cuda.device(devs[0]):
+                    gpu_stream = torch.cuda.Stream()  # the caller's current stream is never blocked or waited on
+
+            def run(x):  # noqa: F811 - the product batch function: frames stay in HBM between the stages
                 if len(devs) > 1 and x.shape[0] > 1:
                     from . import sharding
+                    out = target["out"]
                     return sharding.process_on_devices(
-                        x, lambda y: process_frames(y, ditherer, method, max_size, final_resize_multiplier), devs)
+                        x, lambda y: process_frames(y, ditherer, method, max_size, final_resize_multiplier), devs,
+                        out=None if out is None else out[:x.shape[0]])
                 with torch.cuda.device(devs[0]):
+                    if gpu_stream is not None:
+                        with torch.cuda.stream(gpu_stream):
+                            return process_frames(x.cuda(non_blocking=True), ditherer, method, max_size, final_resize_multiplier)
                     return process_frames(x.cuda(non_blocking=True), ditherer, method, max_size, final_resize_multiplier)
+        def to_host(t):
+            if gpu_stream is not None and t.is_cuda:   # the copy goes behind the kernels, on their stream
+                with torch.cuda.device(t.device), torch.cuda.stream(gpu_stream):
+                    return t.cpu()
+            return t.cpu()
+
         # the byte stream is sliced into frames of exactly w x h: the decoder's output size is made explicit
         dec = subprocess.Popen(["ffmpeg", "-v", "error", "-i", input_path, "-f", "rawvideo", "-pix_fmt",
-                                "rgb24", "-s", f"{w}x{h}", "pipe:1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-        enc = None
-        done = 0
-        pin = torch.cuda.is_available()
-        stage = torch.empty(batch_size * frame_bytes, dtype=torch.uint8, pin_memory=pin)
-        view = memoryview(stage.numpy())
-        out_host = None
-        last_good = None      # the newest good output frame (host tensor): what a failed frame is replaced with
-        leading = 0           # frames that failed before any frame succeeded: they take the first good frame
-        substituted = 0
+                                "rgb24", "-s", f"{w}x{h}", "pipe:1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                               bufsize=0)
+        self._widen_pipe(dec.stdout)
+        state = {"enc": None, "last_good": None, "leading": 0, "substituted": 0, "written": 0}
+        stats = {"mode": "overlapped" if overlap else "serial", "slots": self.PIPE_SLOTS if overlap else 1, "batch_frames": batch_size,
+                 "read_s": 0.0, "gpu_submit_s": 0.0, "gpu_wait_s": 0.0, "write_s": 0.0, "frames": 0}
+        self.last_pipe_stats = stats
 
         def open_encoder(shape):
             oh, ow = int(shape[0]), int(shape[1])
-            return subprocess.Popen(
+            enc = subprocess.Popen(
                 ["ffmpeg", "-y", "-v", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{ow}x{oh}",
                  "-framerate", f"{fps:.5f}", "-i", "pipe:0", "-i", input_path, "-map", "0:v:0", "-map", "1:a?",
                  "-map", "1:s?", "-c:v", "libx264", "-preset", "medium", "-crf", "18", "-pix_fmt", "yuv420p",
                  "-c:a", "copy", "-c:s", "copy", output_path],
-                stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, bufsize=0)
+            self._widen_pipe(enc.stdin)
+            return enc
 
+        def read_batch(view):
+            """-> (whole frames read, bytes read): fills `view` from the decoder until it is full or the stream ends"""
+            t0 = time.perf_counter()
+            got, want = 0, batch_size * frame_bytes
+            while got < want:  # a pipe read returns at most the pipe's capacity at a time
+                n = dec.stdout.readinto(view[got:want])
+                if not n:
+                    break
+                got += n
+            stats["read_s"] += time.perf_counter() - t0
+            if got % frame_bytes:
+                raise RuntimeError(f"decoder stream is not a whole number of {w}x{h} rgb24 frames "
+                                   f"({got % frame_bytes} bytes left over)")
+            return got // frame_bytes, got
+
+        def emit(out_host, n_frames, per_frame):
+            """One batch to the encoder, in frame order, with the substitution policy (state: the encoder, the newest good
+            output frame, frames that failed before any frame succeeded).  out_host: host tensor [>= n_frames, H', W', 3]
+            of a batch that succeeded as a whole; per_frame: list of host tensors / None of one that was retried."""
+            t0 = time.perf_counter()
+            if out_host is not None:  # the usual case: one write of the whole batch
+                if state["enc"] is None:
+                    state["enc"] = open_encoder(out_host.shape[1:])
+                for _ in range(state["leading"]):
+                    self._write_all(state["enc"].stdin, out_host[0].numpy())
+                state["leading"] = 0
+                self._write_all(state["enc"].stdin, out_host[:n_frames].numpy())
+                state["last_good"] = out_host[n_frames - 1].clone()
+            else:
+                for i, o in enumerate(per_frame):
+                    if o is not None:
+                        state["last_good"] = o
+                    else:
+                        state["substituted"] += 1
+                        if state["last_good"] is not None:
+                            o = state["last_good"]  # the previous good frame first (video_processor.py:66-77)
+                        else:  # nothing before it: the next good frame, of this batch or of a later one
+                            o = next((q for q in per_frame[i + 1:] if q is not None), None)
+                            if o is None:
+                                state["leading"] += 1
+                                continue
+                    if state["enc"] is None:
+                        state["enc"] = open_encoder(o.shape)
+                    buf = np.ascontiguousarray(o.numpy())
+                    for _ in range(state["leading"] + 1):
+                        self._write_all(state["enc"].stdin, buf)
+                    state["leading"] = 0
+            state["written"] += n_frames
+            stats["write_s"] += time.perf_counter() - t0
+
+        def progress(done):
+            frac = done / total_hint if total_hint else 0.5
+            self._report_progress(0.1 + 0.8 * min(frac, 1.0), f"Processed {done}/{total_hint or '?'} frames")
+
+        def new_out(shape):
+            return torch.empty((batch_size,) + tuple(shape), dtype=torch.uint8, pin_memory=pin)
+
+        done = 0
+        t_wall = time.perf_counter()
         try:
-            while True:
-                got = 0
-                while got < batch_size * frame_bytes:  # a pipe read returns at most 64 KiB at a time
-                    n = dec.stdout.readinto(view[got:])
-                    if not n:
+            if overlap:
+                done = self._pipe_overlapped(batch_size, frame_bytes, (h, w), out_geom, run, to_host, gpu_stream, target, read_batch, emit,
+                                             progress, new_out, stats, dec)
+            else:
+                stage = torch.empty(batch_size * frame_bytes, dtype=torch.uint8, pin_memory=pin)
+                view = memoryview(stage.numpy())
+                out_host = new_out(tuple(out_geom) + (3,)) if out_geom is not None else None
+                target["out"] = out_host
+                while True:
+                    n_frames, got = read_batch(view)
+                    if n_frames == 0:
                         break
-                    got += n
-                n_frames = got // frame_bytes
-                if got % frame_bytes:
-                    raise RuntimeError(f"decoder stream is not a whole number of {w}x{h} rgb24 frames "
-                                       f"({got % frame_bytes} bytes left over)")
-                if n_frames == 0:
-                    break
-                host_frames = stage[:n_frames * frame_bytes].view(n_frames, h, w, 3)
-                out, per_frame = self._batch_with_retries(host_frames, run)
-                if out is not None:  # the usual case: one copy into the pinned buffer, one write
-                    if enc is None:
-                        enc = open_encoder(out.shape[1:])
-                    if out_host is None:
-                        out_host = torch.empty((batch_size,) + tuple(out.shape[1:]), dtype=torch.uint8, pin_memory=pin)
-                    out_host[:n_frames].copy_(out, non_blocking=True)
-                    if out.is_cuda:
-                        torch.cuda.current_stream(out.device).synchronize()
-                    for _ in range(leading):
-                        enc.stdin.write(memoryview(out_host[0].numpy()).cast("B"))
-                    leading = 0
-                    enc.stdin.write(memoryview(out_host[:n_frames].numpy()).cast("B"))
-                    last_good = out_host[n_frames - 1].clone()
-                else:
-                    for i, o in enumerate(per_frame):
-                        if o is not None:
-                            last_good = o
-                        else:
-                            substituted += 1
-                            if last_good is not None:
-                                o = last_good  # the previous good frame first (video_processor.py:66-77)
-                            else:  # nothing before it: the next good frame, of this batch or of a later one
-                                o = next((q for q in per_frame[i + 1:] if q is not None), None)
-                                if o is None:
-                                    leading += 1
-                                    continue
-                        if enc is None:
-                            enc = open_encoder(o.shape)
-                        buf = memoryview(np.ascontiguousarray(o.numpy())).cast("B")
-                        for _ in range(leading + 1):
-                            enc.stdin.write(buf)
-                        leading = 0
-                done += n_frames
-                frac = done / total_hint if total_hint else 0.5
-                self._report_progress(0.1 + 0.8 * min(frac, 1.0), f"Processed {done}/{total_hint or '?'} frames")
-                if got < batch_size * frame_bytes:
-                    break
-            if substituted:
-                print(f"Fixed {substituted} failed frames by copying from nearest frames", file=sys.stderr)
+                    host_frames = stage[:n_frames * frame_bytes].view(n_frames, h, w, 3)
+                    t0 = time.perf_counter()
+                    out, per_frame = self._batch_with_retries(host_frames, run, to_host)
+                    if out is not None:  # one copy into the pinned buffer
+                        if out_host is None:
+                            out_host = new_out(out.shape[1:])
+                        if out.data_ptr() != out_host.data_ptr():
+                            out_host[:n_frames].copy_(out, non_blocking=True)
+                        if out.is_cuda:
+                            torch.cuda.current_stream(out.device).synchronize()
+                    stats["gpu_wait_s"] += time.perf_counter() - t0
+                    emit(out_host if out is not None else None, n_frames, per_frame)
+                    done += n_frames
+                    progress(done)
+                    if got < batch_size * frame_bytes:
+                        break
+            if state["substituted"]:
+                print(f"Fixed {state['substituted']} failed frames by copying from nearest frames", file=sys.stderr)
             self._report_progress(0.9, "Finishing the encode...")
         finally:
             if dec.stdout:
                 dec.stdout.close()
             rc_dec = dec.wait()
             rc_enc = 0
-            if enc is not None:
-                enc.stdin.close()
-                rc_enc = enc.wait()
+            if state["enc"] is not None:
+                t0 = time.perf_counter()
+                try:
+                    state["enc"].stdin.close()
+                except BrokenPipeError:
+                    pass
+                rc_enc = state["enc"].wait()
+                stats["encoder_drain_s"] = time.perf_counter() - t0
+            stats["frames"] = done
+            stats["wall_s"] = time.perf_counter() - t_wall
         if rc_dec != 0 or rc_enc != 0:
             raise RuntimeError(f"ffmpeg failed (decoder {rc_dec}, encoder {rc_enc})")
         if done == 0:
             raise ValueError("No frames extracted from video")
-        if last_good is None:
+        if state["last_good"] is None:
             raise RuntimeError("no frame of the video could be processed")
+        return done
+
+    def _pipe_overlapped(self, batch_size, frame_bytes, in_geom, out_geom, run, to_host, gpu_stream, target, read_batch, emit, progress,
+                         new_out, stats, dec) -> int:
+        """The three concurrent stages of _stream_through_pipes (see there).  Slots rotate free -> filled -> submitted ->
+        free; every blocking queue operation polls an abort flag, so an error in any stage (a dead encoder, a device that
+        is gone, a malformed stream) ends the other two instead of leaving them blocked on a queue."""
+        import queue
+        import threading
+        import time
+        import torch
+        h, w = in_geom
+        pin = torch.cuda.is_available()
+
+        class Slot:
+            def __init__(self):
+                self.inp = torch.empty(batch_size * frame_bytes, dtype=torch.uint8, pin_memory=pin)
+                self.view = memoryview(self.inp.numpy())
+                self.out = new_out(tuple(out_geom) + (3,)) if out_geom is not None else None
+
+        slots = [Slot() for _ in range(max(2, int(self.PIPE_SLOTS)))]
+        free_q, filled_q, write_q = queue.Queue(), queue.Queue(), queue.Queue()
+        for s in slots:
+            free_q.put(s)
+        abort = threading.Event()
+        errors = []   # (stage, exception) in the order they happened
+
+        class _Abort(Exception):
+            pass
+
+        def take(q):
+            while True:
+                try:
+                    return q.get(timeout=0.05)
+                except queue.Empty:
+                    if abort.is_set():
+                        raise _Abort() from None
+
+        def fail(stage, e):
+            errors.append((stage, e))
+            abort.set()
+
+        def reader():
+            try:
+                while True:
+                    slot = take(free_q)
+                    n_frames, got = read_batch(slot.view)
+                    filled_q.put((slot, n_frames, got))
+                    if n_frames == 0 or got < batch_size * frame_bytes:
+                        return
+            except _Abort:
+                pass
+            except BaseException as e:  # noqa: BLE001 - handed to the submitting thread, which re-raises it
+                fail("reader", e)
+
+        def writer():
+            try:
+                while True:
+                    item = take(write_q)
+                    if item is None:
+                        return
+                    slot, n_frames, out_host, per_frame, event = item
+                    if event is not None:
+                        t0 = time.perf_counter()
+                        event.synchronize()
+                        stats["gpu_wait_s"] += time.perf_counter() - t0
+                    emit(out_host, n_frames, per_frame)
+                    free_q.put(slot)
+            except _Abort:
+                pass
+            except BaseException as e:  # noqa: BLE001
+                fail("writer", e)
+
+        t_read = threading.Thread(target=reader, name="dp-pipe-reader", daemon=True)
+        t_write = threading.Thread(target=writer, name="dp-pipe-writer", daemon=True)
+        t_read.start()
+        t_write.start()
+        done = 0
+        try:
+            while True:
+                slot, n_frames, got = take(filled_q)
+                if n_frames == 0:
+                    break
+                host_frames = slot.inp[:n_frames * frame_bytes].view(n_frames, h, w, 3)
+                t0 = time.perf_counter()
+                target["out"] = slot.out
+                out, per_frame = self._batch_with_retries(host_frames, run, to_host)
+                event, out_host = None, None
+                if out is not None and out.is_cuda:
+                    # D2H into the slot's pinned buffer behind the kernels, on their stream; one event, no host wait
+                    if slot.out is None or tuple(slot.out.shape[1:]) != tuple(out.shape[1:]):
+                        slot.out = new_out(out.shape[1:])
+                    with torch.cuda.device(out.device):
+                        st = gpu_stream if gpu_stream is not None else torch.cuda.current_stream()
+                        with torch.cuda.stream(st):
+                            slot.out[:n_frames].copy_(out, non_blocking=True)
+                            event = torch.cuda.Event()
+                            event.record(st)
+                    out_host = slot.out
+                elif out is not None:
+                    out_host = out   # on the host already (several devices: the workers wrote it into slot.out)
+                stats["gpu_submit_s"] += time.perf_counter() - t0
+                write_q.put((slot, n_frames, out_host, per_frame, event))
+                done += n_frames
+                progress(done)
+                if got < batch_size * frame_bytes:
+                    break
+            write_q.put(None)
+            while t_write.is_alive() and not abort.is_set():
+                t_write.join(0.05)
+        except _Abort:
+            pass
+        except BaseException:
+            abort.set()
+            raise
+        finally:
+            if abort.is_set():
+                try:
+                    dec.kill()   # a reader blocked in read() wakes up on the end of the stream
+                except Exception:  # noqa: BLE001
+                    pass
+            t_read.join(5.0)
+            t_write.join(5.0)
+        if errors:
+            raise errors[0][1]
         return done
 
     def process_video_streaming(self, input_path: str, output_path: str, ditherer: ImageDitherer,

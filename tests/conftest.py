@@ -105,15 +105,17 @@ def case_palette(orc, spec):
     raise ValueError(spec)
 
 
-def fake_ffmpeg_tools(tmp_path, monkeypatch, frames, rotation=None, coded=None):
+def fake_ffmpeg_tools(tmp_path, monkeypatch, frames, rotation=None, coded=None, encoder_dies_after=None, trailing=b""):
     """Stand-ins for ffmpeg / ffprobe on PATH (there is no ffmpeg in the image): the decoder emits `frames` as rgb24, the
-    encoder stores `-s` and the bytes it receives, ffprobe answers the queries get_video_info / _probe_rotation make."""
+    encoder stores `-s` and the bytes it receives, ffprobe answers the queries get_video_info / _probe_rotation make.
+    encoder_dies_after: the encoder exits with code 3 after that many bytes (a crashed ffmpeg); trailing: bytes the
+    decoder appends to the stream (a stream that is not a whole number of frames)."""
     import stat
     import sys
     n, h, w = frames.shape[:3]
     cw, ch = coded if coded else (w, h)
     raw = tmp_path / "input.raw"
-    raw.write_bytes(frames.tobytes())
+    raw.write_bytes(frames.tobytes() + trailing)
     fake_ffmpeg = tmp_path / "ffmpeg"
     fake_ffmpeg.write_text(f"""#!{sys.executable}
 import sys
@@ -123,6 +125,9 @@ if "pipe:1" in a:      # decoder: raw frames to stdout; it must have been asked 
     assert "-noautorotate" not in a
     sys.stdout.buffer.write(open({str(raw)!r}, "rb").read())
 elif "pipe:0" in a:    # encoder: keep the size argument and the bytes
+    if {encoder_dies_after!r} is not None:
+        sys.stdin.buffer.read({encoder_dies_after!r})
+        sys.exit(3)
     open(a[-1], "wb").write(a[a.index("-s") + 1].encode() + b"\\n" + sys.stdin.buffer.read())
 else:
     sys.exit(2)

@@ -2,6 +2,7 @@
 calls), and the host-side logic of the drop-in mirror matches the golden fixtures / the oracle."""
 import ctypes as C
 import os
+import sys
 import pickle
 import re
 
@@ -334,6 +335,118 @@ def test_pipe_path_treats_a_dead_device_as_fatal(tmp_path, monkeypatch):
     assert v.VideoProcessor._device_is_gone(DitherPieError(4, "hipMalloc failed"))
     assert not v.VideoProcessor._device_is_gone(DitherPieError(DP_EINVAL, "bad argument"))
     assert not v.VideoProcessor._device_is_gone(ValueError("frames of one batch differ in size"))
+
+
+@pytest.mark.parametrize("bad", [set(), {3}, {0, 1}, {4, 5, 6, 7, 10, 40}, set(range(9))])
+def test_overlapped_pipe_path_writes_the_bytes_of_the_serial_loop(tmp_path, monkeypatch, bad):
+    """The three concurrent stages on rotating batch slots (reader thread / submit / writer thread) against the serial loop
+    of rounds 2-4, same stream, same batch function with failures injected: identical encoder input, byte for byte,
+    including partial last batches and substituted frames; 41 frames in batches of 4 keep every slot in rotation."""
+    from dither_pie_amd import video_processor as v
+    n, h, w = 41, 6, 8
+    frames = np.random.RandomState(3).randint(0, 256, (n, h, w, 3)).astype(np.uint8)
+    for i in range(n):
+        frames[i, 0, 0, 0] = i
+    _fake_ffmpeg_tools(tmp_path, monkeypatch, frames)
+
+    def run(x):
+        for f in x:
+            if int(f[0, 0, 0]) in bad:
+                raise RuntimeError("injected")
+        return 255 - x.clone()
+
+    blobs = []
+    for overlap in (False, True):
+        vp = v.VideoProcessor()
+        out_path = tmp_path / f"out_{int(overlap)}.bin"
+        done = vp._stream_through_pipes("in.mp4", str(out_path), None, None, 64, 4, None, vp.get_video_info("in.mp4"), run=run,
+                                        overlap=overlap)
+        assert done == n
+        st = vp.last_pipe_stats
+        assert st["mode"] == ("overlapped" if overlap else "serial") and st["frames"] == n and st["wall_s"] > 0
+        blobs.append(out_path.read_bytes())
+    assert blobs[0] == blobs[1]
+    assert len(blobs[0].split(b"\n", 1)[1]) == n * h * w * 3
+
+
+def test_overlapped_pipe_path_ends_when_a_stage_fails(tmp_path, monkeypatch):
+    """No stage may be left blocked on a queue or a pipe when another one fails: an encoder that dies mid-stream (the
+    writer gets EPIPE), a decoder stream that is not a whole number of frames (the reader raises), a batch function that
+    raises a device error (the submitting thread) -- each ends the call with the error, within seconds."""
+    import threading
+    import time
+    from dither_pie_amd import video_processor as v
+    from dither_pie_amd._lib import DP_EHIP, DitherPieError
+    n, h, w = 64, 16, 16
+    frames = np.zeros((n, h, w, 3), np.uint8)
+
+    def call(run, **tools):
+        d = tmp_path / f"t{len(list(tmp_path.iterdir()))}"
+        d.mkdir()
+        _fake_ffmpeg_tools(d, monkeypatch, frames, **tools)
+        vp = v.VideoProcessor()
+        box = {}
+
+        def go():
+            try:
+                box["r"] = vp._stream_through_pipes("in.mp4", str(d / "o.bin"), None, None, 64, 4, None, vp.get_video_info("in.mp4"),
+                                                    run=run)
+            except BaseException as e:  # noqa: BLE001
+                box["e"] = e
+        t = threading.Thread(target=go, daemon=True)
+        t0 = time.time()
+        t.start()
+        t.join(30)
+        assert not t.is_alive(), "the pipe path hangs"
+        assert time.time() - t0 < 30
+        return box
+
+    box = call(lambda x: x.clone(), encoder_dies_after=5 * h * w * 3)
+    assert isinstance(box.get("e"), (BrokenPipeError, RuntimeError)), box        # EPIPE, or "ffmpeg failed (encoder 3)"
+    box = call(lambda x: x.clone(), trailing=b"xyz")
+    assert isinstance(box.get("e"), RuntimeError) and "whole number" in str(box["e"]), box
+
+    def dead(x):
+        if int(x.shape[0]) and dead.calls >= 3:
+            raise DitherPieError(DP_EHIP, "hipErrorIllegalAddress")
+        dead.calls += 1
+        return x.clone()
+    dead.calls = 0
+    box = call(dead)
+    assert isinstance(box.get("e"), DitherPieError), box
+    # and the public entry point turns all of it into False, as the reference does (video_processor.py:386-390)
+    d = tmp_path / "pub"
+    d.mkdir()
+    _fake_ffmpeg_tools(d, monkeypatch, frames, encoder_dies_after=100)
+    assert v.VideoProcessor().process_video_streaming("in.mp4", str(d / "o.bin"), None) is False
+
+
+def test_compiled_pipe_standins_and_a_long_stream(tmp_path, monkeypatch):
+    """tools/pipe_standin.c (what bench.py's c5_pipes leg drives): decoder stream = tools/pipe_standin.frames(), the encoder's
+    order-sensitive checksum and kept frames; 400 frames of 160x120 through the overlapped path in batches of 15."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipe_standin as ps
+    from dither_pie_amd import video_processor as v
+    d = ps.build(str(tmp_path / "bin"))
+    n, h, w = 400, 120, 160
+    for k, val in ps.environment(d, n, h, w, distinct=5, keep=3).items():
+        if k == "PATH" or k.startswith("DP_STANDIN_"):
+            monkeypatch.setenv(k, val)
+    vp = v.VideoProcessor()
+    info = vp.get_video_info("in.mp4")
+    assert (info["width"], info["height"], info["frame_count"], info["fps"]) == (w, h, n, 25.0)
+    out = tmp_path / "o.bin"
+    assert vp._stream_through_pipes("in.mp4", str(out), None, None, 64, 15, None, info, run=lambda x: 255 - x.clone()) == n
+    summary, kept = ps.read_summary(str(out))
+    src = ps.frames(n, h, w, distinct=5)
+    assert [int(np.frombuffer(f[0, 0].tobytes() + f[0, 1, :1].tobytes(), np.uint32)[0]) for f in src[:7]] == list(range(7))
+    assert summary["frames"] == n and summary["bytes"] == n * h * w * 3 and summary["keep"] == 3
+    assert np.array_equal(kept, 255 - src[:3])
+    assert summary["wsum"] == ps.weighted_sum(255 - src)
+    assert vp.last_pipe_stats["mode"] == "overlapped" and vp.last_pipe_stats["frames"] == n
 
 
 @pytest.mark.parametrize("rotation,swap", [(None, False), ("90", True), ("-90.000000", True), ("180", False), ("270", True)])

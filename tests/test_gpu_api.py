@@ -304,6 +304,65 @@ def test_video_pipes_survive_failing_frames_on_the_device_path(d, orc, tmp_path,
         assert np.array_equal(got[i], ref[i - 1] if i in bad else ref[i]), i
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0] * 8])
+def test_overlapped_pipe_path_on_the_device_equals_the_serial_loop(d, orc, tmp_path, monkeypatch, devices):
+    """SURVEY 8(f) rank 4 for real: reader thread / GPU stream / writer thread on rotating pinned slots against the serial
+    loop, around the REAL kernels (regular pixelization -> Bayer -> x2 resize), 47 frames in batches of 4 (devices=None) and
+    through eight worker streams of sharding.process_on_devices on the one GPU (devices=[0]*8: the in-process form of an
+    8-GPU node; 32-frame batches): the encoder receives the same bytes, and they are process_frames() of the input."""
+    import torch
+    from dither_pie_amd import backend, video_processor as v
+    n, w, h = 47, 64, 48
+    frames = np.random.RandomState(8).randint(0, 256, (n, h, w, 3)).astype(np.uint8)
+    fake_ffmpeg_tools(tmp_path, monkeypatch, frames)
+    it = d.ImageDitherer(16, d.DitherMode.BAYER, orc.palr(16, 3), False, {"size": "4x4"})
+    ref = v.process_frames(torch.from_numpy(frames).cuda(), it, "regular", 32, 2).cpu().numpy()
+    assert v.output_size(h, w, "regular", 32, 2) == ref.shape[1:3]
+    blobs = []
+    for overlap in (False, True, True):
+        vp = v.VideoProcessor(devices=devices)
+        out_path = tmp_path / "out.bin"
+        info = vp.get_video_info("in.mp4")
+        assert vp._stream_through_pipes("in.mp4", str(out_path), it, "regular", 32, 4, 2, info, overlap=overlap) == n
+        assert vp.last_pipe_stats["mode"] == ("overlapped" if overlap else "serial")
+        blobs.append(out_path.read_bytes())
+    assert blobs[0] == blobs[1] == blobs[2]
+    size, body = blobs[0].split(b"\n", 1)
+    assert size.decode() == f"{ref.shape[2]}x{ref.shape[1]}"
+    assert np.array_equal(np.frombuffer(body, np.uint8).reshape(ref.shape), ref)
+    if devices is not None:
+        # eight worker streams + the default stream are nine live (device, stream) keys: none of them may have been evicted
+        # and re-allocated per batch (round 4 kept 8)
+        assert backend._ws_keep() >= 9
+        assert len(backend._ws_cache) <= backend._ws_keep()
+        assert all(e[2] == 0 for e in backend._ws_cache.values())
+
+
+@pytest.mark.gpu
+def test_workspace_cache_never_drops_an_entry_in_use(d):
+    """backend._Launch: the per-(device, stream) scratch entry carries the lock that serialises that stream's launch
+    sequences; while a launch is inside (or queued for) an entry, eviction passes it over however many other streams
+    come by -- a fresh entry for the same key would hand a second thread a second lock."""
+    import torch
+    from dither_pie_amd import backend
+    dev = torch.device("cuda", 0)
+    backend.release_workspaces()
+    keep = backend._ws_keep()
+    with backend._Launch(dev, 1 << 20):
+        held_key = (0, torch.cuda.current_stream(dev).cuda_stream)
+        held = backend._ws_cache[held_key]
+        streams = [torch.cuda.Stream() for _ in range(keep + 5)]
+        for st in streams:
+            with torch.cuda.stream(st), backend._Launch(dev, 4096):
+                pass
+        assert backend._ws_cache.get(held_key) is held and held[2] == 1
+        assert len(backend._ws_cache) <= keep + 1
+    assert held[2] == 0
+    backend.release_workspaces()
+    assert len(backend._ws_cache) == 0
+
+
 def _first_occurrences(arr):
     packed = (arr[:, 0].astype(np.uint32) << 16) | (arr[:, 1].astype(np.uint32) << 8) | arr[:, 2]
     _, first = np.unique(packed, return_index=True)
@@ -383,6 +442,35 @@ print('release ok')
     env.update(DP_NO_COMPACT_KERNEL="1", DP_KMEANS_CELLS="0", DP_FORCE_TABLE="u8", DP_ED_TEST_GIVEUP="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "release ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_bench_five_rank_rehearsal():
+    """The widest rehearsal of the driver's 8-GPU SCALE run a one-GPU box allows (its process guard admits six processes on
+    the card: five ranks + this one): bench.py --gpus 5 --rehearse-on-one-gpu, self-launched through torch.distributed.run.
+    Every rank takes its contiguous block of C5's 1000 frames (200 each, two equal launches of 100) and its band of C4's 8K
+    image (864 rows); the collectives run over gloo; one JSON line.  What the real run adds is RCCL itself, nothing else."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.pop("DITHER_PIE_EXPERIMENTS", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--rehearse-on-one-gpu", "--steps", "2",
+                        "--warmup", "1", "--frames", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env,
+                       timeout=1100, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 5 and res["rccl_world_size"] == 5 and "rehearsal" in res
+    assert res["parity_kat_4k"] is True and res["scaling"] == "weak"
+    c5 = res["c5_video"]
+    assert c5["frames_this_rank"] == 200 and c5["n_gpus"] == 5 and c5["scaling"] == "strong"
+    assert c5["launches_per_pass"] == 2 and c5["frames_per_launch"] == [100, 100] and c5["frames_per_s"] > 0
+    assert "5 band(s)" in res["c4_kmeans_pass"]["workload"] and res["c4_kmeans_pass"]["iterations_of_the_fit"] > 0
+    assert "c5_pipes" not in res and "cpu_baseline" not in res   # host-path legs: one rank only
+    assert res["roofline"]["frac"] > 0 and res["value"] > 0
 
 
 @pytest.mark.gpu
