@@ -177,7 +177,7 @@ def _check_out(out, f):
 # kernel) use it in stream order, so two host threads on the SAME stream must not interleave their sequences (ctypes
 # drops the GIL): workspace acquisition + launches run under the lock of that (device, stream).  Different streams
 # have different workspaces and run concurrently.
-_WS_KEEP_MIN = 8             # (device, stream) scratch buffers kept at least; see _ws_keep()
+_WS_KEEP_MIN = 16            # (device, stream) scratch buffers kept at least; see _ws_keep()
 _WS_SHRINK = 8               # a buffer more than this many times larger than a request is replaced by a smaller one
 _ws_cache = OrderedDict()    # key -> [tensor, lock, users]: users = launches inside or waiting for the entry
 _ws_guard = threading.Lock()

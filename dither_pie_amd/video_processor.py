@@ -418,7 +418,10 @@ class VideoProcessor:
                     self._write_all(state["enc"].stdin, out_host[0].numpy())
                 state["leading"] = 0
                 self._write_all(state["enc"].stdin, out_host[:n_frames].numpy())
-                state["last_good"] = out_host[n_frames - 1].clone()
+                # (numpy's single-threaded copy, not tensor.clone(): a torch CPU op wakes the OpenMP pool -- one thread per
+                # visible core, 256 on the bench box -- whose idle spinning burns the container's CPU quota (16 cores) and
+                # gets reader, writer and both ffmpeg processes throttled: measured as ~20 ms lost per batch)
+                state["last_good"] = torch.from_numpy(out_host[n_frames - 1].numpy().copy())
             else:
                 for i, o in enumerate(per_frame):
                     if o is not None:
@@ -469,8 +472,10 @@ class VideoProcessor:
                     if out is not None:  # one copy into the pinned buffer
                         if out_host is None:
                             out_host = new_out(out.shape[1:])
-                        if out.data_ptr() != out_host.data_ptr():
+                        if out.is_cuda:
                             out_host[:n_frames].copy_(out, non_blocking=True)
+                        elif out.data_ptr() != out_host.data_ptr():   # (a host tensor: numpy's copy, see emit())
+                            np.copyto(out_host[:n_frames].numpy(), out.numpy())
                         if out.is_cuda:
                             torch.cuda.current_stream(out.device).synchronize()
                     stats["gpu_wait_s"] += time.perf_counter() - t0
