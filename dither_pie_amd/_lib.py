@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("DP_LIB_PATH") or (EXPERIMENTS_PATH if EXPERIMENTS els
 CSRC = os.path.join(_HERE, "csrc")
 # the ABI revision this binding was written against (include/ditherpie_hip.h: DP_ABI_VERSION); load() refuses a library
 # that reports another one -- a stale build bound through DP_LIB_PATH would otherwise read K as a pointer
-ABI_VERSION = 101
+ABI_VERSION = 102
 
 DP_OK, DP_EINVAL, DP_EUNSUPPORTED, DP_EHIP, DP_ENOMEM, DP_EWORKSPACE = range(6)
 DP_MAX_COLORS = 1024
@@ -114,14 +114,26 @@ def load():
             L = _loaded.get(LIB_PATH)
             if L is None:
                 L = C.CDLL(LIB_PATH)
-                for name, (res, args) in _SIGS.items():
-                    fn = getattr(L, name)
-                    fn.restype = res
-                    fn.argtypes = args
-                got = L.dp_version()
+                # the version first, bound alone: a stale library may lack entry points of _SIGS altogether, and the
+                # message a user needs is "rebuild it", not an AttributeError out of the signature loop
+                try:
+                    ver = L.dp_version
+                except AttributeError:
+                    raise DitherPieError(-1, f"{LIB_PATH} exports no dp_version: not a libditherpie_hip build; rebuild it "
+                                             f"with `make -C {CSRC}`") from None
+                ver.restype, ver.argtypes = C.c_int, []
+                got = ver()
                 if got != ABI_VERSION:
                     raise DitherPieError(-1, f"{LIB_PATH} reports ABI version {got}, this binding was written for "
                                              f"{ABI_VERSION}: rebuild it with `make -C {CSRC}`")
+                for name, (res, args) in _SIGS.items():
+                    try:
+                        fn = getattr(L, name)
+                    except AttributeError:
+                        raise DitherPieError(-1, f"{LIB_PATH} (ABI {got}) does not export {name}: rebuild it with "
+                                                 f"`make -C {CSRC}`") from None
+                    fn.restype = res
+                    fn.argtypes = args
                 _loaded[LIB_PATH] = L
             _lib = L
     return _lib

@@ -425,6 +425,12 @@ class ColourHistogram:
         self.n = (self.n if accumulate else 0) + n
         return self
 
+    def overflowed(self) -> bool:
+        """True when an accumulating build carried a cell's 32-bit pixel count past 2^32 (the device-side check of
+        dp_kmeans_hist_build_u8; add() refuses such totals up front, a direct caller of the C ABI must look)."""
+        word = self.buf[(1 << 26) + 4 * 8193:(1 << 26) + 4 * 8194].view(torch.int32)
+        return bool(int(word.item()) != 0)
+
     def step_into(self, centers, totals, want_sq=True, mean=None):
         """One Lloyd pass over the histogram into the planar totals buffer (see kmeans_step_into)."""
         K = centers.shape[0]

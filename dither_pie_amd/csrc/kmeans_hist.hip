@@ -44,20 +44,48 @@ constexpr size_t kHistInfoBytes = (size_t)4 * (2 * kHistCells + 4);  // pixels p
 // 33 M pixels of the C4 image), and a flat image serialises on one address (376 ms).  Instead (microbenchmark:
 // profiles/microbench/hist24_partition.hip, 0.45 ms on noise):
 //   A  hist_count_kernel    per-workgroup LDS histogram of the 4096 CELL ids -> pixels per cell (the passes need that anyway)
-//   B  hist_plan_kernel     bucket bases (exclusive scan), the parts a cell's bucket is cut into (8192 entries each), their scan
-//   C  hist_scatter_kernel  every pixel's low 12 bits (r_lo, g_lo, b_lo) as a uint16 into its cell's bucket: the rank inside
-//                           the tile from an LDS atomic, one global cursor atomic per (tile, non-empty cell)
-//   D  hist_parts_kernel    one workgroup per part: LDS histogram of its bucket entries (LDS atomics), added to the cell's
-//                           16 KB slice of the table -- plain coalesced read-modify-write when the cell has one part, atomics of the
-//                           non-zero counts when several workgroups share the cell (image-like content: big cells)
-// The buckets (2 bytes per pixel) and the plan live in a caller-provided workspace.
+//   B  hist_plan_kernel     bucket bases (exclusive scan of the bucket CAPACITIES), the parts a cell's bucket is cut into
+//                           (kPartEntries entries each), their scan
+//   C  hist_scatter_kernel  every pixel's low 12 bits (r_lo, g_lo, b_lo) as a uint16 into its cell's bucket -- in whole 32-byte
+//                           SECTORS of 16 entries (round 5): one persistent workgroup per CU keeps a 32-byte staging slot per cell in
+//                           LDS (128 KB), a pixel's place in its cell's stream comes from an LDS atomic, and whenever a slot has
+//                           16 entries the workgroup reserves a sector of the cell's bucket (one global cursor atomic per SECTOR)
+//                           and stores it whole; what a workgroup has left in a slot at the end goes out as one more sector, padded
+//                           with 0xffff.  No 128-byte line of a bucket is ever written two bytes at a time from eight XCDs
+//                           (round 4: one cursor atomic and a run of ~4 two-byte stores per (16 K-pixel tile, cell) -- 568 MB
+//                           written for 66 MB of entries, profiles/r04_pmc_legs.json).
+//                           A build that does not accumulate also zeroes, in the scatter's prologue, the 16 KB slices D will not
+//                           overwrite (cells without pixels; cells whose bucket is cut into several parts): no 64 MB memset.
+//   D  hist_parts_kernel    one workgroup per part: LDS histogram of its bucket entries (LDS atomics), stored as the cell's
+//                           16 KB slice of the table (a cell with one part, not accumulating: no read at all), added to it by a
+//                           coalesced read-modify-write (one part, accumulating) or by atomics of the non-zero counts (several
+//                           workgroups share the cell: image-like content, big cells)
+// The buckets (2 bytes per pixel + the padding of the last sectors) and the plan live in a caller-provided workspace.
 constexpr int kCountThreads = 1024;
 constexpr int kScatterThreads = 1024;
 constexpr int kTileGroups = kScatterThreads * 4;   // groups of 4 pixels per scatter tile (16 pixels per thread)
-constexpr uint32_t kPartEntries = 8192;
+constexpr uint32_t kPartEntries = 16384;
+constexpr uint32_t kSector = 16;                   // bucket entries per sector (32 bytes)
+constexpr int kScatterMaxGrid = 256;               // scatter workgroups at most (each may leave one padded sector per cell)
 
 // the workspace: [0] cell counts of this build | [1] bucket bases | [2] cursors | [3] part bases (4097) ... | buckets
 constexpr size_t kPlanWords = 4 * 4096 + 64;
+
+// scatter workgroups for n pixels: one per CU, fewer when there are fewer tiles than that
+__host__ __device__ inline uint32_t scatter_grid(const int64_t n, const int cus)
+{
+    const int64_t tiles = ((n + 3) / 4 + kTileGroups - 1) / kTileGroups;
+    int64_t g = tiles < (int64_t)cus ? tiles : (int64_t)cus;
+    if (g > kScatterMaxGrid) g = kScatterMaxGrid;
+    return (uint32_t)(g < 1 ? 1 : g);
+}
+
+// entries a cell's bucket must hold: its pixels in whole sectors, plus one partly filled sector per scatter workgroup that saw it
+__host__ __device__ inline uint32_t bucket_capacity(const uint32_t cnt, const uint32_t grid)
+{
+    if (cnt == 0u) return 0u;
+    return ((cnt / kSector) + (cnt < grid ? cnt : grid)) * kSector;
+}
 
 __device__ __forceinline__ void split_colour(const uint32_t v, uint32_t &cell, uint32_t &lo)
 {
@@ -101,6 +129,20 @@ __global__ __launch_bounds__(kCountThreads) void hist_count_kernel(const uint8_t
         uint32_t c[4], lo;
 #pragma unroll
         for (int q = 0; q < 4; ++q) split_colour(v[q], c[q], lo);
+        // (and a wave's lanes mostly share it on coherent content: while at least eight whole-group lanes agree with the first
+        // pending one, one lane adds for all of them -- as hist_scatter_kernel does)
+        const bool all4 = cnt == 4 && c[0] == c[1] && c[1] == c[2] && c[2] == c[3];
+        bool done = false;
+        unsigned long long pend = __ballot(all4);
+        for (int round = 0; round < 3 && __popcll(pend) >= 8; ++round) {   // (wave-uniform)
+            const int leader = __ffsll((long long)pend) - 1;
+            const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)c[0], leader);
+            const unsigned long long m = __ballot(all4 && !done && c[0] == lc);
+            if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&s_cnt[lc], 4u * (uint32_t)__popcll(m));
+            if ((m >> (threadIdx.x & 63u)) & 1ull) done = true;
+            pend &= ~m;
+        }
+        if (done) continue;
         uint32_t run = 1;
 #pragma unroll
         for (int q = 1; q < 4; ++q) {
@@ -119,21 +161,63 @@ __global__ __launch_bounds__(kCountThreads) void hist_count_kernel(const uint8_t
         if (s_cnt[i]) atomicAdd(&cell_count[i], s_cnt[i]);
 }
 
-// One workgroup of 1024 threads, four cells each: bucket bases and cursors (exclusive scan of the counts), part bases (exclusive
-// scan of ceil(count / kPartEntries)), the number of parts; and the passes' per-cell totals: info[cell] (+)= count.
-__global__ __launch_bounds__(1024) void hist_plan_kernel(uint32_t *__restrict__ plan, uint32_t *__restrict__ info, const int accumulate)
+// One block of 1024 threads (the tail of hist_plan_kernel): the occupied cells in ascending order (info[4096] = how many, info[4097 ...] = which; bit 31 of an
+// entry: the cell holds 2^24 pixels or more -- its weighted sums need 64 bits), so that a pass hands its waves occupied cells only
+// and a wave learns everything about its cell from ONE word.
+__device__ __forceinline__ void occupied_list(uint32_t *__restrict__ info)
+{
+    __shared__ uint32_t s_part[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t flag[4], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        flag[i] = info[4 * t + i] != 0u ? 1u : 0u;
+        mine += flag[i];
+    }
+    // inclusive prefix over the wave (row_shr ladder of wave_sum_to_lane63 is an inclusive scan), then over the 16 waves
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_part[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        base += w < wv ? s_part[w] : 0u;
+        total += s_part[w];
+    }
+    uint32_t pos = base + incl - mine;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (flag[i]) info[kHistCells + 1 + pos++] = (uint32_t)(4 * t + i) | (info[4 * t + i] >= (1u << 24) ? 0x80000000u : 0u);
+    if (t == 0) info[kHistCells] = total;
+}
+
+// One workgroup of 1024 threads, four cells each: bucket bases and cursors (exclusive scan of the bucket capacities), part bases
+// (exclusive scan of ceil(capacity / kPartEntries)), the number of parts; and the passes' per-cell totals: info[cell] (+)= count.
+// info[2 * 4096 + 1] becomes non-zero (and stays so) when an accumulating build carries a cell's 32-bit pixel count past 2^32.
+__global__ __launch_bounds__(1024) void hist_plan_kernel(uint32_t *__restrict__ plan, uint32_t *__restrict__ info, const int accumulate,
+                                                          const uint32_t grid)
 {
     __shared__ uint32_t s_a[16], s_b[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t cnt[4], parts[4], sum_c = 0, sum_p = 0;
+    uint32_t cap[4], parts[4], sum_c = 0, sum_p = 0;
+    bool wrapped = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        cnt[i] = plan[4 * t + i];
-        parts[i] = (cnt[i] + kPartEntries - 1) / kPartEntries;
-        sum_c += cnt[i];
+        const uint32_t cnt = plan[4 * t + i];
+        cap[i] = bucket_capacity(cnt, grid);
+        parts[i] = (cap[i] + kPartEntries - 1) / kPartEntries;
+        sum_c += cap[i];
         sum_p += parts[i];
-        info[4 * t + i] = (accumulate ? info[4 * t + i] : 0u) + cnt[i];
+        const uint32_t before = accumulate ? info[4 * t + i] : 0u;
+        info[4 * t + i] = before + cnt;
+        wrapped |= before + cnt < before;
     }
+    if (!accumulate && t == 0) info[2 * kHistCells + 1] = 0u;
+    if (wrapped) info[2 * kHistCells + 1] = 1u;
     uint32_t inc_c = sum_c, inc_p = sum_p;
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t oc = (uint32_t)__shfl_up((int)inc_c, off), op = (uint32_t)__shfl_up((int)inc_p, off);
@@ -157,56 +241,199 @@ __global__ __launch_bounds__(1024) void hist_plan_kernel(uint32_t *__restrict__ 
     uint32_t at_c = base_c + inc_c - sum_c, at_p = base_p + inc_p - sum_p;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        plan[4096 + 4 * t + i] = at_c;       // bucket base
+        plan[4096 + 4 * t + i] = at_c;       // bucket base (a multiple of kSector: every capacity is)
         plan[2 * 4096 + 4 * t + i] = at_c;   // cursor
         plan[3 * 4096 + 4 * t + i] = at_p;   // first part of the cell
-        at_c += cnt[i];
+        at_c += cap[i];
         at_p += parts[i];
     }
     if (t == 0) plan[4 * 4096] = total_p;    // part base of "cell 4096" = number of parts
+    __syncthreads();   // (info[] above: read again below, by other threads' neighbours only through their own entries -- and s_a/s_b reuse)
+    occupied_list(info);
 }
 
-__global__ __launch_bounds__(kScatterThreads) void hist_scatter_kernel(const uint8_t *__restrict__ px, const int64_t n, uint32_t *__restrict__ cursor,
-                                                                        uint16_t *__restrict__ buckets)
+// LDS of the scatter: 32-byte staging slot per cell | per cell: this tile's count, then (sector base | old fill) | per cell: the
+// stream positions below which this tile's entries go straight to the reserved sectors | per cell: entries waiting in the slot
+constexpr int kStageBytes = kHistCells * 32;
+constexpr int kScatterLds = kStageBytes + kHistCells * 4 + kHistCells * 2 + kHistCells;
+
+__global__ __launch_bounds__(kScatterThreads) void hist_scatter_kernel(const uint8_t *__restrict__ px, const int64_t n, uint32_t *__restrict__ plan,
+                                                                        uint16_t *__restrict__ buckets, uint32_t *__restrict__ table,
+                                                                        const int accumulate)
 {
-    __shared__ uint32_t s_cnt[kHistCells];   // per cell: this tile's count, then its base in the cell's bucket
+    __shared__ __align__(16) uint8_t s_raw[kScatterLds];
+    uint16_t *s_stage = reinterpret_cast<uint16_t *>(s_raw);                               // [cell][16]
+    uint32_t *s_a = reinterpret_cast<uint32_t *>(s_raw + kStageBytes);                     // [cell]
+    uint16_t *s_lim = reinterpret_cast<uint16_t *>(s_raw + kStageBytes + kHistCells * 4);  // [cell]
+    uint8_t *s_fill = s_raw + kStageBytes + kHistCells * 4 + kHistCells * 2;               // [cell]
+    uint32_t *cursor = plan + 2 * 4096;
     const int64_t n_groups = (n + 3) / 4;
     const bool aligned = ((uintptr_t)px & 3) == 0;
     const int64_t tiles = (n_groups + kTileGroups - 1) / kTileGroups;
+    const uint3 *px3 = reinterpret_cast<const uint3 *>(px);
+    // a group's twelve bytes as one load when it is whole and the buffer is dword-aligned (else load_group's byte loads, at use)
+    auto whole = [&](const int64_t gi) { return aligned && gi * 4 + 4 <= n; };
+    uint3 nw[4];   // the next tile's groups, in flight while this tile is worked on
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t gi = (int64_t)blockIdx.x * kTileGroups + (int64_t)j * kScatterThreads + threadIdx.x;
+        nw[j] = make_uint3(0u, 0u, 0u);
+        if ((int64_t)blockIdx.x < tiles && whole(gi)) nw[j] = px3[gi];
+    }
+    for (int i = threadIdx.x; i < kHistCells; i += kScatterThreads) {
+        s_a[i] = 0u;
+        s_fill[i] = 0;
+    }
+    // A build that does not accumulate: the slices hist_parts_kernel will not overwrite -- cells without pixels, and cells whose
+    // bucket is cut into several parts (their workgroups add with atomics) -- are zeroed here, each workgroup its share of the
+    // cells, while its first pixels arrive; every other slice is stored whole by its one part (no 64 MB memset, no read).
+    if (!accumulate) {
+        for (uint32_t cell = blockIdx.x; cell < (uint32_t)kHistCells; cell += gridDim.x) {
+            const uint32_t cap = bucket_capacity(plan[cell], gridDim.x);
+            if (cap != 0u && cap <= kPartEntries) continue;   // one part
+            uint4 *o = reinterpret_cast<uint4 *>(table + (size_t)cell * 4096);
+            for (int i = threadIdx.x; i < 1024; i += kScatterThreads) o[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    __syncthreads();
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        for (int i = threadIdx.x; i < kHistCells; i += kScatterThreads) s_cnt[i] = 0u;
-        __syncthreads();
         uint32_t key[16];   // cell << 12 | lo
         uint32_t rank[16];
+        uint3 cw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cw[j] = nw[j];
+        {
+            const int64_t next = tile + gridDim.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t gi = next * kTileGroups + (int64_t)j * kScatterThreads + threadIdx.x;
+                if (next < tiles && whole(gi)) nw[j] = px3[gi];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t gi = tile * kTileGroups + (int64_t)j * kScatterThreads + threadIdx.x;
             uint32_t v[4];
             int cnt;
-            load_group(px, n, gi, aligned, v, cnt);
+            if (whole(gi)) {
+                cnt = 4;
+                v[0] = cw[j].x & 0xffffffu;
+                v[1] = __builtin_amdgcn_perm(cw[j].y, cw[j].x, 0x0c050403u);
+                v[2] = __builtin_amdgcn_perm(cw[j].z, cw[j].y, 0x0c040302u);
+                v[3] = cw[j].z >> 8;
+            } else {
+                load_group(px, n, gi, false, v, cnt);
+            }
+            uint32_t cell[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                uint32_t cell, lo;
-                split_colour(v[q], cell, lo);
-                key[4 * j + q] = (cell << 12) | lo;
-                rank[4 * j + q] = q < cnt ? atomicAdd(&s_cnt[cell], 1u) : 0xffffffffu;
+                uint32_t lo;
+                split_colour(v[q], cell[q], lo);
+                key[4 * j + q] = (cell[q] << 12) | lo;
+            }
+            // Coherent content (an image, a flat frame): a lane's four pixels share a cell, and so do most lanes of the wave -- 64
+            // LDS atomics on one address serialise.  Lanes whose four pixels share a cell take their ranks four at a time, and
+            // while at least eight such lanes agree with the first pending one, ONE lane adds for all of them (three rounds at
+            // most; on noise no lane qualifies and none of this runs).
+            const bool all4 = cnt == 4 && cell[0] == cell[1] && cell[1] == cell[2] && cell[2] == cell[3];
+            uint32_t base4 = 0xffffffffu;
+            unsigned long long pend = __ballot(all4);
+            for (int round = 0; round < 3 && __popcll(pend) >= 8; ++round) {   // (wave-uniform)
+                const int leader = __ffsll((long long)pend) - 1;
+                const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)cell[0], leader);
+                const unsigned long long m = __ballot(all4 && base4 == 0xffffffffu && cell[0] == lc);
+                uint32_t b = 0u;
+                if ((int)(threadIdx.x & 63u) == leader) b = atomicAdd(&s_a[lc], 4u * (uint32_t)__popcll(m));
+                b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+                if ((m >> (threadIdx.x & 63u)) & 1ull)
+                    base4 = b + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                pend &= ~m;
+            }
+            if (all4 && base4 == 0xffffffffu) base4 = atomicAdd(&s_a[cell[0]], 4u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                rank[4 * j + q] = all4 ? base4 + (uint32_t)q : (q < cnt ? atomicAdd(&s_a[cell[q]], 1u) : 0xffffffffu);
+        }
+        __syncthreads();
+        // Per cell: the tile's entries continue the cell's stream behind the f entries waiting in its slot (stream position p = f +
+        // rank); every 16 positions make a sector.  Positions below 16 complete the slot IN LDS, the slot leaves as one whole
+        // 32-byte store, positions from the last sector boundary on (lim) start the slot afresh; only a cell that receives more
+        // than a sector's worth in one tile (coherent content) has positions 16 .. lim - 1, which go straight to their
+        // reserved sectors as runs of two-byte stores.
+        {
+            uint32_t f4[4], tot4[4], lim4[4], base4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cell = threadIdx.x + k * kScatterThreads;
+                f4[k] = s_fill[cell];
+                tot4[k] = f4[k] + s_a[cell];
+                lim4[k] = tot4[k] & ~(kSector - 1u);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // (the four reservations are in flight together: lim / 16 sectors, one atomic each)
+                base4[k] = 0u;
+                if (lim4[k] != 0u) base4[k] = atomicAdd(&cursor[threadIdx.x + k * kScatterThreads], lim4[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cell = threadIdx.x + k * kScatterThreads;
+                s_a[cell] = base4[k] | f4[k];   // (bases are multiples of 16)
+                s_lim[cell] = (uint16_t)lim4[k];
+                s_fill[cell] = (uint8_t)(tot4[k] & (kSector - 1u));
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < kHistCells; i += kScatterThreads) {
-            const uint32_t c = s_cnt[i];
-            if (c) s_cnt[i] = atomicAdd(&cursor[i], c);
+        uint32_t late = 0u;   // bit e: entry e starts the slot afresh (behind the flush)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (rank[e] == 0xffffffffu) continue;
+            const uint32_t cell = key[e] >> 12;
+            const uint32_t a = s_a[cell], lim = s_lim[cell];
+            const uint32_t p = (a & (kSector - 1u)) + rank[e];
+            const uint16_t lo = (uint16_t)(key[e] & 0xfffu);
+            if (p < kSector) s_stage[cell * kSector + p] = lo;
+            else if (p < lim) buckets[(size_t)(a & ~(kSector - 1u)) + p] = lo;
+            else {
+                late |= 1u << e;
+                rank[e] = p - lim;   // its place in the fresh slot
+            }
+        }
+        __syncthreads();
+        for (int cell = threadIdx.x; cell < kHistCells; cell += kScatterThreads) {
+            if (s_lim[cell] == 0) continue;
+            const uint4 *slot = reinterpret_cast<const uint4 *>(s_stage + cell * kSector);
+            uint4 *dst = reinterpret_cast<uint4 *>(buckets + (s_a[cell] & ~(kSector - 1u)));
+            dst[0] = slot[0];
+            dst[1] = slot[1];
         }
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-            if (rank[e] != 0xffffffffu) buckets[(size_t)s_cnt[key[e] >> 12] + rank[e]] = (uint16_t)(key[e] & 0xfffu);
+            if ((late >> e) & 1u) s_stage[(key[e] >> 12) * kSector + rank[e]] = (uint16_t)(key[e] & 0xfffu);
+        for (int i = threadIdx.x; i < kHistCells; i += kScatterThreads) s_a[i] = 0u;
         __syncthreads();
+    }
+    // what is left in the slots: one last sector per cell, padded with 0xffff (hist_parts_kernel skips those)
+    for (int cell = threadIdx.x; cell < kHistCells; cell += kScatterThreads) {
+        const uint32_t f = s_fill[cell];
+        if (f == 0u) continue;
+        const uint32_t base = atomicAdd(&cursor[cell], kSector);
+        const uint32_t *slot = reinterpret_cast<const uint32_t *>(s_stage + cell * kSector);
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t v = slot[k];
+            const uint32_t e0 = 2u * k, e1 = 2u * k + 1u;
+            w[k] = (e0 < f ? (v & 0xffffu) : 0xffffu) | (e1 < f ? (v & 0xffff0000u) : 0xffff0000u);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(buckets + base);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
 }
 
 __global__ __launch_bounds__(256) void hist_parts_kernel(const uint16_t *__restrict__ buckets, const uint32_t *__restrict__ plan,
-                                                         uint32_t *__restrict__ table)
+                                                         uint32_t *__restrict__ table, const int accumulate)
 {
     __shared__ uint32_t s_h[4096];
     __shared__ int s_cell;
@@ -226,17 +453,41 @@ __global__ __launch_bounds__(256) void hist_parts_kernel(const uint16_t *__restr
         }
         __syncthreads();
         const int cell = s_cell;
-        const uint32_t cnt = plan[cell], first = plan[3 * 4096 + cell];
-        const uint32_t parts = (cnt + kPartEntries - 1) / kPartEntries;
-        const uint32_t lo_e = (part - first) * kPartEntries, hi_e = min(cnt, lo_e + kPartEntries);
+        const uint32_t first = plan[3 * 4096 + cell], parts = plan[3 * 4096 + cell + 1] - first;
+        // the bucket as the scatter left it: whole sectors from the base to the cursor, 0xffff where a last sector was padded
+        const uint32_t used = plan[2 * 4096 + cell] - plan[4096 + cell];
+        const uint32_t lo_e = (part - first) * kPartEntries, hi_e = min(used, lo_e + kPartEntries);
         const uint16_t *b = buckets + (size_t)plan[4096 + cell];
-        for (uint32_t i = lo_e + threadIdx.x; i < hi_e; i += 256) atomicAdd(&s_h[b[i]], 1u);
+        bool peel = true;   // (wave-uniform) few colours in this part: see below; given up at the first block of 64 that has many
+        for (uint32_t i0 = lo_e; i0 < hi_e; i0 += 256) {   // (workgroup-uniform trip count: the ballots below are whole-wave)
+            const uint32_t i = i0 + threadIdx.x;
+            const uint32_t e = i < hi_e ? b[i] : 0xffffu;
+            bool mine = e < 4096u;
+            if (peel) {
+                // few colours (a flat frame: ONE): 64 LDS atomics on one address serialise -- while at least sixteen lanes hold the
+                // colour of the first pending one, one lane counts them all (two rounds at most)
+                unsigned long long pend = __ballot(mine);
+                for (int round = 0; round < 2 && pend != 0ull; ++round) {
+                    const int leader = __ffsll((long long)pend) - 1;
+                    const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)e, leader);
+                    const unsigned long long m = __ballot(mine && e == le);
+                    if (__popcll(m) < 16) {
+                        peel = round != 0;   // not even the first colour is shared: noise -- stop looking
+                        break;
+                    }
+                    if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&s_h[le], (uint32_t)__popcll(m));
+                    if ((m >> (threadIdx.x & 63u)) & 1ull) mine = false;
+                    pend &= ~m;
+                }
+            }
+            if (mine) atomicAdd(&s_h[e], 1u);
+        }
         __syncthreads();
         uint32_t *slice = table + (size_t)cell * 4096;
         if (parts == 1) {
             uint4 *o = reinterpret_cast<uint4 *>(slice);
             for (int i = threadIdx.x; i < 1024; i += 256) {
-                uint4 v = o[i];
+                uint4 v = accumulate ? o[i] : make_uint4(0u, 0u, 0u, 0u);
                 v.x += s_h[4 * i];
                 v.y += s_h[4 * i + 1];
                 v.z += s_h[4 * i + 2];
@@ -293,40 +544,6 @@ constexpr int kHistMaxK = 256;
 constexpr int kPassWaves = 4;   // waves per workgroup; every wave works on cells of its own
 constexpr int kPassGrid = 1024; // workgroups (persistent: a wave takes every (4 * grid)-th occupied cell)
 
-// One block, after the build: the occupied cells in ascending order (info[4096] = how many, info[4097 ...] = which; bit 31 of an
-// entry: the cell holds 2^24 pixels or more -- its weighted sums need 64 bits), so that a pass hands its waves occupied cells only
-// and a wave learns everything about its cell from ONE word.
-__global__ __launch_bounds__(1024) void hist_occupied_kernel(uint32_t *__restrict__ info)
-{
-    __shared__ uint32_t s_part[16];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t flag[4], mine = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        flag[i] = info[4 * t + i] != 0u ? 1u : 0u;
-        mine += flag[i];
-    }
-    // inclusive prefix over the wave (row_shr ladder of wave_sum_to_lane63 is an inclusive scan), then over the 16 waves
-    uint32_t incl = mine;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-        if (lane >= off) incl += o;
-    }
-    if (lane == 63) s_part[wv] = incl;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        base += w < wv ? s_part[w] : 0u;
-        total += s_part[w];
-    }
-    uint32_t pos = base + incl - mine;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (flag[i]) info[kHistCells + 1 + pos++] = (uint32_t)(4 * t + i) | (info[4 * t + i] >= (1u << 24) ? 0x80000000u : 0u);
-    if (t == 0) info[kHistCells] = total;
-}
-
 // FUSE: a whole Lloyd iteration in this one launch (single rank: nothing to all-reduce between the pass and the update).  The
 // totals buffer is planar (sums | counts | squared norms, as dp_kmeans_update takes it) and ZERO on entry; every workgroup that
 // has work adds its totals, fences, and takes a ticket; the last one runs the centre update with sklearn's stopping rules
@@ -343,7 +560,7 @@ struct FuseArgs {
 
 template <bool SQ, bool FUSE>
 __global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uint32_t *__restrict__ table, const uint32_t *__restrict__ info,
-                                                                    const double *__restrict__ centers, const double *__restrict__ mean,
+                                                                    const double *centers, const double *__restrict__ mean,
                                                                     const int K, unsigned long long *__restrict__ sums,
                                                                     unsigned long long *__restrict__ counts,
                                                                     unsigned long long *__restrict__ sumsq, const FuseArgs fuse, const int force_split)
@@ -671,8 +888,13 @@ __global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uin
         else atomicAdd(&sums[3 * j + (what - 1)], v);
     }
     if (FUSE) {
+        // (`centers` is NOT __restrict__: in the FUSE instances it is the same memory as fuse.centers_rw, which the last
+        // workgroup rewrites below -- after every workgroup, itself included, has copied the centres into LDS.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "hist_pass_kernel<FUSE>: the fence-free ticket protocol below relies on gfx950 performing device-scope atomics at the coherence point; on another target use pass + all-reduce + update (dp_kmeans_hist_step / dp_kmeans_update)"
+#endif
         __shared__ uint32_t s_ticket;
-        // Ordering without a fence: an agent-scope fence writes back and invalidates the whole L2 of this XCD (1024 workgroups
+        // Ordering without a fence (outside the HIP memory model, deliberately, and only for gfx950 -- the #error above): an agent-scope fence writes back and invalidates the whole L2 of this XCD (1024 workgroups
         // doing that while the others stream the table: measured 2x slower than three separate launches).  The totals are
         // atomics, performed at the device's coherence point; each thread waits until its own are acknowledged (vmcnt), the
         // barrier collects the workgroup, and only then the ticket is taken -- so the workgroup that draws the last ticket
@@ -702,7 +924,13 @@ __global__ __launch_bounds__(64 * kPassWaves, 4) void hist_pass_kernel(const uin
 
 size_t kmeans_hist_bytes() { return kHistTableBytes + kHistInfoBytes; }
 
-size_t kmeans_hist_ws_bytes(int64_t n) { return kPlanWords * 4 + (((size_t)(n > 0 ? n : 0) * 2 + 255) & ~(size_t)255) + 256; }
+// plan + buckets: 2 bytes per pixel, plus one padded sector per (scatter workgroup, cell) at most
+size_t kmeans_hist_ws_bytes(int64_t n)
+{
+    const size_t px = (size_t)(n > 0 ? n : 0);
+    const size_t entries = px + (size_t)kSector * kHistCells * scatter_grid(n, kScatterMaxGrid);
+    return kPlanWords * 4 + ((entries * 2 + 255) & ~(size_t)255) + 256;
+}
 
 int launch_kmeans_hist_build(const uint8_t *px, int64_t n, void *hist, int accumulate, void *ws, hipStream_t s)
 {
@@ -710,28 +938,26 @@ int launch_kmeans_hist_build(const uint8_t *px, int64_t n, void *hist, int accum
     uint32_t *info = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(hist) + kHistTableBytes);
     uint32_t *plan = static_cast<uint32_t *>(ws);
     uint16_t *buckets = reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(ws) + kPlanWords * 4);
-    if (!accumulate) DP_HIP(hipMemsetAsync(table, 0, kHistTableBytes, s));
     DP_HIP(hipMemsetAsync(plan, 0, 4096 * sizeof(uint32_t), s));
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const int64_t groups = (n + 3) / 4;
+    const uint32_t sgrid = scatter_grid(n, cus);
     ProfMark *pm = prof_begin(s);
     if (n > 0) {
         const unsigned cblocks = (unsigned)std::min<int64_t>((groups + kCountThreads - 1) / kCountThreads, (int64_t)cus * 2);
         hipLaunchKernelGGL(hist_count_kernel, dim3(cblocks), dim3(kCountThreads), 0, s, px, n, plan);
     }
-    hipLaunchKernelGGL(hist_plan_kernel, dim3(1), dim3(1024), 0, s, plan, info, accumulate);
+    hipLaunchKernelGGL(hist_plan_kernel, dim3(1), dim3(1024), 0, s, plan, info, accumulate, sgrid);
+    if (n == 0 && !accumulate) DP_HIP(hipMemsetAsync(table, 0, kHistTableBytes, s));
     if (n > 0) {
-        const int64_t tiles = (groups + kTileGroups - 1) / kTileGroups;
-        const unsigned sblocks = (unsigned)std::min<int64_t>(tiles, (int64_t)cus * 4);
-        hipLaunchKernelGGL(hist_scatter_kernel, dim3(sblocks), dim3(kScatterThreads), 0, s, px, n, plan + 2 * 4096, buckets);
-        // (the number of parts is on the device: n / 8192 + 4096 at most; a persistent grid takes them in turn)
-        const int64_t max_parts = n / (int64_t)kPartEntries + 4096;
+        hipLaunchKernelGGL(hist_scatter_kernel, dim3(sgrid), dim3(kScatterThreads), 0, s, px, n, plan, buckets, table, accumulate);
+        // (the number of parts is on the device: capacity / kPartEntries + 4096 at most; a persistent grid takes them in turn)
+        const int64_t max_parts = (n + (int64_t)kSector * kHistCells * sgrid) / (int64_t)kPartEntries + 4096;
         const unsigned pblocks = (unsigned)std::min<int64_t>(max_parts, (int64_t)cus * 16);
-        hipLaunchKernelGGL(hist_parts_kernel, dim3(pblocks), dim3(256), 0, s, buckets, plan, table);
+        hipLaunchKernelGGL(hist_parts_kernel, dim3(pblocks), dim3(256), 0, s, buckets, plan, table, accumulate);
     }
     prof_end(pm, s);
-    hipLaunchKernelGGL(hist_occupied_kernel, dim3(1), dim3(1024), 0, s, info);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }

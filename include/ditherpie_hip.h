@@ -48,9 +48,11 @@ extern "C" {
 
 #define DP_MAX_COLORS 1024
 
-/* 100: rounds 1-2.  101: dp_kmeans_step_u8 takes mean_dev (round 3); round 4: dp_distinct_first_u8, dp_kmeans_hist_*,
- * dp_hybrid_numba_u8, dp_error_diffusion_numba_u8 computes the float64 reading of the numba branch. */
-#define DP_ABI_VERSION 101
+/* 100: rounds 1-2.  101: dp_kmeans_step_u8 takes mean_dev (round 3).  102: round 4's surface (dp_distinct_first_u8,
+ * dp_kmeans_hist_*, dp_hybrid_numba_u8, dp_error_diffusion_numba_u8 computing the float64 reading of the numba branch,
+ * dp_error_diffusion_workspace_bytes at 6 words per column) and round 5's larger dp_kmeans_hist_workspace_bytes (whole
+ * 32-byte sectors per scatter workgroup and cell) with the overflow word in the histogram's info block. */
+#define DP_ABI_VERSION 102
 
 #define DP_MODE_NEAREST 0 /* NoDitherStrategy                     dithering_lib.py:333-341 */
 #define DP_MODE_MATRIX 1  /* MatrixDitherStrategy (Bayer, blue)   dithering_lib.py:346-378 */
@@ -227,10 +229,17 @@ int dp_kmeans_step_u8(const uint8_t *px_dev, int64_t n, const double *centers_de
  * above), same int64 totals as dp_kmeans_step_u8, bit for bit.
  *   dp_kmeans_hist_bytes     size of the caller-owned histogram buffer (2^24 uint32 counts, cell-major, + 4096 cell totals)
  *   dp_kmeans_hist_build_u8  adds n pixels to hist_dev (16-byte aligned); accumulate = 0 clears it first, 1 keeps what it
- *                            holds (several buffers into one histogram).  Fewer than 2^32 pixels in total (32-bit counts).
+ *                            holds (several buffers into one histogram).  Fewer than 2^32 pixels in total (32-bit counts):
+ *                            an accumulating build that carries a cell's pixel count past 2^32 sets the uint32 word at byte
+ *                            offset 4 * (2^24 + 8193) of hist_dev to 1 (it stays set until a build with accumulate = 0) --
+ *                            the counts have wrapped and the histogram is then wrong; callers that add more than 2^32 - 1
+ *                            pixels must check it (the Python wrapper refuses such totals up front).  Accumulating builds
+ *                            into ONE histogram must be ordered on one stream: two concurrent builds race on the table.
  *                            By partition, not by one global atomic per pixel: the pixels are bucketed by their 16^3 cell
- *                            (2 bytes per pixel in workspace_dev, dp_kmeans_hist_workspace_bytes(n), 16-byte aligned), and
- *                            every bucket becomes its cell's table slice through an LDS histogram.
+ *                            (2 bytes per pixel in workspace_dev, written in whole 32-byte sectors: each of up to 256
+ *                            scatter workgroups may leave one padded sector per cell, so dp_kmeans_hist_workspace_bytes(n)
+ *                            is 2 n + up to 32 MB; 16-byte aligned), and every bucket becomes its cell's table slice
+ *                            through an LDS histogram.
  *   dp_kmeans_hist_step      one pass; K <= 256 (DP_EUNSUPPORTED above: use dp_kmeans_step_u8); centers_dev inside the colour
  *                            cube as for dp_kmeans_step_u8; outputs as there (sumsq_dev may be NULL).  Each workgroup builds
  *                            its cell's candidate list from centers_dev itself: no scratch, no second launch.

@@ -234,6 +234,41 @@ def test_colour_histogram_counts(be, orc, kind):
     assert int(empty.buf[:(1 << 26) + 4 * 4097].view(torch.int32).abs().sum().item()) == 0
 
 
+def test_fused_lloyd_iteration_soak_in_the_suite():
+    """The one-launch Lloyd iteration (hist_pass_kernel<FUSE>: totals by atomics, the last ticket runs the centre update, no
+    fence -- outside the HIP memory model, gfx950 only) against the three-step iteration and the pass over the pixels, fit after
+    fit: an ordering bug between the totals and the ticket shows as a fit that differs.  A short soak of tests/fuzz_kmeans_fused.py
+    on every run of the suite (round-4 advisor), so that a toolchain or driver change is caught; the long one runs by hand."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_kmeans_fused.py")
+    spec = importlib.util.spec_from_file_location("fuzz_kmeans_fused", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(5) == 0
+
+
+def test_colour_histogram_flags_a_wrapped_cell_count(be):
+    """dp_kmeans_hist_build_u8 with accumulate = 1 checks the running 32-bit cell totals on the device (round-4 advisor): a cell
+    whose count passes 2^32 sets the overflow word of the info block, which stays set until a build that does not accumulate.
+    (The Python wrapper's own guard counts pixels on the host; here the cell total is pushed to the brink directly.)"""
+    import torch
+    px = torch.tensor([[17, 99, 200]] * 40, dtype=torch.uint8, device="cuda")
+    hist = be.ColourHistogram(px)
+    assert not hist.overflowed()
+    cell = (17 >> 4) << 8 | (99 >> 4) << 4 | (200 >> 4)
+    info = hist.buf[1 << 26:].view(torch.int32)
+    assert int(info[cell].item()) == 40
+    info[cell] = -20                      # 2^32 - 20 pixels in that cell already
+    hist.add(px[:10], accumulate=True)    # 2^32 - 10: fine
+    assert not hist.overflowed()
+    hist.add(px[:30], accumulate=True)    # wraps
+    assert hist.overflowed()
+    hist.add(px[:5], accumulate=True)     # sticky
+    assert hist.overflowed()
+    hist.add(px, accumulate=False)
+    assert not hist.overflowed() and int(info[cell].item()) == 40
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_kmeans_histogram_pass_fuzz(be, orc, seed):
     """Random cluster counts (1..256), centre layouts (float, integer = tie-rich, data points, crowded), pixel counts and
