@@ -105,6 +105,17 @@ def case_palette(orc, spec):
     raise ValueError(spec)
 
 
+def numba_fixtures():
+    """(cases dict, arrays) recorded by `tests/golden/make_golden.py --numba` on a host with numba, or None: the build container
+    has no numba and cannot install it, so until somebody runs that one command the numba branches stay parity-unpinned."""
+    import json
+    jp, zp = os.path.join(GOLDEN, "numba.json"), os.path.join(GOLDEN, "numba.npz")
+    if not (os.path.exists(jp) and os.path.exists(zp)):
+        return None
+    with open(jp) as f:
+        return json.load(f), np.load(zp)
+
+
 def fake_ffmpeg_tools(tmp_path, monkeypatch, frames, rotation=None, coded=None, encoder_dies_after=None, trailing=b""):
     """Stand-ins for ffmpeg / ffprobe on PATH (there is no ffmpeg in the image): the decoder emits `frames` as rgb24, the
     encoder stores `-s` and the bytes it receives, ffprobe answers the queries get_video_info / _probe_rotation make.

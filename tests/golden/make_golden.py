@@ -2,6 +2,10 @@
 """Generate the golden fixtures from the REFERENCE itself (build container only).
 
 Run:  python tests/golden/make_golden.py            (needs /root/reference; ~3-4 min)
+      python tests/golden/make_golden.py --append   (only the cases kat.json does not hold yet)
+      python tests/golden/make_golden.py --numba    (on a host where `import numba` works: records the reference's numba
+                                                     branches into numba.json / numba.npz -- pins SURVEY row a7; a no-op with
+                                                     a message where numba is missing, as in the build container)
 
 Imports dobrosketchkun/dither_pie's dithering_lib from /root/reference (read-only; an
 in-memory stub stands in for the unused `pywt` import, nothing is written there) and
@@ -304,6 +308,100 @@ def append_new():
     print("now", len(npz), "arrays,", len(kat["cases"]), "cases")
 
 
+NUMBA_PROBE_PALETTE = [[84.0, 50.0 + 2.0 ** -18, 50.0], [116.0, 50.0, 50.0]]   # tests/test_oracle_golden.py: _numba_reading_probe
+NUMBA_HYBRID = [(1.0, 0.2), (1.4, 0.0), (0.3, 1.0)]
+
+
+def record_numba():
+    """The reference's numba branches -- _error_diffusion_numba (dithering_lib.py:213-308, dispatched at :638-653) and
+    _hybrid_numba (:1396-1494, dispatched at :1114-1125) -- run by the reference itself, on a host that has numba.  Both
+    dispatches sit in try/except and fall back to the pure-Python loop silently, so the two jitted functions are wrapped and
+    every case checks that the numba function was entered and returned.  Writes tests/golden/numba.json (hashes, versions,
+    case list) and numba.npz (every output in full: the images are small); tests/test_oracle_golden.py and the GPU tests
+    compare with them when they exist and report 'unpinned' when they do not.  Nothing else in tests/golden is touched."""
+    try:
+        import numba
+    except Exception as e:  # noqa: BLE001
+        print(f"numba is not importable here ({type(e).__name__}: {e}): nothing recorded; SURVEY row a7 stays parity-unpinned.\n"
+              "Run this command on a host with numba + the reference checkout (DITHER_PIE_REFERENCE=/path/to/dither_pie).")
+        return 2
+    if not getattr(dl, "_NUMBA_AVAILABLE", False):
+        print("the reference did not enable its numba branch (_NUMBA_AVAILABLE is False): nothing recorded")
+        return 2
+    entered = {"ed": 0, "hy": 0}
+    orig_ed, orig_hy = dl._error_diffusion_numba, dl._hybrid_numba
+
+    def ed(*a, **k):
+        r = orig_ed(*a, **k)
+        entered["ed"] += 1
+        return r
+
+    def hy(*a, **k):
+        r = orig_hy(*a, **k)
+        entered["hy"] += 1
+        return r
+
+    dl._error_diffusion_numba, dl._hybrid_numba = ed, hy
+    import scipy
+    rec = {"versions": {"numba": numba.__version__, "numpy": np.__version__, "scipy": scipy.__version__,
+                        "python": sys.version.split()[0]}, "cases": []}
+    npz = {}
+
+    def through(kind, before):
+        assert entered[kind] == before + 1, f"the reference fell back to its pure-Python loop ({kind}): numba failed to compile?"
+
+    # (1) the 8 kernels x serpentine off / on through the public entry point, two inputs (one with use_gamma: float palette)
+    inputs = [(("rnd", 48, 64, 11), ("palr", 16, 3), False), (("grad", 40, 56), ("U", 16), True)]
+    for ispec, pspec, gamma in inputs:
+        arr, pal = make_input(ispec), make_palette(pspec)
+        for variant in ED_VARIANTS:
+            for serp in ("false", "true"):
+                n0 = entered["ed"]
+                out = run_ref(arr, pal, "error_diffusion", {"variant": variant, "serpentine": serp}, gamma)
+                through("ed", n0)
+                name = f"nb_ed_{variant}_{serp}_{ispec[0]}{'_gamma' if gamma else ''}"
+                rec["cases"].append(dict(name=name, kind="error_diffusion", params={"variant": variant, "serpentine": serp},
+                                         palette=list(pspec), input=list(ispec), gamma=gamma, h_in=H(arr), h_out=H(out)))
+                npz[name] = out
+                print(name, H(out), flush=True)
+    # (2) the input on which the float32 and the float64 reading of the scan choose differently, and the strip of tiny values
+    # against a far colour (float64 error), straight through the strategy contract dither(pixels, palette_arr, (h, w))
+    probe_pal = np.array(NUMBA_PROBE_PALETTE, np.float32)
+    st = dl.ErrorDiffusionDitherStrategy(variant="floyd_steinberg", serpentine="false")
+    n0 = entered["ed"]
+    res = st.dither(np.array([[100.0, 50.0, 50.0]], np.float32), probe_pal, (1, 1))
+    through("ed", n0)
+    npz["nb_probe_rows"] = np.asarray(res, np.float32)
+    rec["probe"] = {"pixels": [[100, 50, 50]], "palette_f32": NUMBA_PROBE_PALETTE, "chosen_row": np.asarray(res).reshape(-1).tolist()}
+    pal2 = np.array([[255.0, 255.0, 255.0], [0.3, 0.3, 0.3], [17.7, 200.1, 3.3]], np.float32)
+    strip = rnd(3, 40, 8)
+    for serp in ("false", "true"):
+        n0 = entered["ed"]
+        res = dl.ErrorDiffusionDitherStrategy(variant="jjn", serpentine=serp).dither(
+            strip.reshape(-1, 3).astype(np.float32), pal2, (3, 40))
+        through("ed", n0)
+        npz[f"nb_strip_jjn_{serp}"] = np.asarray(res, np.float32).reshape(3, 40, 3)
+    rec["strip"] = {"input": ["rnd", 3, 40, 8], "palette_f32": pal2.tolist(), "variant": "jjn"}
+    # (3) _hybrid_numba, three settings, through the public entry point
+    for (lum, col), (ispec, pspec, gamma) in zip(NUMBA_HYBRID, [(("rnd", 13, 17, 3), ("U", 16), False),
+                                                               (("grad", 9, 21), ("palr", 9, 5), True),
+                                                               (("rnd", 11, 8, 4), ("palr", 5, 2), False)]):
+        arr, pal = make_input(ispec), make_palette(pspec)
+        n0 = entered["hy"]
+        out = run_ref(arr, pal, "hybrid", {"lum_factor": lum, "col_factor": col}, gamma)
+        through("hy", n0)
+        name = f"nb_hybrid_{lum}_{col}"
+        rec["cases"].append(dict(name=name, kind="hybrid", params={"lum_factor": lum, "col_factor": col}, palette=list(pspec),
+                                 input=list(ispec), gamma=gamma, h_in=H(arr), h_out=H(out)))
+        npz[name] = out
+        print(name, H(out), flush=True)
+    np.savez_compressed(os.path.join(HERE, "numba.npz"), **npz)
+    with open(os.path.join(HERE, "numba.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print("wrote numba.json / numba.npz:", len(rec["cases"]), "cases; commit both -- row a7 is then pinned by the reference")
+    return 0
+
+
 def main():
     import scipy
     import sklearn
@@ -480,7 +578,9 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--append" in sys.argv:
+    if "--numba" in sys.argv:
+        sys.exit(record_numba())
+    elif "--append" in sys.argv:
         append_new()
     else:
         main()

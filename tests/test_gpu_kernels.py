@@ -196,6 +196,28 @@ def test_error_diffusion_numba_arithmetic_vs_oracle(be, orc, variant, serp):
 
 
 @pytest.mark.gpu
+def test_numba_fixtures_on_the_device_when_present(be, orc):
+    """SURVEY row a7 on the device: dp_error_diffusion_numba_u8 / dp_hybrid_numba_u8 against what the REFERENCE's numba branches
+    produced (tests/golden/numba.*, recorded by make_golden.py --numba on a host that has numba).  Skips with 'unpinned' while
+    nobody has recorded them -- the kernels are then checked against the (equally unpinned) C restatement only."""
+    import torch
+    from conftest import case_input, case_palette, numba_fixtures
+    fx = numba_fixtures()
+    if fx is None:
+        pytest.skip("a7 parity UNPINNED on the device too: tests/golden/numba.{json,npz} absent")
+    rec, arrs = fx
+    for c in rec["cases"]:
+        arr, pal = case_input(orc, c["input"]), case_palette(orc, c["palette"])
+        P = be.Palette(*orc.prepare_palette(pal, c["gamma"]))
+        x = torch.from_numpy(arr).cuda()
+        if c["kind"] == "error_diffusion":
+            taps, div = orc.ed_kernel(c["params"]["variant"])
+            out = be.error_diffusion(x, P, taps, div, c["params"]["serpentine"] == "true", arithmetic="numba")
+        else:
+            out = be.hybrid_numba(x, P, c["params"]["lum_factor"], c["params"]["col_factor"])
+        _assert_same(out.cpu().numpy(), arrs[c["name"]], c["name"])
+
+
 def test_error_diffusion_numba_float64_reading(be, orc):
     """The probe of tests/test_oracle_golden.py::test_numba_branch_follows_float64_unification on the device: the kernel
     takes the entry that is nearer in float64 (numba unifies r to float64), not the one a float32 scan collapses onto; and a

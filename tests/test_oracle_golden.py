@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, case_input, case_palette
+from conftest import GOLDEN, case_input, case_palette, numba_fixtures
 
 with open(os.path.join(GOLDEN, "kat.json")) as _f:
     _KAT = json.load(_f)
@@ -318,6 +318,28 @@ def test_numba_branch_follows_float64_unification():
     for serp in (False, True):
         a = orc.error_diffusion_numba_u8(strip, pal2, oc2, None, "jjn", serp)
         assert np.array_equal(a, orc.error_diffusion_numba_numpy(strip, pal2, oc2, None, "jjn", serp))
+
+
+def test_numba_fixtures_pin_the_restatement_when_present(orc):
+    """the reference's numba branches (dithering_lib.py:213-308, 1396-1494).  With fixtures the C restatement
+    must reproduce every recorded output -- 8 kernels x serpentine x 2 inputs, the float32-vs-float64 probe, the strip of
+    tiny values, three hybrid settings; without them the test SKIPS with the word 'unpinned' (it never passes vacuously)."""
+    fx = numba_fixtures()
+    if fx is None:
+        pytest.skip("a7 parity UNPINNED: tests/golden/numba.{json,npz} absent (python tests/golden/make_golden.py --numba on a host with numba)")
+    rec, arrs = fx
+    for c in rec["cases"]:
+        arr, pal = case_input(orc, c["input"]), case_palette(orc, c["palette"])
+        pal_f32, out_colors, lut_in = orc.prepare_palette(pal, c["gamma"])
+        if c["kind"] == "error_diffusion":
+            got = orc.error_diffusion_numba_u8(arr, pal_f32, out_colors, lut_in, c["params"]["variant"], c["params"]["serpentine"] == "true")
+        else:
+            got = orc.hybrid_numba_u8(arr, pal_f32, out_colors, lut_in, c["params"]["lum_factor"], c["params"]["col_factor"])
+        assert np.array_equal(got, arrs[c["name"]]), c["name"]
+    arr, pal_f32, out_colors = _numba_reading_probe()
+    row = np.asarray(arrs["nb_probe_rows"]).reshape(-1)
+    chosen = int(np.argmin(((pal_f32.astype(np.float64) - row.astype(np.float64)) ** 2).sum(1)))
+    assert orc.error_diffusion_numba_u8(arr, pal_f32, out_colors, None, "floyd_steinberg", False)[0, 0].tolist() == out_colors[chosen].tolist()
 
 
 @pytest.mark.parametrize("lum_factor,col_factor", [(1.0, 0.2), (1.4, 0.0), (0.3, 1.0)])
