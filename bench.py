@@ -82,13 +82,17 @@ _LEG_SOURCES = {"c2_crowded": ("ordered.hip", "accel.hip", "dp_internal.h", "tre
                 "c3": ("ediff.hip", "ed_nearest.hip.h", "dp_internal.h")}
 
 
+PMC_LEGS = "r05_pmc_legs.json"
+
+
 def leg_traffic(result, name, pmc_leg=None):
-    """HBM traffic of a leg's dominant kernel from the committed PMC passes of round 4 (profiles/r04_pmc_legs.json: FETCH_SIZE x 2
-    + WRITE_SIZE, separate --pmc passes of the tools/bench_scripts/*_prof.py workload named there), as the ratio to that
-    workload's algorithmic bytes applied to this leg's -- reported only while the kernel sources are the ones the passes were
-    taken with."""
+    """HBM traffic of a leg's dominant kernel, ESTIMATED from the committed PMC passes of this round (profiles/r05_pmc_legs.json:
+    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes of the tools/bench_scripts/*_prof.py workload named there -- for c3 and the
+    histogram build that workload is the leg's own launch shape): the measured ratio to that workload's algorithmic bytes applied to
+    this leg's.  Nothing is counted during this run (PMC counters cannot be read from inside the process), hence the key's name;
+    reported only while the kernel sources are the ones the passes were taken with."""
     leg = result.get(name)
-    path = os.path.join(ROOT, "profiles", "r04_pmc_legs.json")
+    path = os.path.join(ROOT, "profiles", PMC_LEGS)
     if not leg or not os.path.exists(path):
         return
     try:
@@ -97,16 +101,35 @@ def leg_traffic(result, name, pmc_leg=None):
         if not rec:
             return
         if rec.get("kernel_sources_sha16") != sources_sha16(_LEG_SOURCES[name]):
-            leg["traffic"], leg["traffic_source"] = None, "profiles/r04_pmc_legs.json was taken with other kernel sources: not reported"
+            leg["traffic_estimated_from_profile"] = None
+            leg["traffic_source"] = f"profiles/{PMC_LEGS} was taken with other kernel sources: not reported"
             return
         ratio = rec["derived"].get("traffic_over_algorithmic")
         if ratio:
-            leg["traffic"] = int(ratio * leg["algorithmic_bytes"])
+            leg["traffic_estimated_from_profile"] = int(ratio * leg["algorithmic_bytes"])
             leg["traffic_over_algorithmic"] = round(ratio, 3)
-            leg["traffic_source"] = ("profiles/r04_pmc_legs.json [" + (pmc_leg or name) + "]: FETCH_SIZE x2 + WRITE_SIZE per launch of "
-                                     + rec["workload"] + ", as a ratio to that workload's algorithmic bytes")
+            leg["traffic_source"] = (f"profiles/{PMC_LEGS} [" + (pmc_leg or name) + "]: FETCH_SIZE x2 + WRITE_SIZE per launch of "
+                                     + rec["workload"] + ", as a ratio to that workload's algorithmic bytes (a committed profile of "
+                                     "the same kernel sources, not a counter read in this run)")
     except Exception:  # noqa: BLE001
         return
+
+
+def rocprof_average_ms(kernel_substring, stats_name="r05_kernel_stats.csv"):
+    """AverageNs of a kernel in the committed rocprofv3 --kernel-trace --stats summary of `bench.py --no-extra --no-cpu-baseline`
+    (profiles/r05_kernel_stats.csv: every launch of the run, the slow first ones under the profiler included) -> ms, or None."""
+    import csv
+    path = os.path.join(ROOT, "profiles", stats_name)
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if kernel_substring in row.get("Name", ""):
+                    return float(row["AverageNs"]) / 1e6
+    except Exception:  # noqa: BLE001
+        return None
+    return None
 
 
 def cpu_baseline(n_frames=16):
@@ -492,7 +515,7 @@ def main():
     # comes from the committed rocprofv3 --pmc pass of this same command (profiles/pmc_pass.sh)
     # (profiles/pmc_pass.sh); the file names the kernel sources it was taken with and is ignored when they have changed
     traffic, traffic_src, valu_per_launch = None, None, None
-    pmc_name = "r04_pmc_ordered.json"
+    pmc_name = "r05_pmc_ordered.json"
     pmc_file = os.path.join(ROOT, "profiles", pmc_name)
     if args.frames == 24 and os.path.exists(pmc_file):
         try:
@@ -527,6 +550,13 @@ def main():
         "parity_kat_4k": bool(kat_ok),
         "first_call_ms": round(first_call_ms, 2),
     }
+    # the same fraction from the committed rocprofv3 summary of this command (its average over ALL launches of the run, the slow
+    # first ones included): the least favourable of the three ways to time the kernel, reported next to `frac`
+    rp_ms = rocprof_average_ms("ordered_lean_kernel<1, 8, false, false, false>") if args.frames == 24 else None
+    if rp_ms:
+        result["roofline"]["rocprof_avg_kernel_ms"] = round(rp_ms, 4)
+        result["roofline"]["frac_rocprof_avg"] = round(BYTES_PER_PX * px_per_step / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        result["roofline"]["frac_rocprof_avg_source"] = "profiles/r05_kernel_stats.csv (AverageNs of the kernel over every launch of `bench.py --no-extra --no-cpu-baseline` under rocprofv3 --kernel-trace --stats)"
     if valu_per_launch:
         # what actually bounds the kernel: wave64 VALU instructions of one launch (same PMC file) against
         # the issue rate of 1024 SIMDs, one instruction per 4 cycles, at the 2.4 GHz peak clock
