@@ -111,6 +111,9 @@ struct PalDev {
     const uint32_t *ed_coarse;  // palettes of 9..16 colours: lists of the 16^3 cells, count | 7 index nibbles (count 15: too long)
     const uint32_t *ed_coarse_ext;  // the same for the diffusers that do not clamp (vardiff.hip): the outermost cells stand for the half-spaces beyond the cube
     const uint4 *ed_lists16;    // palettes of 17..256 colours: lists of the 16^3 cells, count byte | up to 15 index bytes (255: too long)
+    const uint32_t *ed_h4;      // palettes of 17..256 colours: hierarchical table of <= 4 entries per leaf (host_logic.h EdTables::h4), or null
+    int ed_h4_words;
+    int ed_h4_global;           // the sixteen-wave instances read it from global memory (set per launch)
     const uint4 *exc;           // colours whose outcome no code expresses, sorted by colour:
     int n_exc;                  //   {colour, k=2 indices i0 | i1<<16, k=1 index, 0}; n_exc < 0: list overflowed
 };

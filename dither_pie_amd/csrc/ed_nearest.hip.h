@@ -153,13 +153,48 @@ __device__ __forceinline__ int nearest_color(const PalDev &pal, const float4 *__
 // palette; a step then needs no load from global memory at all (the 8x8x8 lists live in L2: ~600 cycles of latency that
 // every step of the dependency chain would pay).
 // `lists16` (wavefront kernel on the few-frames schedule, palettes of 17..256 colours; else nullptr): an LDS copy of the
+// The hierarchical table of at most four entries per leaf (host_logic.h: EdTables::h4; palettes of 17..256 colours): the wave pays
+// for the longest candidate list among its 64 lanes, so instead of scanning a 16^3 cell's list in rounds of four, a lane whose cell
+// has more than four possible nearest entries descends to the cell's 8-wide child and, if need be, to the 4-wide and 2-wide ones -- at
+// most three more dependent reads -- and ranks ONE group of four.  Returns the palette index, or -1 when the table has no answer for this
+// point (a 4-wide cell that is still longer, or a float32 near tie): the caller's lists decide then, as before.
+__device__ __forceinline__ bool h4_marker(const uint32_t w) { return (w & 0xffu) >= ((w >> 8) & 0xffu); }
+
+__device__ __forceinline__ int nearest_h4(const uint32_t *__restrict__ h4, const float4 *__restrict__ cand, const float o0, const float o1,
+                                          const float o2)
+{
+    const uint32_t i0 = (uint32_t)o0, i1 = (uint32_t)o1, i2 = (uint32_t)o2;
+    uint32_t w = h4[(i0 >> 4) | ((i1 >> 4) << 4) | ((i2 >> 4) << 8)];
+#pragma unroll
+    for (int bit = 3; bit >= 1; --bit) {   // the 8-wide, 4-wide, 2-wide child: as far as this lane's cell is cut
+        if (!h4_marker(w)) break;
+        if ((w >> 16) == 0xffffu) return -1;
+        w = h4[4096u + (w >> 16) * 8u + (((i0 >> bit) & 1u) | (((i1 >> bit) & 1u) << 1) | (((i2 >> bit) & 1u) << 2))];
+    }
+    if (h4_marker(w)) return -1;
+    const float4 c1 = cand[w & 255u], c2 = cand[(w >> 8) & 255u], c3 = cand[(w >> 16) & 255u], c4 = cand[w >> 24];
+    keep_record_whole(c1);
+    keep_record_whole(c2);
+    keep_record_whole(c3);
+    keep_record_whole(c4);
+    const int k1 = ed_key(c1, o0, o1, o2, 0u), k2 = ed_key(c2, o0, o1, o2, 1u), k3 = ed_key(c3, o0, o1, o2, 2u),
+              k4 = ed_key(c4, o0, o1, o2, 3u);
+    int m0 = min(min(k1, k2), k3), m1 = ed_med3(k1, k2, k3);
+    m1 = ed_med3(m0, m1, k4);
+    m0 = min(m0, k4);
+    // (the margin of the 16^3 key scan: 2e-6 of the float32 evaluation + 7 ulp of the tag bits)
+    const float f0 = __int_as_float(m0 & ~7), f1 = __int_as_float(m1 & ~7);
+    if (f1 > f0 * 1.000003f) return (int)((w >> (8u * ((uint32_t)m0 & 3u))) & 255u);
+    return -1;
+}
+
 // lists of the 16x16x16 cells in the format of the 8x8x8 table (count byte 255: more than 15 entries, use that table).
 // `expanded` (with `coarse`, EXPANDED instances): the candidates' expanded records for ed_key_expanded.
 template <int CAP, bool EXPANDED = false>
 __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const float4 *__restrict__ cand,
                                                    const uint32_t *__restrict__ coarse, const float o0, const float o1,
                                                    const float o2, const uint4 *__restrict__ lists16 = nullptr,
-                                                   const float4 *__restrict__ expanded = nullptr)
+                                                   const float4 *__restrict__ expanded = nullptr, const uint32_t *__restrict__ h4 = nullptr)
 {
     float b0 = __int_as_float(0x7f800000), b1 = b0;
     int i0 = 0;
@@ -238,6 +273,10 @@ __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const floa
             }
             listed = true;
         }
+    }
+    if (!listed && h4) {
+        const int j = nearest_h4(h4, cand, o0, o1, o2);
+        if (j >= 0) return j;
     }
     if (!listed) {
         uint4 blk = make_uint4(255u, 0u, 0u, 0u);

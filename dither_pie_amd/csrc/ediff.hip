@@ -246,11 +246,20 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
         const double n2 = (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z + (double)kEdExpandedBias;
         s_expanded[threadIdx.x] = make_float4(-2.0f * c.x, -2.0f * c.y, -2.0f * c.z, (float)n2);
     }
-    __shared__ uint4 s_lists16[MAXW <= 4 ? 4096 : 1];
+    __shared__ uint4 s_lists16[MAXW <= 4 ? kEdH4MaxWords / 4 : 1];   // the 16^3 lists (64 KB) or the hierarchical table (<= 96 KB)
     const uint4 *lists16 = nullptr;
-    if (MAXW <= 4 && pal.ed_lists16) {
+    const uint32_t *h4 = nullptr;
+    if (MAXW <= 4 && pal.ed_h4) {
+        // the hierarchical <= 4-entry table instead of the 16^3 lists (same LDS): one group of four candidates per step for every
+        // lane; what it cannot answer goes to the 8^3 lists in L2
+        uint32_t *s_h4 = reinterpret_cast<uint32_t *>(s_lists16);
+        for (int i = threadIdx.x; i < pal.ed_h4_words; i += blockDim.x) s_h4[i] = pal.ed_h4[i];
+        h4 = s_h4;
+    } else if (MAXW <= 4 && pal.ed_lists16) {
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_lists16[i] = pal.ed_lists16[i];
         lists16 = s_lists16;
+    } else if (MAXW > 4 && pal.ed_h4 && pal.ed_h4_global) {
+        h4 = pal.ed_h4;   // sixteen waves of rings fill LDS: the table stays in global memory (<= 96 KB, L2-resident)
     }
     if (threadIdx.x < MAXW) s_prog[threadIdx.x] = 0;
     if (threadIdx.x < 4) s_zero[threadIdx.x] = (E)0;
@@ -493,7 +502,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
                     const int j = NB ? nearest_numba_f64(s_pal, pal.K, o0, o1, o2)
-                                     : (pal.ed_cells ? nearest_color_cells<CAP, true>(pal, s_pal, coarse, o0, o1, o2, lists16, s_expanded)
+                                     : (pal.ed_cells ? nearest_color_cells<CAP, true>(pal, s_pal, coarse, o0, o1, o2, lists16, s_expanded, h4)
                                                      : nearest_color<CAP>(pal, s_pal, o0, o1, o2));
                     const float4 pj = s_pal[j];
                     e0 = err_of<NB>(o0, pj.x);
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
             }
             const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
             const int j = NB ? nearest_numba_f64(pal.fcand, pal.K, o0, o1, o2)
-                             : (pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, nullptr, o0, o1, o2)
+                             : (pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, nullptr, o0, o1, o2, nullptr, nullptr, pal.ed_h4)
                                              : nearest_color<CAP>(pal, pal.fcand, o0, o1, o2));
             E *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
             E v0 = err_of<NB>(o0, (float)pal.pts[3 * j]), v1 = err_of<NB>(o1, (float)pal.pts[3 * j + 1]),
@@ -817,7 +826,9 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     const int K = dev.K;
     static_assert(sizeof(U4) == sizeof(uint4), "U4 mirrors uint4");
     uint4 *cells = nullptr;
-    constexpr size_t kCoarseQuads = 4096;  // room for a 16^3-cell table behind the lists (and the nodes): 4096 words or 4096 quads
+    // room behind the lists (and the nodes): the 16^3-cell table(s) -- 4096 quads (K > 16) or 2 x 4096 words (K <= 16) -- and, for
+    // K > 16, the hierarchical table of up to kEdH4MaxWords words
+    constexpr size_t kCoarseQuads = 4096 + kEdH4MaxWords / 4;
     DP_HIP(hipMalloc((void **)&cells, sizeof(uint4) * (kEdCells + kCoarseQuads)));
     hipLaunchKernelGGL(ed_cells_kernel, dim3(kEdCells / 256), dim3(256), 0, 0, dev, cells);
     hipError_t e = hipGetLastError();
@@ -832,6 +843,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     // cells) into an octree down to unit cubes, the 16^3-cell lists for LDS.
     EdTables tb;
     ed_tables_refine(pts, K, host, tb);
+    if (exp_env("DP_ED_H4_REPORT")) fprintf(stderr, "ed tables: K %d, h4 %zu words (%zu wanted, limit %zu), nodes %zu\n", K, tb.h4.size(), tb.h4_wanted, kEdH4MaxWords, tb.nodes.size());
     if (!tb.nodes.empty()) {  // one allocation: cells, then the nodes, then the 16^3-cell table(s)
         uint4 *both = nullptr;
         e = hipMalloc((void **)&both, sizeof(uint4) * (kEdCells + tb.nodes.size() + kCoarseQuads));
@@ -846,6 +858,8 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     uint32_t *d_coarse = reinterpret_cast<uint32_t *>(tail);
     if (e == hipSuccess && !tb.coarse.empty()) e = hipMemcpy(d_coarse, tb.coarse.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
     if (e == hipSuccess && !tb.ext.empty()) e = hipMemcpy(d_coarse + 4096, tb.ext.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
+    uint32_t *d_h4 = reinterpret_cast<uint32_t *>(tail + 4096);
+    if (e == hipSuccess && !tb.h4.empty()) e = hipMemcpy(d_h4, tb.h4.data(), sizeof(uint32_t) * tb.h4.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(cells);
         return hip_fail(e, "error-diffusion candidate lists");
@@ -855,14 +869,19 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     dev.ed_lists16 = tb.l16.empty() ? nullptr : tail;
     dev.ed_coarse = tb.coarse.empty() ? nullptr : d_coarse;
     dev.ed_coarse_ext = tb.ext.empty() ? nullptr : d_coarse + 4096;
+    dev.ed_h4 = tb.h4.empty() ? nullptr : d_h4;
+    dev.ed_h4_words = (int)tb.h4.size();
     *blob_out = cells;
     return DP_OK;
 }
 
-int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal,
+int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, const PalDev &pal_in,
                            const int32_t *dx, const int32_t *dy, const float *wq, int ntaps, int serpentine,
                            void *ws, size_t ws_bytes, hipStream_t s, const double *wq64, const double *hybrid)
 {
+    PalDev pal = pal_in;   // (by-value snapshot; the experiments build may switch a table off for an A/B)
+    if (exp_env("DP_ED_NO_H4")) pal.ed_h4 = nullptr;
+    pal.ed_h4_global = exp_env("DP_ED_H4_LDS_ONLY") ? 0 : 1;
     // wq64 != nullptr: the numba arithmetic (see nearest_numba_f32) with these float64 tap weights
     const bool numba = wq64 != nullptr;
     Taps t;

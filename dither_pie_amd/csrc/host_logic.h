@@ -522,7 +522,15 @@ struct EdTables {
     std::vector<U4> l16;           // K > 16: lists of the 16^3 cells in the 8^3 table's format
     std::vector<uint32_t> coarse;  // K <= 16: lists of the 16^3 cells, count | 7 index nibbles
     std::vector<uint32_t> ext;     // K <= 16: the same over the extended grid (outermost cells = half-spaces)
+    // K > 16: the hierarchical nearest table of at most four entries per leaf (ed_nearest.hip.h: nearest_h4).  Words [0, 4096): the
+    // 16^3 cells; then nodes of 8 words: the 8-wide children of a cell, the 4-wide children of a child, the 2-wide ones of those.  A LEAF word holds four
+    // palette indices, byte 0 < byte 1 (listed entries, then an unlisted far entry as padding); a word with byte 0 >= byte 1 is a
+    // MARKER: 0x00ff | node << 16 (node 0xffff: no answer here, use the lists).  Empty when it would not fit kEdH4MaxWords.
+    std::vector<uint32_t> h4;
+    size_t h4_wanted = 0;          // words the table would take (reported by the experiments build)
 };
+constexpr size_t kEdH4MaxWords = 24576;   // 96 KB: the LDS the few-frames diffusion kernel has for it (256 random colours: 17 320 words)
+constexpr uint32_t kEdH4NoAnswer = 0xffff00ffu;
 
 // cells [kEdCells]: in = the kernel's lists (count byte | up to 15 index bytes, count 255 = overflow), out = sharpened,
 // padded, overflowing cells refined into `nodes`.  pts: K*3 float64 palette coordinates.
@@ -710,6 +718,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
     out.l16.clear();
     out.coarse.clear();
     out.ext.clear();
+    out.h4.clear();
     if (K > 16) {
         // lists of the 16x16x16 cells in the format of the 8x8x8 table, for the LDS of the wavefront kernel's few-frames
         // variant (one wave per SIMD: the read of the 8x8x8 table from L2 is half of a step's latency there)
@@ -724,6 +733,111 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
                 l16[cell] = list.size() <= 15 ? pack(list, lo, 16.0) : make_u4(255u, 0u, 0u, 0u);
             }
         });
+        // The hierarchical table: a wave of the diffusion kernel pays for the LONGEST list among its 64 lanes, and with 256 random
+        // colours 12 % of the 16^3 cells, 0.8 % of the 8-wide and 0.03 % of the 4-wide cells have more than four possible nearest
+        // entries -- so a cell with more than four is cut into its eight 8-wide children, such a child into its 4-wide children,
+        // and every lane ends at a leaf of at most four (what is still longer at 4-wide keeps the lists above).
+        auto leaf = [&](const std::vector<int> &list, const double lo[3], const double size) -> uint32_t {
+            // filler: an unlisted entry far from the box, as pack() chooses it
+            const int oct = (lo[0] + 0.5 * size < 128.0 ? 1 : 0) | (lo[1] + 0.5 * size < 128.0 ? 2 : 0) | (lo[2] + 0.5 * size < 128.0 ? 4 : 0);
+            int filler = corner_entry[oct];
+            if (std::find(list.begin(), list.end(), filler) != list.end()) {
+                filler = -1;
+                double far_d = -1.0;
+                for (int j = 0; j < K; ++j) {
+                    if (std::find(list.begin(), list.end(), j) != list.end()) continue;
+                    double d2 = 0.0;
+                    for (int d = 0; d < 3; ++d) {
+                        const double m = pts[3 * j + d] - (lo[d] + 0.5 * size);
+                        d2 += m * m;
+                    }
+                    if (d2 > far_d) {
+                        far_d = d2;
+                        filler = j;
+                    }
+                }
+            }
+            int b[4];
+            for (int n = 0; n < 4; ++n) b[n] = n < (int)list.size() ? list[n] : filler;
+            // byte 0 < byte 1 marks a leaf: two distinct indices always exist (a list of one is padded with its filler)
+            if (b[0] > b[1]) std::swap(b[0], b[1]);
+            return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        };
+        std::vector<std::vector<uint32_t>> local(4096);   // per cell: [0] its word (marker: local node 0), then its nodes' words
+        parallel_cells(4096, [&](const int c0, const int c1) {
+            // (depth-first: a box with more than four entries becomes a node of its eight half-size children, down to 2-wide boxes)
+            struct Item {
+                size_t slot;
+                double lo[3];
+                double size;
+                std::vector<int> from;
+            };
+            std::vector<Item> todo;
+            std::vector<int> list;
+            for (int cell = c0; cell < c1; ++cell) {
+                std::vector<uint32_t> &lw = local[cell];
+                lw.assign(1, kEdH4NoAnswer);
+                todo.clear();
+                Item top;
+                top.slot = 0;
+                top.lo[0] = (double)((cell & 15) * 16);
+                top.lo[1] = (double)(((cell >> 4) & 15) * 16);
+                top.lo[2] = (double)((cell >> 8) * 16);
+                top.size = 16.0;
+                top.from = all;
+                todo.push_back(std::move(top));
+                while (!todo.empty()) {
+                    Item it = std::move(todo.back());
+                    todo.pop_back();
+                    box_list(it.from, it.lo, it.size, list);
+                    prune_list(it.lo, it.size, list);
+                    if (list.size() <= 4) {
+                        lw[it.slot] = leaf(list, it.lo, it.size);
+                        continue;
+                    }
+                    if (it.size <= 2.0) continue;   // still longer in a 2-wide box: no answer here (the lists decide)
+                    const uint32_t node = (uint32_t)((lw.size() - 1) / 8);   // local node number of the children
+                    lw[it.slot] = 0x00ffu | (node << 16);
+                    lw.resize(lw.size() + 8, kEdH4NoAnswer);
+                    const double hs = it.size * 0.5;
+                    for (int sub = 0; sub < 8; ++sub) {
+                        Item ch;
+                        ch.slot = 1 + 8 * (size_t)node + (size_t)sub;
+                        ch.lo[0] = it.lo[0] + ((sub & 1) ? hs : 0.0);
+                        ch.lo[1] = it.lo[1] + ((sub & 2) ? hs : 0.0);
+                        ch.lo[2] = it.lo[2] + ((sub & 4) ? hs : 0.0);
+                        ch.size = hs;
+                        ch.from = list;
+                        todo.push_back(std::move(ch));
+                    }
+                }
+            }
+        });
+        std::vector<uint32_t> &h4 = out.h4;
+        out.h4_wanted = 0;
+        for (int cell = 0; cell < 4096; ++cell) out.h4_wanted += local[cell].size();
+        h4.assign(4096, kEdH4NoAnswer);
+        bool fits = true;
+        for (int cell = 0; cell < 4096 && fits; ++cell) {
+            const std::vector<uint32_t> &lw = local[cell];
+            if (lw.size() == 1) {
+                h4[cell] = lw[0];
+                continue;
+            }
+            const size_t base = (h4.size() - 4096) / 8;   // global number of this cell's local node 0
+            if (h4.size() + (lw.size() - 1) > kEdH4MaxWords || base + (lw.size() - 1) / 8 >= 0xffffu) {
+                fits = false;
+                break;
+            }
+            h4[cell] = 0x00ffu | ((uint32_t)base << 16);
+            for (size_t i = 1; i < lw.size(); ++i) {
+                uint32_t w = lw[i];
+                const bool marker = (w & 0xffu) >= ((w >> 8) & 0xffu);
+                if (marker && w != kEdH4NoAnswer) w = 0x00ffu | ((uint32_t)(base + (w >> 16)) << 16);
+                h4.push_back(w);
+            }
+        }
+        if (!fits) h4.clear();   // a clustered palette: the lists (and their octree refinement) serve it
     }
     if (K <= 16) {
         // lists of the 16x16x16 cells for the wavefront kernel's LDS: count | up to 7 indices, one nibble each

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     // (perceptual: its waves nearly always hold a point outside the cube -- measured, the lists only cost there)
                     int j;
                     if (model != 4 && coarse) j = nearest_ext<CAP>(pal, s_pal, coarse, o0, o1, o2);
-                    else if (model != 1 && pal.ed_cells && __ballot(!inside) == 0ull) j = nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2);
+                    else if (model != 1 && pal.ed_cells && __ballot(!inside) == 0ull) j = nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2, nullptr, nullptr, pal.ed_h4);
                     else j = nearest_any<CAP>(pal, s_pal, o0, o1, o2);
                     const float4 pj = s_pal[j];
                     e0 = __fsub_rn(o0, pj.x);
