@@ -729,6 +729,13 @@ def main():
         d3b.apply_dithering_frames(frames[:1], out=o24[:1])
         t1b = timed(lambda: d3b.apply_dithering_frames(frames[:1], out=o24[:1]), 2, 1) / 2
         extra["c3_fs_k256_4k_one_frame_ms"] = round(t1b * 1e3, 2)
+        if not args.rehearse_on_one_gpu:   # the same palette, 256 frames in flight (the hierarchical nearest table read from L2)
+            f3b = frames.repeat((256 + args.frames - 1) // args.frames, 1, 1, 1)[:256]
+            o3b = torch.empty_like(f3b)
+            d3b.apply_dithering_frames(f3b, out=o3b)
+            t3b = timed(lambda: d3b.apply_dithering_frames(f3b, out=o3b), 2, 1) / 2
+            extra["c3_fs_k256_4k_mpixel_per_s"] = round(world * 256 * H4K * W4K / t3b / 1e6, 2)
+            del f3b, o3b
         # C4: k-means 32-colour palette from a 7680x4320 image + blue-noise dither, the image split into row
         # bands over the ranks; the per-iteration exchange is one RCCL all-reduce of [32,5] int64
         from dither_pie_amd import kmeans, sharding
