@@ -42,11 +42,17 @@ __device__ uint32_t mt_next(uint32_t *mt, int &pos)
     return y;
 }
 
-// scratch layout (global): coords[n] uint32 (r*size+c in shuffled order), md[n] float, alive handled by md = -1
+// scratch layout: coords[n] uint32 (r*size+c in shuffled order), md[n] float, alive handled by md = -1.  IN_LDS (sizes up to
+// 128: 8 bytes per position, 128 KB): both arrays live in dynamic LDS -- lane 0's serial shuffle swaps 4095 ... 16383 pairs and
+// every round reads and writes md; from global memory those dependent accesses were most of the kernel (64 x 64: 10.6 ms).
+template <bool IN_LDS>
 __global__ __launch_bounds__(kThreads) void blue_noise_kernel(const int size, const uint32_t seed,
-                                                              float *__restrict__ out, uint32_t *__restrict__ coords,
-                                                              float *__restrict__ md)
+                                                              float *__restrict__ out, uint32_t *__restrict__ coords_g,
+                                                              float *__restrict__ md_g)
 {
+    extern __shared__ __align__(16) uint8_t s_dyn[];
+    uint32_t *coords = IN_LDS ? reinterpret_cast<uint32_t *>(s_dyn) : coords_g;
+    float *md = IN_LDS ? reinterpret_cast<float *>(s_dyn + (size_t)size * size * sizeof(uint32_t)) : md_g;
     __shared__ uint32_t s_mt[624];
     __shared__ Best s_part[kThreads / 64];
     __shared__ Best s_best;
@@ -81,6 +87,13 @@ __global__ __launch_bounds__(kThreads) void blue_noise_kernel(const int size, co
     }
     __threadfence_block();
     __syncthreads();
+    // (row, column) split once, not in every round: row << 16 | column
+    for (int i = tid; i < n; i += kThreads) {
+        const uint32_t c = coords[i];
+        const uint32_t rr = c / (uint32_t)size;
+        coords[i] = (rr << 16) | (c - rr * (uint32_t)size);
+    }
+    __syncthreads();
 
     const double denom = (double)(n - 1) + 1e-9;
     int br = 0, bc = 0;
@@ -93,8 +106,8 @@ __global__ __launch_bounds__(kThreads) void blue_noise_kernel(const int size, co
             float v = md[p];
             if (v < 0.0f) continue;  // already placed
             if (it > 0) {
-                const int c = (int)coords[p];
-                const int rr = c / size, cc = c - rr * size;
+                const uint32_t c = coords[p];
+                const int rr = (int)(c >> 16), cc = (int)(c & 0xffffu);
                 const float d2 = (float)((rr - br) * (rr - br) + (cc - bc) * (cc - bc));
                 if (d2 < v) {
                     v = d2;
@@ -129,11 +142,11 @@ __global__ __launch_bounds__(kThreads) void blue_noise_kernel(const int size, co
         }
         __syncthreads();
         const uint32_t bp = s_best.pos;
-        const int c = (int)coords[bp];
-        br = c / size;
-        bc = c - br * size;
+        const uint32_t c = coords[bp];
+        br = (int)(c >> 16);
+        bc = (int)(c & 0xffffu);
         if (tid == 0) {
-            out[c] = (float)((double)it / denom);
+            out[br * size + bc] = (float)((double)it / denom);
             md[bp] = -1.0f;
         }
         __threadfence_block();
@@ -150,7 +163,13 @@ int launch_blue_noise(int size, uint32_t seed, float *out_dev, void *scratch_dev
     const size_t n = (size_t)size * size;
     uint32_t *coords = reinterpret_cast<uint32_t *>(scratch_dev);
     float *md = reinterpret_cast<float *>(coords + n);
-    hipLaunchKernelGGL(blue_noise_kernel, dim3(1), dim3(kThreads), 0, s, size, seed, out_dev, coords, md);
+    const size_t lds = n * (sizeof(uint32_t) + sizeof(float));
+    if (lds <= 128 * 1024) {
+        DP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blue_noise_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((blue_noise_kernel<true>), dim3(1), dim3(kThreads), lds, s, size, seed, out_dev, coords, md);
+    } else {
+        hipLaunchKernelGGL((blue_noise_kernel<false>), dim3(1), dim3(kThreads), 0, s, size, seed, out_dev, coords, md);
+    }
     DP_HIP(hipGetLastError());
     return DP_OK;
 }

@@ -297,6 +297,7 @@ class VideoProcessor:
         return 0
 
     PIPE_SLOTS = 3            # rotating pinned batch slots of the overlapped pipe path (reader / GPU / writer each hold one)
+    PIPE_SLOT_BYTES = 256 << 20   # pinned bytes of a slot's input (or output) buffer at most
     PIPE_BYTES = 1 << 20      # requested pipe capacity (F_SETPIPE_SZ; the kernel default is 64 KiB = one syscall per 64 KiB)
 
     @staticmethod
@@ -344,6 +345,13 @@ class VideoProcessor:
         product_run = run is None
         pin = torch.cuda.is_available()
         out_geom = None   # (H', W') of the product path: known up front, so that the output slots are allocated once
+        if product_run:
+            # a slot is one batch of input + one of output, pinned; three of them rotate: keep a slot's larger half under
+            # PIPE_SLOT_BYTES (4K frames: 10 per batch instead of the reference's 15 -- only the granularity of the retry
+            # policy changes with it, not the result)
+            oh_, ow_ = output_size(h, w, method, max_size, final_resize_multiplier)
+            per_frame = max(frame_bytes, oh_ * ow_ * 3)
+            batch_size = max(len(devs), min(batch_size, self.PIPE_SLOT_BYTES // max(per_frame, 1)))
         gpu_stream = None  # overlap, one device: the stream this call's H2D / kernels / D2H are queued on
         target = {"out": None}   # several devices: the pinned host tensor the workers write the current batch into
         if product_run:
