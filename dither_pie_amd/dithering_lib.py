@@ -51,6 +51,31 @@ def _pinned_pair(nbytes: int):
         bufs.move_to_end(nbytes)
     return pair
 
+def _pil_rgbx_into(rgb, host_u8) -> bool:
+    """The pixels of a PIL 'RGB' image in Pillow's own four-bytes-per-pixel layout, written into `host_u8` (a uint8 numpy view of
+    h * w * 4 bytes) in pieces, with no intermediate bytes object of the whole image: what Image.tobytes("raw", "RGBX") does,
+    minus its b"".join and the caller's copy.  False when the (private, long-stable) encoder interface is not there."""
+    try:
+        from PIL import Image
+        rgb.load()
+        enc = Image._getencoder(rgb.mode, "raw", "RGBX")
+        enc.setimage(rgb.im, (0, 0) + rgb.size)
+        pos, total = 0, host_u8.shape[0]
+        piece = max(1 << 20, rgb.size[0] * 4)   # (the raw encoder emits whole rows: RawEncode.c)
+        while True:
+            _, errcode, data = enc.encode(piece)
+            n = len(data)
+            if pos + n > total:
+                return False
+            host_u8[pos:pos + n] = np.frombuffer(data, dtype=np.uint8)
+            pos += n
+            if errcode:
+                break
+        return errcode > 0 and pos == total
+    except Exception:  # noqa: BLE001 - any surprise: the packed path
+        return False
+
+
 __all__ = [
     "DitherMode", "PixelizeMethod", "PaletteSource", "ImageDitherer", "ColorReducer", "DitherUtils",
     "BaseDitherStrategy", "ErrorDiffusionKernel", "NoDitherStrategy", "MatrixDitherStrategy",
@@ -909,24 +934,38 @@ class ImageDitherer:
         return self
 
     def apply_dithering(self, image):
-        """PIL image -> PIL 'RGB' image (dithering_lib.py:1952-1992).  Host <-> device copies go through
-        per-thread pinned staging buffers that are reused from call to call (the GUI calls this from worker
-        threads): a 4K image takes ~10 ms end to end instead of ~25 ms with pageable temporaries."""
+        """PIL image -> PIL 'RGB' image (dithering_lib.py:1952-1992).  Host <-> device copies go through per-thread pinned
+        staging buffers that are reused from call to call (the GUI calls this from worker threads).
+
+        Pillow stores an 'RGB' image as FOUR bytes per pixel; packing it to three (tobytes: encode in 64 KB pieces, join them, and
+        here one more copy into the pinned buffer) was the largest part of a call (7.6 ms for a 4K image with a 0.02 ms kernel).  So the host side stays in Pillow's own layout: the raw 'RGBX' encoder -- a row memcpy -- writes straight
+        into the pinned buffer (2.0 ms instead of 5.4) and the fourth byte is dropped on the GPU; the result comes back packed
+        and is unpacked by Image.fromarray (2.5 ms; see below why not mapped).  tools/bench_scripts/pil_probe2.py, pil_probe3.py.
+        If Pillow's encoder interface is not what it has been for a decade, the packed path of rounds 1-4 runs instead."""
         import torch
         from PIL import Image
         rgb = image if image.mode == "RGB" else image.convert("RGB")
         w, h = rgb.size
+        if self.palette is None:
+            self._ensure_palette(np.asarray(rgb))
+        n4 = h * w * 4
+        pin_in, pin_out = _pinned_pair(n4)
+        if w > 0 and h > 0 and _pil_rgbx_into(rgb, pin_in.numpy()):
+            dev4 = pin_in.view(h, w, 4).cuda(non_blocking=True)
+            dev_out = self.apply_dithering_frames(dev4[..., :3].contiguous())
+            out3 = pin_out[:h * w * 3]
+            out3.view(h, w, 3).copy_(dev_out.view(h, w, 3), non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            # The way back stays packed: an image mapped onto a four-byte buffer carries the raw mode's name ('RGBX'), and
+            # convert('RGB') from it is a per-pixel loop (3.5 ms) -- slower than unpacking packed RGB into storage of the image's
+            # own (2.5 ms), which also makes the image own its pixels (the staging buffer is overwritten by the next call;
+            # tests/test_cabi_and_host.py checks that).  tools/bench_scripts/pil_probe3.py
+            return Image.fromarray(out3.numpy().reshape(h, w, 3), "RGB")
         pin_in, pin_out = _pinned_pair(h * w * 3)
         host_in = pin_in.numpy().reshape(h, w, 3)
-        # (PIL's packed bytes straight into the staging buffer: np.asarray(image) goes through the same tobytes() and copies once more)
         np.copyto(host_in.reshape(-1), np.frombuffer(rgb.tobytes(), dtype=np.uint8))
-        self._ensure_palette(host_in)
         dev_in = pin_in.view(h, w, 3).cuda(non_blocking=True)
         dev_out = self.apply_dithering_frames(dev_in)
         pin_out.view(h, w, 3).copy_(dev_out, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        # The returned image owns its pixels (the staging buffer is overwritten by the next call): PIL stores 'RGB' as four bytes
-        # per pixel, so building it from packed bytes always unpacks into storage of its own -- only the four-byte modes can be
-        # mapped onto a buffer (tests/test_cabi_and_host.py checks that).  fromarray, not frombuffer(...).copy(): the copy of
-        # the 33 MB it has just written costs more than the unpacking (GPU-box host: 2.5 ms against 17.6, tools/bench_scripts/pil_probe.py).
         return Image.fromarray(pin_out.numpy().reshape(h, w, 3), "RGB")

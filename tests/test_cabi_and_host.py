@@ -561,11 +561,31 @@ def test_expanded_key_error_bound():
 
 
 def test_pil_image_from_the_staging_buffer_owns_its_pixels():
-    """apply_dithering hands out Image.fromarray(staging buffer) and then reuses that buffer: the image must not be a view of it
-    (PIL keeps 'RGB' as four bytes per pixel, packed bytes are always unpacked into storage of the image's own)."""
+    """apply_dithering reuses its staging buffers from call to call: the image it hands out must not be a view of one.
+    The packed fallback path: Image.fromarray(buffer) -- packed bytes are always unpacked into storage of the image's own.
+    The RGBX path (round 5): Image.frombuffer('RGBX', ..., 'raw', 'RGBX', 0, 1) IS a view (that is why it costs nothing) and
+    convert('RGB') gives an image that owns its pixels; and _pil_rgbx_into writes exactly Pillow's four-bytes-per-pixel rows (R, G, B, pad) without ever
+    building a bytes object of the whole image."""
     from PIL import Image
+    from dither_pie_amd.dithering_lib import _pil_rgbx_into
     buf = np.random.RandomState(3).randint(0, 256, 37 * 53 * 3, dtype=np.uint8)
     want = buf.copy().reshape(37, 53, 3)
     img = Image.fromarray(buf.reshape(37, 53, 3), "RGB")
     buf[:] = 0
     assert np.array_equal(np.asarray(img), want)
+    # in: a 53 x 37 image and one whose rows are longer than one encoder piece
+    for hh, ww in ((37, 53), (3, 400_000)):
+        a = np.random.RandomState(hh).randint(0, 256, (hh, ww, 3), dtype=np.uint8)
+        host = np.full(hh * ww * 4, 7, np.uint8)
+        assert _pil_rgbx_into(Image.fromarray(a, "RGB"), host)
+        assert np.array_equal(host.reshape(hh, ww, 4)[..., :3], a)
+        assert not _pil_rgbx_into(Image.fromarray(a, "RGB"), np.empty(hh * ww * 4 - 4, np.uint8))   # a buffer that is too small
+    # out: the mapped image follows the buffer, its copy does not
+    out4 = np.empty((37, 53, 4), np.uint8)
+    out4[..., :3] = want
+    out4[..., 3] = 255
+    view = Image.frombuffer("RGBX", (53, 37), out4.reshape(-1), "raw", "RGBX", 0, 1)
+    own = view.convert("RGB")
+    out4[..., :3] = 0
+    assert own.mode == "RGB" and np.array_equal(np.asarray(own), want)
+    assert not np.array_equal(np.asarray(view)[..., :3], want)   # (a view: what apply_dithering must not return)
