@@ -823,10 +823,15 @@ int dp_pyset_order_host(const uint8_t *rgb_host, int64_t n, uint32_t *order_out,
         set_error("dp_pyset_order_host: bad argument");
         return DP_EINVAL;
     }
-    std::vector<uint32_t> order;
-    pyset_order(rgb_host, (size_t)n, order);
-    std::copy(order.begin(), order.end(), order_out);
-    *n_distinct = (int64_t)order.size();
+    try {   // (no exception may cross the C ABI: ctypes would see std::terminate)
+        std::vector<uint32_t> order;
+        pyset_order(rgb_host, (size_t)n, order);
+        std::copy(order.begin(), order.end(), order_out);
+        *n_distinct = (int64_t)order.size();
+    } catch (const std::exception &e) {
+        set_error("dp_pyset_order_host: %s", e.what());
+        return DP_ENOMEM;
+    }
     return DP_OK;
 }
 
@@ -836,17 +841,22 @@ int dp_median_cut_host(const uint8_t *rgb_host, int64_t n, int depth, int32_t *p
         set_error("dp_median_cut_host: bad argument");
         return DP_EINVAL;
     }
-    std::vector<uint32_t> order;
-    pyset_order(rgb_host, (size_t)n, order);
-    std::vector<uint32_t> colours(order.size() + 1), scratch(order.size() + 1);
-    for (size_t i = 0; i < order.size(); ++i) {
-        const uint8_t *c = rgb_host + 3 * (size_t)order[i];
-        colours[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+    try {   // (bad_alloc out of a vector, also from the cut's helper threads -- carried across their join: host_logic.h)
+        std::vector<uint32_t> order;
+        pyset_order(rgb_host, (size_t)n, order);
+        std::vector<uint32_t> colours(order.size() + 1), scratch(order.size() + 1);
+        for (size_t i = 0; i < order.size(); ++i) {
+            const uint8_t *c = rgb_host + 3 * (size_t)order[i];
+            colours[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+        }
+        std::vector<int32_t> out;
+        median_cut_u32(colours.data(), scratch.data(), order.size(), depth, out, (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
+        std::copy(out.begin(), out.end(), palette_out);
+        *n_out = (int)(out.size() / 3);
+    } catch (const std::exception &e) {
+        set_error("dp_median_cut_host: %s", e.what());
+        return DP_ENOMEM;
     }
-    std::vector<int32_t> out;
-    median_cut_u32(colours.data(), scratch.data(), order.size(), depth, out, (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
-    std::copy(out.begin(), out.end(), palette_out);
-    *n_out = (int)(out.size() / 3);
     return DP_OK;
 }
 

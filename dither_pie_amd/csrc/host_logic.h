@@ -14,6 +14,7 @@
 #include <numeric>
 #include <thread>
 #include <utility>
+#include <exception>
 #include <vector>
 
 #include "../../include/ditherpie_hip.h"
@@ -1138,10 +1139,24 @@ inline void median_cut_u32(uint32_t *cur, uint32_t *other, const size_t n, const
     for (size_t i = 0; i < n; ++i) other[start[(cur[i] >> sh) & 255u]++] = cur[i];
     const size_t half = n / 2;
     if (threads > 1 && n >= 16384) {
+        // (an exception -- bad_alloc while `right` or `out` grows -- must neither leave the lambda, which would call
+        // std::terminate, nor destroy `t` while it is joinable, which would too: it is carried across the join and rethrown)
         std::vector<int32_t> right;
-        std::thread t([&] { median_cut_u32(other + half, cur + half, n - half, depth - 1, right, threads / 2); });
+        std::exception_ptr failed;
+        std::thread t([&] {
+            try {
+                median_cut_u32(other + half, cur + half, n - half, depth - 1, right, threads / 2);
+            } catch (...) {
+                failed = std::current_exception();
+            }
+        });
+        struct Joiner {
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } joiner{t};
         median_cut_u32(other, cur, half, depth - 1, out, threads - threads / 2);
         t.join();
+        if (failed) std::rethrow_exception(failed);
         out.insert(out.end(), right.begin(), right.end());
         return;
     }
