@@ -843,7 +843,17 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     // cells) into an octree down to unit cubes, the 16^3-cell lists for LDS.
     EdTables tb;
     ed_tables_refine(pts, K, host, tb);
-    if (exp_env("DP_ED_H4_REPORT")) fprintf(stderr, "ed tables: K %d, h4 %zu words (%zu wanted, limit %zu), nodes %zu\n", K, tb.h4.size(), tb.h4_wanted, kEdH4MaxWords, tb.nodes.size());
+    if (exp_env("DP_ED_H4_REPORT")) {
+        fprintf(stderr, "ed tables: K %d, h4 %zu words (%zu wanted, limit %zu), nodes %zu\n", K, tb.h4.size(), tb.h4_wanted, kEdH4MaxWords, tb.nodes.size());
+        if (!tb.coarse.empty()) {   // K <= 16: how long the 16^3 nibble lists are (a wave pays for the longest among its 64 lanes)
+            int hist[16] = {0};
+            for (uint32_t w : tb.coarse) ++hist[w & 15u];
+            fprintf(stderr, "ed tables: K %d, 16^3 nibble lists by length:", K);
+            for (int n = 0; n < 16; ++n)
+                if (hist[n]) fprintf(stderr, " %d:%d", n, hist[n]);
+            fprintf(stderr, "\n");
+        }
+    }
     if (!tb.nodes.empty()) {  // one allocation: cells, then the nodes, then the 16^3-cell table(s)
         uint4 *both = nullptr;
         e = hipMalloc((void **)&both, sizeof(uint4) * (kEdCells + tb.nodes.size() + kCoarseQuads));

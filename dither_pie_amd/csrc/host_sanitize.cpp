@@ -112,7 +112,7 @@ static int run_edtables(const std::vector<double> &pts, int K)
     ed_tables_refine(pts.data(), K, cells, tb);
     // sampled points: uniform integers, the palette entries themselves (rounded) and their neighbours
     uint32_t seed = 12345u + (uint32_t)K;
-    long checked = 0, bad = 0;
+    long checked = 0, bad = 0, h4_answers = 0, h4_none = 0;
     auto check_point = [&](const int x[3]) {
         double best = std::numeric_limits<double>::infinity();
         for (int j = 0; j < K; ++j) {
@@ -146,6 +146,34 @@ static int run_edtables(const std::vector<double> &pts, int K)
             ++checked;
             if (!listed(e, 15, j)) ++bad;
             if (!tb.l16.empty() && !listed(tb.l16[c16], 15, j)) ++bad;
+            if (!tb.h4.empty()) {
+                // the hierarchical <= 4-entry table as nearest_h4 (ed_nearest.hip.h) walks it: a leaf must hold every nearest entry
+                auto marker = [](const uint32_t w) { return (w & 0xffu) >= ((w >> 8) & 0xffu); };
+                uint32_t w = tb.h4[c16];
+                bool answer = true;
+                for (int bit = 3; bit >= 1 && marker(w); --bit) {
+                    if ((w >> 16) == 0xffffu) {
+                        answer = false;
+                        break;
+                    }
+                    const size_t at = 4096u + (size_t)(w >> 16) * 8u + (size_t)(((x[0] >> bit) & 1) | (((x[1] >> bit) & 1) << 1) | (((x[2] >> bit) & 1) << 2));
+                    if (at >= tb.h4.size()) {
+                        ++bad;
+                        answer = false;
+                        break;
+                    }
+                    w = tb.h4[at];
+                }
+                if (answer && marker(w)) answer = false;   // (still a node pointer below 2-wide: no answer, the lists decide)
+                if (answer) {
+                    ++h4_answers;
+                    bool on_leaf = false;
+                    for (int b = 0; b < 4; ++b) on_leaf |= (int)((w >> (8 * b)) & 255u) == j;
+                    if (!on_leaf) ++bad;
+                } else {
+                    ++h4_none;
+                }
+            }
             for (const std::vector<uint32_t> *tab : {&tb.coarse, &tb.ext}) {
                 if (tab->empty()) continue;
                 const uint32_t word = (*tab)[c16];
@@ -166,8 +194,9 @@ static int run_edtables(const std::vector<double> &pts, int K)
             for (int k = 0; k < 3; ++k) x[k] = std::min(255, std::max(0, (int)std::lround(pts[3 * j + k]) + d));
             check_point(x);
         }
-    printf("edtables K=%d nodes=%zu give_up=%d l16=%zu coarse=%zu ext=%zu checked=%ld bad=%ld\n", K, tb.nodes.size(),
-           (int)tb.give_up, tb.l16.size(), tb.coarse.size(), tb.ext.size(), checked, bad);
+    printf("edtables K=%d nodes=%zu give_up=%d l16=%zu coarse=%zu ext=%zu h4=%zu (answers %ld, none %ld) checked=%ld bad=%ld\n", K, tb.nodes.size(),
+           (int)tb.give_up, tb.l16.size(), tb.coarse.size(), tb.ext.size(), tb.h4.size(), h4_answers, h4_none, checked, bad);
+    if (K > 16 && !tb.h4.empty() && h4_answers < 100 * std::max(h4_none, 1L)) return 1;   // the table must answer nearly always
     return bad ? 1 : 0;
 }
 
