@@ -934,20 +934,25 @@ __global__ __launch_bounds__(kPpThreads) void kmeans_pp_kernel(const uint8_t *__
         }
         __syncthreads();
         // potentials of the candidates: sum over all points of min(closest, distance to the candidate)
-        uint32_t cand[kPpMaxTrials];
-        unsigned long long part[kPpMaxTrials];
+        // (this loop is most of the kernel -- own points x trials, on ONE compute unit: the squared distance as |x|^2 + |c|^2 - 2 x.c
+        // with v_dot4_u32_u8 is 3 instructions instead of 12, and a thread's partial sum of at most kPpPer distances fits 32
+        // bits; the values are the same integers.  The points are re-read from LDS: keeping them and their norms in registers
+        // spilled at 1024 threads)
+        uint32_t cand[kPpMaxTrials], cnrm[kPpMaxTrials], part[kPpMaxTrials];
 #pragma unroll
         for (int q = 0; q < kPpMaxTrials; ++q) {
             cand[q] = q < n_trials ? s_pt[s_pick[q]] : 0u;
-            part[q] = 0;
+            cnrm[q] = __builtin_amdgcn_udot4(cand[q], cand[q], 0u, false);
+            part[q] = 0u;
         }
 #pragma unroll
         for (int e = 0; e < kPpPer; ++e) {
             if (lo + e < hi) {
                 const uint32_t x = s_pt[lo + e];
+                const uint32_t xn = __builtin_amdgcn_udot4(x, x, 0u, false);
 #pragma unroll
                 for (int q = 0; q < kPpMaxTrials; ++q)
-                    if (q < n_trials) part[q] += min(closest[e], dist2(x, cand[q]));
+                    if (q < n_trials) part[q] += min(closest[e], xn + cnrm[q] - 2u * __builtin_amdgcn_udot4(x, cand[q], 0u, false));
             }
         }
 #pragma unroll
@@ -979,9 +984,13 @@ __global__ __launch_bounds__(kPpThreads) void kmeans_pp_kernel(const uint8_t *__
         }
         __syncthreads();
         const uint32_t nb = s_pt[s_best];
+        const uint32_t nbn = __builtin_amdgcn_udot4(nb, nb, 0u, false);
 #pragma unroll
         for (int e = 0; e < kPpPer; ++e)
-            if (lo + e < hi) closest[e] = min(closest[e], dist2(s_pt[lo + e], nb));
+            if (lo + e < hi) {
+                const uint32_t x = s_pt[lo + e];
+                closest[e] = min(closest[e], __builtin_amdgcn_udot4(x, x, 0u, false) + nbn - 2u * __builtin_amdgcn_udot4(x, nb, 0u, false));
+            }
         __syncthreads();
     }
 }
