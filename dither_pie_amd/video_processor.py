@@ -127,6 +127,63 @@ def _process_single_frame(frame_path: Path, ditherer: ImageDitherer, pixelize_me
         return False
 
 
+class _PipeSplicer:
+    """vmsplice(2) of a buffer's pages into a pipe: the kernel takes references to the pages instead of copying them into pipe
+    buffers of its own -- no copy and no page allocation on the writing side, which on the bench box also speeds the READER of
+    the other pipe up by a third (the two kernel-side copies contend; tools/bench_scripts/pipe_vmsplice.py: writer 650 -> 1890
+    fps, concurrent reader 620 -> 800).  The pages stay referenced until the pipe's reader has consumed them, so the CALLER must
+    not overwrite the buffer before that (the overlapped pipe path holds a slot back until consumed_bytes() has passed it).
+    Linux only; anything unexpected turns it off and the caller writes as before."""
+
+    def __init__(self):
+        self.ok = False
+        try:
+            import ctypes
+            import ctypes.util
+            libc = ctypes.CDLL(ctypes.util.find_library("c") or "libc.so.6", use_errno=True)
+
+            class IoVec(ctypes.Structure):
+                _fields_ = [("base", ctypes.c_void_p), ("len", ctypes.c_size_t)]
+
+            libc.vmsplice.argtypes = [ctypes.c_int, ctypes.POINTER(IoVec), ctypes.c_ulong, ctypes.c_uint]
+            libc.vmsplice.restype = ctypes.c_ssize_t
+            self._ct, self._libc, self._IoVec = ctypes, libc, IoVec
+            self.ok = sys.platform.startswith("linux")
+        except Exception:  # noqa: BLE001
+            pass
+
+    def splice_all(self, fd: int, addr: int, nbytes: int) -> bool:
+        """All nbytes at addr into the pipe fd.  True: done.  False: not available here (nothing was written: the caller
+        falls back to write()).  Raises BrokenPipeError when the reader is gone."""
+        import errno
+        ct = self._ct
+        off = 0
+        while off < nbytes:
+            iov = self._IoVec(addr + off, nbytes - off)
+            n = self._libc.vmsplice(fd, ct.byref(iov), 1, 0)
+            if n < 0:
+                e = ct.get_errno()
+                if e == errno.EINTR:
+                    continue
+                if e == errno.EPIPE:
+                    raise BrokenPipeError(e, "vmsplice: the encoder closed its pipe")
+                if off == 0:
+                    self.ok = False   # EINVAL / EFAULT / ENOSYS: not here
+                    return False
+                raise OSError(e, "vmsplice failed in the middle of a batch")
+            off += n
+        return True
+
+    @staticmethod
+    def unread_bytes(fd: int) -> int:
+        import array
+        import fcntl
+        import termios
+        buf = array.array("i", [0])
+        fcntl.ioctl(fd, termios.FIONREAD, buf)
+        return int(buf[0])
+
+
 class VideoProcessor:
     """video_processor.py:27-390"""
 
@@ -296,8 +353,10 @@ class VideoProcessor:
             print(f"Warning: Could not probe rotation: {e}", file=sys.stderr)
         return 0
 
-    PIPE_SLOTS = 3            # rotating pinned batch slots of the overlapped pipe path (reader / GPU / writer each hold one)
-    PIPE_SLOT_BYTES = 256 << 20   # pinned bytes of a slot's input (or output) buffer at most
+    PIPE_SLOTS = 4            # rotating pinned batch slots of the overlapped pipe path (reader, GPU, writer; the writer keeps a
+                              # spliced slot until the encoder has consumed it)
+    PIPE_ZERO_COPY = True     # vmsplice the output slots into the encoder pipe (see _PipeSplicer)
+    PIPE_SLOT_BYTES = 128 << 20   # pinned bytes of a slot's input (or output) buffer at most
     PIPE_BYTES = 1 << 20      # requested pipe capacity (F_SETPIPE_SZ; the kernel default is 64 KiB = one syscall per 64 KiB)
 
     @staticmethod
@@ -347,7 +406,7 @@ class VideoProcessor:
         out_geom = None   # (H', W') of the product path: known up front, so that the output slots are allocated once
         if product_run:
             # a slot is one batch of input + one of output, pinned; three of them rotate: keep a slot's larger half under
-            # PIPE_SLOT_BYTES (4K frames: 10 per batch instead of the reference's 15 -- only the granularity of the retry
+            # PIPE_SLOT_BYTES (4K frames: 5 per batch instead of the reference's 15 -- only the granularity of the retry
             # policy changes with it, not the result)
             oh_, ow_ = output_size(h, w, method, max_size, final_resize_multiplier)
             per_frame = max(frame_bytes, oh_ * ow_ * 3)
@@ -383,7 +442,7 @@ class VideoProcessor:
                                 "rgb24", "-s", f"{w}x{h}", "pipe:1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                                bufsize=0)
         self._widen_pipe(dec.stdout)
-        state = {"enc": None, "last_good": None, "leading": 0, "substituted": 0, "written": 0}
+        state = {"enc": None, "last_good": None, "leading": 0, "substituted": 0, "written": 0, "piped": 0}
         stats = {"mode": "overlapped" if overlap else "serial", "slots": self.PIPE_SLOTS if overlap else 1, "batch_frames": batch_size,
                  "read_s": 0.0, "gpu_submit_s": 0.0, "gpu_wait_s": 0.0, "write_s": 0.0, "frames": 0}
         self.last_pipe_stats = stats
@@ -414,18 +473,29 @@ class VideoProcessor:
                                    f"({got % frame_bytes} bytes left over)")
             return got // frame_bytes, got
 
-        def emit(out_host, n_frames, per_frame):
+        splicer = _PipeSplicer() if (overlap and self.PIPE_ZERO_COPY) else None
+
+        def emit(out_host, n_frames, per_frame, may_splice=False):
             """One batch to the encoder, in frame order, with the substitution policy (state: the encoder, the newest good
             output frame, frames that failed before any frame succeeded).  out_host: host tensor [>= n_frames, H', W', 3]
-            of a batch that succeeded as a whole; per_frame: list of host tensors / None of one that was retried."""
+            of a batch that succeeded as a whole; per_frame: list of host tensors / None of one that was retried.
+            may_splice: out_host is a slot's own buffer that the caller keeps untouched until the encoder has consumed it.
+            -> True when the batch's pages were handed to the pipe by reference (state["piped"] = bytes piped so far)."""
             t0 = time.perf_counter()
+            spliced = False
             if out_host is not None:  # the usual case: one write of the whole batch
                 if state["enc"] is None:
                     state["enc"] = open_encoder(out_host.shape[1:])
                 for _ in range(state["leading"]):
                     self._write_all(state["enc"].stdin, out_host[0].numpy())
+                    state["piped"] += out_host[0].numel()
                 state["leading"] = 0
-                self._write_all(state["enc"].stdin, out_host[:n_frames].numpy())
+                body = out_host[:n_frames]
+                if may_splice and splicer is not None and splicer.ok and body.is_contiguous():
+                    spliced = splicer.splice_all(state["enc"].stdin.fileno(), body.data_ptr(), body.numel())
+                if not spliced:
+                    self._write_all(state["enc"].stdin, body.numpy())
+                state["piped"] += body.numel()
                 # (numpy's single-threaded copy, not tensor.clone(): a torch CPU op wakes the OpenMP pool -- one thread per
                 # visible core, 256 on the bench box -- whose idle spinning burns the container's CPU quota (16 cores) and
                 # gets reader, writer and both ffmpeg processes throttled: measured as ~20 ms lost per batch)
@@ -448,9 +518,19 @@ class VideoProcessor:
                     buf = np.ascontiguousarray(o.numpy())
                     for _ in range(state["leading"] + 1):
                         self._write_all(state["enc"].stdin, buf)
+                        state["piped"] += buf.size
                     state["leading"] = 0
             state["written"] += n_frames
             stats["write_s"] += time.perf_counter() - t0
+            if spliced:
+                stats["spliced_batches"] = stats.get("spliced_batches", 0) + 1
+            return spliced
+
+        def consumed_bytes():
+            """bytes of the encoder pipe's stream that its reader has taken out of the pipe so far"""
+            if state["enc"] is None:
+                return 0
+            return state["piped"] - _PipeSplicer.unread_bytes(state["enc"].stdin.fileno())
 
         def progress(done):
             frac = done / total_hint if total_hint else 0.5
@@ -464,7 +544,7 @@ class VideoProcessor:
         try:
             if overlap:
                 done = self._pipe_overlapped(batch_size, frame_bytes, (h, w), out_geom, run, to_host, gpu_stream, target, read_batch, emit,
-                                             progress, new_out, stats, dec)
+                                             progress, new_out, stats, dec, consumed_bytes, state)
             else:
                 stage = torch.empty(batch_size * frame_bytes, dtype=torch.uint8, pin_memory=pin)
                 view = memoryview(stage.numpy())
@@ -487,7 +567,7 @@ class VideoProcessor:
                         if out.is_cuda:
                             torch.cuda.current_stream(out.device).synchronize()
                     stats["gpu_wait_s"] += time.perf_counter() - t0
-                    emit(out_host if out is not None else None, n_frames, per_frame)
+                    emit(out_host if out is not None else None, n_frames, per_frame)   # (one buffer, reused at once: copied, not spliced)
                     done += n_frames
                     progress(done)
                     if got < batch_size * frame_bytes:
@@ -519,7 +599,7 @@ class VideoProcessor:
         return done
 
     def _pipe_overlapped(self, batch_size, frame_bytes, in_geom, out_geom, run, to_host, gpu_stream, target, read_batch, emit, progress,
-                         new_out, stats, dec) -> int:
+                         new_out, stats, dec, consumed_bytes, state) -> int:
         """The three concurrent stages of _stream_through_pipes (see there).  Slots rotate free -> filled -> submitted ->
         free; every blocking queue operation polls an abort flag, so an error in any stage (a dead encoder, a device that
         is gone, a malformed stream) ends the other two instead of leaving them blocked on a queue."""
@@ -572,6 +652,7 @@ class VideoProcessor:
                 fail("reader", e)
 
         def writer():
+            held = []   # [(slot, stream offset at which its spliced pages end)]: back to the reader once the encoder is past them
             try:
                 while True:
                     item = take(write_q)
@@ -582,8 +663,24 @@ class VideoProcessor:
                         t0 = time.perf_counter()
                         event.synchronize()
                         stats["gpu_wait_s"] += time.perf_counter() - t0
-                    emit(out_host, n_frames, per_frame)
-                    free_q.put(slot)
+                    own = out_host is not None and slot.out is not None and out_host.data_ptr() == slot.out.data_ptr()
+                    if emit(out_host, n_frames, per_frame, may_splice=own):
+                        held.append((slot, state["piped"]))
+                    else:
+                        free_q.put(slot)
+                    # a spliced slot's pages are referenced by the pipe until read: with the next batch behind them in a
+                    # pipe of at most 1 MiB they always are by now, but it is checked, not assumed (a stalled encoder)
+                    if held:
+                        seen = consumed_bytes()
+                        while held and held[0][1] <= seen:
+                            free_q.put(held.pop(0)[0])
+                        while len(held) > 1:   # never sit on more than one: wait for the encoder instead of starving the reader
+                            if abort.is_set():
+                                raise _Abort()
+                            time.sleep(0.0005)
+                            seen = consumed_bytes()
+                            while held and held[0][1] <= seen:
+                                free_q.put(held.pop(0)[0])
             except _Abort:
                 pass
             except BaseException as e:  # noqa: BLE001

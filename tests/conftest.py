@@ -116,11 +116,12 @@ def numba_fixtures():
         return json.load(f), np.load(zp)
 
 
-def fake_ffmpeg_tools(tmp_path, monkeypatch, frames, rotation=None, coded=None, encoder_dies_after=None, trailing=b""):
+def fake_ffmpeg_tools(tmp_path, monkeypatch, frames, rotation=None, coded=None, encoder_dies_after=None, trailing=b"", encoder_sleeps=0.0):
     """Stand-ins for ffmpeg / ffprobe on PATH (there is no ffmpeg in the image): the decoder emits `frames` as rgb24, the
     encoder stores `-s` and the bytes it receives, ffprobe answers the queries get_video_info / _probe_rotation make.
     encoder_dies_after: the encoder exits with code 3 after that many bytes (a crashed ffmpeg); trailing: bytes the
-    decoder appends to the stream (a stream that is not a whole number of frames)."""
+    decoder appends to the stream (a stream that is not a whole number of frames); encoder_sleeps: seconds the encoder waits
+    before it reads its first byte and again after every 100 000 bytes (a codec that cannot keep up)."""
     import stat
     import sys
     n, h, w = frames.shape[:3]
@@ -139,7 +140,18 @@ elif "pipe:0" in a:    # encoder: keep the size argument and the bytes
     if {encoder_dies_after!r} is not None:
         sys.stdin.buffer.read({encoder_dies_after!r})
         sys.exit(3)
-    open(a[-1], "wb").write(a[a.index("-s") + 1].encode() + b"\\n" + sys.stdin.buffer.read())
+    if {encoder_sleeps!r}:
+        import time
+        got = []
+        while True:
+            time.sleep({encoder_sleeps!r})
+            b = sys.stdin.buffer.read(100000)
+            if not b:
+                break
+            got.append(b)
+        open(a[-1], "wb").write(a[a.index("-s") + 1].encode() + b"\\n" + b"".join(got))
+    else:
+        open(a[-1], "wb").write(a[a.index("-s") + 1].encode() + b"\\n" + sys.stdin.buffer.read())
 else:
     sys.exit(2)
 """)

@@ -449,6 +449,32 @@ def test_compiled_pipe_standins_and_a_long_stream(tmp_path, monkeypatch):
     assert vp.last_pipe_stats["mode"] == "overlapped" and vp.last_pipe_stats["frames"] == n
 
 
+def test_pipe_splicer_hands_pages_to_a_pipe_and_knows_what_was_consumed(tmp_path):
+    """_PipeSplicer (vmsplice): the bytes arrive, in order, next to ordinary writes on the same pipe; unread_bytes() is what the
+    overlapped path's writer uses to decide when a spliced slot may be reused."""
+    import subprocess
+    from dither_pie_amd.video_processor import _PipeSplicer
+    sp = _PipeSplicer()
+    if not sp.ok:
+        pytest.skip("no vmsplice here")
+    a = np.random.RandomState(1).randint(0, 256, 3_000_001, dtype=np.uint8)
+    out = tmp_path / "got.bin"
+    p = subprocess.Popen(["sh", "-c", f"sleep 0.3; cat > {out}"], stdin=subprocess.PIPE, bufsize=0)
+    fd = p.stdin.fileno()
+    p.stdin.write(b"head")
+    assert sp.splice_all(fd, a.ctypes.data, a.size) is True     # blocks until the last page is queued: the reader has started by then
+    assert 0 <= _PipeSplicer.unread_bytes(fd) <= 1 << 20
+    p.stdin.write(b"tail")
+    p.stdin.close()
+    assert p.wait() == 0
+    assert out.read_bytes() == b"head" + a.tobytes() + b"tail"
+    # a reader that is gone: BrokenPipeError, not a dead process
+    q = subprocess.Popen(["true"], stdin=subprocess.PIPE, bufsize=0)
+    q.wait()
+    with pytest.raises(BrokenPipeError):
+        sp.splice_all(q.stdin.fileno(), a.ctypes.data, a.size)
+
+
 @pytest.mark.parametrize("rotation,swap", [(None, False), ("90", True), ("-90.000000", True), ("180", False), ("270", True)])
 def test_pipe_path_follows_rotation_metadata(tmp_path, monkeypatch, rotation, swap):
     """Phone footage: ffprobe reports the CODED size plus a rotate tag / display matrix; ffmpeg rotates while decoding

@@ -340,6 +340,27 @@ def test_overlapped_pipe_path_on_the_device_equals_the_serial_loop(d, orc, tmp_p
 
 
 @pytest.mark.gpu
+def test_spliced_slots_are_not_reused_before_a_slow_encoder_has_read_them(d, orc, tmp_path, monkeypatch):
+    """The overlapped path hands its output slots to the encoder pipe by reference (vmsplice): a slot goes back into rotation only
+    once the encoder is past its pages.  An encoder that sleeps before every 100 KB while 60 batches of 36 KB queue up behind it
+    would receive overwritten frames if a slot came back early; the bytes it stores must be process_frames() of the input."""
+    import torch
+    from dither_pie_amd import video_processor as v
+    n, w, h = 240, 64, 48
+    frames = np.random.RandomState(9).randint(0, 256, (n, h, w, 3)).astype(np.uint8)
+    fake_ffmpeg_tools(tmp_path, monkeypatch, frames, encoder_sleeps=0.02)
+    it = d.ImageDitherer(16, d.DitherMode.BAYER, orc.palr(16, 3), False, {"size": "4x4"})
+    vp = v.VideoProcessor(devices=[0])
+    out_path = tmp_path / "out.bin"
+    assert vp._stream_through_pipes("in.mp4", str(out_path), it, None, 64, 4, None, vp.get_video_info("in.mp4")) == n
+    ref = v.process_frames(torch.from_numpy(frames).cuda(), it, None, 64, None).cpu().numpy()
+    size, body = out_path.read_bytes().split(b"\n", 1)
+    assert np.array_equal(np.frombuffer(body, np.uint8).reshape(ref.shape), ref)
+    if v._PipeSplicer().ok:
+        assert vp.last_pipe_stats.get("spliced_batches", 0) == n // 4
+
+
+@pytest.mark.gpu
 def test_workspace_cache_never_drops_an_entry_in_use(d):
     """backend._Launch: the per-(device, stream) scratch entry carries the lock that serialises that stream's launch
     sequences; while a launch is inside (or queued for) an entry, eviction passes it over however many other streams
