@@ -335,8 +335,9 @@ def pipes_leg(torch, dev, ditherer, n_frames=600, batch=15, h=1080, w=1920):
                                  "both_pipes_at_once_fps": {k: round(v, 1) for k, v in both_best.items()},
                                  "note": "stand-in decoder -> /dev/null; stand-in decoder -> a Python loop that reads into one pinned buffer and "
                                          "discards; a Python loop writing one pinned buffer -> stand-in encoder; and the last two running "
-                                         "TOGETHER as two bare threads (no queues, no GPU) -- the two kernel-side copies slow each other down, "
-                                         "so the slower of THAT pair is what an overlapped pipeline can reach"},
+                                         "TOGETHER as two bare threads (no queues, no GPU) -- the two kernel-side copies slow each other down.  The "
+                                         "pipeline itself hands its output slots to the encoder pipe by reference (vmsplice: no copy on "
+                                         "that side), so it can pass the both-at-once pair and approach the decoder pipe alone"},
                 "frac_of_slower_pipe": round(fps / slower, 3),
                 "frac_of_slower_pipe_with_both_running": round(fps / min(both_best.values()), 3),
                 "serial_loop_frames_per_s": round(serial_fps, 1),
