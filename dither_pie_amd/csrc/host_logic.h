@@ -530,7 +530,7 @@ struct EdTables {
     std::vector<uint32_t> h4;
     size_t h4_wanted = 0;          // words the table would take (reported by the experiments build)
 };
-constexpr size_t kEdH4MaxWords = 24576;   // 96 KB: the LDS the few-frames diffusion kernel has for it (256 random colours: 17 320 words)
+constexpr size_t kEdH4MaxWords = 27648;   // 108 KB: all the LDS the few-frames diffusion kernel has left (256 random colours: 21 336 words, median cut 256 of smooth content: 25 120)
 constexpr uint32_t kEdH4NoAnswer = 0xffff00ffu;
 
 // cells [kEdCells]: in = the kernel's lists (count byte | up to 15 index bytes, count 255 = overflow), out = sharpened,
