@@ -113,7 +113,9 @@ struct PalDev {
     const uint4 *ed_lists16;    // palettes of 17..256 colours: lists of the 16^3 cells, count byte | up to 15 index bytes (255: too long)
     const uint32_t *ed_h4;      // palettes of 17..256 colours: hierarchical table of <= 4 entries per leaf (host_logic.h EdTables::h4), or null
     int ed_h4_words;
+    int ed_h4_shallow;          // mean depth of the table at the palette's own colours <= 0.25: worth reading from L2 (ediff.hip)
     int ed_h4_global;           // the sixteen-wave instances read it from global memory (set per launch)
+    int ed_h4_lds_words;        // the few-frames instances stage it in LDS up to this size (set per launch)
     const uint4 *exc;           // colours whose outcome no code expresses, sorted by colour:
     int n_exc;                  //   {colour, k=2 indices i0 | i1<<16, k=1 index, 0}; n_exc < 0: list overflowed
 };

@@ -246,10 +246,10 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
         const double n2 = (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z + (double)kEdExpandedBias;
         s_expanded[threadIdx.x] = make_float4(-2.0f * c.x, -2.0f * c.y, -2.0f * c.z, (float)n2);
     }
-    __shared__ uint4 s_lists16[MAXW <= 4 ? kEdH4MaxWords / 4 : 1];   // the 16^3 lists (64 KB) or the hierarchical table (<= 96 KB)
+    __shared__ uint4 s_lists16[MAXW <= 4 ? kEdH4LdsWords / 4 : 1];   // the 16^3 lists (64 KB) or the hierarchical table (<= 108 KB)
     const uint4 *lists16 = nullptr;
     const uint32_t *h4 = nullptr;
-    if (MAXW <= 4 && pal.ed_h4) {
+    if (MAXW <= 4 && pal.ed_h4 && pal.ed_h4_words <= pal.ed_h4_lds_words) {
         // the hierarchical <= 4-entry table instead of the 16^3 lists (same LDS): one group of four candidates per step for every
         // lane; what it cannot answer goes to the 8^3 lists in L2
         uint32_t *s_h4 = reinterpret_cast<uint32_t *>(s_lists16);
@@ -259,8 +259,9 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_lists16[i] = pal.ed_lists16[i];
         lists16 = s_lists16;
     } else if (MAXW > 4 && pal.ed_h4 && pal.ed_h4_global) {
-        h4 = pal.ed_h4;   // sixteen waves of rings fill LDS: the table stays in global memory (<= 96 KB, L2-resident)
+        h4 = pal.ed_h4;   // sixteen waves of rings fill LDS: the table stays in global memory (<= 256 KB, L2-resident)
     }
+    if (MAXW <= 4 && h4 == nullptr && pal.ed_h4 && pal.ed_h4_global == 2) h4 = pal.ed_h4;   // (experiments: a table larger than LDS from L2 here too)
     if (threadIdx.x < MAXW) s_prog[threadIdx.x] = 0;
     if (threadIdx.x < 4) s_zero[threadIdx.x] = (E)0;
     const long frame_bytes = (long)h * w * 3;
@@ -844,7 +845,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     EdTables tb;
     ed_tables_refine(pts, K, host, tb);
     if (exp_env("DP_ED_H4_REPORT")) {
-        fprintf(stderr, "ed tables: K %d, h4 %zu words (%zu wanted, limit %zu), nodes %zu\n", K, tb.h4.size(), tb.h4_wanted, kEdH4MaxWords, tb.nodes.size());
+        fprintf(stderr, "ed tables: K %d, h4 %zu words (%zu wanted, limit %zu, in LDS up to %zu), mean depth at the palette's colours %.2f (no answer at %.3f of them), nodes %zu\n", K, tb.h4.size(), tb.h4_wanted, kEdH4MaxWords, kEdH4LdsWords, tb.h4_depth, tb.h4_none, tb.nodes.size());
         if (!tb.coarse.empty()) {   // K <= 16: how long the 16^3 nibble lists are (a wave pays for the longest among its 64 lanes)
             int hist[16] = {0};
             for (uint32_t w : tb.coarse) ++hist[w & 15u];
@@ -881,6 +882,15 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     dev.ed_coarse_ext = tb.ext.empty() ? nullptr : d_coarse + 4096;
     dev.ed_h4 = tb.h4.empty() ? nullptr : d_h4;
     dev.ed_h4_words = (int)tb.h4.size();
+    dev.ed_h4_shallow = (!tb.h4.empty() && tb.h4_depth <= 0.25) ? 1 : 0;
+    // The few-frames instances (table in LDS) take it unless the palette is so crowded that the 8^3 lists themselves overflowed
+    // into their octree (tb.nodes) or the walk is deep where the colours are: median cut of DARK content (colours a unit or two
+    // apart) ran 10-20 % slower on the table than on the lists, of smooth content 3-30 % faster
+    // (tools/bench_scripts/ed_crowded_lds.py: depths 1.9-2.8 with nodes against 0.3-1.6 without)
+    if (!tb.h4.empty() && (!tb.nodes.empty() || tb.h4_depth > 1.75) && !exp_env("DP_ED_H4_ALWAYS")) {
+        dev.ed_h4 = nullptr;
+        dev.ed_h4_words = 0;
+    }
     *blob_out = cells;
     return DP_OK;
 }
@@ -891,7 +901,13 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
 {
     PalDev pal = pal_in;   // (by-value snapshot; the experiments build may switch a table off for an A/B)
     if (exp_env("DP_ED_NO_H4")) pal.ed_h4 = nullptr;
-    pal.ed_h4_global = exp_env("DP_ED_H4_LDS_ONLY") ? 0 : 1;
+    // The sixteen-wave instances (rings fill their LDS) read the table from L2 only when it is SHALLOW where the palette's colours
+    // are -- palettes spread over the cube: 256 frames 9-22 % faster than on the 8^3 lists; a palette extracted from the content
+    // sends most lanes down two or three dependent L2 reads per step and runs 3-31 % SLOWER than on the lists
+    // (tools/bench_scripts/ed_h4_global_policy.py: mean depth 0.00-0.03 against 0.34-2.83)
+    pal.ed_h4_global = exp_env("DP_ED_H4_LDS_ONLY") ? 0 : (exp_env("DP_ED_H4_GLOBAL_TOO") ? 2 : (exp_env("DP_ED_H4_GLOBAL") ? 1 : pal.ed_h4_shallow));
+    pal.ed_h4_lds_words = (int)kEdH4LdsWords;
+    if (const char *e = exp_env("DP_ED_H4_LDS_WORDS")) pal.ed_h4_lds_words = std::min((int)kEdH4LdsWords, atoi(e));
     // wq64 != nullptr: the numba arithmetic (see nearest_numba_f32) with these float64 tap weights
     const bool numba = wq64 != nullptr;
     Taps t;

@@ -267,7 +267,9 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.ed_lists16 = nullptr;
     d.ed_h4 = nullptr;
     d.ed_h4_words = 0;
+    d.ed_h4_shallow = 0;
     d.ed_h4_global = 0;
+    d.ed_h4_lds_words = 0;
     d.ed_coarse_ext = nullptr;
     p->ed_blob = nullptr;
     p->accel_blob = nullptr;

@@ -529,8 +529,12 @@ struct EdTables {
     // MARKER: 0x00ff | node << 16 (node 0xffff: no answer here, use the lists).  Empty when it would not fit kEdH4MaxWords.
     std::vector<uint32_t> h4;
     size_t h4_wanted = 0;          // words the table would take (reported by the experiments build)
+    double h4_none = 0.0;          // fraction of the palette's own colours at which the table has no answer
+    double h4_depth = 0.0;         // mean number of descents of nearest_h4 at the palette's own colours (4 = no answer): where a
+                                   // palette puts its colours is where its images put their pixels
 };
-constexpr size_t kEdH4MaxWords = 27648;   // 108 KB: all the LDS the few-frames diffusion kernel has left (256 random colours: 21 336 words, median cut 256 of smooth content: 25 120)
+constexpr size_t kEdH4LdsWords = 27648;   // 108 KB: all the LDS the few-frames diffusion kernel has left (256 random colours: 21 336 words, median cut 256 of smooth content: 25 120)
+constexpr size_t kEdH4MaxWords = 65536;   // largest table built (256 KB, node numbers stay below 0xffff): beyond the LDS size it is read from L2
 constexpr uint32_t kEdH4NoAnswer = 0xffff00ffu;
 
 // cells [kEdCells]: in = the kernel's lists (count byte | up to 15 index bytes, count 255 = overflow), out = sharpened,
@@ -839,6 +843,27 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
             }
         }
         if (!fits) h4.clear();   // a clustered palette: the lists (and their octree refinement) serve it
+        out.h4_depth = 0.0;
+        out.h4_none = 0.0;
+        if (!h4.empty()) {
+            auto marker = [](const uint32_t w) { return (w & 0xffu) >= ((w >> 8) & 0xffu); };
+            double total = 0.0, none = 0.0;
+            for (int j = 0; j < K; ++j) {
+                uint32_t x[3];
+                for (int d = 0; d < 3; ++d) x[d] = (uint32_t)std::min(255.0, std::max(0.0, std::floor(pts[3 * j + d] + 0.5)));
+                uint32_t w = h4[(x[0] >> 4) | ((x[1] >> 4) << 4) | ((x[2] >> 4) << 8)];
+                int depth = 0;
+                for (int bit = 3; bit >= 1 && marker(w); --bit) {
+                    if ((w >> 16) == 0xffffu) break;
+                    w = h4[4096u + (size_t)(w >> 16) * 8u + (((x[0] >> bit) & 1u) | (((x[1] >> bit) & 1u) << 1) | (((x[2] >> bit) & 1u) << 2))];
+                    ++depth;
+                }
+                total += marker(w) ? 4.0 : (double)depth;
+                none += marker(w) ? 1.0 : 0.0;
+            }
+            out.h4_depth = total / (double)K;
+            out.h4_none = none / (double)K;
+        }
     }
     if (K <= 16) {
         // lists of the 16x16x16 cells for the wavefront kernel's LDS: count | up to 7 indices, one nibble each
