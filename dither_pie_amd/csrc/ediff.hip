@@ -887,7 +887,9 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     // into their octree (tb.nodes) or the walk is deep where the colours are: median cut of DARK content (colours a unit or two
     // apart) ran 10-20 % slower on the table than on the lists, of smooth content 3-30 % faster
     // (tools/bench_scripts/ed_crowded_lds.py: depths 1.9-2.8 with nodes against 0.3-1.6 without)
-    if (!tb.h4.empty() && (!tb.nodes.empty() || tb.h4_depth > 1.75) && !exp_env("DP_ED_H4_ALWAYS")) {
+    // (small palettes have short lists to begin with: the walk must be shallower to pay -- median cut 32 of dark content, depth 1.50,
+    // ran 15 % slower on the table)
+    if (!tb.h4.empty() && (!tb.nodes.empty() || tb.h4_depth > std::min(1.75, (double)K / 25.0)) && !exp_env("DP_ED_H4_ALWAYS")) {
         dev.ed_h4 = nullptr;
         dev.ed_h4_words = 0;
     }
