@@ -112,7 +112,12 @@ CHECK_EVERY_FUSED = 16  # ... when an iteration is one launch that returns at on
 
 def _check_centres_in_cube(c):
     """dp_kmeans_step_u8's float32 ranking is valid for centres inside the colour cube only (include/ditherpie_hip.h)."""
-    lo, hi = float(c.min()), float(c.max())
+    import torch
+    if isinstance(c, torch.Tensor):
+        mm = torch.stack(torch.aminmax(c)).cpu()   # one reduction, one read-back
+        lo, hi = float(mm[0]), float(mm[1])
+    else:
+        lo, hi = float(c.min()), float(c.max())
     if not (lo >= 0.0 and hi <= 255.0):   # also catches NaN
         raise ValueError(f"k-means centres must lie within [0, 255] per channel (got {lo}..{hi})")
 
@@ -120,7 +125,8 @@ def _check_centres_in_cube(c):
 HIST_MIN_PIXELS = 1 << 19   # from here on a fit reads its pixels once into the colour histogram and iterates over that
 
 
-def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sklearn_ties=True, histogram=None, fuse=None, hist=None):
+def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sklearn_ties=True, histogram=None, fuse=None, hist=None,
+          centres_are_data_points=False):
     """Lloyd iterations over the uint8 pixels `px` ([...,3] tensor on the GPU).
 
     histogram: None -- images of HIST_MIN_PIXELS and more (per rank) with K <= 256 are read ONCE into count[colour]
@@ -156,7 +162,8 @@ def lloyd(px, init_centers, max_iter=300, tol=1e-4, group=None, step_fn=None, sk
         centers = init_centers.to(device=dev, dtype=torch.float64).reshape(-1, 3).contiguous().clone()
     else:
         centers = torch.as_tensor(np.array(init_centers, dtype=np.float64).reshape(-1, 3)).to(dev).contiguous()
-    _check_centres_in_cube(centers)
+    if not centres_are_data_points:   # (k-means++ seeds are pixels of the image: inside the cube by construction, nothing to read back)
+        _check_centres_in_cube(centers)
     K = centers.shape[0]
     totals = torch.zeros(5 * max(K, 1), dtype=torch.int64, device=dev)
     prev = torch.zeros(4 * K, dtype=torch.int64, device=dev)
@@ -342,7 +349,7 @@ def fit_palette(px, K, random_state=42, n_total=None, offset=0, group=None, max_
     else:
         sample = seed_sample(px, n_total, offset, random_state, group)
         init = kmeans_plusplus(sample, K, np.random.RandomState(random_state))
-    centers, inertia, n_iter = lloyd(px, init, max_iter=max_iter, tol=tol, group=group, hist=hist)
+    centers, inertia, n_iter = lloyd(px, init, max_iter=max_iter, tol=tol, group=group, hist=hist, centres_are_data_points=True)
     palette = [tuple(int(v) for v in c) for c in centers.astype(int)]
     return palette, centers, inertia, n_iter
 
