@@ -588,6 +588,7 @@ class VideoProcessor:
                     pass
                 rc_enc = state["enc"].wait()
                 stats["encoder_drain_s"] = time.perf_counter() - t0
+            state.pop("slots", None)   # (only now may the pinned slot buffers go back to the allocator)
             stats["frames"] = done
             stats["wall_s"] = time.perf_counter() - t_wall
         if rc_dec != 0 or rc_enc != 0:
@@ -617,6 +618,9 @@ class VideoProcessor:
                 self.out = new_out(tuple(out_geom) + (3,)) if out_geom is not None else None
 
         slots = [Slot() for _ in range(max(2, int(self.PIPE_SLOTS)))]
+        # (the last spliced slot's pages may still sit in the encoder pipe when this function returns: the caller keeps the slots
+        # -- and with them their pinned memory, out of the allocator's hands -- until the encoder has exited)
+        state["slots"] = slots
         free_q, filled_q, write_q = queue.Queue(), queue.Queue(), queue.Queue()
         for s in slots:
             free_q.put(s)
