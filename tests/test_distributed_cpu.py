@@ -52,12 +52,15 @@ def _worker(rank, world, port, h, w, K, q):
         dist.destroy_process_group()
 
 
-def test_kmeans_two_ranks_equal_one_rank():
+@pytest.mark.parametrize("world", [2, 8])
+def test_kmeans_two_ranks_equal_one_rank(world):
+    """world = 8: the shape of the driver's SCALE run (eight row bands, one int64 all-reduce per Lloyd iteration, the seeding
+    sample summed from eight bands) over gloo on the CPU -- h = 123 rows do not divide by eight, so the bands differ in height."""
     import torch
     import torch.multiprocessing as mp
     from dither_pie_amd import kmeans
     from oracle import oracle as orc
-    h, w, K = 120, 101, 8   # 12120 px > 10000: the seeding sample is a strict subset
+    h, w, K = (120 if world == 2 else 123), 101, 8   # > 10000 px: the seeding sample is a strict subset
     img = orc.rnd(h, w, 77)
     full = torch.from_numpy(img)
     sample1 = kmeans.seed_sample(full, h * w, 0, 42)
@@ -67,7 +70,7 @@ def test_kmeans_two_ranks_equal_one_rank():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, h, w, K, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, K, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -109,6 +112,8 @@ class _OracleDitherer:
         a = frames.numpy()
         if a.ndim == 3:
             return torch.from_numpy(orc.apply_dithering(a, self.pal, self.mode, self.params, False, y0=y0, x0=x0))
+        if a.shape[0] == 0:    # a rank with no frames (7 frames over 8 ranks): the product returns an empty batch too
+            return torch.from_numpy(a.copy())
         return torch.from_numpy(np.stack([orc.apply_dithering(f, self.pal, self.mode, self.params, False, y0=y0, x0=x0) for f in a]))
 
 
@@ -139,7 +144,9 @@ def _shard_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_frames_and_row_bands_two_ranks_equal_one_rank():
+@pytest.mark.parametrize("world", [2, 8])
+def test_frames_and_row_bands_two_ranks_equal_one_rank(world):
+    """world 8 is the driver's SCALE shape; with 7 frames one of the eight ranks holds an empty block."""
     import torch.multiprocessing as mp
     from oracle import oracle as orc
     pal = orc.palr(16, 3)
@@ -149,14 +156,22 @@ def test_frames_and_row_bands_two_ranks_equal_one_rank():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=240) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [r[1] for r in res] == [(0, 3), (3, 7)] and [r[3] for r in res] == [(0, 22), (22, 45)]
+    if world == 2:
+        assert [r[1] for r in res] == [(0, 3), (3, 7)] and [r[3] for r in res] == [(0, 22), (22, 45)]
+    else:   # contiguous, ordered, covering; sizes differ by at most one
+        for which, total in ((1, 7), (3, 45)):
+            spans = [r[which] for r in res]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
     for rank, _, video, _, whole in res:
         assert np.array_equal(video, ref_video), rank
         assert np.array_equal(whole, ref_img), rank
