@@ -617,199 +617,204 @@ def main():
     # ---------------- secondary lines (same process, after the headline) -------------------------
     if not args.no_extra:
         extra = {}
-        # what the first call on a new palette pays once: KD-tree + 16^3 cell table + tie codes of all 2^24 colours
-        from dither_pie_amd.dithering_lib import prepare_palette
-        torch.cuda.synchronize()
-        t_b = time.perf_counter()
-        pal_obj = backend.Palette(*prepare_palette(palr(256, 11), False), accel=True)
-        torch.cuda.synchronize()
-        extra["accel_build_ms"] = round((time.perf_counter() - t_b) * 1e3, 2)
-        extra["accel_build_note"] = ("dp_palette_create + dp_palette_build_accel for a fresh 256-colour palette; outside the timed "
-                                     "region (a video keeps its palette), but it is what ONE 4K image pays on top of the kernel")
-        del pal_obj
-        # on-box streaming copy of the same 597 MB batch (3 B read + 3 B written per pixel, like the kernel)
-        tc = timed(lambda: out.copy_(frames), 10, 2) / 10
-        copy_gbs = BYTES_PER_PX * px_per_step / tc / 1e9
-        result["roofline"]["measured_copy_gbs"] = round(copy_gbs, 1)
-        result["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)
-        # C2 on the structured, tie-rich frame of SURVEY 8(d): every frame of the batch = grad(2160, 3840)
-        yy, xx = torch.meshgrid(torch.arange(H4K, device=dev), torch.arange(W4K, device=dev), indexing="ij")
-        gradf = torch.stack([xx % 256, yy % 256, ((xx + yy) // 2) % 256], -1).to(torch.uint8)
-        fg = gradf.unsqueeze(0).expand(args.frames, -1, -1, -1).contiguous()
-        del yy, xx, gradf
-        tg = timed(lambda: dith.apply_dithering_frames(fg, out=out), 5, 1) / 5
-        extra["c2_grad_frames_mpixel_per_s"] = round(world * px_per_step / tg / 1e6, 1)
-        extra["c2_grad_note"] = "same kernel on 24 copies of the structured frame grad(2160,3840) (0.36 % tied pixels)"
-        del fg
-        # C2-shaped, but content and palette as a user has them: smooth image-like frames (gradients + grain) and the
-        # 256-colour median-cut palette of that very content -- the palette crowds into the cells where the pixels are
-        from PIL import Image
-        from dither_pie_amd.dithering_lib import ColorReducer as _CR
-        rs = np.random.RandomState(3)
-        yy, xx = np.mgrid[0:540, 0:960]
-        img = np.clip(np.stack([80 + 60 * np.sin(xx / 300.0) + 40 * (yy / 540.0), 110 + 50 * np.cos(yy / 200.0) + 20 * np.sin(xx / 97.0),
-                                160 + 70 * (yy / 540.0) + 10 * np.sin((xx + yy) / 50.0)], -1) + rs.normal(0, 3, (540, 960, 3)), 0, 255).astype(np.uint8)
-        pal_mc = _CR.reduce_colors(Image.fromarray(img, "RGB"), 256)
-        fi = torch.from_numpy(img).to(dev).repeat(4, 4, 1).unsqueeze(0).repeat(args.frames, 1, 1, 1).contiguous()
-        dmc = ImageDitherer(256, DitherMode.BAYER, pal_mc, False, {"size": "8x8"}).prepare()
-        dmc.apply_dithering_frames(fi, out=out)
-        ti = timed(lambda: dmc.apply_dithering_frames(fi, out=out), 3, 1) / 3
-        extra["c2_image_like_median_cut256_mpixel_per_s"] = round(world * px_per_step / ti / 1e6, 1)
-        extra["c2_image_like_note"] = ("smooth frames with grain + the 256-colour median-cut palette of that content: the palette "
-                                       "crowds a few cells of the colour cube (one-byte-per-entry table over warped cells, the whole "
-                                       "octree in LDS, every pixel resolved in place: ordered_compact_kernel)")
-        kmc_ms, kmc_fix = kernel_ms(lambda: dmc.apply_dithering_frames(fi, out=out))
-        result["c2_crowded"] = leg("ordered_compact_kernel<1,WARP,HALF>", kmc_ms, BYTES_PER_PX * px_per_step, fixup_ms=round(kmc_fix, 4),
-                                   workload="C2-shaped: image-like frames + their own median-cut 256 palette, Bayer 8x8")
-        # what the palette itself costs (the reference's default palette source, once per image / per video): median cut of a
-        # 4K image of that content, distinct colours found on the GPU, CPython's set order replayed natively
-        img4k = Image.fromarray(fi[0].cpu().numpy(), "RGB")
-        _CR.reduce_colors(img4k, 256)
-        mc_ts = []
-        for _ in range(3):
-            t_m = time.perf_counter()
+        try:   # (a secondary leg that fails must not take the headline line down with it)
+            # what the first call on a new palette pays once: KD-tree + 16^3 cell table + tie codes of all 2^24 colours
+            from dither_pie_amd.dithering_lib import prepare_palette
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            pal_obj = backend.Palette(*prepare_palette(palr(256, 11), False), accel=True)
+            torch.cuda.synchronize()
+            extra["accel_build_ms"] = round((time.perf_counter() - t_b) * 1e3, 2)
+            extra["accel_build_note"] = ("dp_palette_create + dp_palette_build_accel for a fresh 256-colour palette; outside the timed "
+                                         "region (a video keeps its palette), but it is what ONE 4K image pays on top of the kernel")
+            del pal_obj
+            # on-box streaming copy of the same 597 MB batch (3 B read + 3 B written per pixel, like the kernel)
+            tc = timed(lambda: out.copy_(frames), 10, 2) / 10
+            copy_gbs = BYTES_PER_PX * px_per_step / tc / 1e9
+            result["roofline"]["measured_copy_gbs"] = round(copy_gbs, 1)
+            result["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)
+            # C2 on the structured, tie-rich frame of SURVEY 8(d): every frame of the batch = grad(2160, 3840)
+            yy, xx = torch.meshgrid(torch.arange(H4K, device=dev), torch.arange(W4K, device=dev), indexing="ij")
+            gradf = torch.stack([xx % 256, yy % 256, ((xx + yy) // 2) % 256], -1).to(torch.uint8)
+            fg = gradf.unsqueeze(0).expand(args.frames, -1, -1, -1).contiguous()
+            del yy, xx, gradf
+            tg = timed(lambda: dith.apply_dithering_frames(fg, out=out), 5, 1) / 5
+            extra["c2_grad_frames_mpixel_per_s"] = round(world * px_per_step / tg / 1e6, 1)
+            extra["c2_grad_note"] = "same kernel on 24 copies of the structured frame grad(2160,3840) (0.36 % tied pixels)"
+            del fg
+            # C2-shaped, but content and palette as a user has them: smooth image-like frames (gradients + grain) and the
+            # 256-colour median-cut palette of that very content -- the palette crowds into the cells where the pixels are
+            from PIL import Image
+            from dither_pie_amd.dithering_lib import ColorReducer as _CR
+            rs = np.random.RandomState(3)
+            yy, xx = np.mgrid[0:540, 0:960]
+            img = np.clip(np.stack([80 + 60 * np.sin(xx / 300.0) + 40 * (yy / 540.0), 110 + 50 * np.cos(yy / 200.0) + 20 * np.sin(xx / 97.0),
+                                    160 + 70 * (yy / 540.0) + 10 * np.sin((xx + yy) / 50.0)], -1) + rs.normal(0, 3, (540, 960, 3)), 0, 255).astype(np.uint8)
+            pal_mc = _CR.reduce_colors(Image.fromarray(img, "RGB"), 256)
+            fi = torch.from_numpy(img).to(dev).repeat(4, 4, 1).unsqueeze(0).repeat(args.frames, 1, 1, 1).contiguous()
+            dmc = ImageDitherer(256, DitherMode.BAYER, pal_mc, False, {"size": "8x8"}).prepare()
+            dmc.apply_dithering_frames(fi, out=out)
+            ti = timed(lambda: dmc.apply_dithering_frames(fi, out=out), 3, 1) / 3
+            extra["c2_image_like_median_cut256_mpixel_per_s"] = round(world * px_per_step / ti / 1e6, 1)
+            extra["c2_image_like_note"] = ("smooth frames with grain + the 256-colour median-cut palette of that content: the palette "
+                                           "crowds a few cells of the colour cube (one-byte-per-entry table over warped cells, the whole "
+                                           "octree in LDS, every pixel resolved in place: ordered_compact_kernel)")
+            kmc_ms, kmc_fix = kernel_ms(lambda: dmc.apply_dithering_frames(fi, out=out))
+            result["c2_crowded"] = leg("ordered_compact_kernel<1,WARP,HALF>", kmc_ms, BYTES_PER_PX * px_per_step, fixup_ms=round(kmc_fix, 4),
+                                       workload="C2-shaped: image-like frames + their own median-cut 256 palette, Bayer 8x8")
+            # what the palette itself costs (the reference's default palette source, once per image / per video): median cut of a
+            # 4K image of that content, distinct colours found on the GPU, CPython's set order replayed natively
+            img4k = Image.fromarray(fi[0].cpu().numpy(), "RGB")
             _CR.reduce_colors(img4k, 256)
-            mc_ts.append((time.perf_counter() - t_m) * 1e3)
-        extra["median_cut256_4k_ms"] = round(sorted(mc_ts)[1], 1)
-        extra["median_cut_note"] = ("ColorReducer.reduce_colors(4K image, 256), median of 3: host side (dp_median_cut_host) after a GPU pass "
-                                    "for the distinct colours; the reference needs seconds for this step")
-        del img4k
-        # the same content with the reference's default palette size: 16 colours by median cut
-        pal_mc16 = _CR.reduce_colors(Image.fromarray(img, "RGB"), 16)
-        dmc16 = ImageDitherer(16, DitherMode.BAYER, pal_mc16, False, {"size": "8x8"}).prepare()
-        dmc16.apply_dithering_frames(fi, out=out)
-        ti16 = timed(lambda: dmc16.apply_dithering_frames(fi, out=out), 3, 1) / 3
-        extra["c2_image_like_median_cut16_mpixel_per_s"] = round(world * px_per_step / ti16 / 1e6, 1)
-        del fi, yy, xx
-        # C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in): the float cell table
-        dgam = ImageDitherer(256, DitherMode.BAYER, pal256, True, {"size": "8x8"}).prepare()
-        dgam.apply_dithering_frames(frames, out=out)
-        tgm = timed(lambda: dgam.apply_dithering_frames(frames, out=out), 3, 1) / 3
-        extra["c2_use_gamma_mpixel_per_s"] = round(world * px_per_step / tgm / 1e6, 1)
-        kg_ms, kg_fix = kernel_ms(lambda: dgam.apply_dithering_frames(frames, out=out))
-        result["c2_use_gamma"] = leg("ordered_compact_float_kernel<2>", kg_ms, BYTES_PER_PX * px_per_step, fixup_ms=round(kg_fix, 4),
-                                     workload="C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in)")
-        # what the unchanged CLI / GUI sees per image: apply_dithering(PIL) on one 4K image, host -> device -> host included
-        pil_img = Image.fromarray(frames[0].cpu().numpy(), "RGB")
-        dith.apply_dithering(pil_img)
-        pil_ts = []
-        for _ in range(10):
-            t_p = time.perf_counter()
+            mc_ts = []
+            for _ in range(3):
+                t_m = time.perf_counter()
+                _CR.reduce_colors(img4k, 256)
+                mc_ts.append((time.perf_counter() - t_m) * 1e3)
+            extra["median_cut256_4k_ms"] = round(sorted(mc_ts)[1], 1)
+            extra["median_cut_note"] = ("ColorReducer.reduce_colors(4K image, 256), median of 3: host side (dp_median_cut_host) after a GPU pass "
+                                        "for the distinct colours; the reference needs seconds for this step")
+            del img4k
+            # the same content with the reference's default palette size: 16 colours by median cut
+            pal_mc16 = _CR.reduce_colors(Image.fromarray(img, "RGB"), 16)
+            dmc16 = ImageDitherer(16, DitherMode.BAYER, pal_mc16, False, {"size": "8x8"}).prepare()
+            dmc16.apply_dithering_frames(fi, out=out)
+            ti16 = timed(lambda: dmc16.apply_dithering_frames(fi, out=out), 3, 1) / 3
+            extra["c2_image_like_median_cut16_mpixel_per_s"] = round(world * px_per_step / ti16 / 1e6, 1)
+            del fi, yy, xx
+            # C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in): the float cell table
+            dgam = ImageDitherer(256, DitherMode.BAYER, pal256, True, {"size": "8x8"}).prepare()
+            dgam.apply_dithering_frames(frames, out=out)
+            tgm = timed(lambda: dgam.apply_dithering_frames(frames, out=out), 3, 1) / 3
+            extra["c2_use_gamma_mpixel_per_s"] = round(world * px_per_step / tgm / 1e6, 1)
+            kg_ms, kg_fix = kernel_ms(lambda: dgam.apply_dithering_frames(frames, out=out))
+            result["c2_use_gamma"] = leg("ordered_compact_float_kernel<2>", kg_ms, BYTES_PER_PX * px_per_step, fixup_ms=round(kg_fix, 4),
+                                         workload="C2 with use_gamma=True (float32 palette coordinates, pixels through lut_in)")
+            # what the unchanged CLI / GUI sees per image: apply_dithering(PIL) on one 4K image, host -> device -> host included
+            pil_img = Image.fromarray(frames[0].cpu().numpy(), "RGB")
             dith.apply_dithering(pil_img)
-            pil_ts.append((time.perf_counter() - t_p) * 1e3)
-        extra["pil_4k_ms"] = round(sorted(pil_ts)[len(pil_ts) // 2], 2)
-        extra["pil_4k_note"] = ("ImageDitherer.apply_dithering(PIL image) on one 3840x2160 image, median of 10: PIL -> pinned host "
-                                "buffer -> HBM -> kernel -> pinned host buffer -> PIL (PCIe both ways; the kernel share is ~0.02 ms)")
-        del out
-        from dither_pie_amd.dithering_lib import ColorReducer
-        # C3: Floyd-Steinberg, 16 colours, 4K, a batch of frames (one wave per frame)
-        nf3 = 8 if args.rehearse_on_one_gpu else 256   # (a rehearsal puts every rank's buffers on ONE GPU)
-        d3 = ImageDitherer(16, DitherMode.ERROR_DIFFUSION, ColorReducer.generate_uniform_palette(16), False,
-                           {"variant": "floyd_steinberg", "serpentine": "false"})
-        f3 = frames[:min(nf3, args.frames)].repeat((nf3 + args.frames - 1) // args.frames, 1, 1, 1)[:nf3]
-        o3 = torch.empty_like(f3)
-        t3 = timed(lambda: d3.apply_dithering_frames(f3, out=o3), 2, 1) / 2
-        extra["c3_fs_k16_4k_mpixel_per_s"] = round(world * nf3 * H4K * W4K / t3 / 1e6, 2)
-        k3_ms, k3_rep = kernel_ms(lambda: d3.apply_dithering_frames(f3, out=o3), 2)
-        result["c3"] = leg("ed_wavefront_kernel (one workgroup of 16 waves per frame)", k3_ms, BYTES_PER_PX * nf3 * H4K * W4K,
-                           frames_in_flight=nf3, bound="dependency chain of the raster scan (W + skew*H steps per frame), not HBM",
-                           workload="C3: Floyd-Steinberg, 16 uniform colours, 3840x2160")
-        # the C3 batch as SURVEY 8(d) words it (the 24 frames of C2), and one frame: few frames in flight, each frame's
-        # bands spread over several workgroups
-        o24 = o3[:args.frames]
-        d3.apply_dithering_frames(frames, out=o24)
-        t24 = timed(lambda: d3.apply_dithering_frames(frames, out=o24), 2, 1) / 2
-        extra["c3_fs_k16_4k_24_frames_ms"] = round(t24 * 1e3, 2)
-        t1f = timed(lambda: d3.apply_dithering_frames(frames[:1], out=o24[:1]), 2, 1) / 2
-        extra["c3_fs_k16_4k_one_frame_ms"] = round(t1f * 1e3, 2)
-        extra["c3_note"] = (f"{nf3} frames in flight per GPU (one workgroup of 16 waves per frame), "
-                            "bit-exact float32 error accumulation")
-        # a batch larger than the device (what a video is): one persistent workgroup per CU whose waves run on into the next
-        # frame's bands, so that the tail of a frame (34 bands over 16 waves: the third round has two waves busy) is not idle
-        nf3l = 3 * nf3
-        f3l = f3.repeat(3, 1, 1, 1)
-        o3l = torch.empty_like(f3l)
-        t3l = timed(lambda: d3.apply_dithering_frames(f3l, out=o3l), 2, 1) / 2
-        extra["c3_fs_k16_4k_long_batch_mpixel_per_s"] = round(world * nf3l * H4K * W4K / t3l / 1e6, 2)
-        extra["c3_long_batch_note"] = (f"{nf3l} frames per GPU in one call: persistent workgroups, three frames each")
-        del f3l, o3l
-        # the same frame with 256 (random) colours: candidate lists instead of a 16-entry table
-        pal3b = [tuple(int(v) for v in c) for c in np.random.RandomState(7).randint(0, 256, (256, 3))]
-        d3b = ImageDitherer(256, DitherMode.ERROR_DIFFUSION, pal3b, False, {"variant": "floyd_steinberg", "serpentine": "false"})
-        d3b.apply_dithering_frames(frames[:1], out=o24[:1])
-        t1b = timed(lambda: d3b.apply_dithering_frames(frames[:1], out=o24[:1]), 2, 1) / 2
-        extra["c3_fs_k256_4k_one_frame_ms"] = round(t1b * 1e3, 2)
-        if not args.rehearse_on_one_gpu:   # the same palette, 256 frames in flight (the hierarchical nearest table read from L2)
-            f3b = frames.repeat((256 + args.frames - 1) // args.frames, 1, 1, 1)[:256]
-            o3b = torch.empty_like(f3b)
-            d3b.apply_dithering_frames(f3b, out=o3b)
-            t3b = timed(lambda: d3b.apply_dithering_frames(f3b, out=o3b), 2, 1) / 2
-            extra["c3_fs_k256_4k_mpixel_per_s"] = round(world * 256 * H4K * W4K / t3b / 1e6, 2)
-            del f3b, o3b
-        # C4: k-means 32-colour palette from a 7680x4320 image + blue-noise dither, the image split into row
-        # bands over the ranks; the per-iteration exchange is one RCCL all-reduce of [32,5] int64
-        from dither_pie_amd import kmeans, sharding
-        del f3, o3
-        lo4, hi4 = sharding.shard_range(4320, rank, world)
-        # SURVEY 8(d)'s C4 image rnd(4320, 7680, 99) (numpy legacy RNG on the host, ~1 s), this rank's row band of it
-        band = torch.from_numpy(np.random.RandomState(99).randint(0, 256, (4320, 7680, 3), dtype=np.uint8)[lo4:hi4]).to(dev).contiguous()
+            pil_ts = []
+            for _ in range(10):
+                t_p = time.perf_counter()
+                dith.apply_dithering(pil_img)
+                pil_ts.append((time.perf_counter() - t_p) * 1e3)
+            extra["pil_4k_ms"] = round(sorted(pil_ts)[len(pil_ts) // 2], 2)
+            extra["pil_4k_note"] = ("ImageDitherer.apply_dithering(PIL image) on one 3840x2160 image, median of 10: PIL -> pinned host "
+                                    "buffer -> HBM -> kernel -> pinned host buffer -> PIL (PCIe both ways; the kernel share is ~0.02 ms)")
+            del out
+            from dither_pie_amd.dithering_lib import ColorReducer
+            # C3: Floyd-Steinberg, 16 colours, 4K, a batch of frames (one wave per frame)
+            nf3 = 8 if args.rehearse_on_one_gpu else 256   # (a rehearsal puts every rank's buffers on ONE GPU)
+            d3 = ImageDitherer(16, DitherMode.ERROR_DIFFUSION, ColorReducer.generate_uniform_palette(16), False,
+                               {"variant": "floyd_steinberg", "serpentine": "false"})
+            f3 = frames[:min(nf3, args.frames)].repeat((nf3 + args.frames - 1) // args.frames, 1, 1, 1)[:nf3]
+            o3 = torch.empty_like(f3)
+            t3 = timed(lambda: d3.apply_dithering_frames(f3, out=o3), 2, 1) / 2
+            extra["c3_fs_k16_4k_mpixel_per_s"] = round(world * nf3 * H4K * W4K / t3 / 1e6, 2)
+            k3_ms, k3_rep = kernel_ms(lambda: d3.apply_dithering_frames(f3, out=o3), 2)
+            result["c3"] = leg("ed_wavefront_kernel (one workgroup of 16 waves per frame)", k3_ms, BYTES_PER_PX * nf3 * H4K * W4K,
+                               frames_in_flight=nf3, bound="dependency chain of the raster scan (W + skew*H steps per frame), not HBM",
+                               workload="C3: Floyd-Steinberg, 16 uniform colours, 3840x2160")
+            # the C3 batch as SURVEY 8(d) words it (the 24 frames of C2), and one frame: few frames in flight, each frame's
+            # bands spread over several workgroups
+            o24 = o3[:args.frames]
+            d3.apply_dithering_frames(frames, out=o24)
+            t24 = timed(lambda: d3.apply_dithering_frames(frames, out=o24), 2, 1) / 2
+            extra["c3_fs_k16_4k_24_frames_ms"] = round(t24 * 1e3, 2)
+            t1f = timed(lambda: d3.apply_dithering_frames(frames[:1], out=o24[:1]), 2, 1) / 2
+            extra["c3_fs_k16_4k_one_frame_ms"] = round(t1f * 1e3, 2)
+            extra["c3_note"] = (f"{nf3} frames in flight per GPU (one workgroup of 16 waves per frame), "
+                                "bit-exact float32 error accumulation")
+            # a batch larger than the device (what a video is): one persistent workgroup per CU whose waves run on into the next
+            # frame's bands, so that the tail of a frame (34 bands over 16 waves: the third round has two waves busy) is not idle
+            nf3l = 3 * nf3
+            f3l = f3.repeat(3, 1, 1, 1)
+            o3l = torch.empty_like(f3l)
+            t3l = timed(lambda: d3.apply_dithering_frames(f3l, out=o3l), 2, 1) / 2
+            extra["c3_fs_k16_4k_long_batch_mpixel_per_s"] = round(world * nf3l * H4K * W4K / t3l / 1e6, 2)
+            extra["c3_long_batch_note"] = (f"{nf3l} frames per GPU in one call: persistent workgroups, three frames each")
+            del f3l, o3l
+            # the same frame with 256 (random) colours: candidate lists instead of a 16-entry table
+            pal3b = [tuple(int(v) for v in c) for c in np.random.RandomState(7).randint(0, 256, (256, 3))]
+            d3b = ImageDitherer(256, DitherMode.ERROR_DIFFUSION, pal3b, False, {"variant": "floyd_steinberg", "serpentine": "false"})
+            d3b.apply_dithering_frames(frames[:1], out=o24[:1])
+            t1b = timed(lambda: d3b.apply_dithering_frames(frames[:1], out=o24[:1]), 2, 1) / 2
+            extra["c3_fs_k256_4k_one_frame_ms"] = round(t1b * 1e3, 2)
+            if not args.rehearse_on_one_gpu:   # the same palette, 256 frames in flight (the hierarchical nearest table read from L2)
+                f3b = frames.repeat((256 + args.frames - 1) // args.frames, 1, 1, 1)[:256]
+                o3b = torch.empty_like(f3b)
+                d3b.apply_dithering_frames(f3b, out=o3b)
+                t3b = timed(lambda: d3b.apply_dithering_frames(f3b, out=o3b), 2, 1) / 2
+                extra["c3_fs_k256_4k_mpixel_per_s"] = round(world * 256 * H4K * W4K / t3b / 1e6, 2)
+                del f3b, o3b
+            # C4: k-means 32-colour palette from a 7680x4320 image + blue-noise dither, the image split into row
+            # bands over the ranks; the per-iteration exchange is one RCCL all-reduce of [32,5] int64
+            from dither_pie_amd import kmeans, sharding
+            del f3, o3
+            lo4, hi4 = sharding.shard_range(4320, rank, world)
+            # SURVEY 8(d)'s C4 image rnd(4320, 7680, 99) (numpy legacy RNG on the host, ~1 s), this rank's row band of it
+            band = torch.from_numpy(np.random.RandomState(99).randint(0, 256, (4320, 7680, 3), dtype=np.uint8)[lo4:hi4]).to(dev).contiguous()
 
-        def c4(src=None):
-            src = band if src is None else src
-            pal, _, _, iters = kmeans.fit_palette(src.reshape(-1, 3), 32, 42, n_total=4320 * 7680, offset=lo4 * 7680)
-            d4 = ImageDitherer(32, DitherMode.BLUE_NOISE, pal, False, {"size": 64, "seed": 42})
-            sharding.dither_band(d4, src, lo4)
-            return iters
+            def c4(src=None):
+                src = band if src is None else src
+                pal, _, _, iters = kmeans.fit_palette(src.reshape(-1, 3), 32, 42, n_total=4320 * 7680, offset=lo4 * 7680)
+                d4 = ImageDitherer(32, DitherMode.BLUE_NOISE, pal, False, {"size": 64, "seed": 42})
+                sharding.dither_band(d4, src, lo4)
+                return iters
 
-        iters4 = c4()
-        t4 = min(timed(c4, 1, 0) for _ in range(3))   # (one fit + dither per measurement; the best of three)
-        extra["c4_8k_kmeans32_plus_blue_noise_seconds"] = round(t4, 4)
-        # the same on image-like content (smooth gradients + grain): what a photograph looks like to the fit
-        yy4, xx4 = torch.meshgrid(torch.arange(lo4, hi4, device=dev), torch.arange(7680, device=dev), indexing="ij")
-        g4 = torch.Generator(device=dev)
-        g4.manual_seed(99)
-        smooth = torch.stack([(xx4 * 255 // 7679), (yy4 * 255 // 4319), ((xx4 + yy4) * 255 // (7679 + 4319))], -1).to(torch.int16)
-        smooth = (smooth + torch.randint(-6, 7, smooth.shape, device=dev, generator=g4).to(torch.int16)).clamp(0, 255).to(torch.uint8).contiguous()
-        del yy4, xx4
-        iters4s = c4(smooth)
-        t4s = min(timed(lambda: c4(smooth), 1, 0) for _ in range(3))
-        extra["c4_8k_image_like_kmeans32_plus_blue_noise_seconds"] = round(t4s, 4)
-        # the fit's two kernels, each against its own bytes: the histogram build reads the pixels once (3 B/px); a Lloyd
-        # iteration reads 16 KB per occupied 16^3 cell of the colour cube (64 MB when all 4096 are occupied), not the pixels
-        from dither_pie_amd import backend as _be
-        c4c = torch.from_numpy(np.random.RandomState(1).rand(32, 3) * 255.0).to(dev)
-        tot4 = torch.zeros(160, dtype=torch.int64, device=dev)
-        bpx = band.reshape(-1, 3)
-        n4 = bpx.numel() // 3
-        hist4 = _be.ColourHistogram(bpx)
-        kb_ms, _ = kernel_ms(lambda: hist4.add(bpx, accumulate=False), 3)
-        info4 = hist4.buf[1 << 26:].view(torch.int32)
-        occ4 = int(info4[4096].item())
-        result["c4_kmeans_histogram"] = leg("hist_count / plan / scatter / parts kernels (pixels -> count[colour] over 2^24 colours by "
-                                            "partition, once per fit; kernel_ms = the four together)", kb_ms, 3 * n4,
-                                            bound="LDS atomics and scattered 2-byte stores of the partition (pixels read twice, 2 B/px of "
-                                                  "buckets written and read, 64 MB of table): not HBM",
-                                            workload=f"C4: the {n4} pixels of this rank's band of rnd(4320,7680,99) ({world} band(s))")
-        hist4.step_into(c4c, tot4, False)
-        kp_ms, _ = kernel_ms(lambda: hist4.step_into(c4c, tot4, False), 5)
-        tp4 = timed(lambda: hist4.step_into(c4c, tot4, False), 10, 2) / 10
-        result["c4_kmeans_pass"] = leg("hist_pass_kernel<false,false> (one Lloyd pass over the colour histogram, candidate lists built in-kernel)",
-                                       kp_ms, occ4 * 16384, occupied_cells=occ4, pass_ms_with_memset=round(tp4 * 1e3, 4),
-                                       iterations_of_the_fit=int(iters4),
-                                       workload=f"C4: one Lloyd pass, K=32, over the histogram of this rank's band of the 7680x4320 image ({world} band(s)); "
-                                                "algorithmic bytes = 16 KB per occupied cell")
-        # the pass over the PIXELS (what fits with more than 256 clusters, or fewer than 2^19 pixels, still run): 3 B/px
-        _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False)
-        kx_ms, _ = kernel_ms(lambda: _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False), 5)
-        result["c4_kmeans_pixel_pass"] = leg("kmeans_cells_kernel<false,2> (its list build launch not included)", kx_ms, 3 * n4,
-                                             workload="the same pass over the pixels themselves (round 3's Lloyd pass)")
-        extra["c4_kmeans_pass_ms"] = round(tp4 * 1e3, 4)
-        extra["c4_note"] = (f"rnd(4320,7680,99) in {world} row band(s); per rank: pixels -> colour histogram once, then Lloyd over the "
-                            f"histogram ({iters4} iterations on noise, {iters4s} on the image-like content; one launch per iteration on one "
-                            "rank, pass / int64 all-reduce / update when sharded), blue-noise(64,42) dither of the band with global coordinates")
-        del hist4, smooth
-        for _leg in ("c2_crowded", "c2_use_gamma", "c3", "c4_kmeans_pass", "c4_kmeans_histogram"):
-            leg_traffic(result, _leg)
+            iters4 = c4()
+            t4 = min(timed(c4, 1, 0) for _ in range(3))   # (one fit + dither per measurement; the best of three)
+            extra["c4_8k_kmeans32_plus_blue_noise_seconds"] = round(t4, 4)
+            # the same on image-like content (smooth gradients + grain): what a photograph looks like to the fit
+            yy4, xx4 = torch.meshgrid(torch.arange(lo4, hi4, device=dev), torch.arange(7680, device=dev), indexing="ij")
+            g4 = torch.Generator(device=dev)
+            g4.manual_seed(99)
+            smooth = torch.stack([(xx4 * 255 // 7679), (yy4 * 255 // 4319), ((xx4 + yy4) * 255 // (7679 + 4319))], -1).to(torch.int16)
+            smooth = (smooth + torch.randint(-6, 7, smooth.shape, device=dev, generator=g4).to(torch.int16)).clamp(0, 255).to(torch.uint8).contiguous()
+            del yy4, xx4
+            iters4s = c4(smooth)
+            t4s = min(timed(lambda: c4(smooth), 1, 0) for _ in range(3))
+            extra["c4_8k_image_like_kmeans32_plus_blue_noise_seconds"] = round(t4s, 4)
+            # the fit's two kernels, each against its own bytes: the histogram build reads the pixels once (3 B/px); a Lloyd
+            # iteration reads 16 KB per occupied 16^3 cell of the colour cube (64 MB when all 4096 are occupied), not the pixels
+            from dither_pie_amd import backend as _be
+            c4c = torch.from_numpy(np.random.RandomState(1).rand(32, 3) * 255.0).to(dev)
+            tot4 = torch.zeros(160, dtype=torch.int64, device=dev)
+            bpx = band.reshape(-1, 3)
+            n4 = bpx.numel() // 3
+            hist4 = _be.ColourHistogram(bpx)
+            kb_ms, _ = kernel_ms(lambda: hist4.add(bpx, accumulate=False), 3)
+            info4 = hist4.buf[1 << 26:].view(torch.int32)
+            occ4 = int(info4[4096].item())
+            result["c4_kmeans_histogram"] = leg("hist_count / plan / scatter / parts kernels (pixels -> count[colour] over 2^24 colours by "
+                                                "partition, once per fit; kernel_ms = the four together)", kb_ms, 3 * n4,
+                                                bound="LDS atomics and scattered 2-byte stores of the partition (pixels read twice, 2 B/px of "
+                                                      "buckets written and read, 64 MB of table): not HBM",
+                                                workload=f"C4: the {n4} pixels of this rank's band of rnd(4320,7680,99) ({world} band(s))")
+            hist4.step_into(c4c, tot4, False)
+            kp_ms, _ = kernel_ms(lambda: hist4.step_into(c4c, tot4, False), 5)
+            tp4 = timed(lambda: hist4.step_into(c4c, tot4, False), 10, 2) / 10
+            result["c4_kmeans_pass"] = leg("hist_pass_kernel<false,false> (one Lloyd pass over the colour histogram, candidate lists built in-kernel)",
+                                           kp_ms, occ4 * 16384, occupied_cells=occ4, pass_ms_with_memset=round(tp4 * 1e3, 4),
+                                           iterations_of_the_fit=int(iters4),
+                                           workload=f"C4: one Lloyd pass, K=32, over the histogram of this rank's band of the 7680x4320 image ({world} band(s)); "
+                                                    "algorithmic bytes = 16 KB per occupied cell")
+            # the pass over the PIXELS (what fits with more than 256 clusters, or fewer than 2^19 pixels, still run): 3 B/px
+            _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False)
+            kx_ms, _ = kernel_ms(lambda: _be.kmeans_step_into(bpx, c4c, tot4, want_sq=False), 5)
+            result["c4_kmeans_pixel_pass"] = leg("kmeans_cells_kernel<false,2> (its list build launch not included)", kx_ms, 3 * n4,
+                                                 workload="the same pass over the pixels themselves (round 3's Lloyd pass)")
+            extra["c4_kmeans_pass_ms"] = round(tp4 * 1e3, 4)
+            extra["c4_note"] = (f"rnd(4320,7680,99) in {world} row band(s); per rank: pixels -> colour histogram once, then Lloyd over the "
+                                f"histogram ({iters4} iterations on noise, {iters4s} on the image-like content; one launch per iteration on one "
+                                "rank, pass / int64 all-reduce / update when sharded), blue-noise(64,42) dither of the band with global coordinates")
+            del hist4, smooth
+            for _leg in ("c2_crowded", "c2_use_gamma", "c3", "c4_kmeans_pass", "c4_kmeans_histogram"):
+                leg_traffic(result, _leg)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            extra["error"] = f"{type(e).__name__}: {e}"
+            print(f"bench.py: a secondary leg failed on rank {rank}:\n{traceback.format_exc()}", file=sys.stderr)
         result["extra"] = extra
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
