@@ -261,7 +261,10 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
     } else if (MAXW > 4 && pal.ed_h4 && pal.ed_h4_global) {
         h4 = pal.ed_h4;   // sixteen waves of rings fill LDS: the table stays in global memory (<= 256 KB, L2-resident)
     }
-    if (MAXW <= 4 && h4 == nullptr && pal.ed_h4 && pal.ed_h4_global == 2) h4 = pal.ed_h4;   // (experiments: a table larger than LDS from L2 here too)
+    // (MAXW <= 4: h4 is an LDS pointer or null and nothing else -- with one assignment from global memory next to it the compiler
+    // no longer knows the address space and walks the table with flat_load instead of ds_read: measured 9.97 -> 10.73 ms per 4K
+    // frame at 256 colours.  A table larger than LDS read from L2 by these instances was tried that way and lost; see
+    // profiles/experiments/r05_priced_structures.md section 2.)
     if (threadIdx.x < MAXW) s_prog[threadIdx.x] = 0;
     if (threadIdx.x < 4) s_zero[threadIdx.x] = (E)0;
     const long frame_bytes = (long)h * w * 3;
@@ -907,7 +910,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
     // are -- palettes spread over the cube: 256 frames 9-22 % faster than on the 8^3 lists; a palette extracted from the content
     // sends most lanes down two or three dependent L2 reads per step and runs 3-31 % SLOWER than on the lists
     // (tools/bench_scripts/ed_h4_global_policy.py: mean depth 0.00-0.03 against 0.34-2.83)
-    pal.ed_h4_global = exp_env("DP_ED_H4_LDS_ONLY") ? 0 : (exp_env("DP_ED_H4_GLOBAL_TOO") ? 2 : (exp_env("DP_ED_H4_GLOBAL") ? 1 : pal.ed_h4_shallow));
+    pal.ed_h4_global = exp_env("DP_ED_H4_LDS_ONLY") ? 0 : (exp_env("DP_ED_H4_GLOBAL") ? 1 : pal.ed_h4_shallow);
     pal.ed_h4_lds_words = (int)kEdH4LdsWords;
     if (const char *e = exp_env("DP_ED_H4_LDS_WORDS")) pal.ed_h4_lds_words = std::min((int)kEdH4LdsWords, atoi(e));
     // wq64 != nullptr: the numba arithmetic (see nearest_numba_f32) with these float64 tap weights

@@ -21,8 +21,8 @@ pal = ColorReducer.reduce_colors(Image.fromarray(img, "RGB"), 256)
 d = ImageDitherer(256, DitherMode.ERROR_DIFFUSION, pal, False, {"variant": "floyd_steinberg", "serpentine": "false"})
 ref = None
 for label, env in (("lists only", {"DP_ED_NO_H4": "1"}), ("h4 in LDS / global batched", {}), ("h4 too big for LDS -> lists (1, 24), global batched", {"DP_ED_H4_LDS_WORDS": "20000"}),
-                   ("h4 too big for LDS -> global everywhere", {"DP_ED_H4_LDS_WORDS": "20000", "DP_ED_H4_GLOBAL_TOO": "1"}), ("h4 LDS, batched lists", {"DP_ED_H4_LDS_ONLY": "1"})):
-    for k in ("DP_ED_NO_H4", "DP_ED_H4_LDS_WORDS", "DP_ED_H4_GLOBAL_TOO", "DP_ED_H4_LDS_ONLY"): os.environ.pop(k, None)
+                   ("h4 LDS, batched lists", {"DP_ED_H4_LDS_ONLY": "1"})):   # (a fifth variant, the few-frames instances reading a table larger than LDS from L2, lost and cost the LDS path its ds_read addressing: removed from the kernel)
+    for k in ("DP_ED_NO_H4", "DP_ED_H4_LDS_WORDS", "DP_ED_H4_LDS_ONLY"): os.environ.pop(k, None)
     os.environ.update(env)
     r = [t(d, n) for n in (1, 24, 256)]
     h = int(out[:24].to(torch.int64).sum().item())
