@@ -185,7 +185,11 @@ constexpr int kEdProgWords = 64;
 // frame's bands over up to 16 workgroups of <= 4 waves, one wave per SIMD).  The small one has the registers of a
 // 256-thread workgroup (no spills) and LDS to spare, which it uses for the 16^3-cell lists of palettes above 16 colours.
 // NB: the numba arithmetic (above)
-template <int CAP, int NT, bool EXACT, int MAXW, bool NB = false>
+// PALS: which palettes the instance has code for -- 1: at most 16 colours only (the nibble lists of the 16^3 cells, `coarse`),
+// 2: more than 16 only (16^3 lists, hierarchical table), 0: both.  With everything in one instance the hierarchical table's walk cost
+// the 16-colour configuration (C3) 4 % (12.9 -> 13.5 ms per 256 4K frames), and the nibble-list code cost 256 colours as much.  Which
+// instance a launch takes is a measured choice (launch_error_diffusion; same-process A/B of the three, tools/bench_scripts/ab_libs.py).
+template <int CAP, int NT, bool EXACT, int MAXW, bool NB = false, int PALS = 0>
 __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
                                                                       const int w, const PalDev pal, const Taps taps,
@@ -236,20 +240,23 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
     const int gw = (int)(blockIdx.x % (unsigned)G) * NW + wv;  // this wave's number among them
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = pal.lut_in ? pal.lut_in[i] : (uint8_t)i;
     for (int i = threadIdx.x; i < pal.K; i += blockDim.x) s_pal[i] = pal.fcand[i];
-    if (pal.ed_coarse)
+    constexpr bool kSmall = PALS != 2, kLarge = PALS != 1;   // code for palettes of <= 16 / > 16 colours
+    if (kSmall && pal.ed_coarse)
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_coarse[i] = pal.ed_coarse[i];
-    const uint32_t *coarse = pal.ed_coarse ? s_coarse : nullptr;
+    const uint32_t *coarse = (kSmall && pal.ed_coarse) ? s_coarse : nullptr;
     // ... and their expanded records for the key scan (ed_nearest.hip.h, ed_key_expanded): |c|^2 rounded once, from float64
     __shared__ float4 s_expanded[16];
-    if (pal.ed_coarse && threadIdx.x < 16) {
+    if (kSmall && pal.ed_coarse && threadIdx.x < 16) {
         const float4 c = threadIdx.x < (unsigned)pal.K ? pal.fcand[threadIdx.x] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const double n2 = (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z + (double)kEdExpandedBias;
         s_expanded[threadIdx.x] = make_float4(-2.0f * c.x, -2.0f * c.y, -2.0f * c.z, (float)n2);
     }
-    __shared__ uint4 s_lists16[MAXW <= 4 ? kEdH4LdsWords / 4 : 1];   // the 16^3 lists (64 KB) or the hierarchical table (<= 108 KB)
+    __shared__ uint4 s_lists16[(MAXW <= 4 && kLarge) ? kEdH4LdsWords / 4 : 1];   // the 16^3 lists (64 KB) or the hierarchical table (<= 108 KB)
     const uint4 *lists16 = nullptr;
     const uint32_t *h4 = nullptr;
-    if (MAXW <= 4 && pal.ed_h4 && pal.ed_h4_words <= pal.ed_h4_lds_words) {
+    if (!kLarge) {
+        // (no tables of larger palettes)
+    } else if (MAXW <= 4 && pal.ed_h4 && pal.ed_h4_words <= pal.ed_h4_lds_words) {
         // the hierarchical <= 4-entry table instead of the 16^3 lists (same LDS): one group of four candidates per step for every
         // lane; what it cannot answer goes to the 8^3 lists in L2
         uint32_t *s_h4 = reinterpret_cast<uint32_t *>(s_lists16);
@@ -1005,21 +1012,30 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
             if (G == 1 && v >= 1 && v <= n_frames && (n_frames + v - 1) / v * n_bands < 60000) pgrid = v;
         }
         const uint32_t nfr = (uint32_t)n_frames;
-#define DP_EDW(C, N, X)                                                                                                   \
+#define DP_EDW(C, N, X, S4, S)                                                                                               \
     do {                                                                                                                 \
         if (nw <= 4)                                                                                                     \
-            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, 4>), dim3((unsigned)pgrid), dim3(64 * nw), 0, s, in, out, h, w, \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, 4, false, S4>), dim3((unsigned)pgrid), dim3(64 * nw), 0, s, in, out, h, w, \
                                pal, t, ws, G, gprog, test_giveup, nfr);                            \
         else                                                                                                             \
-            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves>), dim3((unsigned)pgrid), dim3(64 * nw), 0, s, in,  \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves, false, S>), dim3((unsigned)pgrid), dim3(64 * nw), 0, s, in,  \
                                out, h, w, pal, t, ws, G, gprog, test_giveup, nfr);                 \
         if (G > 1)                                                                                                       \
-            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out,  \
+            hipLaunchKernelGGL((ed_wavefront_kernel<C, N, X, kMaxWaves, false, S>), dim3((unsigned)n_frames), dim3(64 * nw1), 0, s, in, out,  \
                                h, w, pal, t, ws, 1, gprog, 0, nfr);                                \
     } while (0)
+        // (a palette of at most 16 colours has at most 15 inner nodes: its instances are the small-queue ones)
+        // Measured (ab_libs.py, one process, bytes identical): sixteen waves, 16 colours: the <= 16-only instance 12.98 ms per 256 4K
+        // frames against 13.61 with everything; 256 colours: the > 16-only one 21.6 against 22.8, one frame 9.65 against 10.02 ms.
+        // Up to four waves with 16 colours the <= 16-only instance wins by 0.5-8 % with 3, 7, 10 and 12 taps (Stucki / JJN: 11.4 against
+        // 12.3 ms per frame) and LOSES 1.2 / 2.2 % with 4 and 6 (Floyd-Steinberg 7.47 against 7.38 ms, Atkinson 8.08 against 7.90): code
+        // placement in a 30 KB loop, not arithmetic -- those two tap counts keep the instance with everything there.
+        const bool small_k = pal.ed_coarse != nullptr && pal.n_inner <= kQueueSmall;
 #define DP_EDN(N, X)                                                                                                      \
     do {                                                                                                                 \
-        if (pal.n_inner > kQueueSmall) DP_EDW(kQueueLarge, N, X); else DP_EDW(kQueueSmall, N, X);                         \
+        if (pal.n_inner > kQueueSmall) DP_EDW(kQueueLarge, N, X, 0, 0);                                                   \
+        else if (small_k) DP_EDW(kQueueSmall, N, X, (((N) == 4 || (N) == 6) ? 0 : 1), 1);                                 \
+        else DP_EDW(kQueueSmall, N, X, 2, 2);                                                                             \
     } while (0)
         if (numba) {  // one general instance per workgroup size (a full float64 palette scan per pixel, no candidate lists);
             // float64 error rings: 8 waves per workgroup fill LDS (158 KB)
