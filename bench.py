@@ -709,7 +709,7 @@ def main():
                                {"variant": "floyd_steinberg", "serpentine": "false"})
             f3 = frames[:min(nf3, args.frames)].repeat((nf3 + args.frames - 1) // args.frames, 1, 1, 1)[:nf3]
             o3 = torch.empty_like(f3)
-            t3 = timed(lambda: d3.apply_dithering_frames(f3, out=o3), 2, 1) / 2
+            t3 = min(timed(lambda: d3.apply_dithering_frames(f3, out=o3), 2, 1 - i) for i in range(2)) / 2   # (the better of two pairs)
             extra["c3_fs_k16_4k_mpixel_per_s"] = round(world * nf3 * H4K * W4K / t3 / 1e6, 2)
             k3_ms, k3_rep = kernel_ms(lambda: d3.apply_dithering_frames(f3, out=o3), 2)
             result["c3"] = leg("ed_wavefront_kernel (one workgroup of 16 waves per frame)", k3_ms, BYTES_PER_PX * nf3 * H4K * W4K,
@@ -744,7 +744,7 @@ def main():
                 f3b = frames.repeat((256 + args.frames - 1) // args.frames, 1, 1, 1)[:256]
                 o3b = torch.empty_like(f3b)
                 d3b.apply_dithering_frames(f3b, out=o3b)
-                t3b = timed(lambda: d3b.apply_dithering_frames(f3b, out=o3b), 2, 1) / 2
+                t3b = min(timed(lambda: d3b.apply_dithering_frames(f3b, out=o3b), 2, 0) for _ in range(2)) / 2   # (the better of two pairs: one preempted 22 ms launch once read as 65 Gpx/s)
                 extra["c3_fs_k256_4k_mpixel_per_s"] = round(world * 256 * H4K * W4K / t3b / 1e6, 2)
                 del f3b, o3b
             # C4: k-means 32-colour palette from a 7680x4320 image + blue-noise dither, the image split into row
