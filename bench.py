@@ -79,7 +79,8 @@ _LEG_SOURCES = {"c2_crowded": ("ordered.hip", "accel.hip", "dp_internal.h", "tre
                 "c2_use_gamma": ("ordered.hip", "accel.hip", "dp_internal.h", "tree_query.hip.h"),
                 "c4_kmeans_pass": ("kmeans_hist.hip", "kmeans_label.hip.h", "wave_util.hip.h"),
                 "c4_kmeans_histogram": ("kmeans_hist.hip", "kmeans_label.hip.h", "wave_util.hip.h"),
-                "c3": ("ediff.hip", "ed_nearest.hip.h", "dp_internal.h")}
+                "c3": ("ediff.hip", "ed_nearest.hip.h", "dp_internal.h"),
+                "c5_video": ("ordered.hip", "accel.hip", "dp_internal.h", "tree_query.hip.h")}
 
 
 PMC_LEGS = "r05_pmc_legs.json"
@@ -610,6 +611,7 @@ def main():
                                   f"resident in HBM ({2 * n5r * 1080 * 1920 * 3 / 1e9:.1f} GB in + out), one pass walks every one of them once: "
                                   f"frames {lo}..{lo + n5np - 1} are rnd(1080,1920,seed=frame number) of SURVEY 8(d) (numpy legacy RNG), the other "
                                   f"{n5r - n5np} come from torch's device generator (same distribution), as make_frames does for C2"}
+    leg_traffic(result, "c5_video")
     del f5, o5
     if world == 1 and not args.no_extra:
         result["c5_pipes"] = pipes_leg(torch, dev, d5)

@@ -36,6 +36,8 @@ LEGS = {
                        "(all 4096 cells occupied: 64 MB)"),
     "c4_kmeans_pass_image_like": ("pmc_khist_smooth_summary.json", "hist_pass_kernel<false, false>", None, N8K, KMEANS_SRC,
                                   "tools/bench_scripts/prof_kmeans_hist.py 32 smooth: the same on image-like content (852 occupied cells)"),
+    "c5_video": ("pmc_c5_summary.json", "ordered_lean_kernel<1, 4", 6 * 100 * 1080 * 1920, 100 * 1080 * 1920, ORDERED_SRC,
+                 "tools/bench_scripts/c5_prof.py: C5's launch -- 100 1080p noise frames, Bayer 4x4, 16 uniform colours"),
     "c3": ("pmc_ed_summary.json", "ed_wavefront_kernel", 6 * 256 * 2160 * 3840, 256 * 2160 * 3840, ED_SRC,
            "tools/bench_scripts/ed_prof.py 16 256: Floyd-Steinberg, 16 uniform colours, 256 4K frames in flight -- the launch shape of "
            "bench.py's c3 leg itself (round 4 took the ratio on 64 frames and applied it to 256)"),

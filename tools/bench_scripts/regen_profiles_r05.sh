@@ -13,7 +13,8 @@ timeout -k 10 300 bash profiles/pmc_pass_cmd4.sh $O/pmc_gamma python3 tools/benc
 timeout -k 10 300 bash profiles/pmc_pass_cmd4.sh $O/pmc_khist_noise python3 tools/bench_scripts/prof_kmeans_hist.py 32 noise && python3 profiles/pmc_summarise.py $O/pmc_khist_noise $O/pmc_khist_noise_summary.json hist_ > /dev/null && rm -rf $O/pmc_khist_noise/p? && echo "pmc kmeans noise done" && \
 timeout -k 10 300 bash profiles/pmc_pass_cmd4.sh $O/pmc_khist_smooth python3 tools/bench_scripts/prof_kmeans_hist.py 32 smooth && python3 profiles/pmc_summarise.py $O/pmc_khist_smooth $O/pmc_khist_smooth_summary.json hist_ > /dev/null && rm -rf $O/pmc_khist_smooth/p? && echo "pmc kmeans smooth done" && \
 timeout -k 10 300 bash profiles/pmc_pass_cmd4.sh $O/pmc_kpix python3 tools/bench_scripts/prof_kmeans.py 32 && python3 profiles/pmc_summarise.py $O/pmc_kpix $O/pmc_kpix_summary.json kmeans_ > /dev/null && rm -rf $O/pmc_kpix/p? && echo "pmc kmeans over pixels done" && \
-timeout -k 10 300 bash profiles/pmc_pass_cmd4.sh $O/pmc_ed python3 tools/bench_scripts/ed_prof.py 16 256 && python3 profiles/pmc_summarise.py $O/pmc_ed $O/pmc_ed_summary.json ed_wavefront > /dev/null && rm -rf $O/pmc_ed/p? && echo "pmc ed done"
+timeout -k 10 300 bash profiles/pmc_pass_cmd4.sh $O/pmc_ed python3 tools/bench_scripts/ed_prof.py 16 256 && python3 profiles/pmc_summarise.py $O/pmc_ed $O/pmc_ed_summary.json ed_wavefront > /dev/null && rm -rf $O/pmc_ed/p? && echo "pmc ed done" && \
+timeout -k 10 300 bash profiles/pmc_pass_cmd4.sh $O/pmc_c5 python3 tools/bench_scripts/c5_prof.py 4 && python3 profiles/pmc_summarise.py $O/pmc_c5 $O/pmc_c5_summary.json ordered_ > /dev/null && rm -rf $O/pmc_c5/p? && echo "pmc c5 done"
 else
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --no-extra --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.err && \
 python3 profiles/trace_headline.py $O/kt $O/trace_headline.csv && \
