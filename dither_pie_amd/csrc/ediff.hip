@@ -186,9 +186,9 @@ constexpr int kEdProgWords = 64;
 // 256-thread workgroup (no spills) and LDS to spare, which it uses for the 16^3-cell lists of palettes above 16 colours.
 // NB: the numba arithmetic (above)
 // PALS: which palettes the instance has code for -- 1: at most 16 colours only (the nibble lists of the 16^3 cells, `coarse`),
-// 2: more than 16 only (16^3 lists, hierarchical table), 0: both.  With everything in one instance the hierarchical table's walk cost
-// the 16-colour configuration (C3) 4 % (12.9 -> 13.5 ms per 256 4K frames), and the nibble-list code cost 256 colours as much.  Which
-// instance a launch takes is a measured choice (launch_error_diffusion; same-process A/B of the three, tools/bench_scripts/ab_libs.py).
+// 2: more than 16 only (16^3 lists, hierarchical table), 0: both (large-queue palettes, i.e. degenerate trees).  With everything in one
+// instance the hierarchical table's walk cost the 16-colour configuration (C3) 4 % (12.9 -> 13.5 ms per 256 4K frames), and the
+// nibble-list code cost 256 colours as much (launch_error_diffusion has the same-process A/B, tools/bench_scripts/ab_libs.py).
 template <int CAP, int NT, bool EXACT, int MAXW, bool NB = false, int PALS = 0>
 __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *__restrict__ in,
                                                                       uint8_t *__restrict__ out, const int h,
@@ -1025,16 +1025,14 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
                                h, w, pal, t, ws, 1, gprog, 0, nfr);                                \
     } while (0)
         // (a palette of at most 16 colours has at most 15 inner nodes: its instances are the small-queue ones)
-        // Measured (ab_libs.py, one process, bytes identical): sixteen waves, 16 colours: the <= 16-only instance 12.98 ms per 256 4K
-        // frames against 13.61 with everything; 256 colours: the > 16-only one 21.6 against 22.8, one frame 9.65 against 10.02 ms.
-        // Up to four waves with 16 colours the <= 16-only instance wins by 0.5-8 % with 3, 7, 10 and 12 taps (Stucki / JJN: 11.4 against
-        // 12.3 ms per frame) and LOSES 1.2 / 2.2 % with 4 and 6 (Floyd-Steinberg 7.47 against 7.38 ms, Atkinson 8.08 against 7.90): code
-        // placement in a 30 KB loop, not arithmetic -- those two tap counts keep the instance with everything there.
+        // Measured (ab_libs.py, one process, bytes identical; <= 16-only / > 16-only instance against one with everything):
+        // sixteen waves, 16 colours 12.98 against 13.61 ms per 256 4K frames, 256 colours 21.6 against 22.8; one frame, 256 colours
+        // 9.65 against 10.02 ms, 16 colours with 7-12 taps 2-8 % faster, with 3-6 taps within +-2 % (the sign follows code placement).
         const bool small_k = pal.ed_coarse != nullptr && pal.n_inner <= kQueueSmall;
 #define DP_EDN(N, X)                                                                                                      \
     do {                                                                                                                 \
         if (pal.n_inner > kQueueSmall) DP_EDW(kQueueLarge, N, X, 0, 0);                                                   \
-        else if (small_k) DP_EDW(kQueueSmall, N, X, (((N) == 4 || (N) == 6) ? 0 : 1), 1);                                 \
+        else if (small_k) DP_EDW(kQueueSmall, N, X, 1, 1);                                                                \
         else DP_EDW(kQueueSmall, N, X, 2, 2);                                                                             \
     } while (0)
         if (numba) {  // one general instance per workgroup size (a full float64 palette scan per pixel, no candidate lists);
