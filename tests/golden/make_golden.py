@@ -149,6 +149,22 @@ CASES += [
     ("c3_ed_fs_U16_rnd4k", "error_diffusion", {"variant": "floyd_steinberg", "serpentine": "false"}, ("U", 16),
      ("rnd", 2160, 3840, 1234), False, False),
 ]
+# Round 5: error diffusion with 17..256 colours (the hierarchical <= 4-entry nearest table of ed_nearest.hip.h and its policies)
+# on images of two to four 64-row bands, hashed by the reference: random, median-cut (table kept) and dark median-cut (lists kept)
+# palettes, the boundary size 17, use_gamma.
+CASES += [
+    ("r5_ed_fs_p32_rnd", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 32), ("rnd", 150, 200, 51), False, False),
+    ("r5_ed_fs_p64_grad", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 64), ("grad", 200, 150), False, False),
+    ("r5_ed_atkinson_p128_rnd", "error_diffusion", {}, ("palr", 128), ("rnd", 140, 180, 52), False, False),
+    ("r5_ed_fs_p256_rnd", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 256), ("rnd", 200, 260, 53), False, False),
+    ("r5_ed_jjn_p100_grad", "error_diffusion", {"variant": "jjn"}, ("palr", 100), ("grad", 130, 170), False, False),
+    ("r5_ed_stucki_p17_rnd", "error_diffusion", {"variant": "stucki"}, ("palr", 17), ("rnd", 100, 140, 54), False, False),
+    ("r5_ed_sierra_p200_gamma_grad", "error_diffusion", {"variant": "sierra"}, ("palr", 200), ("grad", 100, 130), True, False),
+    ("r5_ed_fs_mc64_smooth", "error_diffusion", {"variant": "floyd_steinberg"}, ("mc", 64), ("imgl", 160, 200, 55, "smooth"), False, False),
+    ("r5_ed_atkinson_mc128_smooth", "error_diffusion", {}, ("mc", 128), ("imgl", 150, 190, 56, "smooth"), False, False),
+    ("r5_ed_fs_mc256_dark", "error_diffusion", {"variant": "floyd_steinberg"}, ("mc", 256), ("imgl", 140, 180, 57, "dark"), False, False),
+    ("r5_ed_burkes_mc32_dark", "error_diffusion", {"variant": "burkes"}, ("mc", 32), ("imgl", 130, 170, 58, "dark"), False, False),
+]
 # Round 3: the kernels for crowded palettes (ordered_compact_kernel) and for use_gamma (ordered_compact_float_kernel) at 1080p,
 # hashed by the reference: image-like content with its own median-cut 256 palette (the reference's default palette source),
 # all three ordered decision modes, and the float path on noise and on image-like content.
