@@ -165,6 +165,19 @@ CASES += [
     ("r5_ed_fs_mc256_dark", "error_diffusion", {"variant": "floyd_steinberg"}, ("mc", 256), ("imgl", 140, 180, 57, "dark"), False, False),
     ("r5_ed_burkes_mc32_dark", "error_diffusion", {"variant": "burkes"}, ("mc", 32), ("imgl", 130, 170, 58, "dark"), False, False),
 ]
+# Round 5: the variable-coefficient diffusers (vardiff.hip) over two or three 64-row bands and with more than 16 colours (their
+# fixtures so far were single-band, at most 64 colours), hashed by the reference.
+CASES += [
+    ("r5_perceptual_p64_rnd", "perceptual", {}, ("palr", 64), ("rnd", 150, 130, 61), False, False),
+    ("r5_perceptual_mc32_smooth", "perceptual", {}, ("mc", 32), ("imgl", 140, 120, 62, "smooth"), False, False),
+    ("r5_hybrid_p32_grad", "hybrid", {}, ("palr", 32), ("grad", 140, 160), False, False),
+    ("r5_hybrid_l12_c05_p128_rnd", "hybrid", {"lum_factor": 1.2, "col_factor": 0.5}, ("palr", 128), ("rnd", 130, 110, 63), False, False),
+    ("r5_adaptive_p128_rnd", "adaptive_variance", {}, ("palr", 128), ("rnd", 130, 150, 64), False, False),
+    ("r5_adaptive_t200_r3_mc64_dark", "adaptive_variance", {"var_threshold": 200.0, "window_radius": 3}, ("mc", 64), ("imgl", 150, 100, 65, "dark"), False, False),
+    ("r5_ostro_false_p32_rnd", "ostromoukhov", {"serpentine": "false"}, ("palr", 32), ("rnd", 160, 140, 66), False, False),
+    ("r5_ostro_true_p256_grad", "ostromoukhov", {"serpentine": "true"}, ("palr", 256), ("grad", 130, 100), False, False),
+    ("r5_ostro_false_U16_gamma_rnd", "ostromoukhov", {"serpentine": "false"}, ("U", 16), ("rnd", 140, 90, 67), True, False),
+]
 # Round 3: the kernels for crowded palettes (ordered_compact_kernel) and for use_gamma (ordered_compact_float_kernel) at 1080p,
 # hashed by the reference: image-like content with its own median-cut 256 palette (the reference's default palette source),
 # all three ordered decision modes, and the float path on noise and on image-like content.
