@@ -174,8 +174,14 @@ __global__ __launch_bounds__(256) void ed_cells_kernel(const PalDev pal, uint4 *
     cells[cell] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// 16-step I/O period of the wavefront kernel: all global traffic happens at period boundaries
+// I/O period of the wavefront kernel: all global traffic happens at period boundaries.  A band follows the one above it at the
+// dependency distance (63 * skew + 2 steps) PLUS three periods of hand-off (its boundary errors are stored at the end of their period,
+// acknowledged one period later when the stores have landed, and fetched one period before use): with 16 steps that is 48 of ~175
+// steps per band, 33 times per 4K frame -- 18 % of a lone frame.  The instances of the few-frames schedule (<= 4 waves, every wave
+// with a SIMD to itself: their time IS that chain) therefore run 8-step periods; the sixteen-wave instances, bound by the
+// instructions they issue, keep 16 (half as many period boundaries per step).
 constexpr int kPeriod = 16;
+constexpr int kPeriodFew = 8;
 // progress words per frame when a frame's bands are spread over several workgroups (the last one: give-up flag)
 constexpr int kEdProgWords = 64;
 
@@ -198,6 +204,9 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                                                                       const uint32_t n_frames)
 {
     typedef typename ErrT<NB>::type E;  // an error: float, or double with the numba arithmetic
+    constexpr int PERIOD = MAXW <= 4 ? kPeriodFew : kPeriod;   // steps per I/O period (a multiple of 4)
+    constexpr int PW = PERIOD * 3 / 4;                          // dwords of a period's pixels
+    static_assert(PERIOD % 4 == 0 && PERIOD >= 4 && PERIOD <= 16, "the boundary fetch covers 32 columns per period");
     E *__restrict__ bnd_all = reinterpret_cast<E *>(bnd_all_v);
     // G == 1 with progress words given: the REPAIR launch that follows a G > 1 launch on the stream -- only the frames
     // whose give-up flag is set are done again, one workgroup per frame (the others return at once).
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
     // pipe 80 % busy with 16 waves per CU); 27 makes the accesses conflict-free at skew 2 and two-way at skew 3.
     __shared__ E s_ring[MAXW][64][kRingStride];
     __shared__ E s_vring[MAXW][2][64][3];                // errors of the two rows above the band (64-column ring)
-    __shared__ E s_bout[MAXW][2][kPeriod][3];            // this period's errors of rows 62/63, flushed to global
+    __shared__ E s_bout[MAXW][2][PERIOD][3];            // this period's errors of rows 62/63, flushed to global
     __shared__ uint8_t s_lut[256];
     __shared__ volatile uint32_t s_prog[MAXW];           // (running band number << 16) | (acknowledged column of row 63 + 1024)
     // {x, y, z, out_rgb bits} of the palette; palettes of 9..16 colours keep the candidate lists of the 16^3 cells
@@ -311,21 +320,21 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
             tbase[k] = exists ? (lds_float_t *)row : (lds_float_t *)s_zero;
             tmask[k] = exists ? (rel >= 0 ? (uint32_t)(kRing - 1) : 63u) : 0u;
         }
-        uint32_t pix[12], cur[13], outb[13];  // 16 pixels in flight / being consumed / being produced (raw bytes)
+        uint32_t pix[PW], cur[PW + 1], outb[PW + 1];  // a period's pixels in flight / being consumed / being produced (raw bytes)
         E pb0 = 0, pb1 = 0, pb2 = 0;  // boundary errors in flight (one column per lane)
         int pb_col = 0;
         bool pb_valid = false;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) pix[k] = 0;
+        for (int k = 0; k < PW; ++k) pix[k] = 0;
 #pragma unroll
-        for (int k = 0; k < 13; ++k) cur[k] = outb[k] = 0;
+        for (int k = 0; k < PW + 1; ++k) cur[k] = outb[k] = 0;
 
-        for (int t0 = -kPeriod; t0 < steps + kPeriod; t0 += kPeriod) {
+        for (int t0 = -PERIOD; t0 < steps + PERIOD; t0 += PERIOD) {
             // ================= period boundary: everything issued one period ago has landed =================
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (L == 0) {
-                // boundary columns produced in steps < t0 - kPeriod are acknowledged
-                int ack = t0 - kPeriod - 63 * skew + 1024;
+                // boundary columns produced in steps < t0 - PERIOD are acknowledged
+                int ack = t0 - PERIOD - 63 * skew + 1024;
                 ack = ack < 0 ? 0 : ack;
                 const uint32_t word = ((uint32_t)gb << 16) | (uint32_t)ack;
                 if (G == 1) s_prog[wv] = word;
@@ -338,18 +347,18 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                 dst[1] = pb1;
                 dst[2] = pb2;
             }
-            // ---- flush the outputs of the period that just ended: columns [xs, xs+16) of row r
+            // ---- flush the outputs of the period that just ended: columns [xs, xs+PERIOD) of row r
             {
-                const int xs = (t0 - kPeriod) - skew * L;
-                const int lo = xs < 0 ? 0 : xs, hi = xs + kPeriod > w ? w : xs + kPeriod;
+                const int xs = (t0 - PERIOD) - skew * L;
+                const int lo = xs < 0 ? 0 : xs, hi = xs + PERIOD > w ? w : xs + PERIOD;
                 if (row_ok && hi > lo) {
                     const long B = row_byte + (long)xs * 3;
-                    if (lo == xs && hi == xs + kPeriod) {
+                    if (lo == xs && hi == xs + PERIOD) {
 #pragma unroll
-                        for (int k = 0; k < 12; ++k) *reinterpret_cast<uint32_t *>(fout + B + 4 * k) = outb[k];
+                        for (int k = 0; k < PW; ++k) *reinterpret_cast<uint32_t *>(fout + B + 4 * k) = outb[k];
                     } else {
 #pragma unroll
-                        for (int i = 0; i < kPeriod; ++i) {
+                        for (int i = 0; i < PERIOD; ++i) {
                             if (xs + i >= 0 && xs + i < w) {
                                 const int bo = 3 * i;
                                 const uint32_t c = __funnelshift_r(outb[bo >> 2], outb[(bo >> 2) + 1], (bo & 3) * 8);
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 13; ++k) outb[k] = 0;
+                for (int k = 0; k < PW + 1; ++k) outb[k] = 0;
                 // rows 62/63: this band's boundary errors of the same period go to the global row buffer
                 if (L >= 62 && row_ok && hi > lo) {
                     for (int i = lo - xs; i < hi - xs; ++i) {
@@ -379,19 +388,19 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     }
                 }
             }
-            // ---- the pixels fetched during the previous period become current; fetch the next 16
+            // ---- the pixels fetched during the previous period become current; fetch the next period's
 #pragma unroll
-            for (int k = 0; k < 12; ++k) cur[k] = pix[k];
+            for (int k = 0; k < PW; ++k) cur[k] = pix[k];
             {
-                const int xn = (t0 + kPeriod) - skew * L;  // first column of the NEXT period
+                const int xn = (t0 + PERIOD) - skew * L;  // first column of the NEXT period
                 const long B = row_byte + (long)xn * 3;
-                if (row_ok && xn + kPeriod > 0 && xn < w) {
-                    if (B >= 0 && B + 48 <= frame_bytes) {
+                if (row_ok && xn + PERIOD > 0 && xn < w) {
+                    if (B >= 0 && B + 4 * PW <= frame_bytes) {
 #pragma unroll
-                        for (int k = 0; k < 12; ++k) pix[k] = *reinterpret_cast<const uint32_t *>(fin + B + 4 * k);
+                        for (int k = 0; k < PW; ++k) pix[k] = *reinterpret_cast<const uint32_t *>(fin + B + 4 * k);
                     } else {
 #pragma unroll
-                        for (int k = 0; k < 12; ++k) {
+                        for (int k = 0; k < PW; ++k) {
                             uint32_t v = 0;
 #pragma unroll
                             for (int bb = 0; bb < 4; ++bb) {
@@ -403,13 +412,14 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     }
                 }
             }
-            // ---- boundary rows of the band above: columns [x0n-14, x0n+18) around lane 0's next period
+            // ---- boundary rows of the band above: the 32 columns that end two past lane 0's next period, [x0n+PERIOD+2-32, x0n+PERIOD+2)
             pb_valid = false;
             if (band > 0) {
-                const int x0n = t0 + kPeriod;      // lane 0's first column of the next period (wave-uniform)
-                int need = x0n + 18;               // one past the last column fetched
+                const int x0n = t0 + PERIOD;       // lane 0's first column of the next period (wave-uniform)
+                constexpr int kFirst = PERIOD + 2 - 32;   // (-14 with 16 steps: lane 1's taps reach back skew + 2 columns)
+                int need = x0n + PERIOD + 2;       // one past the last column fetched
                 need = need > w ? w : need;
-                if (x0n - 14 < w && need > 0) {
+                if (x0n + kFirst < w && need > 0) {
                     const uint32_t want = (uint32_t)(need + 1024);
                     for (uint32_t spins = 0;; ++spins) {
                         const uint32_t v = G == 1 ? s_prog[pw] : __hip_atomic_load(&gprog[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                             return;
                         }
                     }
-                    const int col = x0n - 14 + (L & 31);
+                    const int col = x0n + kFirst + (L & 31);
                     if (col >= 0 && col < w) {
                         // lanes 0..31 -> row -2 (lane 62 of band-1), lanes 32..63 -> row -1 (lane 63); the buffer was
                         // written by another wave of this workgroup and is reused every 2 bands: bypass L1
@@ -443,11 +453,11 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
-            // ================= 16 steps that touch LDS and registers only =================
-            // Four steps per round of the loop: the round's pixels are bytes 0..11 of cur[] and its colours become bytes
-            // 36..47 of outb[] at fixed positions, then both 48-byte buffers move down by three whole registers -- a
-            // per-step rotation by three bytes costs 24 funnel shifts per step.
-            for (int i4 = 0; i4 < kPeriod; i4 += 4) {
+            // ================= PERIOD steps that touch LDS and registers only =================
+            // Four steps per round of the loop: the round's pixels are bytes 0..11 of cur[] and its colours become the LAST twelve
+            // bytes of outb[] at fixed positions, then both buffers move down by three whole registers -- a per-step rotation by
+            // three bytes costs 24 funnel shifts per step.
+            for (int i4 = 0; i4 < PERIOD; i4 += 4) {
               uint32_t cb[4];
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
@@ -552,14 +562,14 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
               // the round's twelve bytes are consumed / produced: both buffers move down by three registers; the colour of
               // step i will have travelled to byte 3*i by the time the period is flushed
 #pragma unroll
-              for (int k = 0; k < 9; ++k) {
+              for (int k = 0; k < PW - 3; ++k) {
                   cur[k] = cur[k + 3];
                   outb[k] = outb[k + 3];
               }
-              cur[9] = cur[10] = cur[11] = 0u;
-              outb[9] = cb[0] | (cb[1] << 24);
-              outb[10] = (cb[1] >> 8) | (cb[2] << 16);
-              outb[11] = (cb[2] >> 16) | (cb[3] << 8);
+              cur[PW - 3] = cur[PW - 2] = cur[PW - 1] = 0u;
+              outb[PW - 3] = cb[0] | (cb[1] << 24);
+              outb[PW - 2] = (cb[1] >> 8) | (cb[2] << 16);
+              outb[PW - 1] = (cb[2] >> 16) | (cb[3] << 8);
             }
         }
         // band finished: once its boundary stores are acknowledged the next band may read any column
