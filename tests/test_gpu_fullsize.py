@@ -108,6 +108,50 @@ def test_c3_long_batch_of_4k_frames_on_persistent_workgroups(d, orc):
         assert torch.equal(out[i], it.apply_dithering_frames(batch[i:i + 1])[0]), i
 
 
+@pytest.mark.parametrize("K,variant", [(256, "floyd_steinberg"), (64, "atkinson")])
+def test_error_diffusion_17_to_256_colours_4k_all_schedules(d, orc, K, variant):
+    """The hierarchical nearest table at full size on the product library: one 4K frame (34 bands over 16 workgroups, table in LDS,
+    8-step periods), and a batch of 280 frames (persistent sixteen-wave workgroups reading the table from L2) in which two contents
+    alternate -- every frame of the batch against the oracle's result for its content (3 s per content on one core)."""
+    import torch
+    pal = orc.palr(K, 7)
+    params = {"variant": variant, "serpentine": "false"}
+    it = d.ImageDitherer(K, d.DitherMode.ERROR_DIFFUSION, pal, False, dict(params))
+    a0, a1 = orc.rnd(2160, 3840, 4100 + K), orc.rnd(2160, 3840, 4200 + K)
+    r0 = torch.from_numpy(orc.apply_dithering(a0, pal, "error_diffusion", params)).cuda()
+    r1 = torch.from_numpy(orc.apply_dithering(a1, pal, "error_diffusion", params)).cuda()
+    x0, x1 = torch.from_numpy(a0).cuda(), torch.from_numpy(a1).cuda()
+    assert torch.equal(it.apply_dithering_frames(x0), r0)                       # one frame
+    assert torch.equal(it.apply_dithering_frames(torch.stack([x0, x1, x0]))[1], r1)   # three frames: still the few-frames schedule
+    n = 280
+    batch = torch.empty((n, 2160, 3840, 3), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        batch[i].copy_(x1 if i % 3 == 1 else x0)
+    out = it.apply_dithering_frames(batch)
+    del batch
+    for i in range(n):
+        assert torch.equal(out[i], r1 if i % 3 == 1 else r0), i
+
+
+@pytest.mark.parametrize("kind,K", [("smooth", 256), ("dark", 128)])
+def test_error_diffusion_with_the_content_s_own_palette_4k(d, orc, kind, K):
+    """A palette extracted from the content (median cut of the frame itself: crowded cells; the smooth one keeps the hierarchical table
+    in LDS for few frames and the lists for batches, the dark one the lists and their octree everywhere): one 4K frame and a batch of 40
+    against the oracle."""
+    import torch
+    from PIL import Image
+    a0 = orc.imgl(2160, 3840, 71, kind)
+    pal = d.ColorReducer.reduce_colors(Image.fromarray(a0, "RGB"), K)
+    params = {"variant": "floyd_steinberg", "serpentine": "false"}
+    it = d.ImageDitherer(K, d.DitherMode.ERROR_DIFFUSION, pal, False, dict(params))
+    r0 = torch.from_numpy(orc.apply_dithering(a0, pal, "error_diffusion", params)).cuda()
+    x0 = torch.from_numpy(a0).cuda()
+    assert torch.equal(it.apply_dithering_frames(x0), r0)
+    out = it.apply_dithering_frames(x0.unsqueeze(0).repeat(40, 1, 1, 1))
+    for i in range(40):
+        assert torch.equal(out[i], r0), i
+
+
 def test_error_diffusion_gives_up_and_repairs(d, be, orc, switches):
     """A workgroup of a multi-workgroup launch that gives up waiting sets a flag; the repair launch behind it redoes the
     frame.  DP_ED_TEST_GIVEUP makes every workgroup of the first launch give up before it writes anything."""
