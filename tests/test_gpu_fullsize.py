@@ -152,6 +152,24 @@ def test_error_diffusion_with_the_content_s_own_palette_4k(d, orc, kind, K):
         assert torch.equal(out[i], r0), i
 
 
+@pytest.mark.parametrize("mode,params,K", [("perceptual", {}, 64), ("hybrid", {"lum_factor": 0.9, "col_factor": 0.4}, 256),
+                                           ("adaptive_variance", {"var_threshold": 150.0, "window_radius": 2}, 100),
+                                           ("ostromoukhov", {"serpentine": "false"}, 256)])
+def test_variable_diffusers_1080p_more_than_16_colours(d, orc, mode, params, K):
+    """The variable-coefficient diffusers at 1080p (17 bands) with palettes whose candidate lists / hierarchical table they read from
+    L2: one frame and a batch of 20 against the oracle, product library."""
+    import torch
+    pal = orc.palr(K, 5)
+    a0 = orc.rnd(1080, 1920, 900 + K)
+    ref = torch.from_numpy(orc.apply_dithering(a0, pal, mode, params, False)).cuda()
+    it = d.ImageDitherer(K, d.DitherMode(mode), pal, False, dict(params))
+    x0 = torch.from_numpy(a0).cuda()
+    assert torch.equal(it.apply_dithering_frames(x0), ref)
+    out = it.apply_dithering_frames(x0.unsqueeze(0).repeat(20, 1, 1, 1))
+    for i in range(20):
+        assert torch.equal(out[i], ref), i
+
+
 def test_error_diffusion_gives_up_and_repairs(d, be, orc, switches):
     """A workgroup of a multi-workgroup launch that gives up waiting sets a flag; the repair launch behind it redoes the
     frame.  DP_ED_TEST_GIVEUP makes every workgroup of the first launch give up before it writes anything."""
