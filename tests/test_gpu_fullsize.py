@@ -170,6 +170,30 @@ def test_variable_diffusers_1080p_more_than_16_colours(d, orc, mode, params, K):
         assert torch.equal(out[i], ref), i
 
 
+@pytest.mark.parametrize("K", [300, 1024])
+def test_palettes_above_256_colours_1080p(d, orc, K):
+    """257..1024 colours at 1080p on the product library with the accelerator built (cell table whose deeper split nodes stay in
+    global memory) and without it (brute-force kernels), nearest / Bayer / IGN, and Floyd-Steinberg error diffusion, against the
+    oracle."""
+    import torch
+    pal = orc.palr(K, 11)
+    a0 = orc.rnd(1080, 1920, 300 + K)
+    x0 = torch.from_numpy(a0).cuda()
+    for mode, params in (("none", {}), ("bayer", {"size": "8x8"}), ("IGN", {"scale": 1.3, "seed": 5})):
+        ref = torch.from_numpy(orc.apply_dithering(a0, pal, mode, params, False)).cuda()
+        plain = d.ImageDitherer(K, d.DitherMode(mode), pal, False, dict(params))
+        assert torch.equal(plain.apply_dithering_frames(x0), ref), (mode, "brute force")
+        d.drop_device_caches()
+        fast = d.ImageDitherer(K, d.DitherMode(mode), pal, False, dict(params)).prepare()
+        assert torch.equal(fast.apply_dithering_frames(x0), ref), (mode, "accelerator")
+        assert torch.equal(fast.apply_dithering_frames(x0.unsqueeze(0).repeat(5, 1, 1, 1))[4], ref), (mode, "batch")
+    params = {"variant": "floyd_steinberg", "serpentine": "false"}
+    ref = torch.from_numpy(orc.apply_dithering(a0, pal, "error_diffusion", params, False)).cuda()
+    it = d.ImageDitherer(K, d.DitherMode.ERROR_DIFFUSION, pal, False, dict(params))
+    assert torch.equal(it.apply_dithering_frames(x0), ref)
+    assert torch.equal(it.apply_dithering_frames(x0.unsqueeze(0).repeat(3, 1, 1, 1))[2], ref)
+
+
 def test_error_diffusion_gives_up_and_repairs(d, be, orc, switches):
     """A workgroup of a multi-workgroup launch that gives up waiting sets a flag; the repair launch behind it redoes the
     frame.  DP_ED_TEST_GIVEUP makes every workgroup of the first launch give up before it writes anything."""
