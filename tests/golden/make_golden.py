@@ -178,6 +178,15 @@ CASES += [
     ("r5_ostro_true_p256_grad", "ostromoukhov", {"serpentine": "true"}, ("palr", 256), ("grad", 130, 100), False, False),
     ("r5_ostro_false_U16_gamma_rnd", "ostromoukhov", {"serpentine": "false"}, ("U", 16), ("rnd", 140, 90, 67), True, False),
 ]
+# Round 5: palettes of 257..1024 colours (the 10-bit index keys, the cell table with split nodes beyond LDS), hashed by the reference.
+CASES += [
+    ("r5_bayer8_p300_rnd", "bayer", {"size": "8x8"}, ("palr", 300), ("rnd", 203, 317, 71), False, False),
+    ("r5_none_p1024_grad", "none", {}, ("palr", 1024), ("grad", 240, 320), False, False),
+    ("r5_ign_p700_rnd", "IGN", {"scale": 1.7, "seed": 9}, ("palr", 700), ("rnd", 200, 300, 72), False, False),
+    ("r5_blue32_p512_gamma_grad", "blue_noise", {"size": 32, "seed": 5}, ("palr", 512), ("grad", 150, 210), True, False),
+    ("r5_ed_fs_p300_rnd", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 300), ("rnd", 130, 170, 73), False, False),
+    ("r5_ed_atkinson_p1024_grad", "error_diffusion", {}, ("palr", 1024), ("grad", 100, 140), False, False),
+]
 # Round 3: the kernels for crowded palettes (ordered_compact_kernel) and for use_gamma (ordered_compact_float_kernel) at 1080p,
 # hashed by the reference: image-like content with its own median-cut 256 palette (the reference's default palette source),
 # all three ordered decision modes, and the float path on noise and on image-like content.
