@@ -313,6 +313,9 @@ def append_kmeans_few(kat, npz):
         print(nm, "distinct palettes in", KM_FEW_REPEATS, "runs of the reference:", len(pals), flush=True)
 
 
+BLUE_EXTRA = [(96, 1), (128, 42), (130, 7)]
+
+
 def append_new():
     """Adds the cases of CASES that kat.json does not hold yet (and their median-cut palettes) and the KM_EXTRA k-means
     fixtures without touching the rest."""
@@ -323,6 +326,16 @@ def append_new():
     append_kmeans_few(kat, npz)
     if "kmeans_fixture_host" not in kat["versions"]:
         record_kmeans_host(kat)
+    # round 5: blue-noise matrices at the largest size the GUI offers (128: the last one whose arrays fit the kernel's LDS), beyond
+    # it (130: the global-memory instance) and in between -- the reference needs n^2 Python steps (2-3 minutes each)
+    for size, seed in BLUE_EXTRA:
+        key = f"blue_{size}_{seed}"
+        if key in kat["misc"]:
+            continue
+        bn = dl.generate_blue_noise(size, seed)
+        npz[key] = bn
+        kat["misc"][key] = H(bn)
+        print(key, H(bn), flush=True)
     have = {c["name"] for c in kat["cases"]}
     for name, mode, params, pspec, ispec, gamma, keep in CASES:
         if name in have:

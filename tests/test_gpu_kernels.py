@@ -151,7 +151,7 @@ def test_unaligned_input_pointer(be, orc):
     _assert_same(out, orc.apply_dithering(arr, pal, "bayer", {"size": "4x4"}), "unaligned")
 
 
-@pytest.mark.parametrize("size,seed", [(32, 42), (64, 42), (32, 0), (33, 9999)])
+@pytest.mark.parametrize("size,seed", [(32, 42), (64, 42), (32, 0), (33, 9999), (96, 1), (128, 42), (130, 7)])
 def test_blue_noise_on_device(be, gold, size, seed):
     bn = be.Thresholds.blue_noise(size, seed).numpy()
     assert np.array_equal(bn, gold[f"blue_{size}_{seed}"])
@@ -349,6 +349,29 @@ def test_resize_nearest_matches_pillow(be, orc):
     out = be.resize_nearest(_dev(frames), 16, 22).cpu().numpy()
     for i in range(3):
         assert np.array_equal(out[i], np.array(Image.fromarray(frames[i]).resize((22, 16), Image.NEAREST)))
+
+
+def test_resize_nearest_sweep_matches_pillow(be, orc):
+    """The geometries the video path produces (video_processor.py:547-577, 393-420): 1080p / 4K / odd sources down to max_size
+    32..256 on the smaller side (even dimensions) and back up by 2..8, plus 60 random size pairs -- Pillow's NEAREST decides."""
+    from PIL import Image
+    from dither_pie_amd.video_processor import _even_dimensions, _final_size
+    rs = np.random.RandomState(77)
+    pairs = []
+    for (h, w) in [(1080, 1920), (2160, 3840), (719, 1279), (480, 853), (1920, 1080)]:
+        for ms in (32, 64, 100, 127, 256):
+            tw, th = _even_dimensions(w, h, ms)
+            pairs.append((h, w, th, tw))
+            for m in (2, 3, 8):
+                nw, nh = _final_size(tw, th, m)
+                pairs.append((th, tw, nh, nw))
+    for _ in range(60):
+        pairs.append((int(rs.randint(1, 700)), int(rs.randint(1, 900)), int(rs.randint(1, 900)), int(rs.randint(1, 1100))))
+    for (h, w, oh, ow) in pairs:
+        arr = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        ref = np.array(Image.fromarray(arr).resize((ow, oh), Image.NEAREST))
+        out = be.resize_nearest(_dev(arr), oh, ow).cpu().numpy()
+        assert np.array_equal(out, ref), (h, w, oh, ow)
 
 
 def test_accelerator_is_built_for_integer_and_float_palettes(be, orc):

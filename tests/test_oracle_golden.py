@@ -45,7 +45,7 @@ def test_ign_thresholds(orc, gold, kat):
     assert np.array_equal(orc.ign_thresholds(10, 20, 0.1, 9999, y0=7, x0=13), full[7:17, 13:33])
 
 
-@pytest.mark.parametrize("size,seed", [(32, 42), (64, 42), (32, 0), (33, 9999)])
+@pytest.mark.parametrize("size,seed", [(32, 42), (64, 42), (32, 0), (33, 9999), (96, 1), (128, 42), (130, 7)])
 def test_blue_noise(orc, gold, kat, size, seed):
     bn = orc.blue_noise(size, seed)
     assert np.array_equal(bn, gold[f"blue_{size}_{seed}"])
