@@ -33,17 +33,20 @@ class Palette:
     pal_f32 [K,3] float32 as the KD-tree sees it; out_colors [K,3] uint8 written for each entry;
     lut_in optional 256-entry uint8 map applied to the input bytes."""
 
-    # Building the search accelerator (KD-tree aside: a scan of all 2^24 colours, cell table, tie codes) takes ~12 ms,
-    # once per palette; the brute-force kernels need ~9 K vector instructions per pixel against ~70 with it.  A palette
-    # therefore runs on the brute-force kernels until the pixels it has served would have paid for the build
-    # (break-even ~ 4.9e10 / K pixels: 190 Mpixel at 256 colours, 3 Gpixel at 16) and builds it then -- never more
-    # than twice the cost of the better choice, whatever follows.  One image or a GUI preview never builds it; a
-    # video does within its first frames.  build_accel() forces it (long-running jobs that know what is coming).
-    ACCEL_BUILD_SECONDS = 0.012
+    # Building the search accelerator (KD-tree aside: a scan of all 2^24 colours, cell table, tie codes) takes ~3.5 ms up to 256
+    # colours and ~25 ms at 1024 (rounds 1-4: 7-12 ms; tools/bench_scripts/accel_build_stages.py), once per palette; the brute-force
+    # kernels need ~9 K vector instructions per pixel against ~70 with it.  A palette therefore runs on the brute-force kernels
+    # until the pixels it has served would have paid for the build (break-even ~ 1.4e10 / K pixels up to 256 colours: 56 Mpixel
+    # = seven 4K frames at 256, 0.9 Gpixel at 16) and builds it then -- never more than twice the cost of the better choice,
+    # whatever follows.  One image or a GUI preview never builds it; a video does within its first frames.  build_accel() forces
+    # it (long-running jobs that know what is coming).
+    ACCEL_BUILD_SECONDS = 0.0035
+    ACCEL_BUILD_SECONDS_LARGE = 0.025            # more than 256 colours (128-byte membership masks, deeper tables)
     BRUTE_SECONDS_PER_PIXEL_PER_COLOUR = 2.46e-13
 
     def accel_break_even_pixels(self):
-        return self.ACCEL_BUILD_SECONDS / (self.BRUTE_SECONDS_PER_PIXEL_PER_COLOUR * max(self.K, 1))
+        build = self.ACCEL_BUILD_SECONDS if self.K <= 256 else self.ACCEL_BUILD_SECONDS_LARGE
+        return build / (self.BRUTE_SECONDS_PER_PIXEL_PER_COLOUR * max(self.K, 1))
 
     def note_pixels(self, n_px):
         """Account n_px pixels about to be processed; builds the accelerator once they have paid for it."""

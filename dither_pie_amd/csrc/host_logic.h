@@ -187,24 +187,27 @@ int assemble_table(const std::vector<uint32_t> &masks, const int mw, const int b
     tab.assign((size_t)kCells * bw, 0u);
     std::vector<int> list, extra;
     std::vector<uint64_t> dkey;
-    // members of a mask, padded to bw with the unused entries nearest to (cr,cg,cb); false if more than bw
+    // members of a mask, padded to bw with unused entries; false if more than bw
     auto make_block = [&](const uint32_t *mask, int cr, int cg, int cb, uint32_t *out8) {
         list.clear();
-        extra.clear();
-        for (int j = 0; j < K; ++j) ((mask[j >> 5] >> (j & 31) & 1u) ? list : extra).push_back(j);
+        for (int wi = 0; wi < mw && 32 * wi < K; ++wi)   // the members: the set bits of the mask below K
+            for (uint32_t bits = mask[wi]; bits; bits &= bits - 1u) {
+                const int j = 32 * wi + __builtin_ctz(bits);
+                if (j < K) list.push_back(j);
+            }
         st.max_cnt = std::max(st.max_cnt, (int)list.size());
         if (list.size() > (size_t)bw) return false;
         if (list.size() < (size_t)bw) {
-            // pad with the unused entries nearest to the centre (any real entry is harmless)
+            extra.clear();   // the lowest unused indices, as many as the padding needs
+            for (int j = 0; j < K && extra.size() < (size_t)bw; ++j)
+                if (!(mask[j >> 5] >> (j & 31) & 1u)) extra.push_back(j);
+            // pad with unused entries: ANY real entry is harmless (it is not among the three nearest of any colour of the box, so its
+            // key never decides anything), so the lowest unused indices do.  Rounds 2-5 took the unused entries nearest to the
+            // centre -- a distance key for every unused entry of every cell and a partial sort: 3 of the 4.4 ms this assembly took
+            // for 256 colours (tools/bench_scripts/accel_build_stages.py).
             const size_t need = (size_t)bw - list.size();
-            dkey.resize(extra.size());
-            for (size_t q = 0; q < extra.size(); ++q) {
-                const uint32_t c = coord4[extra[q]];
-                const int r = c & 255, g = (c >> 8) & 255, b = (c >> 16) & 255;
-                dkey[q] = ((uint64_t)((r - cr) * (r - cr) + (g - cg) * (g - cg) + (b - cb) * (b - cb)) << 16) | (uint64_t)extra[q];
-            }
-            std::partial_sort(dkey.begin(), dkey.begin() + need, dkey.end());
-            for (size_t q = 0; q < need; ++q) list.push_back((int)(dkey[q] & 0xffff));
+            (void)cr, (void)cg, (void)cb;
+            for (size_t q = 0; q < need; ++q) list.push_back(extra[q]);
             std::sort(list.begin(), list.end());  // key ties must break towards the lower palette index
         }
         for (int i = 0; i < bw; ++i) out8[i] = word[list[i]];

@@ -942,7 +942,7 @@ class ImageDitherer:
             return strategy._run(frames, pal, y0=y0, x0=x0, out=out)
 
     def prepare(self, device=None, accel=True):
-        """Create the device-side palette now (and, with accel=True, its search accelerator: ~12 ms once) instead of on
+        """Create the device-side palette now (and, with accel=True, its search accelerator: ~3.5 ms once) instead of on
         first use / once enough pixels have been served -- for long-running jobs (a video) that know what is coming.
         An addition to the reference's interface; nothing is stored on the (picklable) object."""
         import torch

@@ -90,7 +90,7 @@ int dp_palette_info(const dp_palette *p, int *K, int *is_integer, int *n_nodes);
  * palettes (4..1024 colours whose output colours are the palette colours) also per-colour tie codes and an
  * exception list, so that scipy's tie order needs no tree traversal; float palettes (use_gamma, 8..256
  * colours) get the same table over the lut_in-mapped pixel values.  Building it scans all 2^24 colours once
- * (~8-12 ms all told, synchronous), which pays off only after ~4.9e10 / K pixels (190 Mpixel at 256 colours: the
+ * (~3.5 ms up to 256 colours, ~25 ms at 1024, synchronous), which pays off only after ~1.4e10 / K pixels (56 Mpixel at 256 colours: the
  * brute-force kernels need ~9 K vector instructions per pixel, the table kernels ~70); without it dp_ordered_u8 runs
  * the brute-force kernels.  dp_palette_build_accel is idempotent and returns DP_OK
  * without building when the palette does not qualify or the table would not fit LDS.
