@@ -502,11 +502,11 @@ constexpr int kEdCells = 32 * 32 * 32;
 // The per-cell loops below are independent: split them over a few host threads (the tables of a new palette are built
 // at its first diffusion call, i.e. in front of a user's image).  Each thread writes only the cells of its own range.
 template <class F>
-inline void parallel_cells(const int n, F &&body)
+inline void parallel_cells(const int n, F &&body, const int serial_below = 1024)
 {
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
-    if (n < 1024 || nt == 1) {
+    if (n < serial_below || nt == 1) {
         body(0, n);
         return;
     }
@@ -668,53 +668,84 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
             host[cell] = pack(list, lo, 8.0);  // (re-packed even when nothing was dropped: the padding)
         }
     });
+    // The cells whose geometric list overflowed: their full pruned lists and, where even those are longer than 15, their octrees.
+    // Each such cell is refined on its own (in parallel: a crowded palette has hundreds of them, and a list of a hundred entries
+    // costs ten thousand pairwise tests) into a LOCAL node array whose node numbers are made global when the arrays are
+    // joined below -- in cell order and with the same depth-first order inside a cell as the single stack of rounds 2-5 had,
+    // so the tables come out byte for byte as before.
+    std::vector<int> over;
     for (int cell = 0; cell < kEdCells; ++cell)
-        if ((host[cell].x & 255u) == 255u) {
-            Work wk;
-            wk.slot = (size_t)cell;
-            wk.top = true;
-            wk.lo[0] = (double)((cell & 31) * 8);
-            wk.lo[1] = (double)(((cell >> 5) & 31) * 8);
-            wk.lo[2] = (double)((cell >> 10) * 8);
-            wk.size = 8.0;
-            box_list(all, wk.lo, 8.0, wk.from);  // the cell's full list
-            prune_list(wk.lo, 8.0, wk.from);
-            stack.push_back(std::move(wk));
+        if ((host[cell].x & 255u) == 255u) over.push_back(cell);
+    struct Local {
+        U4 top;
+        std::vector<U4> nodes;   // 8 per local node; child pointers hold LOCAL node numbers
+    };
+    std::vector<Local> locals(over.size());
+    auto refine_cell = [&](const int cell, Local &lc) {
+        std::vector<Work> st;
+        Work w0;
+        w0.slot = 0;
+        w0.top = true;
+        w0.lo[0] = (double)((cell & 31) * 8);
+        w0.lo[1] = (double)(((cell >> 5) & 31) * 8);
+        w0.lo[2] = (double)((cell >> 10) * 8);
+        w0.size = 8.0;
+        box_list(all, w0.lo, 8.0, w0.from);  // the cell's full list
+        prune_list(w0.lo, 8.0, w0.from);
+        st.push_back(std::move(w0));
+        while (!st.empty()) {
+            Work wk = std::move(st.back());
+            st.pop_back();
+            U4 entry;
+            if (wk.from.size() <= 15) {
+                entry = pack(wk.from, wk.lo, wk.size);
+            } else if (wk.size <= 1.0) {
+                entry = make_u4(255u, 0u, 0u, 0u);  // a unit cube that still sees more than 15 entries: scan the palette
+            } else {
+                const size_t node = lc.nodes.size() / 8;
+                lc.nodes.resize(lc.nodes.size() + 8, make_u4(255u, 0u, 0u, 0u));
+                entry = make_u4(254u | ((uint32_t)node << 8), 0u, 0u, 0u);
+                const double hs = wk.size * 0.5;
+                for (int sub = 0; sub < 8; ++sub) {
+                    Work ch;
+                    ch.slot = node * 8 + (size_t)sub;
+                    ch.top = false;
+                    ch.lo[0] = wk.lo[0] + ((sub & 1) ? hs : 0.0);
+                    ch.lo[1] = wk.lo[1] + ((sub & 2) ? hs : 0.0);
+                    ch.lo[2] = wk.lo[2] + ((sub & 4) ? hs : 0.0);
+                    ch.size = hs;
+                    box_list(wk.from, ch.lo, hs, ch.from);
+                    prune_list(ch.lo, hs, ch.from);
+                    st.push_back(std::move(ch));
+                }
+            }
+            if (wk.top) lc.top = entry;
+            else lc.nodes[wk.slot] = entry;
         }
+    };
+    if (over.size() >= 16) {
+        parallel_cells((int)over.size(), [&](const int i0, const int i1) {
+            for (int i = i0; i < i1; ++i) refine_cell(over[(size_t)i], locals[(size_t)i]);
+        }, 16);
+    } else {
+        for (size_t i = 0; i < over.size(); ++i) refine_cell(over[i], locals[i]);
+    }
     bool give_up = false;
-    std::vector<U4> top_saved;  // the overflowing cells' entries before refinement (restored if the refinement is abandoned)
-    while (!stack.empty() && !give_up) {
-        Work wk = std::move(stack.back());
-        stack.pop_back();
-        U4 entry;
-        if (wk.from.size() <= 15) {
-            entry = pack(wk.from, wk.lo, wk.size);
-        } else if (wk.size <= 1.0) {
-            entry = make_u4(255u, 0u, 0u, 0u);  // a unit cube that still sees more than 15 entries: scan the palette
-        } else {
-            const size_t node = nodes.size() / 8;
-            if (node >= (1u << 22)) {
-                give_up = true;
-                break;
-            }
-            nodes.resize(nodes.size() + 8, make_u4(255u, 0u, 0u, 0u));
-            entry = make_u4(254u | ((uint32_t)node << 8), 0u, 0u, 0u);
-            const double hs = wk.size * 0.5;
-            for (int sub = 0; sub < 8; ++sub) {
-                Work ch;
-                ch.slot = node * 8 + (size_t)sub;
-                ch.top = false;
-                ch.lo[0] = wk.lo[0] + ((sub & 1) ? hs : 0.0);
-                ch.lo[1] = wk.lo[1] + ((sub & 2) ? hs : 0.0);
-                ch.lo[2] = wk.lo[2] + ((sub & 4) ? hs : 0.0);
-                ch.size = hs;
-                box_list(wk.from, ch.lo, hs, ch.from);
-                prune_list(ch.lo, hs, ch.from);
-                stack.push_back(std::move(ch));
-            }
+    (void)stack;
+    // joined in the order the single stack visited them: it held the overflowing cells in ascending order and popped the LAST first
+    for (size_t ii = over.size(); ii-- > 0 && !give_up;) {
+        const Local &lc = locals[ii];
+        const size_t base = nodes.size() / 8;
+        if (base + lc.nodes.size() / 8 >= (1u << 22)) {
+            give_up = true;
+            break;
         }
-        if (wk.top) host[wk.slot] = entry;
-        else nodes[wk.slot] = entry;
+        auto fix = [&](U4 e) {
+            if ((e.x & 255u) == 254u) e.x = 254u | ((uint32_t)(base + (e.x >> 8)) << 8);
+            return e;
+        };
+        host[(size_t)over[ii]] = fix(lc.top);
+        for (const U4 &e : lc.nodes) nodes.push_back(fix(e));
     }
     out.give_up = give_up;
     if (give_up) {
@@ -732,9 +763,10 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
         // variant (one wave per SIMD: the read of the 8x8x8 table from L2 is half of a step's latency there)
         std::vector<U4> &l16 = out.l16;
         l16.resize(4096);
+        std::vector<std::vector<int>> top16(4096);   // the cells' pruned lists: the hierarchical table below starts from them
         parallel_cells(4096, [&](const int c0, const int c1) {
-            std::vector<int> list;
             for (int cell = c0; cell < c1; ++cell) {
+                std::vector<int> &list = top16[cell];
                 const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
                 box_list(all, lo, 16.0, list);
                 prune_list(lo, 16.0, list);
@@ -792,13 +824,16 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
                 top.lo[1] = (double)(((cell >> 4) & 15) * 16);
                 top.lo[2] = (double)((cell >> 8) * 16);
                 top.size = 16.0;
-                top.from = all;
                 todo.push_back(std::move(top));
                 while (!todo.empty()) {
                     Item it = std::move(todo.back());
                     todo.pop_back();
-                    box_list(it.from, it.lo, it.size, list);
-                    prune_list(it.lo, it.size, list);
+                    if (it.size == 16.0) {
+                        list = top16[cell];   // (box_list + prune_list of the whole palette: done above)
+                    } else {
+                        box_list(it.from, it.lo, it.size, list);
+                        prune_list(it.lo, it.size, list);
+                    }
                     if (list.size() <= 4) {
                         lw[it.slot] = leaf(list, it.lo, it.size);
                         continue;
