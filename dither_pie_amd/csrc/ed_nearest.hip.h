@@ -190,7 +190,19 @@ __device__ __forceinline__ int nearest_h4(const uint32_t *__restrict__ h4, const
 
 // lists of the 16x16x16 cells in the format of the 8x8x8 table (count byte 255: more than 15 entries, use that table).
 // `expanded` (with `coarse`, EXPANDED instances): the candidates' expanded records for ed_key_expanded.
-template <int CAP, bool EXPANDED = false>
+// entry `pos` (0-based) of a WIDE list block -- palettes of 257..1024 colours: ten bits per entry from bit 8 on (host_logic.h:
+// ed_list_put; ediff.hip: ed_cells_kernel)
+__device__ __forceinline__ int ed_wide_entry(const uint4 blk, const uint32_t pos)
+{
+    const uint32_t off = 8u + 10u * pos, wi = off >> 5, sh = off & 31u;
+    const uint32_t lo = wi == 0u ? blk.x : (wi == 1u ? blk.y : (wi == 2u ? blk.z : blk.w));
+    const uint32_t hi = wi == 0u ? blk.y : (wi == 1u ? blk.z : (wi == 2u ? blk.w : 0u));
+    return (int)(__funnelshift_r(lo, hi, sh) & 1023u);
+}
+
+// WIDE_OK: the instance also reads the wide list blocks of palettes above 256 colours (only the large-queue instances do: the
+// launchers send every such palette there)
+template <int CAP, bool EXPANDED = false, bool WIDE_OK = false>
 __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const float4 *__restrict__ cand,
                                                    const uint32_t *__restrict__ coarse, const float o0, const float o1,
                                                    const float o2, const uint4 *__restrict__ lists16 = nullptr,
@@ -296,6 +308,37 @@ __device__ __forceinline__ int nearest_color_cells(const PalDev &pal, const floa
             }
         }
         if (n > 15) return nearest_color<CAP>(pal, cand, o0, o1, o2);
+        if (WIDE_OK && pal.K > 256) {
+            // 257..1024 colours: up to twelve ten-bit entries (padded to a multiple of four positions by the builder).  The same two
+            // stages as below: the key scan in groups of four, then -- near ties -- the exact scan over the listed entries.
+            int m0 = 0x7fffffff, m1 = 0x7fffffff;
+            for (uint32_t g = 0; (int)g < n; g += 4u) {
+                const int j1 = ed_wide_entry(blk, g), j2 = ed_wide_entry(blk, g + 1u), j3 = ed_wide_entry(blk, g + 2u), j4 = ed_wide_entry(blk, g + 3u);
+                const float4 c1 = cand[j1], c2 = cand[j2], c3 = cand[j3], c4 = cand[j4];
+                const int k1 = ed_key16(c1, o0, o1, o2, g), k2 = ed_key16(c2, o0, o1, o2, g + 1u), k3 = ed_key16(c3, o0, o1, o2, g + 2u),
+                          k4 = ed_key16(c4, o0, o1, o2, g + 3u);
+                m1 = ed_med3(m0, m1, k1);
+                m0 = min(m0, k1);
+                m1 = ed_med3(m0, m1, k2);
+                m0 = min(m0, k2);
+                m1 = ed_med3(m0, m1, k3);
+                m0 = min(m0, k3);
+                m1 = ed_med3(m0, m1, k4);
+                m0 = min(m0, k4);
+            }
+            const float f0 = __int_as_float(m0 & ~15), f1 = __int_as_float(m1 & ~15);
+            if (n >= 1 && f1 > f0 * 1.000004f) return ed_wide_entry(blk, (uint32_t)m0 & 15u);
+            for (int i = 0; i < n; ++i) {
+                const int j = ed_wide_entry(blk, (uint32_t)i);
+                visit(cand[j], j, true);
+            }
+            if (b1 > b0 * 1.000002f) return i0;
+            if (b0 == b1) {
+                const int tied = integer_tie_choice(pal, cand, o0, o1, o2, b0, i0);
+                if (tied >= 0) return tied;
+            }
+            return nearest_f64<CAP>(pal, o0, o1, o2);
+        }
         // Lists of up to 12 entries (padded to a multiple of 4 positions by the builder, ediff.hip: pack): the key scan first --
         // float32 distance bits with the position in the low 4 bits, the two smallest kept by v_med3 / v_min, groups of
         // four without per-position tests; a second key within 4e-6 (relative: 2e-6 of the evaluation + 15 ulp of the tag)

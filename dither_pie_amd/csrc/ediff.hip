@@ -167,10 +167,16 @@ __global__ __launch_bounds__(256) void ed_cells_kernel(const PalDev pal, uint4 *
         }
         if (near2 <= bound) {
             ++n;
-            if (n <= 15) w[n >> 2] |= (uint32_t)j << (8 * (n & 3));
+            if (K <= 256) {
+                if (n <= 15) w[n >> 2] |= (uint32_t)j << (8 * (n & 3));
+            } else if (n <= 12) {   // 257..1024 colours: ten bits per entry from bit 8 on (host_logic.h: ed_list_put)
+                const int off = 8 + 10 * (n - 1), wi = off >> 5, sh = off & 31;
+                w[wi] |= (uint32_t)j << sh;
+                if (sh > 22 && wi < 3) w[wi + 1] |= (uint32_t)j >> (32 - sh);
+            }
         }
     }
-    w[0] |= n <= 15 ? (uint32_t)n : 255u;
+    w[0] |= n <= (K <= 256 ? 15 : 12) ? (uint32_t)n : 255u;
     cells[cell] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(64 * MAXW) void ed_wavefront_kernel(const uint8_t *
                     }
                     const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
                     const int j = NB ? nearest_numba_f64(s_pal, pal.K, o0, o1, o2)
-                                     : (pal.ed_cells ? nearest_color_cells<CAP, true>(pal, s_pal, coarse, o0, o1, o2, lists16, s_expanded, h4)
+                                     : (pal.ed_cells ? nearest_color_cells<CAP, true, CAP == kQueueLarge>(pal, s_pal, coarse, o0, o1, o2, lists16, s_expanded, h4)
                                                      : nearest_color<CAP>(pal, s_pal, o0, o1, o2));
                     const float4 pj = s_pal[j];
                     e0 = err_of<NB>(o0, pj.x);
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(64) void ed_serial_kernel(const uint8_t *__restrict
             }
             const float o0 = clamp255(a0), o1 = clamp255(a1), o2 = clamp255(a2);
             const int j = NB ? nearest_numba_f64(pal.fcand, pal.K, o0, o1, o2)
-                             : (pal.ed_cells ? nearest_color_cells<CAP>(pal, pal.fcand, nullptr, o0, o1, o2, nullptr, nullptr, pal.ed_h4)
+                             : (pal.ed_cells ? nearest_color_cells<CAP, false, CAP == kQueueLarge>(pal, pal.fcand, nullptr, o0, o1, o2, nullptr, nullptr, pal.ed_h4)
                                              : nearest_color<CAP>(pal, pal.fcand, o0, o1, o2));
             E *e = ring + (((size_t)(y % 3) * w + x) * 3) * nf + f;
             E v0 = err_of<NB>(o0, (float)pal.pts[3 * j]), v1 = err_of<NB>(o1, (float)pal.pts[3 * j + 1]),
@@ -1041,7 +1047,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         const bool small_k = pal.ed_coarse != nullptr && pal.n_inner <= kQueueSmall;
 #define DP_EDN(N, X)                                                                                                      \
     do {                                                                                                                 \
-        if (pal.n_inner > kQueueSmall) DP_EDW(kQueueLarge, N, X, 0, 0);                                                   \
+        if (pal.n_inner > kQueueSmall || pal.K > 256) DP_EDW(kQueueLarge, N, X, 0, 0);   /* (wide lists: these instances) */ \
         else if (small_k) DP_EDW(kQueueSmall, N, X, 1, 1);                                                                \
         else DP_EDW(kQueueSmall, N, X, 2, 2);                                                                             \
     } while (0)
@@ -1096,7 +1102,7 @@ int launch_error_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames, in
         if (numba)  // serpentine scan with the numba arithmetic: the frame-parallel kernel (lane = frame)
             hipLaunchKernelGGL((ed_serial_kernel<kQueueSmall, true>), dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h,
                                w, pal, t, serpentine, ws);
-        else if (pal.n_inner > kQueueSmall)
+        else if (pal.n_inner > kQueueSmall || pal.K > 256)
             hipLaunchKernelGGL(ed_serial_kernel<kQueueLarge>, dim3((unsigned)blocks), dim3(64), 0, s, in, out, n_frames, h,
                                w, pal, t, serpentine, ws);
         else

@@ -312,7 +312,7 @@ static int ensure_ed_tables(const dp_palette *pal_c)
     std::lock_guard<std::mutex> lock(p->build_mu);
     if (p->ed_tried) return DP_OK;
     p->ed_tried = true;
-    if (p->dev.K > 8 && p->dev.K <= 256) {
+    if (p->dev.K > 8 && p->dev.K <= DP_MAX_COLORS) {   // (257..1024 colours: ten-bit list entries, host_logic.h)
         dp::PalDev d = snapshot(p);
         const int rc = build_ed_cells(d, p->pts_host.data(), &p->ed_blob);
         if (rc != DP_OK) return rc;

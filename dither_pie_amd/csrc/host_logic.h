@@ -542,8 +542,34 @@ constexpr uint32_t kEdH4NoAnswer = 0xffff00ffu;
 
 // cells [kEdCells]: in = the kernel's lists (count byte | up to 15 index bytes, count 255 = overflow), out = sharpened,
 // padded, overflowing cells refined into `nodes`.  pts: K*3 float64 palette coordinates.
+// A list block (8^3 cells, their octree nodes, 16^3 cells): word 0's low byte is the count (254: node pointer in the upper 24 bits,
+// 255: too long -- scan the palette), then the entries' palette indices: one BYTE each (up to 15) for palettes of up to 256 colours,
+// TEN BITS each from bit 8 on (up to 12: 8 + 120 = 128 bits) for 257..1024 colours ("wide"; round 5 -- until then error diffusion with
+// more than 256 colours had no lists at all and ran the KD-tree query at every pixel step: 0.44 s per 4K frame at 1024 colours).
+inline int ed_list_cap(const int K) { return K > 256 ? 12 : 15; }
+inline int ed_list_get(const uint32_t (&w)[4], const int pos /* 0-based */, const bool wide)
+{
+    if (!wide) return (int)((w[(pos + 1) >> 2] >> (8 * ((pos + 1) & 3))) & 255u);
+    const int off = 8 + 10 * pos, wi = off >> 5, sh = off & 31;
+    uint32_t v = w[wi] >> sh;
+    if (sh > 22 && wi < 3) v |= w[wi + 1] << (32 - sh);
+    return (int)(v & 1023u);
+}
+inline void ed_list_put(uint32_t (&w)[4], const int pos /* 0-based */, const int j, const bool wide)
+{
+    if (!wide) {
+        w[(pos + 1) >> 2] |= (uint32_t)j << (8 * ((pos + 1) & 3));
+        return;
+    }
+    const int off = 8 + 10 * pos, wi = off >> 5, sh = off & 31;
+    w[wi] |= (uint32_t)j << sh;
+    if (sh > 22 && wi < 3) w[wi + 1] |= (uint32_t)j >> (32 - sh);
+}
+
 inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &host, EdTables &out)
 {
+    const bool wide = K > 256;
+    const int cap = ed_list_cap(K);
     std::vector<U4> &nodes = out.nodes;
     nodes.clear();
     auto box_list = [&](const std::vector<int> &from, const double lo[3], const double size, std::vector<int> &list) {
@@ -617,7 +643,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
     // rounding bring it within the margin of the nearest, the exact scan -- which honours the count -- decides.
     auto pack = [&](const std::vector<int> &list, const double *lo = nullptr, const double size = 0.0) {
         uint32_t w[4] = {(uint32_t)list.size(), 0u, 0u, 0u};
-        for (size_t n = 1; n <= list.size(); ++n) w[n >> 2] |= (uint32_t)list[n - 1] << (8 * (n & 3));
+        for (size_t n = 1; n <= list.size(); ++n) ed_list_put(w, (int)n - 1, list[n - 1], wide);
         if (lo && !list.empty() && list.size() <= 12 && (int)list.size() < K) {
             // (any unlisted entry will do; a far one keeps it out of the margin: the entry nearest to the cube corner
             // opposite to the box, unless that one is listed -- then the farthest by scan)
@@ -640,7 +666,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
                 }
             }
             const size_t upto = (list.size() + 3) / 4 * 4;
-            for (size_t n = list.size() + 1; n <= upto && filler >= 0; ++n) w[n >> 2] |= (uint32_t)filler << (8 * (n & 3));
+            for (size_t n = list.size() + 1; n <= upto && filler >= 0; ++n) ed_list_put(w, (int)n - 1, filler, wide);
         }
         return make_u4(w[0], w[1], w[2], w[3]);
     };
@@ -660,9 +686,9 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
         for (int cell = c0; cell < c1; ++cell) {
             const uint32_t w4[4] = {host[cell].x, host[cell].y, host[cell].z, host[cell].w};
             const int n = (int)(w4[0] & 255u);
-            if (n < 1 || n > 15) continue;
+            if (n < 1 || n > cap) continue;
             list.clear();
-            for (int i = 1; i <= n; ++i) list.push_back((int)((w4[i >> 2] >> (8 * (i & 3))) & 255u));
+            for (int i = 1; i <= n; ++i) list.push_back(ed_list_get(w4, i - 1, wide));
             const double lo[3] = {(double)((cell & 31) * 8), (double)(((cell >> 5) & 31) * 8), (double)((cell >> 10) * 8)};
             prune_list(lo, 8.0, list);
             host[cell] = pack(list, lo, 8.0);  // (re-packed even when nothing was dropped: the padding)
@@ -697,7 +723,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
             Work wk = std::move(st.back());
             st.pop_back();
             U4 entry;
-            if (wk.from.size() <= 15) {
+            if ((int)wk.from.size() <= cap) {
                 entry = pack(wk.from, wk.lo, wk.size);
             } else if (wk.size <= 1.0) {
                 entry = make_u4(255u, 0u, 0u, 0u);  // a unit cube that still sees more than 15 entries: scan the palette
@@ -770,9 +796,13 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
                 const double lo[3] = {(double)((cell & 15) * 16), (double)(((cell >> 4) & 15) * 16), (double)((cell >> 8) * 16)};
                 box_list(all, lo, 16.0, list);
                 prune_list(lo, 16.0, list);
-                l16[cell] = list.size() <= 15 ? pack(list, lo, 16.0) : make_u4(255u, 0u, 0u, 0u);
+                l16[cell] = (int)list.size() <= cap ? pack(list, lo, 16.0) : make_u4(255u, 0u, 0u, 0u);
             }
         });
+        out.h4_wanted = 0;
+        out.h4_depth = 0.0;
+        out.h4_none = 0.0;
+        if (!wide) {   // (its leaves hold index BYTES: palettes of up to 256 colours)
         // The hierarchical table: a wave of the diffusion kernel pays for the LONGEST list among its 64 lanes, and with 256 random
         // colours 12 % of the 16^3 cells, 0.8 % of the 8-wide and 0.03 % of the 4-wide cells have more than four possible nearest
         // entries -- so a cell with more than four is cut into its eight 8-wide children, such a child into its 4-wide children,
@@ -901,6 +931,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
             }
             out.h4_depth = total / (double)K;
             out.h4_none = none / (double)K;
+        }
         }
     }
     if (K <= 16) {

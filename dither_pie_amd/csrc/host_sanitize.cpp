@@ -80,31 +80,33 @@ static void geometric_list(const std::vector<double> &pts, int K, const double l
     }
 }
 
-static bool listed(const U4 &e, int n_max, int j)
+static bool listed(const U4 &e, int n_max, int j, bool wide = false)
 {
     const uint32_t w[4] = {e.x, e.y, e.z, e.w};
     const int n = (int)(w[0] & 255u);
     if (n > n_max) return true;  // overflow marker: the kernel scans the palette
     for (int i = 1; i <= n; ++i)
-        if ((int)((w[i >> 2] >> (8 * (i & 3))) & 255u) == j) return true;
+        if (ed_list_get(w, i - 1, wide) == j) return true;
     return false;
 }
 
 static int run_edtables(const std::vector<double> &pts, int K)
 {
-    if (K < 9 || K > 256) {
-        fprintf(stderr, "edtables: 9 <= K <= 256\n");
+    if (K < 9 || K > 1024) {
+        fprintf(stderr, "edtables: 9 <= K <= 1024\n");
         return 2;
     }
+    const bool wide = K > 256;   // ten-bit list entries (host_logic.h: ed_list_put)
+    const int cap = ed_list_cap(K);
     std::vector<U4> cells(kEdCells);
     std::vector<int> list;
     for (int cell = 0; cell < kEdCells; ++cell) {
         const double lo[3] = {(double)((cell & 31) * 8), (double)(((cell >> 5) & 31) * 8), (double)((cell >> 10) * 8)};
         geometric_list(pts, K, lo, 8.0, list);
         uint32_t w[4] = {255u, 0u, 0u, 0u};
-        if (list.size() <= 15) {
+        if ((int)list.size() <= cap) {
             w[0] = (uint32_t)list.size();
-            for (size_t n = 1; n <= list.size(); ++n) w[n >> 2] |= (uint32_t)list[n - 1] << (8 * (n & 3));
+            for (size_t n = 1; n <= list.size(); ++n) ed_list_put(w, (int)n - 1, list[n - 1], wide);
         }
         cells[cell] = make_u4(w[0], w[1], w[2], w[3]);
     }
@@ -144,8 +146,8 @@ static int run_edtables(const std::vector<double> &pts, int K)
             for (int k = 0; k < 3; ++k) d += (x[k] - pts[3 * j + k]) * (x[k] - pts[3 * j + k]);
             if (d != best) continue;
             ++checked;
-            if (!listed(e, 15, j)) ++bad;
-            if (!tb.l16.empty() && !listed(tb.l16[c16], 15, j)) ++bad;
+            if (!listed(e, cap, j, wide)) ++bad;
+            if (!tb.l16.empty() && !listed(tb.l16[c16], cap, j, wide)) ++bad;
             if (!tb.h4.empty()) {
                 // the hierarchical <= 4-entry table as nearest_h4 (ed_nearest.hip.h) walks it: a leaf must hold every nearest entry
                 auto marker = [](const uint32_t w) { return (w & 0xffu) >= ((w >> 8) & 0xffu); };

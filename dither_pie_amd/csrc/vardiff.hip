@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     // (perceptual: its waves nearly always hold a point outside the cube -- measured, the lists only cost there)
                     int j;
                     if (model != 4 && coarse) j = nearest_ext<CAP>(pal, s_pal, coarse, o0, o1, o2);
-                    else if (model != 1 && pal.ed_cells && __ballot(!inside) == 0ull) j = nearest_color_cells<CAP>(pal, s_pal, coarse, o0, o1, o2, nullptr, nullptr, pal.ed_h4);
+                    else if (model != 1 && pal.ed_cells && __ballot(!inside) == 0ull) j = nearest_color_cells<CAP, false, CAP == kQueueLarge>(pal, s_pal, coarse, o0, o1, o2, nullptr, nullptr, pal.ed_h4);
                     else j = nearest_any<CAP>(pal, s_pal, o0, o1, o2);
                     const float4 pj = s_pal[j];
                     e0 = __fsub_rn(o0, pj.x);
@@ -1009,7 +1009,7 @@ int launch_variable_diffusion(const uint8_t *in, uint8_t *out, int64_t n_frames,
         else if (model == 3) DP_VARW(C, 3); \
         else DP_VARW(C, 4);            \
     } while (0)
-        if (pal.n_inner > kQueueSmall) DP_VARW_M(kQueueLarge);
+        if (pal.n_inner > kQueueSmall || pal.K > 256) DP_VARW_M(kQueueLarge);   // (wide lists of 257..1024 colours: these instances)
         else DP_VARW_M(kQueueSmall);
 #undef DP_VARW_M
 #undef DP_VARW

@@ -60,10 +60,11 @@ def test_diffusion_tables_under_sanitizers(tools, gold, tmp_path, san):
     """ed_tables_refine with its up-to-8-thread per-cell loops: random / uniform-grid / float (gamma) / crowded palettes
     (the crowded ones overflow cells and go through the octree refinement); the harness checks on 40 000 points that the
     true nearest entries are on every list a kernel would search."""
+    wide = np.random.RandomState(5).randint(0, 256, (700, 3)).astype(np.float64)   # 257..1024 colours: ten-bit list entries
     cases = [gold["tree_p256_pts"], gold["tree_p32_pts"], gold["tree_p11_pts"], gold["tree_U16_pts"], gold["tree_lin256_pts"],
-             gold["tree_dup40_pts"], _crowded(200, 1), _crowded(16, 2)]
+             gold["tree_dup40_pts"], _crowded(200, 1), _crowded(16, 2), wide, _crowded(300, 3)]
     if san == "tsan":
-        cases = [cases[0], cases[3], cases[6]]
+        cases = [cases[0], cases[3], cases[6], cases[9]]
     for pts in cases:
         out = _run(tools[san], "edtables", pts, tmp_path)
         assert " bad=0" in out, out
