@@ -110,6 +110,7 @@ struct PalDev {
     const uint4 *ed_nodes;      // refinement of overflowing cells: 8 entries per node (count byte 254 = refined further)
     const uint32_t *ed_coarse;  // palettes of 9..16 colours: lists of the 16^3 cells, count | 7 index nibbles (count 15: too long)
     const uint32_t *ed_coarse_ext;  // the same for the diffusers that do not clamp (vardiff.hip): the outermost cells stand for the half-spaces beyond the cube
+    const uint4 *ed_ext16;       // 17..256 colours: the 16^3 lists whose outermost cells are unbounded (EdTables::ext16), for the unclamped diffusers; or null
     const uint4 *ed_lists16;    // palettes of 17..256 colours: lists of the 16^3 cells, count byte | up to 15 index bytes (255: too long)
     const uint32_t *ed_h4;      // palettes of 17..256 colours: hierarchical table of <= 4 entries per leaf (host_logic.h EdTables::h4), or null
     int ed_h4_words;

@@ -271,6 +271,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.ed_h4_global = 0;
     d.ed_h4_lds_words = 0;
     d.ed_coarse_ext = nullptr;
+    d.ed_ext16 = nullptr;
     p->ed_blob = nullptr;
     p->accel_blob = nullptr;
     p->accel_bytes = 0;

@@ -526,6 +526,8 @@ struct EdTables {
     std::vector<U4> l16;           // K > 16: lists of the 16^3 cells in the 8^3 table's format
     std::vector<uint32_t> coarse;  // K <= 16: lists of the 16^3 cells, count | 7 index nibbles
     std::vector<uint32_t> ext;     // K <= 16: the same over the extended grid (outermost cells = half-spaces)
+    std::vector<U4> ext16;         // 17..256 colours: l16 with the OUTERMOST cells standing for everything beyond them (unbounded boxes),
+                                   // for the diffusers that do not clamp their values (vardiff.hip: nearest_ext16); count 255: too long
     // K > 16: the hierarchical nearest table of at most four entries per leaf (ed_nearest.hip.h: nearest_h4).  Words [0, 4096): the
     // 16^3 cells; then nodes of 8 words: the 8-wide children of a cell, the 4-wide children of a child, the 2-wide ones of those.  A LEAF word holds four
     // palette indices, byte 0 < byte 1 (listed entries, then an unlisted far entry as padding); a word with byte 0 >= byte 1 is a
@@ -783,6 +785,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
     out.l16.clear();
     out.coarse.clear();
     out.ext.clear();
+    out.ext16.clear();
     out.h4.clear();
     if (K > 16) {
         // lists of the 16x16x16 cells in the format of the 8x8x8 table, for the LDS of the wavefront kernel's few-frames
@@ -799,6 +802,66 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
                 l16[cell] = (int)list.size() <= cap ? pack(list, lo, 16.0) : make_u4(255u, 0u, 0u, 0u);
             }
         });
+        // The extended table for query points that are NOT clamped to the cube (perceptual / hybrid / adaptive-variance): a point is
+        // looked up in the cell of its clamped coordinates, so an outermost cell stands for everything beyond it.  Over such an
+        // unbounded box the geometric criterion lists everybody; the pairwise test alone decides -- entry j stays unless some k is
+        // closer on the WHOLE box (in a direction in which the box is unbounded and |x - c_k|^2 - |x - c_j|^2 grows, k cannot be).
+        // Candidates k are tried nearest to the cell first (most entries fall to one of the first few).  Until round 5 these
+        // diffusers scanned the whole palette at every step above 16 colours: 59 ms per 1080p frame at 256 colours against 4.6 ms
+        // for plain error diffusion (tools/bench_scripts/cliff_hunt.py).
+        out.ext16.clear();
+        if (!wide) {
+            std::vector<U4> &ext16 = out.ext16;
+            ext16 = l16;
+            const double kInfE = std::numeric_limits<double>::infinity();
+            std::vector<int> shell;
+            for (int cell = 0; cell < 4096; ++cell) {
+                const int c0 = cell & 15, c1 = (cell >> 4) & 15, c2 = cell >> 8;
+                if (c0 == 0 || c0 == 15 || c1 == 0 || c1 == 15 || c2 == 0 || c2 == 15) shell.push_back(cell);
+            }
+            parallel_cells((int)shell.size(), [&](const int i0, const int i1) {
+                std::vector<std::pair<double, int>> order((size_t)K);
+                std::vector<int> list;
+                for (int si = i0; si < i1; ++si) {
+                    const int cell = shell[(size_t)si];
+                    const int ci[3] = {cell & 15, (cell >> 4) & 15, cell >> 8};
+                    double blo[3], bhi[3], lo[3];
+                    for (int d = 0; d < 3; ++d) {
+                        lo[d] = (double)(ci[d] * 16);
+                        blo[d] = ci[d] == 0 ? -kInfE : lo[d];
+                        bhi[d] = ci[d] == 15 ? kInfE : lo[d] + 16.0;
+                    }
+                    for (int j = 0; j < K; ++j) {
+                        double d2 = 0.0;
+                        for (int d = 0; d < 3; ++d) {
+                            const double c = pts[3 * j + d];
+                            const double m = std::max(std::max(lo[d] - c, c - (lo[d] + 16.0)), 0.0);
+                            d2 += m * m;
+                        }
+                        order[(size_t)j] = {d2, j};
+                    }
+                    std::sort(order.begin(), order.end());
+                    list.clear();
+                    for (int j = 0; j < K; ++j) {
+                        bool dominated = false;
+                        for (int kk = 0; kk < K && !dominated; ++kk) {
+                            const int k = order[(size_t)kk].second;
+                            if (k == j) continue;
+                            double mx = 0.0;
+                            for (int d = 0; d < 3; ++d) {
+                                const double a = 2.0 * (pts[3 * j + d] - pts[3 * k + d]);
+                                if (a > 0.0) mx += bhi[d] == kInfE ? kInfE : a * bhi[d];
+                                else if (a < 0.0) mx += blo[d] == -kInfE ? kInfE : a * blo[d];
+                                mx += pts[3 * k + d] * pts[3 * k + d] - pts[3 * j + d] * pts[3 * j + d];
+                            }
+                            if (mx < -1e-9 * (1.0 + std::fabs(mx))) dominated = true;
+                        }
+                        if (!dominated) list.push_back(j);
+                    }
+                    ext16[(size_t)cell] = (int)list.size() <= cap ? pack(list, lo, 16.0) : make_u4(255u, 0u, 0u, 0u);
+                }
+            }, 64);
+        }
         out.h4_wanted = 0;
         out.h4_depth = 0.0;
         out.h4_none = 0.0;

@@ -196,6 +196,35 @@ static int run_edtables(const std::vector<double> &pts, int K)
             for (int k = 0; k < 3; ++k) x[k] = std::min(255, std::max(0, (int)std::lround(pts[3 * j + k]) + d));
             check_point(x);
         }
+    // the extended 16^3 lists (17..256 colours, unclamped diffusers): points in and around the cube, looked up by their clamped cell
+    long ext_checked = 0, ext_long = 0;
+    if (!tb.ext16.empty()) {
+        for (int i = 0; i < 60000; ++i) {
+            double x[3];
+            for (int k = 0; k < 3; ++k) x[k] = (double)((int)(lcg(seed) % 640u) - 192) + (double)(lcg(seed) & 255u) / 256.0;   // [-192, 448)
+            double best = std::numeric_limits<double>::infinity();
+            for (int j = 0; j < K; ++j) {
+                double d = 0;
+                for (int k = 0; k < 3; ++k) d += (x[k] - pts[3 * j + k]) * (x[k] - pts[3 * j + k]);
+                best = std::min(best, d);
+            }
+            int c[3];
+            for (int k = 0; k < 3; ++k) c[k] = std::min(15, std::max(0, (int)x[k] >> 4));   // as nearest_ext16 (vardiff.hip)
+            const U4 &e = tb.ext16[(size_t)(c[0] | (c[1] << 4) | (c[2] << 8))];
+            if ((e.x & 255u) > 15u) {
+                ++ext_long;
+                continue;
+            }
+            for (int j = 0; j < K; ++j) {
+                double d = 0;
+                for (int k = 0; k < 3; ++k) d += (x[k] - pts[3 * j + k]) * (x[k] - pts[3 * j + k]);
+                if (d != best) continue;
+                ++ext_checked;
+                if (!listed(e, 15, j)) ++bad;
+            }
+        }
+    }
+    printf("ext16=%zu (checked %ld, in cells with long lists %ld) ", tb.ext16.size(), ext_checked, ext_long);
     printf("edtables K=%d nodes=%zu give_up=%d l16=%zu coarse=%zu ext=%zu h4=%zu (answers %ld, none %ld) checked=%ld bad=%ld\n", K, tb.nodes.size(),
            (int)tb.give_up, tb.l16.size(), tb.coarse.size(), tb.ext.size(), tb.h4.size(), h4_answers, h4_none, checked, bad);
     if (K > 16 && !tb.h4.empty() && h4_answers < 100 * std::max(h4_none, 1L)) return 1;   // the table must answer nearly always

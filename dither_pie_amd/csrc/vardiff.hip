@@ -124,6 +124,81 @@ __device__ __forceinline__ int nearest_ext(const PalDev &pal, const float4 *__re
     return nearest_any<CAP>(pal, cand, o0, o1, o2);  // long lists, near ties, exact ties: the full scan and its validation
 }
 
+// Palettes of 17..256 colours, any query point: the key scan over the byte list of the point's cell in the extended 16^3 table
+// (host_logic.h: EdTables::ext16 -- the outermost cells are unbounded, a point is looked up by its clamped coordinates).  Lists of
+// up to twelve entries are padded to a multiple of four positions by the builder; longer ones, near ties and exact ties go to the full
+// scan and its validation.  Until round 5 every step of these diffusers scanned the whole palette above 16 colours.
+template <int CAP>
+__device__ __forceinline__ int nearest_ext16(const PalDev &pal, const float4 *__restrict__ cand, const uint4 *__restrict__ ext16,
+                                             const float o0, const float o1, const float o2, const bool inside)
+{
+    const int c0 = min(max((int)o0 >> 4, 0), 15), c1 = min(max((int)o1 >> 4, 0), 15), c2 = min(max((int)o2 >> 4, 0), 15);
+    const uint4 blk = ext16[c0 | (c1 << 4) | (c2 << 8)];
+    const int n = (int)(blk.x & 255u);
+    if (n >= 1 && n <= 12) {
+        uint4 b = blk;
+        b.x = __funnelshift_r(b.x, b.y, 8);  // drop the count byte
+        b.y = __funnelshift_r(b.y, b.z, 8);
+        b.z = __funnelshift_r(b.z, b.w, 8);
+        int m0 = 0x7fffffff, m1 = 0x7fffffff;
+        uint32_t tag = 0u;
+        for (int left = n; left > 0; left -= 4, tag += 4u) {
+            const int j1 = (int)(b.x & 255u), j2 = (int)((b.x >> 8) & 255u), j3 = (int)((b.x >> 16) & 255u), j4 = (int)(b.x >> 24);
+            const float4 q1 = cand[j1], q2 = cand[j2], q3 = cand[j3], q4 = cand[j4];
+            const int k1 = ed_key16(q1, o0, o1, o2, tag), k2 = ed_key16(q2, o0, o1, o2, tag + 1u), k3 = ed_key16(q3, o0, o1, o2, tag + 2u),
+                      k4 = ed_key16(q4, o0, o1, o2, tag + 3u);
+            m1 = ed_med3(m0, m1, k1);
+            m0 = min(m0, k1);
+            m1 = ed_med3(m0, m1, k2);
+            m0 = min(m0, k2);
+            m1 = ed_med3(m0, m1, k3);
+            m0 = min(m0, k3);
+            m1 = ed_med3(m0, m1, k4);
+            m0 = min(m0, k4);
+            b.x = b.y;
+            b.y = b.z;
+            b.z = 0u;
+        }
+        const float f0 = __int_as_float(m0 & ~15), f1 = __int_as_float(m1 & ~15);
+        if (f1 > f0 * 1.000004f) {
+            const uint32_t pos = ((uint32_t)m0 & 15u) + 1u;  // byte 1..12 of the block
+            const uint32_t wsel = pos < 4u ? blk.x : (pos < 8u ? blk.y : (pos < 12u ? blk.z : blk.w));
+            return (int)((wsel >> ((pos & 3u) * 8u)) & 255u);
+        }
+    }
+    if (n >= 1 && n <= 15) {
+        // longer lists and near ties of the key scan: the float32 scan of nearest_any over the LISTED entries only (a wave pays for
+        // the slowest of its 64 lanes: sending it through the whole palette for one lane's 13-entry list cost most of the gain)
+        float b0 = __int_as_float(0x7f800000), b1 = b0;
+        int i0 = 0;
+        uint4 b = blk;
+        b.x = __funnelshift_r(b.x, b.y, 8);
+        b.y = __funnelshift_r(b.y, b.z, 8);
+        b.z = __funnelshift_r(b.z, b.w, 8);
+        b.w >>= 8;
+        for (int i = 0; i < n; ++i) {
+            const int j = (int)(b.x & 255u);
+            const float4 c = cand[j];
+            const float a0 = c.x - o0, a1 = c.y - o1, a2 = c.z - o2;
+            const float d = __fmaf_rn(a0, a0, __fmaf_rn(a1, a1, a2 * a2));
+            const bool lt0 = d < b0;
+            b1 = lt0 ? b0 : (d < b1 ? d : b1);
+            i0 = lt0 ? j : i0;
+            b0 = lt0 ? d : b0;
+            b.x = __funnelshift_r(b.x, b.y, 8);
+            b.y = __funnelshift_r(b.y, b.z, 8);
+            b.z = __funnelshift_r(b.z, b.w, 8);
+            b.w >>= 8;
+        }
+        if (b1 > b0 * 1.000002f) return i0;
+    }
+    // a 16-wide cell with more than 15 possible nearest entries (a crowded palette -- e.g. any palette under use_gamma, whose dark
+    // entries crowd the low end of the linear scale): a point INSIDE the cube has the 8^3 lists and their octree (error diffusion's
+    // path); only points beyond the cube in such a cell scan the whole palette
+    if (n > 15 && inside && pal.ed_cells) return nearest_color_cells<CAP, false, false>(pal, cand, nullptr, o0, o1, o2, nullptr, nullptr, nullptr);
+    return nearest_any<CAP>(pal, cand, o0, o1, o2);
+}
+
 struct VarParams {
     int model;
     int serpentine;
@@ -679,6 +754,7 @@ __global__ __launch_bounds__(64 * kVWaves) void var_wavefront_kernel(const uint8
                     // (perceptual: its waves nearly always hold a point outside the cube -- measured, the lists only cost there)
                     int j;
                     if (model != 4 && coarse) j = nearest_ext<CAP>(pal, s_pal, coarse, o0, o1, o2);
+                    else if (model != 4 && pal.ed_ext16) j = nearest_ext16<CAP>(pal, s_pal, pal.ed_ext16, o0, o1, o2, inside);
                     else if (model != 1 && pal.ed_cells && __ballot(!inside) == 0ull) j = nearest_color_cells<CAP, false, CAP == kQueueLarge>(pal, s_pal, coarse, o0, o1, o2, nullptr, nullptr, pal.ed_h4);
                     else j = nearest_any<CAP>(pal, s_pal, o0, o1, o2);
                     const float4 pj = s_pal[j];
