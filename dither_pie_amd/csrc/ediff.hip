@@ -909,22 +909,10 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     dev.ed_coarse = tb.coarse.empty() ? nullptr : d_coarse;
     dev.ed_coarse_ext = tb.ext.empty() ? nullptr : d_coarse + 4096;
     dev.ed_ext16 = tb.ext16.empty() ? nullptr : d_ext16;
-    if (!tb.ext16.empty() && !exp_env("DP_ED_EXT16_ALWAYS")) {
-        // The extended lists pay while nearly every lane of a wave finds a list of at most 15 entries: a wave whose lanes split
-        // between the list scan, the 8^3 lists of a crowded cell and the whole-palette scan of a point beyond the cube in such a
-        // cell executes all three.  Where the palette's own colours sit in cells with longer lists (a palette crowded into a
-        // corner of the cube -- any palette under use_gamma is, at the dark end of the linear scale) the diffusers keep the
-        // whole-palette scan they had: 256 random colours 59 -> 13-16 ms per 1080p frame with the lists, the same palette under
-        // use_gamma 59 -> 87 ms (tools/bench_scripts/cliff_hunt.py).
-        int long_cells = 0;
-        for (int j = 0; j < K; ++j) {
-            int c[3];
-            for (int d = 0; d < 3; ++d) c[d] = std::min(15, std::max(0, (int)std::floor(pts[3 * j + d]) >> 4));
-            long_cells += (tb.ext16[(size_t)(c[0] | (c[1] << 4) | (c[2] << 8))].x & 255u) > 15u ? 1 : 0;
-        }
-        if (long_cells * 100 > K) dev.ed_ext16 = nullptr;   // more than 1 % of the colours
-        if (exp_env("DP_ED_H4_REPORT")) fprintf(stderr, "ed tables: K %d, extended 16^3 lists: %d of the palette's colours in cells with more than 15 entries -> %s\n", K, long_cells, dev.ed_ext16 ? "used" : "not used");
-    }
+    // (No policy switch is needed for these lists: a wave that holds a lane without a usable list beyond the cube takes the
+    // whole-palette scan with ALL its lanes -- vardiff.hip: nearest_ext16 -- so a palette crowded at a face of the cube, as every
+    // palette under use_gamma is at the dark end, costs what it cost without them: 256 colours under use_gamma 59 -> 57 ms per
+    // 1080p frame, 64 colours 17.5 -> 14.3; 256 random colours 59 -> 12-15 ms.)
     dev.ed_h4 = tb.h4.empty() ? nullptr : d_h4;
     dev.ed_h4_words = (int)tb.h4.size();
     dev.ed_h4_shallow = (!tb.h4.empty() && tb.h4_depth <= 0.25) ? 1 : 0;

@@ -135,6 +135,11 @@ __device__ __forceinline__ int nearest_ext16(const PalDev &pal, const float4 *__
     const int c0 = min(max((int)o0 >> 4, 0), 15), c1 = min(max((int)o1 >> 4, 0), 15), c2 = min(max((int)o2 >> 4, 0), 15);
     const uint4 blk = ext16[c0 | (c1 << 4) | (c2 << 8)];
     const int n = (int)(blk.x & 255u);
+    // A lane whose cell has no usable list and whose point lies beyond the cube must scan the whole palette -- and then the wave
+    // executes that scan anyway: all its lanes take it, instead of the scan PLUS the list paths of the others (a palette crowded at a
+    // face of the cube -- any palette under use_gamma, at the dark end -- has such a lane in most waves: 256 colours 59 -> 87 ms per
+    // 1080p frame with the three paths side by side).
+    if (__ballot((n < 1 || n > 15) && !(inside && pal.ed_cells != nullptr)) != 0ull) return nearest_any<CAP>(pal, cand, o0, o1, o2);
     if (n >= 1 && n <= 12) {
         uint4 b = blk;
         b.x = __funnelshift_r(b.x, b.y, 8);  // drop the count byte
