@@ -152,17 +152,24 @@ def test_error_diffusion_with_the_content_s_own_palette_4k(d, orc, kind, K):
         assert torch.equal(out[i], r0), i
 
 
-@pytest.mark.parametrize("mode,params,K", [("perceptual", {}, 64), ("hybrid", {"lum_factor": 0.9, "col_factor": 0.4}, 256),
-                                           ("adaptive_variance", {"var_threshold": 150.0, "window_radius": 2}, 100),
-                                           ("ostromoukhov", {"serpentine": "false"}, 256)])
-def test_variable_diffusers_1080p_more_than_16_colours(d, orc, mode, params, K):
-    """The variable-coefficient diffusers at 1080p (17 bands) with palettes whose candidate lists / hierarchical table they read from
-    L2: one frame and a batch of 20 against the oracle, product library."""
+@pytest.mark.parametrize("mode,params,K,gamma,kind", [
+    ("perceptual", {}, 64, False, "rnd"), ("hybrid", {"lum_factor": 0.9, "col_factor": 0.4}, 256, False, "rnd"),
+    ("adaptive_variance", {"var_threshold": 150.0, "window_radius": 2}, 100, False, "rnd"),
+    ("ostromoukhov", {"serpentine": "false"}, 256, False, "rnd"),
+    # the extended 16^3 lists (outermost cells unbounded): use_gamma crowds the palette at the dark faces of the cube, and a frame of
+    # pure 0 / 255 values sends the accumulated errors beyond the cube at most pixels
+    ("perceptual", {}, 128, True, "rnd"), ("hybrid", {"lum_factor": 1.3, "col_factor": 0.2}, 64, False, "extreme"),
+    ("adaptive_variance", {"var_threshold": 80.0, "window_radius": 1}, 256, True, "extreme"), ("perceptual", {}, 17, False, "extreme")])
+def test_variable_diffusers_1080p_more_than_16_colours(d, orc, mode, params, K, gamma, kind):
+    """The variable-coefficient diffusers at 1080p (17 bands) with palettes whose candidate lists they read from L2 -- for the
+    unclamped ones the extended 16^3 lists: one frame and a batch of 20 against the oracle, product library."""
     import torch
     pal = orc.palr(K, 5)
     a0 = orc.rnd(1080, 1920, 900 + K)
-    ref = torch.from_numpy(orc.apply_dithering(a0, pal, mode, params, False)).cuda()
-    it = d.ImageDitherer(K, d.DitherMode(mode), pal, False, dict(params))
+    if kind == "extreme":
+        a0 = np.where(a0 < 128, 0, 255).astype(np.uint8)
+    ref = torch.from_numpy(orc.apply_dithering(a0, pal, mode, params, gamma)).cuda()
+    it = d.ImageDitherer(K, d.DitherMode(mode), pal, gamma, dict(params))
     x0 = torch.from_numpy(a0).cuda()
     assert torch.equal(it.apply_dithering_frames(x0), ref)
     out = it.apply_dithering_frames(x0.unsqueeze(0).repeat(20, 1, 1, 1))
