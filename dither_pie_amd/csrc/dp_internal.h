@@ -111,6 +111,7 @@ struct PalDev {
     const uint32_t *ed_coarse;  // palettes of 9..16 colours: lists of the 16^3 cells, count | 7 index nibbles (count 15: too long)
     const uint32_t *ed_coarse_ext;  // the same for the diffusers that do not clamp (vardiff.hip): the outermost cells stand for the half-spaces beyond the cube
     const uint4 *ed_ext16;       // 17..256 colours: the 16^3 lists whose outermost cells are unbounded (EdTables::ext16), for the unclamped diffusers; or null
+    const uint4 *ed_ext_nodes;   // the octree below its outermost cells whose list is too long (EdTables::ext_nodes), or null
     const uint4 *ed_lists16;    // palettes of 17..256 colours: lists of the 16^3 cells, count byte | up to 15 index bytes (255: too long)
     const uint32_t *ed_h4;      // palettes of 17..256 colours: hierarchical table of <= 4 entries per leaf (host_logic.h EdTables::h4), or null
     int ed_h4_words;
@@ -151,6 +152,7 @@ struct dp_palette {
     size_t blob_bytes;
     void *accel_blob;  // cell lists + tie codes (may be null)
     void *ed_blob;     // dev.ed_cells (may be null)
+    void *ext_blob;    // dev.ed_ext16 / ed_ext_nodes (may be null)
     size_t accel_bytes;
     bool accel_tried, same_out;
     std::vector<uint32_t> p4_host;
@@ -162,6 +164,7 @@ struct dp_palette {
     // (host.cpp: ensure_ed_tables): ordered-only users -- one palette per image in the CLI -- never pay for them
     std::vector<double> pts_host;  // K*3 float64 (KD-tree points)
     bool ed_tried;
+    bool ext_tried;
     // `dev` is what the kernels are launched with.  The accelerator and the diffusion tables are added to it lazily,
     // possibly while other host threads are launching with the same palette (ctypes drops the GIL): builders serialise
     // on build_mu, fill a private copy and publish it with one assignment under dev_mu; every launch works on a
@@ -195,6 +198,7 @@ namespace dp {
 int build_accel(PalDev &dev, const std::vector<uint32_t> &p4_host, void **blob_out, size_t *blob_bytes);
 int build_accel_float(PalDev &dev, const float *pal_f32, const uint8_t *lut_host, void **blob_out, size_t *blob_bytes);
 int build_ed_cells(PalDev &dev, const double *pts_host, void **blob_out);
+int build_ed_ext(PalDev &dev, const double *pts_host, void **blob_out);   // the unclamped diffusers' extended lists (ediff.hip)
 int launch_ordered(const uint8_t *in, uint8_t *out, int64_t n_frames, int h, int w, int y0, int x0,
                    const PalDev &pal, int mode, const ThrDev *thr, float ign_scale, int ign_seed, void *ws,
                    size_t ws_bytes, hipStream_t s);

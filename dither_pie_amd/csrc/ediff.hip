@@ -855,7 +855,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     uint4 *cells = nullptr;
     // room behind the lists (and the nodes): the 16^3-cell table(s) -- 4096 quads (K > 16) or 2 x 4096 words (K <= 16) -- and, for
     // K > 16, the hierarchical table of up to kEdH4MaxWords words
-    constexpr size_t kCoarseQuads = 4096 + kEdH4MaxWords / 4 + 4096;   // 16^3 lists (or nibble tables) | hierarchical table | extended 16^3 lists
+    constexpr size_t kCoarseQuads = 4096 + kEdH4MaxWords / 4;   // 16^3 lists (or nibble tables) | hierarchical table
     DP_HIP(hipMalloc((void **)&cells, sizeof(uint4) * (kEdCells + kCoarseQuads)));
     hipLaunchKernelGGL(ed_cells_kernel, dim3(kEdCells / 256), dim3(256), 0, 0, dev, cells);
     hipError_t e = hipGetLastError();
@@ -897,8 +897,6 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     if (e == hipSuccess && !tb.ext.empty()) e = hipMemcpy(d_coarse + 4096, tb.ext.data(), sizeof(uint32_t) * 4096, hipMemcpyHostToDevice);
     uint32_t *d_h4 = reinterpret_cast<uint32_t *>(tail + 4096);
     if (e == hipSuccess && !tb.h4.empty()) e = hipMemcpy(d_h4, tb.h4.data(), sizeof(uint32_t) * tb.h4.size(), hipMemcpyHostToDevice);
-    uint4 *d_ext16 = tail + 4096 + kEdH4MaxWords / 4;
-    if (e == hipSuccess && !tb.ext16.empty()) e = hipMemcpy(d_ext16, tb.ext16.data(), sizeof(uint4) * 4096, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(cells);
         return hip_fail(e, "error-diffusion candidate lists");
@@ -908,11 +906,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     dev.ed_lists16 = tb.l16.empty() ? nullptr : tail;
     dev.ed_coarse = tb.coarse.empty() ? nullptr : d_coarse;
     dev.ed_coarse_ext = tb.ext.empty() ? nullptr : d_coarse + 4096;
-    dev.ed_ext16 = tb.ext16.empty() ? nullptr : d_ext16;
-    // (No policy switch is needed for these lists: a wave that holds a lane without a usable list beyond the cube takes the
-    // whole-palette scan with ALL its lanes -- vardiff.hip: nearest_ext16 -- so a palette crowded at a face of the cube, as every
-    // palette under use_gamma is at the dark end, costs what it cost without them: 256 colours under use_gamma 59 -> 57 ms per
-    // 1080p frame, 64 colours 17.5 -> 14.3; 256 random colours 59 -> 12-15 ms.)
+    // (dev.ed_ext16 / ed_ext_nodes: build_ed_ext below, when an unclamped diffuser first meets the palette)
     dev.ed_h4 = tb.h4.empty() ? nullptr : d_h4;
     dev.ed_h4_words = (int)tb.h4.size();
     dev.ed_h4_shallow = (!tb.h4.empty() && tb.h4_depth <= 0.25) ? 1 : 0;
@@ -927,6 +921,35 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
         dev.ed_h4_words = 0;
     }
     *blob_out = cells;
+    return DP_OK;
+}
+
+// The extended 16^3 lists of the unclamped diffusers (host_logic.h: EdTables::ext16 / ext_nodes), 17..256 colours: built when such a
+// diffuser first meets the palette (5-16 ms of host time that plain error diffusion never needs).  No policy switch: a wave that
+// holds a lane without a usable list beyond the cube takes the whole-palette scan with ALL its lanes (vardiff.hip: nearest_ext16),
+// so a palette crowded at a face of the cube -- every palette under use_gamma is, at the dark end -- never costs more than without.
+int build_ed_ext(PalDev &dev, const double *pts, void **blob_out)
+{
+    *blob_out = nullptr;
+    const int K = dev.K;
+    if (K <= 16 || K > 256) return DP_OK;
+    std::vector<U4> none;
+    EdTables tb;
+    ed_tables_refine(pts, K, none, tb, 2);
+    if (tb.ext16.empty()) return DP_OK;
+    uint4 *blob = nullptr;
+    DP_HIP(hipMalloc((void **)&blob, sizeof(uint4) * (4096 + tb.ext_nodes.size())));
+    hipError_t e = hipMemcpy(blob, tb.ext16.data(), sizeof(uint4) * 4096, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !tb.ext_nodes.empty())
+        e = hipMemcpy(blob + 4096, tb.ext_nodes.data(), sizeof(uint4) * tb.ext_nodes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        return hip_fail(e, "extended candidate lists");
+    }
+    if (exp_env("DP_ED_H4_REPORT")) fprintf(stderr, "ed tables: K %d, extended 16^3 lists with %zu refinement nodes\n", K, tb.ext_nodes.size() / 8);
+    dev.ed_ext16 = blob;
+    dev.ed_ext_nodes = tb.ext_nodes.empty() ? nullptr : blob + 4096;
+    *blob_out = blob;
     return DP_OK;
 }
 

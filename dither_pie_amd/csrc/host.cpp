@@ -272,7 +272,9 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     d.ed_h4_lds_words = 0;
     d.ed_coarse_ext = nullptr;
     d.ed_ext16 = nullptr;
+    d.ed_ext_nodes = nullptr;
     p->ed_blob = nullptr;
+    p->ext_blob = nullptr;
     p->accel_blob = nullptr;
     p->accel_bytes = 0;
     p->accel_tried = false;
@@ -288,6 +290,7 @@ int dp_palette_create(const float *pal_f32, const uint8_t *out_colors, int K, co
     }
     p->pts_host = pts;  // for the candidate tables of the diffusion kernels, built when first needed (ensure_ed_tables)
     p->ed_tried = false;
+    p->ext_tried = false;
     *out = p;
     return DP_OK;
 }
@@ -322,10 +325,27 @@ static int ensure_ed_tables(const dp_palette *pal_c)
     return DP_OK;
 }
 
+// the extended lists of the unclamped diffusers: only when one of them meets the palette (build_ed_ext)
+static int ensure_ed_ext(const dp_palette *pal_c)
+{
+    dp_palette *p = const_cast<dp_palette *>(pal_c);
+    std::lock_guard<std::mutex> lock(p->build_mu);
+    if (p->ext_tried) return DP_OK;
+    p->ext_tried = true;
+    if (p->dev.K > 16 && p->dev.K <= 256) {
+        dp::PalDev d = snapshot(p);
+        const int rc = build_ed_ext(d, p->pts_host.data(), &p->ext_blob);
+        if (rc != DP_OK) return rc;
+        publish(p, d);
+    }
+    return DP_OK;
+}
+
 void dp_palette_destroy(dp_palette *p)
 {
     if (!p) return;
     if (p->ed_blob) (void)hipFree(p->ed_blob);
+    if (p->ext_blob) (void)hipFree(p->ext_blob);
     if (p->blob) (void)hipFree(p->blob);
     if (p->accel_blob) (void)hipFree(p->accel_blob);
     delete p;
@@ -706,6 +726,10 @@ int dp_variable_diffusion_u8(const uint8_t *in_dev, uint8_t *out_dev, int64_t n_
     }
     const int rc_tab = ensure_ed_tables(pal);
     if (rc_tab != DP_OK) return rc_tab;
+    if (model != DP_DIFFUSER_OSTROMOUKHOV) {   // (Ostromoukhov clamps its values: the plain lists)
+        const int rc_ext = ensure_ed_ext(pal);
+        if (rc_ext != DP_OK) return rc_ext;
+    }
     return launch_variable_diffusion(in_dev, out_dev, n_frames, h, w, snapshot(pal), model, p0, p1, serpentine ? 1 : 0,
                                      gate_dev, coef_dev, workspace_dev, (hipStream_t)stream);
 }

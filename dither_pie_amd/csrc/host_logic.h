@@ -528,6 +528,8 @@ struct EdTables {
     std::vector<uint32_t> ext;     // K <= 16: the same over the extended grid (outermost cells = half-spaces)
     std::vector<U4> ext16;         // 17..256 colours: l16 with the OUTERMOST cells standing for everything beyond them (unbounded boxes),
                                    // for the diffusers that do not clamp their values (vardiff.hip: nearest_ext16); count 255: too long
+    std::vector<U4> ext_nodes;     // ... and the octree below the outermost cells whose list is too long (count 254 | node << 8: eight
+                                   // half-size children, the outer ones unbounded again), at most kEdExtMaxNodes nodes
     // K > 16: the hierarchical nearest table of at most four entries per leaf (ed_nearest.hip.h: nearest_h4).  Words [0, 4096): the
     // 16^3 cells; then nodes of 8 words: the 8-wide children of a cell, the 4-wide children of a child, the 2-wide ones of those.  A LEAF word holds four
     // palette indices, byte 0 < byte 1 (listed entries, then an unlisted far entry as padding); a word with byte 0 >= byte 1 is a
@@ -548,6 +550,7 @@ constexpr uint32_t kEdH4NoAnswer = 0xffff00ffu;
 // 255: too long -- scan the palette), then the entries' palette indices: one BYTE each (up to 15) for palettes of up to 256 colours,
 // TEN BITS each from bit 8 on (up to 12: 8 + 120 = 128 bits) for 257..1024 colours ("wide"; round 5 -- until then error diffusion with
 // more than 256 colours had no lists at all and ran the KD-tree query at every pixel step: 0.44 s per 4K frame at 1024 colours).
+constexpr size_t kEdExtMaxNodes = 2048;   // refinement nodes of the extended 16^3 lists (8 entries each: 256 KB)
 inline int ed_list_cap(const int K) { return K > 256 ? 12 : 15; }
 inline int ed_list_get(const uint32_t (&w)[4], const int pos /* 0-based */, const bool wide)
 {
@@ -568,7 +571,10 @@ inline void ed_list_put(uint32_t (&w)[4], const int pos /* 0-based */, const int
     if (sh > 22 && wi < 3) w[wi + 1] |= (uint32_t)j >> (32 - sh);
 }
 
-inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &host, EdTables &out)
+// what: 1 = the tables every diffusion kernel uses (the 8^3 lists in `host` refined in place, their octree, 16^3 lists, hierarchical
+// table, nibble tables), 2 = ONLY the extended 16^3 lists of the unclamped diffusers (ext16 / ext_nodes; `host` is not touched) --
+// built when such a diffuser first meets the palette, so that plain error diffusion does not pay for them (5-16 ms) -- 3 = both.
+inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &host, EdTables &out, const int what = 1)
 {
     const bool wide = K > 256;
     const int cap = ed_list_cap(K);
@@ -683,7 +689,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
     std::vector<int> all(K);
     for (int j = 0; j < K; ++j) all[j] = j;
     // the kernel's lists (the geometric criterion), sharpened by the pairwise test
-    parallel_cells(kEdCells, [&](const int c0, const int c1) {
+    if (what & 1) parallel_cells(kEdCells, [&](const int c0, const int c1) {
         std::vector<int> list;
         for (int cell = c0; cell < c1; ++cell) {
             const uint32_t w4[4] = {host[cell].x, host[cell].y, host[cell].z, host[cell].w};
@@ -702,7 +708,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
     // joined below -- in cell order and with the same depth-first order inside a cell as the single stack of rounds 2-5 had,
     // so the tables come out byte for byte as before.
     std::vector<int> over;
-    for (int cell = 0; cell < kEdCells; ++cell)
+    for (int cell = 0; (what & 1) && cell < kEdCells; ++cell)
         if ((host[cell].x & 255u) == 255u) over.push_back(cell);
     struct Local {
         U4 top;
@@ -786,6 +792,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
     out.coarse.clear();
     out.ext.clear();
     out.ext16.clear();
+    out.ext_nodes.clear();
     out.h4.clear();
     if (K > 16) {
         // lists of the 16x16x16 cells in the format of the 8x8x8 table, for the LDS of the wavefront kernel's few-frames
@@ -810,7 +817,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
         // diffusers scanned the whole palette at every step above 16 colours: 59 ms per 1080p frame at 256 colours against 4.6 ms
         // for plain error diffusion (tools/bench_scripts/cliff_hunt.py).
         out.ext16.clear();
-        if (!wide) {
+        if (!wide && (what & 2)) {
             std::vector<U4> &ext16 = out.ext16;
             ext16 = l16;
             const double kInfE = std::numeric_limits<double>::infinity();
@@ -819,53 +826,122 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
                 const int c0 = cell & 15, c1 = (cell >> 4) & 15, c2 = cell >> 8;
                 if (c0 == 0 || c0 == 15 || c1 == 0 || c1 == 15 || c2 == 0 || c2 == 15) shell.push_back(cell);
             }
+            // the entries of `from` that no other entry of `from` dominates over the box [blo, bhi] (sides may be infinite); `lo`/`size`:
+            // the box's bounded part (where a point's clamped coordinates fall), by which the candidates are tried nearest-first
+            auto dom_list = [&](const std::vector<int> &from, const double blo[3], const double bhi[3], const double lo[3], const double size,
+                                std::vector<std::pair<double, int>> &order, std::vector<int> &list) {
+                order.clear();
+                for (int j : from) {
+                    double d2 = 0.0;
+                    for (int d = 0; d < 3; ++d) {
+                        const double c = pts[3 * j + d];
+                        const double m = std::max(std::max(lo[d] - c, c - (lo[d] + size)), 0.0);
+                        d2 += m * m;
+                    }
+                    order.emplace_back(d2, j);
+                }
+                std::sort(order.begin(), order.end());
+                list.clear();
+                for (int j : from) {
+                    bool dominated = false;
+                    for (size_t kk = 0; kk < order.size() && !dominated; ++kk) {
+                        const int k = order[kk].second;
+                        if (k == j) continue;
+                        double mx = 0.0;
+                        for (int d = 0; d < 3; ++d) {
+                            const double a = 2.0 * (pts[3 * j + d] - pts[3 * k + d]);
+                            if (a > 0.0) mx += bhi[d] == kInfE ? kInfE : a * bhi[d];
+                            else if (a < 0.0) mx += blo[d] == -kInfE ? kInfE : a * blo[d];
+                            mx += pts[3 * k + d] * pts[3 * k + d] - pts[3 * j + d] * pts[3 * j + d];
+                        }
+                        if (mx < -1e-9 * (1.0 + std::fabs(mx))) dominated = true;
+                    }
+                    if (!dominated) list.push_back(j);
+                }
+            };
+            // A cell whose list is too long (a palette crowded at a face of the cube -- every palette under use_gamma, at the dark end)
+            // is cut into its eight half-size children like the 8^3 cells are: an outer child stays unbounded on its outer side, a point
+            // beyond the cube falls into it by its clamped coordinates.  Local node arrays, joined in cell order below.
+            struct XItem {
+                size_t slot;   // 0: the cell's own entry; else 1 + index into the local node array
+                double blo[3], bhi[3], lo[3], size;
+                std::vector<int> from;
+            };
+            std::vector<std::vector<U4>> xlocal(shell.size());   // per shell cell: [0] its entry, then its nodes' entries (8 per node)
             parallel_cells((int)shell.size(), [&](const int i0, const int i1) {
-                std::vector<std::pair<double, int>> order((size_t)K);
+                std::vector<std::pair<double, int>> order;
                 std::vector<int> list;
+                std::vector<XItem> todo;
                 for (int si = i0; si < i1; ++si) {
                     const int cell = shell[(size_t)si];
                     const int ci[3] = {cell & 15, (cell >> 4) & 15, cell >> 8};
-                    double blo[3], bhi[3], lo[3];
+                    std::vector<U4> &xl = xlocal[(size_t)si];
+                    xl.assign(1, make_u4(255u, 0u, 0u, 0u));
+                    XItem top;
+                    top.slot = 0;
+                    top.size = 16.0;
                     for (int d = 0; d < 3; ++d) {
-                        lo[d] = (double)(ci[d] * 16);
-                        blo[d] = ci[d] == 0 ? -kInfE : lo[d];
-                        bhi[d] = ci[d] == 15 ? kInfE : lo[d] + 16.0;
+                        top.lo[d] = (double)(ci[d] * 16);
+                        top.blo[d] = ci[d] == 0 ? -kInfE : top.lo[d];
+                        top.bhi[d] = ci[d] == 15 ? kInfE : top.lo[d] + 16.0;
                     }
-                    for (int j = 0; j < K; ++j) {
-                        double d2 = 0.0;
-                        for (int d = 0; d < 3; ++d) {
-                            const double c = pts[3 * j + d];
-                            const double m = std::max(std::max(lo[d] - c, c - (lo[d] + 16.0)), 0.0);
-                            d2 += m * m;
+                    top.from = all;
+                    todo.clear();
+                    todo.push_back(std::move(top));
+                    while (!todo.empty()) {
+                        XItem it = std::move(todo.back());
+                        todo.pop_back();
+                        dom_list(it.from, it.blo, it.bhi, it.lo, it.size, order, list);
+                        if ((int)list.size() <= cap) {
+                            xl[it.slot] = pack(list, it.lo, it.size);
+                            continue;
                         }
-                        order[(size_t)j] = {d2, j};
-                    }
-                    std::sort(order.begin(), order.end());
-                    list.clear();
-                    for (int j = 0; j < K; ++j) {
-                        bool dominated = false;
-                        for (int kk = 0; kk < K && !dominated; ++kk) {
-                            const int k = order[(size_t)kk].second;
-                            if (k == j) continue;
-                            double mx = 0.0;
+                        // (stays 255, the whole-palette scan: unit boxes; more than 24 nodes in one cell; and cells far from every
+                        // colour of the palette -- error diffusion keeps its values near the palette, and it is exactly the far
+                        // cells of a crowded palette, to which all its colours look alike, that are expensive to refine: with them
+                        // the tables of a 256-colour median-cut palette took 77 ms instead of 17)
+                        if (it.size <= 1.0 || (xl.size() - 1) / 8 >= 24 || order.empty() || order[0].first > 40.0 * 40.0) continue;
+                        const size_t node = (xl.size() - 1) / 8;
+                        xl[it.slot] = make_u4(254u | ((uint32_t)node << 8), 0u, 0u, 0u);
+                        xl.resize(xl.size() + 8, make_u4(255u, 0u, 0u, 0u));
+                        const double hs = it.size * 0.5;
+                        for (int sub = 0; sub < 8; ++sub) {
+                            XItem ch;
+                            ch.slot = 1 + 8 * node + (size_t)sub;
+                            ch.size = hs;
                             for (int d = 0; d < 3; ++d) {
-                                const double a = 2.0 * (pts[3 * j + d] - pts[3 * k + d]);
-                                if (a > 0.0) mx += bhi[d] == kInfE ? kInfE : a * bhi[d];
-                                else if (a < 0.0) mx += blo[d] == -kInfE ? kInfE : a * blo[d];
-                                mx += pts[3 * k + d] * pts[3 * k + d] - pts[3 * j + d] * pts[3 * j + d];
+                                const int bit = (sub >> d) & 1;
+                                ch.lo[d] = it.lo[d] + (bit ? hs : 0.0);
+                                ch.blo[d] = (!bit && it.blo[d] == -kInfE) ? -kInfE : ch.lo[d];
+                                ch.bhi[d] = (bit && it.bhi[d] == kInfE) ? kInfE : ch.lo[d] + hs;
                             }
-                            if (mx < -1e-9 * (1.0 + std::fabs(mx))) dominated = true;
+                            ch.from = list;
+                            todo.push_back(std::move(ch));
                         }
-                        if (!dominated) list.push_back(j);
                     }
-                    ext16[(size_t)cell] = (int)list.size() <= cap ? pack(list, lo, 16.0) : make_u4(255u, 0u, 0u, 0u);
                 }
             }, 64);
+            std::vector<U4> &xn = out.ext_nodes;
+            xn.clear();
+            for (size_t si = 0; si < shell.size(); ++si) {
+                const std::vector<U4> &xl = xlocal[si];
+                const size_t base = xn.size() / 8;
+                U4 topw = xl[0];
+                if (xl.size() > 1 && base + (xl.size() - 1) / 8 > kEdExtMaxNodes) topw = make_u4(255u, 0u, 0u, 0u);   // no room: scan
+                else
+                    for (size_t i = 1; i < xl.size(); ++i) {
+                        U4 e = xl[i];
+                        if ((e.x & 255u) == 254u) e.x = 254u | ((uint32_t)(base + (e.x >> 8)) << 8);
+                        xn.push_back(e);
+                    }
+                if ((topw.x & 255u) == 254u) topw.x = 254u | ((uint32_t)(base + (topw.x >> 8)) << 8);
+                ext16[(size_t)shell[si]] = topw;
+            }
         }
         out.h4_wanted = 0;
         out.h4_depth = 0.0;
         out.h4_none = 0.0;
-        if (!wide) {   // (its leaves hold index BYTES: palettes of up to 256 colours)
+        if (!wide && (what & 1)) {   // (its leaves hold index BYTES: palettes of up to 256 colours)
         // The hierarchical table: a wave of the diffusion kernel pays for the LONGEST list among its 64 lanes, and with 256 random
         // colours 12 % of the 16^3 cells, 0.8 % of the 8-wide and 0.03 % of the 4-wide cells have more than four possible nearest
         // entries -- so a cell with more than four is cut into its eight 8-wide children, such a child into its 4-wide children,
@@ -997,7 +1073,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
         }
         }
     }
-    if (K <= 16) {
+    if (K <= 16 && (what & 1)) {
         // lists of the 16x16x16 cells for the wavefront kernel's LDS: count | up to 7 indices, one nibble each
         std::vector<uint32_t> &coarse = out.coarse;
         coarse.resize(4096);

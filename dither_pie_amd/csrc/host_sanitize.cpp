@@ -111,7 +111,7 @@ static int run_edtables(const std::vector<double> &pts, int K)
         cells[cell] = make_u4(w[0], w[1], w[2], w[3]);
     }
     EdTables tb;
-    ed_tables_refine(pts.data(), K, cells, tb);
+    ed_tables_refine(pts.data(), K, cells, tb, 3);   // (the diffusion tables AND the extended lists of the unclamped diffusers)
     // sampled points: uniform integers, the palette entries themselves (rounded) and their neighbours
     uint32_t seed = 12345u + (uint32_t)K;
     long checked = 0, bad = 0, h4_answers = 0, h4_none = 0;
@@ -210,7 +210,18 @@ static int run_edtables(const std::vector<double> &pts, int K)
             }
             int c[3];
             for (int k = 0; k < 3; ++k) c[k] = std::min(15, std::max(0, (int)x[k] >> 4));   // as nearest_ext16 (vardiff.hip)
-            const U4 &e = tb.ext16[(size_t)(c[0] | (c[1] << 4) | (c[2] << 8))];
+            U4 e = tb.ext16[(size_t)(c[0] | (c[1] << 4) | (c[2] << 8))];
+            int xi[3];
+            for (int k = 0; k < 3; ++k) xi[k] = std::min(255, std::max(0, (int)x[k]));   // clamped integer coordinates choose the children
+            for (int bit = 3; (e.x & 255u) == 254u; --bit) {
+                const size_t at = (size_t)(e.x >> 8) * 8 + (size_t)(((xi[0] >> bit) & 1) | (((xi[1] >> bit) & 1) << 1) | (((xi[2] >> bit) & 1) << 2));
+                if (bit < 0 || at >= tb.ext_nodes.size()) {
+                    ++bad;
+                    break;
+                }
+                e = tb.ext_nodes[at];
+            }
+            if ((e.x & 255u) == 254u) continue;
             if ((e.x & 255u) > 15u) {
                 ++ext_long;
                 continue;
@@ -224,7 +235,7 @@ static int run_edtables(const std::vector<double> &pts, int K)
             }
         }
     }
-    printf("ext16=%zu (checked %ld, in cells with long lists %ld) ", tb.ext16.size(), ext_checked, ext_long);
+    printf("ext16=%zu nodes=%zu (checked %ld, in cells with long lists %ld) ", tb.ext16.size(), tb.ext_nodes.size() / 8, ext_checked, ext_long);
     printf("edtables K=%d nodes=%zu give_up=%d l16=%zu coarse=%zu ext=%zu h4=%zu (answers %ld, none %ld) checked=%ld bad=%ld\n", K, tb.nodes.size(),
            (int)tb.give_up, tb.l16.size(), tb.coarse.size(), tb.ext.size(), tb.h4.size(), h4_answers, h4_none, checked, bad);
     if (K > 16 && !tb.h4.empty() && h4_answers < 100 * std::max(h4_none, 1L)) return 1;   // the table must answer nearly always

@@ -133,8 +133,18 @@ __device__ __forceinline__ int nearest_ext16(const PalDev &pal, const float4 *__
                                              const float o0, const float o1, const float o2, const bool inside)
 {
     const int c0 = min(max((int)o0 >> 4, 0), 15), c1 = min(max((int)o1 >> 4, 0), 15), c2 = min(max((int)o2 >> 4, 0), 15);
-    const uint4 blk = ext16[c0 | (c1 << 4) | (c2 << 8)];
-    const int n = (int)(blk.x & 255u);
+    uint4 blk = ext16[c0 | (c1 << 4) | (c2 << 8)];
+    int n = (int)(blk.x & 255u);
+    if (n == 254) {
+        // an outermost cell with too long a list: down its octree by the CLAMPED integer coordinates (a point beyond the cube falls
+        // into the outer children, which are unbounded on that side); sizes 8, 4, 2, 1 -- a unit child is a list or 255
+        const uint32_t i0 = (uint32_t)min(max((int)o0, 0), 255), i1 = (uint32_t)min(max((int)o1, 0), 255), i2 = (uint32_t)min(max((int)o2, 0), 255);
+        for (int bit = 3; n == 254 && bit >= 0; --bit) {
+            const uint32_t sub = ((i0 >> bit) & 1u) | (((i1 >> bit) & 1u) << 1) | (((i2 >> bit) & 1u) << 2);
+            blk = pal.ed_ext_nodes[(size_t)(blk.x >> 8) * 8 + sub];
+            n = (int)(blk.x & 255u);
+        }
+    }
     // A lane whose cell has no usable list and whose point lies beyond the cube must scan the whole palette -- and then the wave
     // executes that scan anyway: all its lanes take it, instead of the scan PLUS the list paths of the others (a palette crowded at a
     // face of the cube -- any palette under use_gamma, at the dark end -- has such a lane in most waves: 256 colours 59 -> 87 ms per
