@@ -924,7 +924,7 @@ int build_ed_cells(PalDev &dev, const double *pts, void **blob_out)
     return DP_OK;
 }
 
-// The extended 16^3 lists of the unclamped diffusers (host_logic.h: EdTables::ext16 / ext_nodes), 17..256 colours: built when such a
+// The extended 16^3 lists of the unclamped diffusers (host_logic.h: EdTables::ext16 / ext_nodes), 17..1024 colours: built when such a
 // diffuser first meets the palette (5-16 ms of host time that plain error diffusion never needs).  No policy switch: a wave that
 // holds a lane without a usable list beyond the cube takes the whole-palette scan with ALL its lanes (vardiff.hip: nearest_ext16),
 // so a palette crowded at a face of the cube -- every palette under use_gamma is, at the dark end -- never costs more than without.
@@ -932,7 +932,7 @@ int build_ed_ext(PalDev &dev, const double *pts, void **blob_out)
 {
     *blob_out = nullptr;
     const int K = dev.K;
-    if (K <= 16 || K > 256) return DP_OK;
+    if (K <= 16) return DP_OK;
     std::vector<U4> none;
     EdTables tb;
     ed_tables_refine(pts, K, none, tb, 2);

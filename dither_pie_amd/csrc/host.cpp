@@ -332,7 +332,7 @@ static int ensure_ed_ext(const dp_palette *pal_c)
     std::lock_guard<std::mutex> lock(p->build_mu);
     if (p->ext_tried) return DP_OK;
     p->ext_tried = true;
-    if (p->dev.K > 16 && p->dev.K <= 256) {
+    if (p->dev.K > 16) {
         dp::PalDev d = snapshot(p);
         const int rc = build_ed_ext(d, p->pts_host.data(), &p->ext_blob);
         if (rc != DP_OK) return rc;

@@ -817,7 +817,7 @@ inline void ed_tables_refine(const double *pts, const int K, std::vector<U4> &ho
         // diffusers scanned the whole palette at every step above 16 colours: 59 ms per 1080p frame at 256 colours against 4.6 ms
         // for plain error diffusion (tools/bench_scripts/cliff_hunt.py).
         out.ext16.clear();
-        if (!wide && (what & 2)) {
+        if (what & 2) {   // (byte entries up to 256 colours, ten-bit entries above: pack())
             std::vector<U4> &ext16 = out.ext16;
             ext16 = l16;
             const double kInfE = std::numeric_limits<double>::infinity();

@@ -222,7 +222,7 @@ static int run_edtables(const std::vector<double> &pts, int K)
                 e = tb.ext_nodes[at];
             }
             if ((e.x & 255u) == 254u) continue;
-            if ((e.x & 255u) > 15u) {
+            if ((int)(e.x & 255u) > cap) {
                 ++ext_long;
                 continue;
             }
@@ -231,7 +231,7 @@ static int run_edtables(const std::vector<double> &pts, int K)
                 for (int k = 0; k < 3; ++k) d += (x[k] - pts[3 * j + k]) * (x[k] - pts[3 * j + k]);
                 if (d != best) continue;
                 ++ext_checked;
-                if (!listed(e, 15, j)) ++bad;
+                if (!listed(e, cap, j, wide)) ++bad;
             }
         }
     }

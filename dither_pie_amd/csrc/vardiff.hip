@@ -150,6 +150,43 @@ __device__ __forceinline__ int nearest_ext16(const PalDev &pal, const float4 *__
     // face of the cube -- any palette under use_gamma, at the dark end -- has such a lane in most waves: 256 colours 59 -> 87 ms per
     // 1080p frame with the three paths side by side).
     if (__ballot((n < 1 || n > 15) && !(inside && pal.ed_cells != nullptr)) != 0ull) return nearest_any<CAP>(pal, cand, o0, o1, o2);
+    if (pal.K > 256) {
+        // 257..1024 colours: up to twelve ten-bit entries (ed_nearest.hip.h: ed_wide_entry); the same two stages as below
+        if (n >= 1 && n <= 12) {
+            int m0 = 0x7fffffff, m1 = 0x7fffffff;
+            for (uint32_t g = 0; (int)g < n; g += 4u) {
+                const int j1 = ed_wide_entry(blk, g), j2 = ed_wide_entry(blk, g + 1u), j3 = ed_wide_entry(blk, g + 2u), j4 = ed_wide_entry(blk, g + 3u);
+                const float4 q1 = cand[j1], q2 = cand[j2], q3 = cand[j3], q4 = cand[j4];
+                const int k1 = ed_key16(q1, o0, o1, o2, g), k2 = ed_key16(q2, o0, o1, o2, g + 1u), k3 = ed_key16(q3, o0, o1, o2, g + 2u),
+                          k4 = ed_key16(q4, o0, o1, o2, g + 3u);
+                m1 = ed_med3(m0, m1, k1);
+                m0 = min(m0, k1);
+                m1 = ed_med3(m0, m1, k2);
+                m0 = min(m0, k2);
+                m1 = ed_med3(m0, m1, k3);
+                m0 = min(m0, k3);
+                m1 = ed_med3(m0, m1, k4);
+                m0 = min(m0, k4);
+            }
+            const float f0 = __int_as_float(m0 & ~15), f1 = __int_as_float(m1 & ~15);
+            if (f1 > f0 * 1.000004f) return ed_wide_entry(blk, (uint32_t)m0 & 15u);
+            float b0 = __int_as_float(0x7f800000), b1 = b0;
+            int i0 = 0;
+            for (int i = 0; i < n; ++i) {
+                const int j = ed_wide_entry(blk, (uint32_t)i);
+                const float4 c = cand[j];
+                const float a0 = c.x - o0, a1 = c.y - o1, a2 = c.z - o2;
+                const float d = __fmaf_rn(a0, a0, __fmaf_rn(a1, a1, a2 * a2));
+                const bool lt0 = d < b0;
+                b1 = lt0 ? b0 : (d < b1 ? d : b1);
+                i0 = lt0 ? j : i0;
+                b0 = lt0 ? d : b0;
+            }
+            if (b1 > b0 * 1.000002f) return i0;
+        }
+        if (n > 12 && inside && pal.ed_cells) return nearest_color_cells<CAP, false, CAP == kQueueLarge>(pal, cand, nullptr, o0, o1, o2, nullptr, nullptr, nullptr);
+        return nearest_any<CAP>(pal, cand, o0, o1, o2);
+    }
     if (n >= 1 && n <= 12) {
         uint4 b = blk;
         b.x = __funnelshift_r(b.x, b.y, 8);  // drop the count byte
