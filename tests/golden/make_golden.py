@@ -187,6 +187,16 @@ CASES += [
     ("r5_ed_fs_p300_rnd", "error_diffusion", {"variant": "floyd_steinberg"}, ("palr", 300), ("rnd", 130, 170, 73), False, False),
     ("r5_ed_atkinson_p1024_grad", "error_diffusion", {}, ("palr", 1024), ("grad", 100, 140), False, False),
 ]
+# Round 5, late: the unclamped diffusers above 256 colours (extended lists with ten-bit entries) and under use_gamma with 64 / 256 colours
+# (palettes crowded at the dark faces of the cube: the octree below the outermost cells), hashed by the reference.
+CASES += [
+    ("r5_perceptual_p300_rnd", "perceptual", {}, ("palr", 300), ("rnd", 130, 110, 81), False, False),
+    ("r5_hybrid_p1024_grad", "hybrid", {"lum_factor": 0.8, "col_factor": 0.6}, ("palr", 1024), ("grad", 120, 140), False, False),
+    ("r5_adaptive_p512_gamma_rnd", "adaptive_variance", {"var_threshold": 120.0}, ("palr", 512), ("rnd", 110, 130, 82), True, False),
+    ("r5_perceptual_p256_gamma_grad", "perceptual", {}, ("palr", 256), ("grad", 140, 120), True, False),
+    ("r5_hybrid_p64_gamma_rnd", "hybrid", {}, ("palr", 64), ("rnd", 150, 100, 83), True, False),
+    ("r5_ostro_false_p700_rnd", "ostromoukhov", {"serpentine": "false"}, ("palr", 700), ("rnd", 140, 100, 84), False, False),
+]
 # Round 3: the kernels for crowded palettes (ordered_compact_kernel) and for use_gamma (ordered_compact_float_kernel) at 1080p,
 # hashed by the reference: image-like content with its own median-cut 256 palette (the reference's default palette source),
 # all three ordered decision modes, and the float path on noise and on image-like content.
